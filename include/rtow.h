@@ -1,0 +1,296 @@
+/*
+ * rtow.h - C ABI of the MI355X-native sample-batch path (librtow_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of renaudbedard/raytracing-in-one-weekend:
+ * the Burst `SampleBatchJob` (per-pixel sample loop + BVH traversal + Sphere.Hit +
+ * Material.Scatter) and the post passes immediately downstream of it.  The Unity C# host
+ * (scene build, camera, textures, blit, denoiser hand-off) stays; it P/Invokes these
+ * entry points instead of scheduling the Burst job.  See INTEGRATION.md for the C# stub.
+ *
+ * Conventions follow the reference's own native-plugin boundary
+ * (OptixDenoiser/OptixDenoiser/OptixDenoiser.h:1-67 and
+ *  Assets/ThirdParty/nVidia OptiX Denoiser/OptixApi.cs:24-251):
+ *   - extern "C", flat exported functions, cdecl;
+ *   - every call returns an int error enum, 0 == success (OptixApi.cs:24-31,42-78);
+ *   - opaque handles are single pointers with create(..., &handle) / destroy(handle) pairs
+ *     (OptixApi.cs:172-224);
+ *   - POD option structs are passed by pointer (OptixApi.cs:106-142);
+ *   - host buffers are raw pointers owned by the caller for the duration of the call only
+ *     (Runtime/Jobs/DenoiseJobs.cs:75-78,116-117);
+ *   - explicit device alloc / copy / free (OptixDenoiser.h:57-64, OptixApi.cs:226-251).
+ *
+ * All file:line citations are relative to the reference repository root, with
+ *   JOBS/ = RaytracingInOneWeekend/Assets/Scripts/Runtime/Jobs/
+ *   RT/   = RaytracingInOneWeekend/Assets/Scripts/Runtime/
+ *   UNITY/= RaytracingInOneWeekend/Assets/Scripts/Unity/
+ *
+ * No torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef RTOW_H
+#define RTOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define RTOW_API __declspec(dllexport)
+#else
+#define RTOW_API __attribute__((visibility("default")))
+#endif
+
+#define RTOW_API_VERSION 1
+
+/* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
+typedef enum RtowResult {
+    RTOW_SUCCESS = 0,
+    RTOW_ERROR_INVALID_VALUE = 1,     /* null pointer, bad size, bad enum                      */
+    RTOW_ERROR_MEMORY_ALLOCATION = 2, /* hipMalloc / host allocation failed                     */
+    RTOW_ERROR_NO_DEVICE = 3,         /* no gfx950 device / HIP runtime unusable                */
+    RTOW_ERROR_NO_SCENE = 4,          /* rtowSampleBatch* before rtowUploadScene                */
+    RTOW_ERROR_UNSUPPORTED = 5,       /* entity / material / noise kind not built yet           */
+    RTOW_ERROR_LAUNCH_FAILURE = 6,    /* kernel launch or stream error (hipError in the log)    */
+    RTOW_ERROR_CANCELLED = 7,         /* cancellation flag observed; outputs unspecified        */
+    RTOW_ERROR_CAPACITY = 8,          /* scene exceeds a compiled-in bound (traversal stack...) */
+    RTOW_ERROR_INTERNAL = 99
+} RtowResult;
+
+/* ---- small vector PODs (Unity.Mathematics float2/float3/float4, tightly packed) ---- */
+typedef struct RtowFloat2 { float x, y; } RtowFloat2;
+typedef struct RtowFloat3 { float x, y, z; } RtowFloat3;
+typedef struct RtowFloat4 { float x, y, z, w; } RtowFloat4; /* quaternion: (x,y,z,w) = quaternion.value */
+
+/* ---- enums mirroring the reference's runtime enums ---- */
+typedef enum RtowEntityType {      /* RT/Entity.cs:13-20 */
+    RTOW_ENTITY_NONE = 0,
+    RTOW_ENTITY_SPHERE = 1,
+    RTOW_ENTITY_RECT = 2,
+    RTOW_ENTITY_BOX = 3,
+    RTOW_ENTITY_TRIANGLE = 4
+} RtowEntityType;
+
+typedef enum RtowMaterialType {    /* RT/Material.cs:9-14 */
+    RTOW_MATERIAL_STANDARD = 0,
+    RTOW_MATERIAL_DIELECTRIC = 1,
+    RTOW_MATERIAL_PROBABILISTIC_VOLUME = 2
+} RtowMaterialType;
+
+typedef enum RtowTextureType {     /* RT/Texture.cs:13-21 */
+    RTOW_TEXTURE_NONE = 0,
+    RTOW_TEXTURE_CONSTANT = 1,
+    RTOW_TEXTURE_CHECKER_PATTERN = 2, /* dead in the reference (commented out, RT/Texture.cs:61-78) */
+    RTOW_TEXTURE_PERLIN_NOISE = 3,    /* dead in the reference                                      */
+    RTOW_TEXTURE_IMAGE = 4,           /* not built yet -> RTOW_ERROR_UNSUPPORTED                    */
+    RTOW_TEXTURE_CONSTANT_SCALAR = 5
+} RtowTextureType;
+
+typedef enum RtowSkyType {         /* RT/Environment.cs:5-10 */
+    RTOW_SKY_NONE = 0,
+    RTOW_SKY_GRADIENT = 1,
+    RTOW_SKY_CUBEMAP = 2              /* not built yet -> RTOW_ERROR_UNSUPPORTED */
+} RtowSkyType;
+
+typedef enum RtowNoiseColor {      /* RT/RandomSource.cs:8-13 */
+    RTOW_NOISE_WHITE = 0,
+    RTOW_NOISE_BLUE = 1,              /* not built (texture-driven) -> RTOW_ERROR_UNSUPPORTED */
+    RTOW_NOISE_SPATIOTEMPORAL_BLUE = 2
+} RtowNoiseColor;
+
+/* ---- scene description: flat, index-based PODs ----
+ * The reference links BvhNode* / Entity* / Material* / void* Content by host pointer
+ * (RT/BvhNode.cs:8-9, RT/Entity.cs:35-37); that graph cannot cross to a device, so the
+ * boundary takes the same information as flat arrays with indices. */
+
+/* Constant subset of RT/Texture.cs:23-49 (Type, MainColor, Parameter, ScalarValueChannel). */
+typedef struct RtowTexture {
+    int32_t type;               /* RtowTextureType */
+    RtowFloat3 mainColor;       /* Texture.MainColor */
+    float parameter;            /* Texture.Parameter (ConstantValue for ConstantScalar) */
+    int32_t scalarValueChannel; /* Texture.ScalarValueChannel (0..2) */
+} RtowTexture;
+
+/* RT/Material.cs:16-47.  `parameter` is IndexOfRefraction (Dielectric) or Density (Volume);
+ * the reference ctor leaves it 0 for Standard (Material.cs:36-45). */
+typedef struct RtowMaterial {
+    int32_t type;               /* RtowMaterialType */
+    RtowTexture albedo, glossiness, emission, metallic;
+    float parameter;
+} RtowMaterial;
+
+/* RT/Entity.cs:27-56 + the Content struct it points to (RT/EntityTypes/Sphere.cs:6-24 ...).
+ * `size`: Sphere -> (radius, -, -)  [signed radius, Sphere.cs:8-14]
+ *         Rect   -> (sizeX, sizeY, -), Box -> (sizeX, sizeY, sizeZ); Triangle -> contentIndex. */
+typedef struct RtowEntity {
+    int32_t type;                   /* RtowEntityType */
+    int32_t moving;                 /* Entity.Moving (0/1) */
+    RtowFloat4 rotation;            /* Entity.OriginTransform.rot */
+    RtowFloat3 position;            /* Entity.OriginTransform.pos */
+    RtowFloat3 destinationOffset;   /* Entity.DestinationOffset */
+    RtowFloat2 timeRange;           /* Entity.TimeRange */
+    int32_t materialIndex;          /* index into RtowSceneDesc.materials (Entity.Material) */
+    RtowFloat3 size;                /* content parameters, see above */
+    int32_t contentIndex;           /* reserved for triangle payloads */
+} RtowEntity;
+
+typedef struct RtowSceneDesc {
+    const RtowEntity* entities;
+    int32_t entityCount;
+    const RtowMaterial* materials;
+    int32_t materialCount;
+    int32_t maxBvhDepth;            /* UNITY/Raytracer.cs:88 (prefab default 32); 0 = builder default */
+} RtowSceneDesc;
+
+typedef struct RtowSceneInfo {
+    int32_t entityCount;
+    int32_t materialCount;
+    int32_t bvhNodeCount;           /* inner nodes of the native BVH */
+    int32_t bvhDepth;               /* max leaf depth == traversal-stack bound */
+    int32_t ldsBytesScene;          /* bytes of scene data staged into LDS per workgroup */
+    int32_t sceneInLds;             /* 1 if the whole scene is LDS resident, 0 if only the top levels */
+    uint64_t sceneBytesDevice;      /* bytes of scene data resident in HBM */
+} RtowSceneInfo;
+
+/* ---- the operator's parameter block: SampleBatchJob's public fields (JOBS/SampleBatchJob.cs:23-51) ---- */
+
+/* RT/View.cs:8-14 (7 x float3 + float = 88 bytes). Built on the host by View's ctor (View.cs:16-36). */
+typedef struct RtowView {
+    RtowFloat3 origin;
+    RtowFloat3 lowerLeftCorner;
+    RtowFloat3 horizontal, vertical;
+    RtowFloat3 forward, up, right;
+    float lensRadius;
+} RtowView;
+
+/* RT/Environment.cs:12-17 without the cubemap handle. */
+typedef struct RtowEnvironment {
+    int32_t skyType;                /* RtowSkyType */
+    RtowFloat3 skyBottomColor;
+    RtowFloat3 skyTopColor;
+} RtowEnvironment;
+
+typedef struct RtowSampleParams {
+    RtowFloat2 size;                /* SampleBatchJob.Size (float2; coordinates use (int)Size.x, :64-67) */
+    int32_t sliceOffset;            /* :26  rows with (row % sliceDivider) != sliceOffset are skipped (:69-70) */
+    int32_t sliceDivider;           /* :27  (>= 1) */
+    uint32_t seed;                  /* :28 */
+    RtowView view;                  /* :29 */
+    RtowEnvironment environment;    /* :30 */
+    uint32_t sampleCountRange[2];   /* :31  uint2 (x = min, y = max per batch) */
+    int32_t traceDepth;             /* :32 */
+    int32_t subPixelJitter;         /* :33  bool */
+    int32_t noiseColor;             /* :38  RtowNoiseColor */
+    RtowFloat2 sampleCountWeightExtrema; /* :39 */
+    int32_t diagnosticsStride;      /* bytes per pixel of the diagnostics buffer: 4 = {RayCount},
+                                       16 = FULL_DIAGNOSTICS {RayCount, BoundsHitCount, CandidateCount,
+                                       SampleCountWeight} (UNITY/Raytracer.cs:54-64) */
+    int32_t reserved;
+} RtowSampleParams;
+
+/* The four accumulation buffers (JOBS/SampleBatchJob.cs:41-49): W*H elements each, tightly packed,
+ * pixel index = row * W + col with row 0 at the BOTTOM of the image (:64-67, RT/View.cs:44-46).
+ * color.xyz is the colour SUM, color.w the successful-sample COUNT as a float (:72-78,159). */
+typedef struct RtowAccumBuffers {
+    float* color;               /* float4[W*H] */
+    float* normal;              /* float3[W*H] */
+    float* albedo;              /* float3[W*H] */
+    float* sampleCountWeight;   /* float [W*H] */
+} RtowAccumBuffers;
+
+/* ---- context ---- */
+typedef struct RtowContext_t* RtowContext;
+
+/* level: 0 disable, 1 fatal, 2 error, 3 warning, 4 print (OptixLogLevel, OptixApi.cs:80-87).
+ * May be invoked from any thread (OptixApi.cs:145-152). */
+typedef void (*RtowLogCallback)(int32_t level, const char* tag, const char* message, void* userData);
+
+typedef struct RtowContextOptions {
+    int32_t deviceOrdinal;          /* HIP device ordinal */
+    RtowLogCallback logCallback;    /* may be NULL */
+    void* logCallbackData;
+    int32_t logCallbackLevel;
+} RtowContextOptions;
+
+RTOW_API int rtowGetApiVersion(void);
+RTOW_API const char* rtowErrorString(int result);
+
+/* replaces: nothing in the Burst path (in-process job); modelled on createDeviceContext / destroyDeviceContext
+ * (OptixDenoiser.h:21-25). Fails with RTOW_ERROR_NO_DEVICE when no HIP device is usable: there is NO CPU fallback. */
+RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* outContext);
+RTOW_API int rtowDestroyContext(RtowContext context);
+
+/* replaces: the tail of Raytracer.RebuildWorld (UNITY/Raytracer.cs:1167-1183): RebuildEntityBuffers' Entity/Material
+ * buffers (:1185-1304) and RebuildBvh (:1306-1351, UNITY/BvhNodeData.cs:122-213, JOBS/BuildRuntimeBvhJob.cs:20-39).
+ * Copies the description, builds the native BVH, uploads the flat GPU layout. Called only when the world changes. */
+RTOW_API int rtowUploadScene(RtowContext context, const RtowSceneDesc* scene);
+RTOW_API int rtowGetSceneInfo(RtowContext context, RtowSceneInfo* outInfo);
+
+/* replaces: sampleBatchJob.Schedule(totalBufferSize, 1, ...) bracketed by RecordTimeJob 0/1
+ * (UNITY/Raytracer.cs:729-738) == SampleBatchJob.Execute for every pixel index (JOBS/SampleBatchJob.cs:59-164).
+ * Host-buffer form: uploads `in`, runs the kernel, downloads `out` + diagnostics; blocks until done, like IJob.Execute().
+ * `diagnostics` has W*H records of params->diagnosticsStride bytes (may be NULL).
+ * `cancel` (may be NULL) is polled while the kernel runs (JOBS/SampleBatchJob.cs:61-62); when it becomes non-zero
+ * the call returns RTOW_ERROR_CANCELLED and `out` is unspecified (the host discards it, UNITY/Raytracer.cs:489-516).
+ * Pixels skipped by the slice test are NOT written (the host pre-copies them, UNITY/Raytracer.cs:719-726). */
+RTOW_API int rtowSampleBatch(RtowContext context, const RtowSampleParams* params,
+                             const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                             void* diagnostics, const volatile uint8_t* cancel);
+
+/* Same operator with DEVICE-resident buffers (pointers from rtowDeviceAlloc or any HIP allocation in this process),
+ * enqueued on `stream` (a hipStream_t, NULL = the context's own stream). Does not block unless `cancel` is non-NULL.
+ * `in` and `out` may alias element-for-element (each pixel is read before it is written by the same lane). */
+RTOW_API int rtowSampleBatchDevice(RtowContext context, const RtowSampleParams* params,
+                                   const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                                   void* diagnostics, void* stream, const volatile uint8_t* cancel);
+
+/* Device time (ms) of the most recent sample kernel of this context, measured with HIP events recorded on the
+ * stream the kernel was launched on (the RecordTimeJob 0/1 bracket, JOBS/UtilJobs.cs:77-86). Synchronises on the end event. */
+RTOW_API int rtowGetLastSampleKernelMs(RtowContext context, float* outMs);
+
+/* replaces: ReduceMetricsJob.Execute (JOBS/ReduceMetricsJob.cs:22-45). Device buffers in, host scalars out. */
+typedef struct RtowMetrics {
+    int32_t totalRayCount;              /* sum of (int)RayCount */
+    int32_t totalSamples;               /* sum of (int)color.w */
+    RtowFloat2 sampleCountWeightExtrema;/* min / max of sampleCountWeight / sampleCount */
+    int32_t sampleCountExtrema[2];      /* min / max of (int)color.w */
+    int64_t totalRayCount64;            /* same sums without the reference's int32 wrap */
+    int64_t totalSamples64;
+} RtowMetrics;
+RTOW_API int rtowReduceMetricsDevice(RtowContext context, int32_t pixelCount, const void* diagnostics,
+                                     int32_t diagnosticsStride, const float* color, const float* sampleCountWeight,
+                                     void* stream, RtowMetrics* outMetrics);
+
+/* replaces: CombineJob.Execute (JOBS/CombineJob.cs:29-71): sum -> mean, interlace look-around, NaN handling. */
+typedef struct RtowCombineParams {
+    int32_t width, height;          /* CombineJob.Size */
+    int32_t debugMode;              /* CombineJob.DebugMode */
+    int32_t ldrAlbedo;              /* CombineJob.LdrAlbedo */
+} RtowCombineParams;
+RTOW_API int rtowCombineDevice(RtowContext context, const RtowCombineParams* params,
+                               const float* inColor /*float4*/, const float* inNormal, const float* inAlbedo,
+                               float* outColor /*float3*/, float* outNormal, float* outAlbedo, void* stream);
+
+/* replaces: FinalizeTexturesJob.Execute (JOBS/FinalizeTexturesJob.cs:23-55): gamma + RGBA32 pack. */
+RTOW_API int rtowFinalizeDevice(RtowContext context, int32_t pixelCount,
+                                const float* inColor /*float3*/, const float* inNormal, const float* inAlbedo,
+                                uint8_t* outColor /*RGBA32*/, uint8_t* outNormal, uint8_t* outAlbedo, void* stream);
+
+/* replaces: allocateCudaBuffer / copyCudaBuffer / deallocateCudaBuffer (OptixDenoiser.h:57-64). kind: RtowMemcpyKind. */
+typedef enum RtowMemcpyKind {       /* CudaMemcpyKind, OptixApi.cs:33-40 */
+    RTOW_MEMCPY_HOST_TO_HOST = 0,
+    RTOW_MEMCPY_HOST_TO_DEVICE = 1,
+    RTOW_MEMCPY_DEVICE_TO_HOST = 2,
+    RTOW_MEMCPY_DEVICE_TO_DEVICE = 3
+} RtowMemcpyKind;
+RTOW_API int rtowDeviceAlloc(RtowContext context, size_t sizeInBytes, void** outPointer);
+RTOW_API int rtowDeviceFree(RtowContext context, void* pointer);
+RTOW_API int rtowDeviceCopy(RtowContext context, const void* source, void* destination, size_t sizeInBytes, int kind);
+RTOW_API int rtowDeviceMemset(RtowContext context, void* pointer, int value, size_t sizeInBytes);
+RTOW_API int rtowSynchronize(RtowContext context);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTOW_H */

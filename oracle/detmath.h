@@ -1,0 +1,131 @@
+/*
+ * detmath.h - ORACLE copy of the deterministic float32 transcendental functions.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/README.md).  Nothing in the product may include this file;
+ * the HIP side carries its own, separately written copy of the same numeric specification
+ * (raytracing-in-one-weekend_amd/csrc/rtow_detmath.hip.h) and tests/ compare the two bit for bit.
+ *
+ * Why these exist: the reference path calls Unity.Mathematics math.sincos / math.log / math.pow
+ * (RT/RandomSource.cs:58,80,126; RT/Microfacet.cs:72; RT/Material.cs:80,216; JOBS/SampleBatchJob.cs:332),
+ * which Burst lowers to its own FloatPrecision.Medium approximations (JOBS/SampleBatchJob.cs:16) that are
+ * neither published nor runnable here.  A path tracer is chaotic (a 1-ulp difference flips
+ * `rng.NextFloat() < reflectionChance`, RT/Material.cs:91), so CPU<->GPU parity needs transcendental
+ * functions that are *the same float program* on both sides.  The specification below is built only from
+ * IEEE-754 binary32 +,-,*,fma, round-to-nearest-even integer rounding and bit manipulation, all of which
+ * are correctly rounded on x86-64 and on gfx950, so both sides produce identical bits.
+ * Accuracy against float64 libm is <= 2 ulp on the ranges the path uses (tests/test_oracle_kat.py).
+ *
+ * Polynomial coefficients are the classic single-precision Cephes minimax sets (sinf/cosf/logf/exp2f).
+ */
+#ifndef RTOW_ORACLE_DETMATH_H
+#define RTOW_ORACLE_DETMATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline uint32_t dm_asuint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float dm_asfloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* sin and cos of x (any finite x of moderate magnitude; the path only uses [0, 2*pi]). */
+static inline void dm_sincosf(float x, float* s, float* c)
+{
+    const float kf = rintf(x * 0.636619772367581343f);      /* nearest multiple of pi/2, ties to even */
+    const int k = (int)kf;
+    float r = fmaf(kf, -1.5703125f, x);                      /* Cody-Waite, pi/2 = hi + mid + lo */
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+
+    float sp = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp = fmaf(sp, z, -1.6666654611e-1f);
+    sp = sp * z;
+    const float sr = fmaf(sp, r, r);
+
+    float cp = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp = fmaf(cp, z, 4.166664568298827e-2f);
+    cp = cp * z;
+    const float cr = fmaf(cp, z, fmaf(-0.5f, z, 1.0f));
+
+    switch (k & 3) {
+        case 0: *s = sr; *c = cr; break;
+        case 1: *s = cr; *c = -sr; break;
+        case 2: *s = -sr; *c = -cr; break;
+        default: *s = -cr; *c = sr; break;
+    }
+}
+
+/* natural logarithm; x == 0 -> -inf, x < 0 -> NaN, subnormals are treated via the same bit path (not used). */
+static inline float dm_logf(float x)
+{
+    if (x == 0.0f) return -INFINITY;
+    if (!(x > 0.0f)) return NAN;
+    if (x == INFINITY) return INFINITY;
+    const uint32_t bits = dm_asuint(x);
+    int e = (int)((bits >> 23) & 0xffu) - 126;
+    float m = dm_asfloat((bits & 0x007fffffu) | 0x3f000000u); /* [0.5, 1) */
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; }
+    else { m = m - 1.0f; }
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m;
+    y = y * z;
+    const float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+/* 2^t for |t| <= 126 */
+static inline float dm_exp2f(float t)
+{
+    if (t > 126.0f) t = 126.0f;
+    if (t < -126.0f) t = -126.0f;
+    const float nf = rintf(t);
+    const float f = t - nf;                                   /* [-0.5, 0.5], exact */
+    float p = 1.535336188319500e-4f;
+    p = fmaf(p, f, 1.339887440266574e-3f);
+    p = fmaf(p, f, 9.618437357674640e-3f);
+    p = fmaf(p, f, 5.550332471162809e-2f);
+    p = fmaf(p, f, 2.402264791363012e-1f);
+    p = fmaf(p, f, 6.931472028550421e-1f);
+    p = fmaf(p, f, 1.0f);
+    const int n = (int)nf;
+    return p * dm_asfloat((uint32_t)(n + 127) << 23);
+}
+
+/*
+ * pow(x, y).  Spec:
+ *  - y integral with 0 <= y <= 64: binary exponentiation, low bit first
+ *      (result = 1; base = x; while n: if (n&1) result *= base; n >>= 1; if (n) base *= base;)
+ *    so pow(x,2) == x*x, pow(x,5) == x*((x*x)*(x*x)), pow(2,depth) exact.
+ *  - otherwise: x < 0 -> NaN; x == 0 -> (y > 0 ? 0 : +inf); else exp2(y * (log(x) * log2(e))).
+ */
+static inline float dm_powf(float x, float y)
+{
+    if (y >= 0.0f && y <= 64.0f && y == rintf(y)) {
+        unsigned n = (unsigned)y;
+        float result = 1.0f, base = x;
+        while (n) {
+            if (n & 1u) result = result * base;
+            n >>= 1;
+            if (n) base = base * base;
+        }
+        return result;
+    }
+    if (x < 0.0f || x != x) return NAN;
+    if (x == 0.0f) return y > 0.0f ? 0.0f : INFINITY;
+    return dm_exp2f(y * (dm_logf(x) * 1.44269504088896341f));
+}
+
+#endif

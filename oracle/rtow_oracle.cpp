@@ -1,0 +1,1297 @@
+/*
+ * rtow_oracle.cpp - CPU ORACLE for the sample-batch path.  TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library
+ * (oracle/README.md).  The product (librtow_hip.so) shares no code with it.
+ *
+ * What it is: a function-by-function restatement, in strict IEEE-754 binary32, of the reference's
+ * Burst job `SampleBatchJob` and everything beneath it, keeping the reference's ALGORITHMIC SHAPE:
+ * collect every overlapped BVH leaf without closest-hit pruning, test every candidate through the
+ * general Entity transform, sort the hits, take element 0 (JOBS/SampleBatchJob.cs:403-475).
+ * Each function cites the reference file:line it follows.  Paths are relative to the reference root:
+ *   JOBS/ = RaytracingInOneWeekend/Assets/Scripts/Runtime/Jobs/
+ *   RT/   = RaytracingInOneWeekend/Assets/Scripts/Runtime/
+ *   UNITY/= RaytracingInOneWeekend/Assets/Scripts/Unity/
+ *   UTIL/ = RaytracingInOneWeekend/Assets/Scripts/Util/
+ *
+ * PARITY UNPINNED at one boundary: the reference ships no tests, golden
+ * images or known-answer vectors, its C# cannot be compiled or run here (no dotnet/mono/Unity/Burst),
+ * and the arithmetic it calls lives in third-party packages that are NOT vendored under /root/reference:
+ *   com.unity.mathematics 1.2.5  (Packages/manifest.json:7)  - Random (xorshift32), math.* intrinsics
+ *   com.unity.burst 1.7.0-pre.1  (Packages/manifest.json:3)  - FloatMode.Fast codegen
+ *   com.unity.collections 1.0.0-pre.6 (manifest.json:4)      - NativeSortExtension.Sort
+ * Their published semantics are restated below (section "Unity.Mathematics restatement") and pinned by
+ * analytic / float64 known-answer tests in tests/test_oracle_kat.py; there is nothing of the reference's
+ * own to pin them against.  Burst's FloatMode.Fast (reassociation, FMA contraction, ~3.5 ulp
+ * transcendentals) is deliberately NOT imitated: this oracle is the literal left-to-right IEEE evaluation
+ * of the C# source, with sin/cos/log/pow replaced by the deterministic functions in detmath.h.
+ *
+ * Build: oracle/Makefile (g++ -O2 -ffp-contract=off -fno-fast-math; a second -O3 -ffast-math build of the
+ * same source is the timed "CPU baseline" that mirrors [BurstCompile(FloatMode.Fast)]).
+ */
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../include/rtow.h" /* POD scene / parameter structs only (data layout of the boundary) */
+#include "detmath.h"
+
+#define ORACLE_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+/* ===================================================================================================
+ * Unity.Mathematics restatement (com.unity.mathematics 1.2.5 - NOT under /root/reference; assumed
+ * semantics from the published package, see header).
+ * =================================================================================================== */
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+
+inline float3 f3(float x, float y, float z) { return float3{x, y, z}; }
+inline float3 f3(float s) { return float3{s, s, s}; }
+inline float3 f3(const RtowFloat3& v) { return float3{v.x, v.y, v.z}; }
+inline float4 f4(const RtowFloat4& v) { return float4{v.x, v.y, v.z, v.w}; }
+
+inline float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline float3 operator-(float3 a) { return f3(-a.x, -a.y, -a.z); }
+inline float3 operator*(float3 a, float3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+inline float3 operator*(float s, float3 a) { return f3(s * a.x, s * a.y, s * a.z); }
+inline float3 operator/(float3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+inline float3 operator/(float3 a, float3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline float3& operator+=(float3& a, float3 b) { a = a + b; return a; }
+inline float3& operator*=(float3& a, float3 b) { a = a * b; return a; }
+
+/* bit-pattern tests so that the -ffast-math timing build cannot fold them away */
+inline bool um_isnan(float x) { return (dm_asuint(x) & 0x7fffffffu) > 0x7f800000u; }
+inline bool um_isinf(float x) { return (dm_asuint(x) & 0x7fffffffu) == 0x7f800000u; }
+/* math.min/max: `float.IsNaN(y) || x < y ? x : y` - the FIRST operand wins when the second is NaN. */
+inline float um_min(float x, float y) { return (um_isnan(y) || x < y) ? x : y; }
+inline float um_max(float x, float y) { return (um_isnan(y) || x > y) ? x : y; }
+inline float3 um_min(float3 a, float3 b) { return f3(um_min(a.x, b.x), um_min(a.y, b.y), um_min(a.z, b.z)); }
+inline float3 um_max(float3 a, float3 b) { return f3(um_max(a.x, b.x), um_max(a.y, b.y), um_max(a.z, b.z)); }
+inline float um_cmax(float3 v) { return um_max(um_max(v.x, v.y), v.z); }
+inline float um_cmin(float3 v) { return um_min(um_min(v.x, v.y), v.z); }
+inline float um_clamp(float x, float a, float b) { return um_max(a, um_min(b, x)); }
+inline float um_saturate(float x) { return um_clamp(x, 0.0f, 1.0f); }
+inline float3 um_saturate(float3 v) { return f3(um_saturate(v.x), um_saturate(v.y), um_saturate(v.z)); }
+inline float um_lerp(float x, float y, float s) { return x + s * (y - x); }
+inline float3 um_lerp(float3 x, float3 y, float s) { return x + s * (y - x); }
+inline float um_unlerp(float a, float b, float x) { return (x - a) / (b - a); }
+inline float um_rcp(float x) { return 1.0f / x; }
+inline float um_round(float x) { return rintf(x); } /* (float)System.Math.Round(x): half to even */
+inline float um_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float um_dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+/* cross(x, y) = (x * y.yzx - x.yzx * y).yzx */
+inline float3 um_cross(float3 a, float3 b)
+{
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline float um_rsqrt(float x) { return 1.0f / sqrtf(x); }
+inline float3 um_normalize(float3 v) { return um_rsqrt(um_dot(v, v)) * v; }
+inline float3 um_normalizesafe(float3 v)
+{
+    const float len = um_dot(v, v);
+    return len > 1.175494351e-38f ? v * um_rsqrt(len) : f3(0.0f);
+}
+/* reflect(i, n) = i - 2f * n * dot(i, n) */
+inline float3 um_reflect(float3 i, float3 n) { return i - 2.0f * n * um_dot(i, n); }
+/* mul(quaternion q, float3 v): t = 2 * cross(q.xyz, v); v + q.w * t + cross(q.xyz, t) */
+inline float3 um_rotate(float4 q, float3 v)
+{
+    const float3 qv = f3(q.x, q.y, q.z);
+    const float3 t = 2.0f * um_cross(qv, v);
+    return v + q.w * t + um_cross(qv, t);
+}
+inline float4 um_inverse(float4 q)
+{
+    const float r = um_rcp(um_dot(q, q));
+    return float4{r * q.x * -1.0f, r * q.y * -1.0f, r * q.z * -1.0f, r * q.w * 1.0f};
+}
+struct RigidTransform { float4 rot; float3 pos; };
+inline float3 um_transform(const RigidTransform& a, float3 p) { return um_rotate(a.rot, p) + a.pos; }
+inline float3 um_rotate(const RigidTransform& a, float3 d) { return um_rotate(a.rot, d); }
+inline RigidTransform um_inverse(const RigidTransform& t)
+{
+    const float4 invRot = um_inverse(t.rot);
+    return RigidTransform{invRot, um_rotate(invRot, -t.pos)};
+}
+const float UM_PI = 3.14159265f;
+const float UM_EPSILON = 1.1920928955078125e-7f;
+
+/* Unity.Mathematics.Random (xorshift32).  Random(seed): state = seed; NextState().
+ * NextState(): t = state; state ^= state << 13; state ^= state >> 17; state ^= state << 5; return t. */
+struct UmRandom {
+    uint32_t state;
+    uint32_t NextState()
+    {
+        const uint32_t t = state;
+        state ^= state << 13;
+        state ^= state >> 17;
+        state ^= state << 5;
+        return t;
+    }
+    void Init(uint32_t seed) { state = seed; NextState(); }
+    float NextFloat() { return dm_asfloat(0x3f800000u | (NextState() >> 9)) - 1.0f; }
+    float2 NextFloat2() { float2 r; r.x = NextFloat(); r.y = NextFloat(); return r; }
+    float NextFloat(float mn, float mx) { return NextFloat() * (mx - mn) + mn; }
+};
+
+/* ===================================================================================================
+ * RT/ runtime structs
+ * =================================================================================================== */
+
+/* RT/Ray.cs:5-20 */
+struct Ray {
+    float3 Origin, Direction;
+    float Time;
+    Ray() : Origin(f3(0)), Direction(f3(0)), Time(0) {}
+    Ray(float3 o, float3 d, float t = 0) : Origin(o), Direction(d), Time(t) {}
+    Ray OffsetTowards(float3 n) const { return Ray(Origin + 0.001f * n, Direction, Time); } /* :18 */
+    float3 GetPoint(float t) const { return Origin + t * Direction; }                       /* :20 */
+};
+
+struct Entity;
+
+/* RT/HitRecord.cs:6-26 */
+struct HitRecord {
+    float Distance;
+    float3 Point, Normal;
+    float2 TexCoords;
+    const Entity* EntityPtr;
+};
+
+/* RT/AxisAlignedBoundingBox.cs:6-22 */
+struct AABB {
+    float3 Min, Max;
+    float3 Size() const { return Max - Min; }
+    static AABB Enclose(const AABB& l, const AABB& r) { return AABB{um_min(l.Min, r.Min), um_max(l.Max, r.Max)}; }
+};
+
+/* RT/Texture.cs:23-139, constant branches only (:55-59, :100-104); None samples as 0 (:92,137). */
+struct Texture {
+    int Type;
+    float3 MainColor;
+    float Parameter;
+    int ScalarValueChannel;
+    float3 SampleColor() const
+    {
+        switch (Type) {
+            case RTOW_TEXTURE_CONSTANT: return MainColor;
+            case RTOW_TEXTURE_CONSTANT_SCALAR: return f3(Parameter);
+        }
+        return f3(0);
+    }
+    float SampleScalar() const
+    {
+        switch (Type) {
+            case RTOW_TEXTURE_CONSTANT:
+                return ScalarValueChannel == 0 ? MainColor.x : ScalarValueChannel == 1 ? MainColor.y : MainColor.z;
+            case RTOW_TEXTURE_CONSTANT_SCALAR: return Parameter;
+        }
+        return 0.0f;
+    }
+};
+
+/* RT/RandomSource.cs:15-150, NoiseColor.White branches; RandomEvents counter :33-37. */
+struct RandomSource {
+    UmRandom whiteNoise;
+    float RandomEvents;
+    uint32_t draws; /* oracle-only: number of NextState() calls, for the draw-order KAT */
+
+    float NextFloat() { draws += 1; return whiteNoise.NextFloat(); }             /* :130-139 */
+    float2 NextFloat2() { draws += 2; return whiteNoise.NextFloat2(); }          /* :141-150 */
+
+    float2 InUnitDisk()                                                           /* :40-61 */
+    {
+        draws += 2;
+        const float theta = whiteNoise.NextFloat(0.0f, 2.0f * UM_PI);
+        const float radius = sqrtf(whiteNoise.NextFloat());
+        float sinTheta, cosTheta;
+        dm_sincosf(theta, &sinTheta, &cosTheta);
+        return float2{radius * cosTheta, radius * sinTheta};
+    }
+    float3 OnCosineWeightedHemisphere(float3 normal);                             /* :63-89 */
+    float3 NextFloat3Direction()                                                  /* :113-128 */
+    {
+        const float2 rnd = NextFloat2();
+        const float z = rnd.x * 2.0f - 1.0f;
+        const float r = sqrtf(um_max(1.0f - z * z, 0.0f));
+        const float angle = rnd.y * UM_PI * 2.0f;
+        float s, c;
+        dm_sincosf(angle, &s, &c);
+        return f3(c * r, s * r, z);
+    }
+};
+
+/* UTIL/Tools.cs:19-28 (corrected Frisvad / Pixar orthonormal basis) */
+inline void GetOrthonormalBasis(float3 normal, float3* tangent, float3* bitangent)
+{
+    const float s = normal.z >= 0 ? 1.0f : -1.0f;
+    const float a = -1 / (s + normal.z);
+    const float b = normal.x * normal.y * a;
+    *tangent = f3(1 + s * normal.x * normal.x * a, s * b, -s * normal.x);
+    *bitangent = f3(b, s + normal.y * normal.y * a, -normal.y);
+}
+/* UTIL/Tools.cs:30-37; float3x3(c0,c1,c2) takes COLUMNS, mul(M, v) = c0*v.x + c1*v.y + c2*v.z */
+inline float3 TangentToWorldSpace(float3 v, float3 normal)
+{
+    float3 tangent, bitangent;
+    GetOrthonormalBasis(normal, &tangent, &bitangent);
+    const float3 result = tangent * v.x + normal * v.y + bitangent * v.z;
+    return um_normalize(result);
+}
+float3 RandomSource::OnCosineWeightedHemisphere(float3 normal)
+{
+    const float2 uv = NextFloat2();
+    const float u = uv.x;
+    const float radius = sqrtf(u);
+    const float theta = uv.y * 2 * UM_PI;
+    float sinTheta, cosTheta;
+    dm_sincosf(theta, &sinTheta, &cosTheta);
+    const float2 xz = float2{radius * cosTheta, radius * sinTheta};
+    const float3 tangentSpaceDirection = f3(xz.x, sqrtf(1 - u), xz.y);
+    return TangentToWorldSpace(tangentSpaceDirection, normal);
+}
+
+/* RT/Microfacet.cs:53-80 */
+inline float RoughnessToAlpha(float roughness)
+{
+    roughness = um_max(roughness, 1e-3f);
+    const float x = dm_logf(roughness);
+    return 1.62142f +
+           0.819955f * x +
+           0.1734f * x * x +
+           0.0171201f * x * x * x +
+           0.000640711f * x * x * x * x;
+}
+inline float Lambda(float3 w, float3 normal, float roughness)
+{
+    const float cosTheta = um_dot(normal, w);
+    const float sqCosTheta = cosTheta * cosTheta;
+    const float sqSinTheta = um_max(0.0f, 1 - sqCosTheta);
+    const float sinTheta = sqrtf(sqSinTheta);
+    const float tanTheta = sinTheta / cosTheta;
+    const float absTanTheta = fabsf(tanTheta);
+    if (um_isinf(absTanTheta)) return 0;
+    const float alpha = RoughnessToAlpha(roughness);
+    const float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+    return (-1 + sqrtf(1 + alpha2Tan2Theta)) / 2;
+}
+/* RT/Microfacet.cs:9-12 */
+inline float SmithMaskingShadowing(float3 w, float3 normal, float roughness)
+{
+    return 1 / (1 + Lambda(w, normal, roughness));
+}
+
+/* RT/Material.cs:16-218 */
+struct Material {
+    int Type;
+    Texture Albedo, Glossiness, Emission, Metallic;
+    float parameter;
+    float IndexOfRefraction() const { return parameter; }
+    float Density() const { return parameter; }
+
+    static bool AlmostEquals(float lhs, float rhs) { return fabsf(rhs - lhs) < 1e-6f; } /* UTIL/MathExtensions.cs:24-27 */
+
+    /* :181-196 */
+    bool IsPerfectSpecular() const
+    {
+        switch (Type) {
+            case RTOW_MATERIAL_DIELECTRIC: return true;
+            case RTOW_MATERIAL_STANDARD:
+                return Metallic.Type == RTOW_TEXTURE_CONSTANT &&
+                       AlmostEquals(Metallic.MainColor.x, 1) && AlmostEquals(Metallic.MainColor.y, 1) && AlmostEquals(Metallic.MainColor.z, 1) &&
+                       Glossiness.Type == RTOW_TEXTURE_CONSTANT &&
+                       AlmostEquals(Glossiness.MainColor.x, 1) && AlmostEquals(Glossiness.MainColor.y, 1) && AlmostEquals(Glossiness.MainColor.z, 1);
+        }
+        return false;
+    }
+    /* :198-210 */
+    static bool Refract(float3 v, float3 n, float niOverNt, float3* refracted)
+    {
+        const float dt = um_dot(v, n);
+        const float discriminant = 1 - niOverNt * niOverNt * (1 - dt * dt);
+        if (discriminant > 0) {
+            *refracted = niOverNt * (v - n * dt) - n * sqrtf(discriminant);
+            return true;
+        }
+        *refracted = f3(0);
+        return false;
+    }
+    /* :212-217 */
+    static float Schlick(float cosine, float refractiveIndex)
+    {
+        float r0 = (1 - refractiveIndex) / (1 + refractiveIndex);
+        r0 *= r0;
+        return r0 + (1 - r0) * dm_powf(1 - cosine, 5);
+    }
+    /* :176-179 */
+    float3 Emit() const { return Emission.SampleColor(); }
+
+    /* :49-65 */
+    bool ProbabilisticHit(float* hitDistance, RandomSource& rng) const
+    {
+        if (Type != RTOW_MATERIAL_PROBABILISTIC_VOLUME) return false;
+        rng.RandomEvents++;
+        const float volumeHitDistance = -(1 / um_max(Density(), UM_EPSILON)) * dm_logf(rng.NextFloat());
+        if (volumeHitDistance < *hitDistance) {
+            *hitDistance = volumeHitDistance;
+            return true;
+        }
+        return false;
+    }
+
+    /* :68-173 */
+    void Scatter(const Ray& ray, const HitRecord& rec, RandomSource& rng, float3* reflectance, Ray* scattered) const
+    {
+        *reflectance = Albedo.SampleColor();
+        switch (Type) {
+            case RTOW_MATERIAL_STANDARD: {
+                const float metallic = Metallic.SampleScalar();
+                const float glossiness = Glossiness.SampleScalar();
+
+                const float roughness = dm_powf(1 - glossiness, 2);
+                const float3 roughNormal = roughness > 0
+                    ? um_normalize(um_lerp(rec.Normal, rng.OnCosineWeightedHemisphere(rec.Normal), roughness))
+                    : rec.Normal;
+
+                const float incidentCosine = -um_dot(ray.Direction, roughNormal);
+                const float ior = um_lerp(1.5f /*PlasticIor*/, 1.1f /*MetalIor*/, metallic);
+                const float fresnel = Schlick(incidentCosine, ior);
+                const float maskingShadowing = SmithMaskingShadowing(ray.Direction, rec.Normal, roughness);
+                const float reflectionChance = um_saturate(fresnel * glossiness * maskingShadowing);
+
+                if (reflectionChance > 0 && rng.NextFloat() < reflectionChance) {
+                    /* Glossy reflection (untinted!) */
+                    *scattered = Ray(rec.Point, um_reflect(ray.Direction, roughNormal), ray.Time);
+                    *reflectance = f3(1);
+                } else {
+                    if (metallic > 0 && rng.NextFloat() < metallic) {
+                        /* Rough metal */
+                        *scattered = Ray(rec.Point, um_reflect(ray.Direction, roughNormal), ray.Time);
+                    } else {
+                        /* Lambertian diffuse */
+                        *scattered = Ray(rec.Point, rng.OnCosineWeightedHemisphere(rec.Normal), ray.Time);
+                    }
+                }
+
+                /* Scatter type choices */
+                if (reflectionChance > 0 && reflectionChance < 1) rng.RandomEvents++;
+                if (metallic > 0 && metallic < 1) rng.RandomEvents++;
+
+                /* Random lobe sizes */
+                rng.RandomEvents += roughness * (reflectionChance + (1 - reflectionChance) * metallic);
+                rng.RandomEvents += (1 - reflectionChance) * (1 - metallic);
+                break;
+            }
+            case RTOW_MATERIAL_DIELECTRIC: {
+                const float roughness = 1 - Glossiness.SampleScalar();
+                const float3 roughNormal = um_normalize(rec.Normal + roughness * rng.NextFloat3Direction());
+
+                float niOverNt, cosine;
+                float3 outwardRoughNormal;
+                if (um_dot(ray.Direction, roughNormal) > 0) {
+                    outwardRoughNormal = -roughNormal;
+                    niOverNt = IndexOfRefraction();
+                    cosine = IndexOfRefraction() * um_dot(ray.Direction, roughNormal);
+                } else {
+                    outwardRoughNormal = roughNormal;
+                    niOverNt = 1 / IndexOfRefraction();
+                    cosine = -um_dot(ray.Direction, roughNormal);
+                }
+
+                float3 scatterDirection;
+                float3 refracted;
+                if (Refract(ray.Direction, outwardRoughNormal, niOverNt, &refracted) &&
+                    rng.NextFloat() > Schlick(cosine, IndexOfRefraction())) {
+                    scatterDirection = refracted;
+                } else {
+                    scatterDirection = um_reflect(ray.Direction, roughNormal);
+                    *reflectance = f3(1);
+                }
+
+                *scattered = Ray(rec.Point, scatterDirection, ray.Time);
+
+                /* Scatter type choices */
+                rng.RandomEvents++;
+                /* Random lobe sizes */
+                rng.RandomEvents += roughness;
+                break;
+            }
+            case RTOW_MATERIAL_PROBABILISTIC_VOLUME:
+                *scattered = Ray(rec.Point, rng.NextFloat3Direction()); /* Time := 0 (:164) */
+                rng.RandomEvents += 2;
+                break;
+            default:
+                *scattered = Ray();
+                break;
+        }
+    }
+};
+
+/* RT/EntityTypes/Sphere.cs:6-24 */
+struct Sphere {
+    float SquaredRadius, Radius;
+    AABB Bounds() const { const float a = fabsf(Radius); return AABB{f3(-a), f3(a)}; }
+};
+
+/* RT/HitTests.cs:9-21 */
+inline bool HitAabb(const AABB& aabb, float3 rayOrigin, float3 rayInvDirection)
+{
+    const float3 t0 = (aabb.Min - rayOrigin) * rayInvDirection;
+    const float3 t1 = (aabb.Max - rayOrigin) * rayInvDirection;
+    const float tMin = um_max(0.0f, um_cmax(um_min(t0, t1)));
+    const float tMax = um_cmin(um_max(t0, t1));
+    return tMin < tMax;
+}
+
+/* RT/HitTests.cs:23-60 */
+inline bool HitSphere(const Sphere& s, const Ray& r, float tMin, float tMax, float* distance, float3* normal)
+{
+    const float squaredRadius = s.SquaredRadius;
+    const float radius = s.Radius;
+
+    const float3 oc = r.Origin;
+    const float a = um_dot(r.Direction, r.Direction);
+    const float b = um_dot(oc, r.Direction);
+    const float c = um_dot(oc, oc) - squaredRadius;
+    const float discriminant = b * b - a * c;
+
+    if (discriminant > 0) {
+        const float sqrtDiscriminant = sqrtf(discriminant);
+        float t = (-b - sqrtDiscriminant) / a;
+        if (t < tMax && t > tMin) {
+            *distance = t;
+            *normal = r.GetPoint(t) / radius;
+            return true;
+        }
+        t = (-b + sqrtDiscriminant) / a;
+        if (t < tMax && t > tMin) {
+            *distance = t;
+            *normal = r.GetPoint(t) / radius;
+            return true;
+        }
+    }
+    *distance = 0;
+    *normal = f3(0);
+    return false;
+}
+
+/* RT/Entity.cs:27-127 */
+struct Entity {
+    int Type;
+    bool Moving;
+    RigidTransform OriginTransform, InverseTransform;
+    float3 DestinationOffset;
+    float2 TimeRange;
+    const Material* MaterialPtr;
+    Sphere SphereContent;
+    int SourceIndex; /* oracle-only: index in the caller's entity array */
+
+    /* :124-127 */
+    RigidTransform TransformAtTime(float t) const
+    {
+        return RigidTransform{OriginTransform.rot,
+                              OriginTransform.pos +
+                              DestinationOffset * um_clamp(um_unlerp(TimeRange.x, TimeRange.y, t), 0.0f, 1.0f)};
+    }
+    /* :105-122 */
+    bool HitContent(const Ray& r, float tMin, float tMax, float* distance, float3* normal, float2* texCoord) const
+    {
+        *texCoord = float2{0, 0};
+        switch (Type) {
+            case RTOW_ENTITY_SPHERE: return HitSphere(SphereContent, r, tMin, tMax, distance, normal);
+            default:
+                *distance = 0;
+                *normal = f3(0);
+                return false;
+        }
+    }
+    /* :74-103 */
+    bool HitInternal(const Ray& ray, float tMin, float tMax, float* distance, float3* entitySpaceNormal, float2* texCoord,
+                     RigidTransform* transformAtTime) const
+    {
+        RigidTransform inverseTransform;
+        if (!Moving) {
+            *transformAtTime = OriginTransform;
+            inverseTransform = InverseTransform;
+        } else {
+            *transformAtTime = TransformAtTime(ray.Time);
+            inverseTransform = um_inverse(*transformAtTime);
+        }
+        Ray entitySpaceRay;
+        if (Type == RTOW_ENTITY_TRIANGLE)
+            entitySpaceRay = ray;
+        else
+            entitySpaceRay = Ray(um_transform(inverseTransform, ray.Origin), um_rotate(inverseTransform, ray.Direction));
+        return HitContent(entitySpaceRay, tMin, tMax, distance, entitySpaceNormal, texCoord);
+    }
+    /* :58-72 */
+    bool Hit(const Ray& ray, float tMin, float tMax, HitRecord* rec) const
+    {
+        float distance;
+        float3 entityLocalNormal;
+        float2 texCoord;
+        RigidTransform transformAtTime;
+        if (HitInternal(ray, tMin, tMax, &distance, &entityLocalNormal, &texCoord, &transformAtTime)) {
+            rec->Distance = distance;
+            rec->Point = ray.GetPoint(distance);
+            rec->Normal = um_normalize(um_rotate(transformAtTime, entityLocalNormal));
+            rec->TexCoords = texCoord;
+            rec->EntityPtr = nullptr;
+            return true;
+        }
+        memset(rec, 0, sizeof(*rec));
+        return false;
+    }
+};
+
+/* RT/BvhNode.cs:5-22 (index-linked instead of pointer-linked) */
+struct BvhNode {
+    AABB Bounds;
+    int Left, Right;       /* node indices, -1 = null */
+    int EntitiesStart;     /* index into bvhEntities, -1 = null */
+    int EntityCount;
+    bool IsLeaf() const { return EntitiesStart >= 0; }
+};
+
+/* RT/View.cs:8-48 (fields only; the ctor runs on the host) */
+struct View {
+    float3 Origin, LowerLeftCorner, Horizontal, Vertical, Forward, Up, Right;
+    float LensRadius;
+    /* :38-48 */
+    Ray GetRay(float2 normalizedCoordinates, RandomSource& rng) const
+    {
+        float2 rd;
+        if (LensRadius == 0) rd = float2{0, 0};
+        else { const float2 d = rng.InUnitDisk(); rd = float2{LensRadius * d.x, LensRadius * d.y}; }
+        const float3 offset = Right * rd.x + Up * rd.y;
+        const float3 origin = Origin + offset;
+        const float3 direction = um_normalize(LowerLeftCorner - offset +
+                                              normalizedCoordinates.x * Horizontal +
+                                              normalizedCoordinates.y * Vertical);
+        const float time = rng.NextFloat();
+        return Ray(origin, direction, time);
+    }
+};
+
+/* ===================================================================================================
+ * Scene: entity/material buffers + the reference's BVH builder
+ * =================================================================================================== */
+struct BvhBuildingEntity { int entity; AABB Bounds; };
+
+struct OracleScene {
+    std::vector<Material> materials;
+    std::vector<Entity> entities;      /* entityBuffer */
+    std::vector<Entity> bvhEntities;   /* entities re-ordered by the builder (UNITY/BvhNodeData.cs:157-160) */
+    std::vector<BvhNode> nodes;        /* node 0 = root */
+    int maxDepthSeen = 0;
+    bool unsupported = false;
+
+    /* UNITY/BvhNodeData.cs:23-81 : world-space bounds of an entity (moving: union of start/end boxes) */
+    static AABB EntityBounds(const Entity& e)
+    {
+        AABB Bounds = e.SphereContent.Bounds();
+        const float3 corners[8] = {
+            f3(Bounds.Min.x, Bounds.Min.y, Bounds.Min.z), f3(Bounds.Min.x, Bounds.Min.y, Bounds.Max.z),
+            f3(Bounds.Min.x, Bounds.Max.y, Bounds.Min.z), f3(Bounds.Max.x, Bounds.Min.y, Bounds.Min.z),
+            f3(Bounds.Min.x, Bounds.Max.y, Bounds.Max.z), f3(Bounds.Max.x, Bounds.Max.y, Bounds.Min.z),
+            f3(Bounds.Max.x, Bounds.Min.y, Bounds.Max.z), f3(Bounds.Max.x, Bounds.Max.y, Bounds.Max.z)};
+        float3 minimum = f3(INFINITY), maximum = f3(-INFINITY);
+        if (e.Moving) {
+            const float3 destinationPosition = e.OriginTransform.pos + e.DestinationOffset;
+            const RigidTransform minTransform{e.OriginTransform.rot, um_min(e.OriginTransform.pos, destinationPosition)};
+            const RigidTransform maxTransform{e.OriginTransform.rot, um_max(e.OriginTransform.pos, destinationPosition)};
+            for (int i = 0; i < 8; i++) {
+                minimum = um_min(minimum, um_transform(minTransform, corners[i]));
+                maximum = um_max(maximum, um_transform(maxTransform, corners[i]));
+            }
+        } else {
+            for (int i = 0; i < 8; i++) {
+                const float3 c = um_transform(e.OriginTransform, corners[i]);
+                minimum = um_min(minimum, c);
+                maximum = um_max(maximum, c);
+            }
+        }
+        return AABB{minimum, maximum};
+    }
+
+    static float axisOf(float3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
+
+    /* UNITY/BvhNodeData.cs:122-213.  Returns the index of the node it filled.
+     * NativeSlice.Sort is an unstable sort in the reference; a stable sort is used here - only the leaf
+     * composition of ties can differ, never the set of hits (documented in DESIGN.md). */
+    int BuildNode(std::vector<BvhBuildingEntity>& ents, int begin, int end, int maxDepth, int depth, int sortAxis)
+    {
+        const int self = (int)nodes.size();
+        nodes.push_back(BvhNode{});
+        maxDepthSeen = std::max(maxDepthSeen, depth);
+
+        AABB entireBounds{f3(3.40282347e38f), f3(-3.40282347e38f)}; /* float.MaxValue / float.MinValue */
+        for (int i = begin; i < end; i++) entireBounds = AABB::Enclose(entireBounds, ents[i].Bounds);
+
+        int biggestPartition = -1;
+        float biggestPartitionSize = -3.40282347e38f;
+        const float3 entireSize = entireBounds.Size();
+        for (int i = 0; i < 3; i++) {
+            const float size = axisOf(entireSize, i);
+            if (size > biggestPartitionSize) { biggestPartition = i; biggestPartitionSize = size; }
+        }
+        if (sortAxis != biggestPartition && biggestPartition >= 0) {
+            const int ax = biggestPartition;
+            std::stable_sort(ents.begin() + begin, ents.begin() + end,
+                             [ax](const BvhBuildingEntity& l, const BvhBuildingEntity& r) {
+                                 return axisOf(l.Bounds.Min, ax) - axisOf(r.Bounds.Min, ax) < 0; /* (int)sign(l - r) < 0 */
+                             });
+        }
+        const int biggestAxis = biggestPartition;
+        const int length = end - begin;
+
+        BvhNode n{};
+        if (depth == maxDepth || length <= 1) {
+            n.EntitiesStart = (int)bvhEntities.size();
+            for (int i = begin; i < end; i++) bvhEntities.push_back(entities[ents[i].entity]);
+            if (length > 0) {
+                n.Bounds = ents[begin].Bounds;
+                for (int i = begin + 1; i < end; i++) n.Bounds = AABB::Enclose(n.Bounds, ents[i].Bounds);
+            } else {
+                n.Bounds = AABB{f3(0), f3(0)};
+            }
+            n.EntityCount = length;
+            n.Left = n.Right = -1;
+            nodes[self] = n;
+        } else {
+            n.EntitiesStart = -1;
+            n.EntityCount = 0;
+            int partitionLength = 0;
+            const float partitionStart = axisOf(ents[begin].Bounds.Min, biggestAxis);
+            for (int i = begin; i < end; i++) {
+                partitionLength++;
+                const AABB& bounds = ents[i].Bounds;
+                if (axisOf(bounds.Min, biggestAxis) - partitionStart > biggestPartitionSize / 2 ||
+                    axisOf(bounds.Size(), biggestAxis) > biggestPartitionSize / 2)
+                    break;
+            }
+            if (partitionLength == length) partitionLength--;
+            n.Left = BuildNode(ents, begin, begin + partitionLength, maxDepth, depth + 1, biggestPartition);
+            n.Right = BuildNode(ents, begin + partitionLength, end, maxDepth, depth + 1, biggestPartition);
+            n.Bounds = AABB::Enclose(nodes[n.Left].Bounds, nodes[n.Right].Bounds);
+            nodes[self] = n;
+        }
+        return self;
+    }
+
+    void Build(const RtowSceneDesc* d)
+    {
+        materials.resize(d->materialCount);
+        for (int i = 0; i < d->materialCount; i++) {
+            const RtowMaterial& m = d->materials[i];
+            auto tex = [this](const RtowTexture& t) {
+                if (t.type != RTOW_TEXTURE_NONE && t.type != RTOW_TEXTURE_CONSTANT && t.type != RTOW_TEXTURE_CONSTANT_SCALAR)
+                    unsupported = true;
+                return Texture{t.type, f3(t.mainColor), t.parameter, t.scalarValueChannel};
+            };
+            /* RT/Material.cs:28-46: `parameter` only stored for Dielectric / ProbabilisticVolume */
+            float parameter = 0;
+            if (m.type == RTOW_MATERIAL_DIELECTRIC || m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) parameter = m.parameter;
+            if (m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) unsupported = true; /* next row, SURVEY 8(f)#3 */
+            materials[i] = Material{m.type, tex(m.albedo), tex(m.glossiness), tex(m.emission), tex(m.metallic), parameter};
+        }
+        entities.resize(d->entityCount);
+        for (int i = 0; i < d->entityCount; i++) {
+            const RtowEntity& s = d->entities[i];
+            Entity e{};
+            e.Type = s.type;
+            e.Moving = s.moving != 0;
+            e.OriginTransform = RigidTransform{f4(s.rotation), f3(s.position)};
+            e.DestinationOffset = f3(s.destinationOffset);
+            e.TimeRange = float2{s.timeRange.x, s.timeRange.y};
+            e.MaterialPtr = &materials[s.materialIndex];
+            e.SphereContent = Sphere{s.size.x * s.size.x, s.size.x}; /* Sphere.cs:10-14 */
+            e.SourceIndex = i;
+            if (!e.Moving) e.InverseTransform = um_inverse(e.OriginTransform); /* Entity.cs:51-52 */
+            else e.InverseTransform = RigidTransform{float4{0, 0, 0, 0}, f3(0)};
+            if (s.type != RTOW_ENTITY_SPHERE) unsupported = true; /* Rect/Box/Triangle: next row, SURVEY 8(f)#3 */
+            entities[i] = e;
+        }
+        /* UNITY/Raytracer.cs:1306-1351 */
+        std::vector<BvhBuildingEntity> building(entities.size());
+        for (size_t i = 0; i < entities.size(); i++) building[i] = BvhBuildingEntity{(int)i, EntityBounds(entities[i])};
+        nodes.clear();
+        bvhEntities.clear();
+        bvhEntities.reserve(entities.size());
+        const int maxDepth = d->maxBvhDepth > 0 ? d->maxBvhDepth : 32; /* Assets/Prefabs/Raytracer.prefab default */
+        BuildNode(building, 0, (int)building.size(), maxDepth, 0, -1);
+    }
+};
+
+/* ===================================================================================================
+ * SampleBatchJob (JOBS/SampleBatchJob.cs)
+ * =================================================================================================== */
+struct Diagnostics { float RayCount, BoundsHitCount, CandidateCount, SampleCountWeight; };
+
+struct Counters {
+    uint64_t rays = 0, boundsHit = 0, candidates = 0, nodesVisited = 0, hits = 0;
+    uint32_t maxNodeStack = 0, maxCandidates = 0, maxHits = 0;
+};
+
+struct Job {
+    const OracleScene* scene;
+    RtowSampleParams p;
+    View view;
+    const float *InputColor, *InputNormal, *InputAlbedo, *InputSampleCountWeight;
+    float *OutputColor, *OutputNormal, *OutputAlbedo, *OutputSampleCountWeight;
+    uint8_t* OutputDiagnostics;
+
+    struct Scratch {
+        std::vector<float3> emissionStack, attenuationStack;
+        std::vector<int> nodeTraversalBuffer;              /* HybridPtrStack<BvhNode>, UTIL/HybridCollections.cs:8-52 */
+        std::vector<const Entity*> hitCandidateBuffer;     /* HybridPtrStack<Entity> */
+        std::vector<HitRecord> hitRecordBuffer;            /* HybridList<HitRecord>, :54-86 */
+        Counters counters;
+    };
+
+    /* :403-448 */
+    void FindHitCandidates(const Ray& ray, Scratch& s, Diagnostics& diagnostics) const
+    {
+        float3 rayInvDirection = f3(um_rcp(ray.Direction.x), um_rcp(ray.Direction.y), um_rcp(ray.Direction.z));
+        /* Convert NaN to INFINITY (:411-412) */
+        if (um_isnan(rayInvDirection.x)) rayInvDirection.x = INFINITY;
+        if (um_isnan(rayInvDirection.y)) rayInvDirection.y = INFINITY;
+        if (um_isnan(rayInvDirection.z)) rayInvDirection.z = INFINITY;
+
+        s.nodeTraversalBuffer.clear();
+        s.hitCandidateBuffer.clear();
+        s.nodeTraversalBuffer.push_back(0);
+
+        while (!s.nodeTraversalBuffer.empty()) {
+            s.counters.maxNodeStack = std::max<uint32_t>(s.counters.maxNodeStack, (uint32_t)s.nodeTraversalBuffer.size());
+            const BvhNode& node = scene->nodes[s.nodeTraversalBuffer.back()];
+            s.nodeTraversalBuffer.pop_back();
+            s.counters.nodesVisited++;
+
+            if (!HitAabb(node.Bounds, ray.Origin, rayInvDirection)) continue;
+
+            diagnostics.BoundsHitCount++;
+            s.counters.boundsHit++;
+
+            if (node.IsLeaf()) {
+                for (int i = 0; i < node.EntityCount; i++) s.hitCandidateBuffer.push_back(&scene->bvhEntities[node.EntitiesStart + i]);
+                diagnostics.CandidateCount += node.EntityCount;
+                s.counters.candidates += node.EntityCount;
+            } else {
+                s.nodeTraversalBuffer.push_back(node.Left);
+                s.nodeTraversalBuffer.push_back(node.Right);
+            }
+        }
+        s.counters.maxCandidates = std::max<uint32_t>(s.counters.maxCandidates, (uint32_t)s.hitCandidateBuffer.size());
+    }
+
+    /* :450-475 (volume exit-hit injection :463-469 is a next row; volumes are rejected at scene build) */
+    void FindHits(const Ray& ray, Scratch& s) const
+    {
+        s.hitRecordBuffer.clear();
+        while (!s.hitCandidateBuffer.empty()) {
+            const Entity* hitCandidate = s.hitCandidateBuffer.back();
+            s.hitCandidateBuffer.pop_back();
+            HitRecord thisRec;
+            if (hitCandidate->Hit(ray, 0, INFINITY, &thisRec)) {
+                thisRec.EntityPtr = hitCandidate;
+                s.hitRecordBuffer.push_back(thisRec);
+            }
+        }
+        s.counters.hits += s.hitRecordBuffer.size();
+        s.counters.maxHits = std::max<uint32_t>(s.counters.maxHits, (uint32_t)s.hitRecordBuffer.size());
+        /* NativeSortExtension.Sort with HitRecord.DistanceComparer (RT/HitRecord.cs:22-25). Unstable in the
+         * reference; ties (two entities at the bit-identical distance) are left in candidate order here. */
+        if (s.hitRecordBuffer.size() > 1)
+            std::stable_sort(s.hitRecordBuffer.begin(), s.hitRecordBuffer.end(),
+                             [](const HitRecord& x, const HitRecord& y) { return x.Distance < y.Distance; });
+    }
+
+    /* :166-401 */
+    bool Sample(const Ray& eyeRay, RandomSource& rng, Scratch& s, float3* sampleColor, float3* sampleNormal, float3* sampleAlbedo,
+                Diagnostics& diagnostics, float* randomEventsAcc) const
+    {
+        size_t cursor = 0; /* emissionCursor / attenuationCursor */
+        float randomEventsLocalAcc = 0;
+        int depth = 0;
+        bool firstNonSpecularHit = false;
+        *sampleColor = *sampleNormal = *sampleAlbedo = f3(0);
+        const int TraceDepth = p.traceDepth;
+
+        Ray ray = eyeRay;
+
+        for (; depth < TraceDepth; depth++) {
+            FindHitCandidates(ray, s, diagnostics);
+            FindHits(ray, s);
+            /* DetermineVolumeContainment (:194-201, :477-508) returns null unless a ProbabilisticVolume hit exists. */
+
+            diagnostics.RayCount++;
+            s.counters.rays++;
+
+            int hitIndex = 0;
+            const int hitCount = (int)s.hitRecordBuffer.size();
+            while (hitIndex < hitCount) {
+                const HitRecord rec = s.hitRecordBuffer[hitIndex];
+                const Material* material = rec.EntityPtr->MaterialPtr;
+                /* volume branch :212-303 not reachable: no ProbabilisticVolume materials */
+
+                float3 albedo;
+                Ray scatteredRay;
+                material->Scatter(ray, rec, rng, &albedo, &scatteredRay);                    /* :308 */
+
+                const float3 emission = material->Emit();                                    /* :310 */
+                s.emissionStack[cursor] = emission;                                          /* :311 */
+
+                if (depth == 0) *sampleNormal = rec.Normal;                                  /* :313-314 */
+
+                if (!firstNonSpecularHit) {                                                  /* :316-328 */
+                    if (material->IsPerfectSpecular()) {
+                    } else {
+                        *sampleAlbedo = emission + albedo;
+                        *sampleNormal = rec.Normal;
+                        firstNonSpecularHit = true;
+                    }
+                }
+
+                s.attenuationStack[cursor] = albedo;                                         /* :330 */
+                cursor++;
+
+                randomEventsLocalAcc += rng.RandomEvents / dm_powf(2, (float)depth);          /* :332 */
+                rng.RandomEvents = 0;
+
+                ray = scatteredRay;                                                          /* :335-336 */
+                ray = ray.OffsetTowards(um_dot(scatteredRay.Direction, rec.Normal) >= 0 ? rec.Normal : -rec.Normal);
+                break;
+            }
+
+            /* No hit? (:341-374) */
+            if (hitIndex >= hitCount) {
+                float3 hitSkyColor = f3(0);
+                switch (p.environment.skyType) {
+                    case RTOW_SKY_GRADIENT:
+                        hitSkyColor = um_lerp(f3(p.environment.skyBottomColor), f3(p.environment.skyTopColor),
+                                              0.5f * (ray.Direction.y + 1));
+                        break;
+                }
+                s.emissionStack[cursor] = hitSkyColor;
+                s.attenuationStack[cursor] = f3(1);
+                cursor++;
+                randomEventsLocalAcc += rng.RandomEvents / dm_powf(2, (float)depth);
+                rng.RandomEvents = 0;
+
+                if (!firstNonSpecularHit) {
+                    *sampleAlbedo = hitSkyColor;
+                    *sampleNormal = -ray.Direction;
+                }
+                break;
+            }
+        }
+
+        *sampleColor = f3(0);
+
+        /* Safety : fail this sample if the trace depth limit is reached (:379-381) */
+        if (depth == TraceDepth) return false;
+
+        /* Attenuate colors from the tail of the hit stack to the head (:384-396) */
+        while (cursor != 0) {
+            --cursor;
+            const float3 a = s.attenuationStack[cursor];
+            const float3 e = s.emissionStack[cursor];
+            *sampleColor *= a;
+            *sampleColor += e;
+        }
+
+        *randomEventsAcc += randomEventsLocalAcc;                                            /* :398 */
+        return true;
+    }
+
+    /* :59-164 */
+    void Execute(int index, Scratch& s) const
+    {
+        const int width = (int)p.size.x;
+        const int cx = index % width; /* column */
+        const int cy = index / width; /* row */
+
+        if (cy % p.sliceDivider != p.sliceOffset) return;                                    /* :69-70 */
+
+        const float* lastColor = InputColor + 4 * (size_t)index;                             /* :72-78 */
+        float3 colorAcc = f3(lastColor[0], lastColor[1], lastColor[2]);
+        float3 normalAcc = f3(InputNormal[3 * (size_t)index], InputNormal[3 * (size_t)index + 1], InputNormal[3 * (size_t)index + 2]);
+        float3 albedoAcc = f3(InputAlbedo[3 * (size_t)index], InputAlbedo[3 * (size_t)index + 1], InputAlbedo[3 * (size_t)index + 2]);
+        float sampleCountWeightAcc = InputSampleCountWeight[index];
+        int sampleCount = (int)lastColor[3];
+
+        /* :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)) */
+        RandomSource rng;
+        rng.whiteNoise.Init((p.seed * 0x8C4CA03Fu) ^ ((uint32_t)index * 0x7383ED49u));
+        rng.RandomEvents = 0;
+        rng.draws = 0;
+
+        if (s.emissionStack.size() < (size_t)p.traceDepth + 1) {                              /* stackalloc :103-104 */
+            s.emissionStack.resize((size_t)p.traceDepth + 1);
+            s.attenuationStack.resize((size_t)p.traceDepth + 1);
+        }
+
+        float3 fallbackAlbedo = f3(0), fallbackNormal = f3(0);
+        Diagnostics diagnostics{0, 0, 0, 0};
+
+        /* :118-126 */
+        uint32_t samplesToAccumulate;
+        const float sampleCountWeight = sampleCountWeightAcc / (float)sampleCount;
+        if (sampleCountWeight == 0)
+            samplesToAccumulate = p.sampleCountRange[0];
+        else {
+            const float normalizedSampleCountWeight =
+                um_saturate(um_unlerp(p.sampleCountWeightExtrema.x, p.sampleCountWeightExtrema.y, sampleCountWeight));
+            samplesToAccumulate =
+                (uint32_t)um_round(um_lerp((float)p.sampleCountRange[0], (float)p.sampleCountRange[1], normalizedSampleCountWeight));
+        }
+        diagnostics.SampleCountWeight = sampleCountWeight;                                   /* :128-130 */
+
+        for (uint32_t smp = 0; smp < samplesToAccumulate; smp++) {                            /* :132-157 */
+            float2 jitter;
+            if (p.subPixelJitter) jitter = rng.NextFloat2();
+            else jitter = float2{0.5f, 0.5f};
+            const float2 normalizedCoordinates = float2{((float)cx + jitter.x) / p.size.x, ((float)cy + jitter.y) / p.size.y};
+            const Ray eyeRay = view.GetRay(normalizedCoordinates, rng);
+
+            float3 sampleColor, sampleNormal, sampleAlbedo;
+            if (Sample(eyeRay, rng, s, &sampleColor, &sampleNormal, &sampleAlbedo, diagnostics, &sampleCountWeightAcc)) {
+                colorAcc += sampleColor;
+                normalAcc += sampleNormal;
+                albedoAcc += sampleAlbedo;
+                sampleCount++;
+            }
+            if (smp == 0) {
+                fallbackNormal = sampleNormal;
+                fallbackAlbedo = sampleAlbedo;
+            }
+        }
+
+        float* oc = OutputColor + 4 * (size_t)index;                                         /* :159-163 */
+        oc[0] = colorAcc.x; oc[1] = colorAcc.y; oc[2] = colorAcc.z; oc[3] = (float)sampleCount;
+        const float3 on = sampleCount == 0 ? fallbackNormal : normalAcc;
+        const float3 oa = sampleCount == 0 ? fallbackAlbedo : albedoAcc;
+        OutputNormal[3 * (size_t)index] = on.x; OutputNormal[3 * (size_t)index + 1] = on.y; OutputNormal[3 * (size_t)index + 2] = on.z;
+        OutputAlbedo[3 * (size_t)index] = oa.x; OutputAlbedo[3 * (size_t)index + 1] = oa.y; OutputAlbedo[3 * (size_t)index + 2] = oa.z;
+        OutputSampleCountWeight[index] = sampleCountWeightAcc;
+        if (OutputDiagnostics) {
+            if (p.diagnosticsStride >= 16) memcpy(OutputDiagnostics + (size_t)index * p.diagnosticsStride, &diagnostics, 16);
+            else memcpy(OutputDiagnostics + (size_t)index * p.diagnosticsStride, &diagnostics.RayCount, 4);
+        }
+    }
+};
+
+View MakeView(const RtowView& v)
+{
+    View r;
+    r.Origin = f3(v.origin); r.LowerLeftCorner = f3(v.lowerLeftCorner);
+    r.Horizontal = f3(v.horizontal); r.Vertical = f3(v.vertical);
+    r.Forward = f3(v.forward); r.Up = f3(v.up); r.Right = f3(v.right);
+    r.LensRadius = v.lensRadius;
+    return r;
+}
+
+/* UTIL/MathExtensions.cs:17-21 */
+inline float LinearToGamma1(float value)
+{
+    value = um_max(value, 0.0f);
+    return um_max(1.055f * dm_powf(value, 0.416666667f) - 0.055f, 0.0f);
+}
+
+} // namespace
+
+/* ===================================================================================================
+ * exported C entry points (ctypes)
+ * =================================================================================================== */
+struct OracleCountersOut {
+    uint64_t rays, boundsHit, candidates, nodesVisited, hits;
+    uint32_t maxNodeStack, maxCandidates, maxHits, bvhNodeCount, bvhDepth, threads;
+};
+
+ORACLE_API void* oracle_scene_create(const RtowSceneDesc* desc)
+{
+    if (!desc || desc->entityCount <= 0 || !desc->entities || !desc->materials) return nullptr;
+    for (int i = 0; i < desc->entityCount; i++)
+        if (desc->entities[i].materialIndex < 0 || desc->entities[i].materialIndex >= desc->materialCount) return nullptr;
+    OracleScene* s = new OracleScene();
+    s->Build(desc);
+    if (s->unsupported) { delete s; return nullptr; }
+    return s;
+}
+ORACLE_API void oracle_scene_destroy(void* scene) { delete (OracleScene*)scene; }
+ORACLE_API int oracle_scene_node_count(void* scene) { return (int)((OracleScene*)scene)->nodes.size(); }
+ORACLE_API int oracle_scene_depth(void* scene) { return ((OracleScene*)scene)->maxDepthSeen; }
+
+/* SampleBatchJob.Schedule(W*H, 1): one task per pixel index, dynamic hand-out (UNITY/Raytracer.cs:730). */
+ORACLE_API int oracle_sample_batch(void* scenePtr, const RtowSampleParams* params,
+                                   const float* inColor, const float* inNormal, const float* inAlbedo, const float* inScw,
+                                   float* outColor, float* outNormal, float* outAlbedo, float* outScw,
+                                   void* diagnostics, int nthreads, OracleCountersOut* countersOut)
+{
+    if (!scenePtr || !params) return 1;
+    if (params->noiseColor != RTOW_NOISE_WHITE) return 5;
+    if (params->sliceDivider < 1 || params->traceDepth < 0) return 1;
+    const OracleScene* scene = (const OracleScene*)scenePtr;
+    Job job;
+    job.scene = scene;
+    job.p = *params;
+    job.view = MakeView(params->view);
+    job.InputColor = inColor; job.InputNormal = inNormal; job.InputAlbedo = inAlbedo; job.InputSampleCountWeight = inScw;
+    job.OutputColor = outColor; job.OutputNormal = outNormal; job.OutputAlbedo = outAlbedo; job.OutputSampleCountWeight = outScw;
+    job.OutputDiagnostics = (uint8_t*)diagnostics;
+
+    const int total = (int)params->size.x * (int)params->size.y;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    std::atomic<int> next{0};
+    std::vector<Counters> perThread(nthreads);
+    auto worker = [&](int tid) {
+        Job::Scratch scratch;
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= total) break;
+            job.Execute(i, scratch);
+        }
+        perThread[tid] = scratch.counters;
+    };
+    if (nthreads == 1) worker(0);
+    else {
+        std::vector<std::thread> threads;
+        for (int t = 0; t < nthreads; t++) threads.emplace_back(worker, t);
+        for (auto& t : threads) t.join();
+    }
+    if (countersOut) {
+        OracleCountersOut o{};
+        for (const Counters& c : perThread) {
+            o.rays += c.rays; o.boundsHit += c.boundsHit; o.candidates += c.candidates; o.nodesVisited += c.nodesVisited; o.hits += c.hits;
+            o.maxNodeStack = std::max(o.maxNodeStack, c.maxNodeStack);
+            o.maxCandidates = std::max(o.maxCandidates, c.maxCandidates);
+            o.maxHits = std::max(o.maxHits, c.maxHits);
+        }
+        o.bvhNodeCount = (uint32_t)scene->nodes.size();
+        o.bvhDepth = (uint32_t)scene->maxDepthSeen;
+        o.threads = (uint32_t)nthreads;
+        *countersOut = o;
+    }
+    return 0;
+}
+
+/* ---- post passes ---- */
+
+/* JOBS/CombineJob.cs:29-71 */
+ORACLE_API void oracle_combine(int width, int height, int debugMode, int ldrAlbedo,
+                               const float* inColor4, const float* inNormal, const float* inAlbedo,
+                               float* outColor, float* outNormal, float* outAlbedo)
+{
+    const int n = width * height;
+    for (int index = 0; index < n; index++) {
+        float4 inputColor{inColor4[4 * index], inColor4[4 * index + 1], inColor4[4 * index + 2], inColor4[4 * index + 3]};
+        int realSampleCount = (int)inputColor.w;
+        float3 finalColor;
+        auto anyNan = [](float4 c) { return um_isnan(c.x) || um_isnan(c.y) || um_isnan(c.z) || um_isnan(c.w); };
+        if (!debugMode) {
+            if (realSampleCount == 0) {
+                int tentativeIndex = index;
+                while (realSampleCount == 0 && (tentativeIndex -= width) >= 0) {
+                    inputColor = float4{inColor4[4 * tentativeIndex], inColor4[4 * tentativeIndex + 1], inColor4[4 * tentativeIndex + 2], inColor4[4 * tentativeIndex + 3]};
+                    realSampleCount = (int)inputColor.w;
+                }
+            }
+            if (realSampleCount == 0) finalColor = f3(0);
+            else if (anyNan(inputColor)) finalColor = f3(0);
+            else finalColor = f3(inputColor.x, inputColor.y, inputColor.z) / (float)realSampleCount;
+        } else {
+            if (realSampleCount == 0) finalColor = f3(1, 0, 1);
+            else if (anyNan(inputColor)) finalColor = f3(0, 1, 1);
+            else finalColor = f3(inputColor.x, inputColor.y, inputColor.z) / (float)realSampleCount;
+        }
+        const float denom = (float)std::max(realSampleCount, 1);
+        float3 finalAlbedo = f3(inAlbedo[3 * index], inAlbedo[3 * index + 1], inAlbedo[3 * index + 2]) / denom;
+        if (ldrAlbedo) finalAlbedo = um_min(finalAlbedo, f3(1));
+        const float3 nrm = um_normalizesafe(f3(inNormal[3 * index], inNormal[3 * index + 1], inNormal[3 * index + 2]) / denom);
+        outColor[3 * index] = finalColor.x; outColor[3 * index + 1] = finalColor.y; outColor[3 * index + 2] = finalColor.z;
+        outNormal[3 * index] = nrm.x; outNormal[3 * index + 1] = nrm.y; outNormal[3 * index + 2] = nrm.z;
+        outAlbedo[3 * index] = finalAlbedo.x; outAlbedo[3 * index + 1] = finalAlbedo.y; outAlbedo[3 * index + 2] = finalAlbedo.z;
+    }
+}
+
+/* JOBS/FinalizeTexturesJob.cs:23-55 */
+ORACLE_API void oracle_finalize(int n, const float* inColor, const float* inNormal, const float* inAlbedo,
+                                uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo)
+{
+    for (int index = 0; index < n; index++) {
+        for (int c = 0; c < 3; c++) {
+            const float oc = um_saturate(LinearToGamma1(inColor[3 * index + c])) * 255;
+            outColor[4 * index + c] = (uint8_t)oc;
+            const float on = um_saturate(LinearToGamma1(inNormal[3 * index + c] * 0.5f + 0.5f)) * 255;
+            outNormal[4 * index + c] = (uint8_t)on;
+            const float oa = um_saturate(LinearToGamma1(inAlbedo[3 * index + c])) * 255;
+            outAlbedo[4 * index + c] = (uint8_t)oa;
+        }
+        outColor[4 * index + 3] = 255; outNormal[4 * index + 3] = 255; outAlbedo[4 * index + 3] = 255;
+    }
+}
+
+/* JOBS/ReduceMetricsJob.cs:22-45 */
+ORACLE_API void oracle_reduce_metrics(int n, const void* diagnostics, int diagnosticsStride, const float* color4, const float* scw,
+                                      RtowMetrics* out)
+{
+    int totalRayCount = 0;
+    float minSampleCountWeight = INFINITY, maxSampleCountWeight = -INFINITY;
+    float minSamples = INFINITY, maxSamples = -INFINITY;
+    int totalSamples = 0;
+    int64_t rays64 = 0, samples64 = 0;
+    for (int i = 0; i < n; i++) {
+        float rayCount;
+        memcpy(&rayCount, (const uint8_t*)diagnostics + (size_t)i * diagnosticsStride, 4);
+        totalRayCount = (int)((uint32_t)totalRayCount + (uint32_t)(int)rayCount);
+        rays64 += (int)rayCount;
+        const int sampleCount = (int)color4[4 * (size_t)i + 3];
+        totalSamples = (int)((uint32_t)totalSamples + (uint32_t)sampleCount);
+        samples64 += sampleCount;
+        const float sampleCountWeight = scw[i] / (float)sampleCount;
+        minSampleCountWeight = um_min(minSampleCountWeight, sampleCountWeight);
+        maxSampleCountWeight = um_max(maxSampleCountWeight, sampleCountWeight);
+        minSamples = um_min(minSamples, (float)sampleCount);
+        maxSamples = um_max(maxSamples, (float)sampleCount);
+    }
+    out->totalRayCount = totalRayCount;
+    out->totalSamples = totalSamples;
+    out->sampleCountWeightExtrema = RtowFloat2{minSampleCountWeight, maxSampleCountWeight};
+    out->sampleCountExtrema[0] = (int)minSamples;
+    out->sampleCountExtrema[1] = (int)maxSamples;
+    out->totalRayCount64 = rays64;
+    out->totalSamples64 = samples64;
+}
+
+/* ---- known-answer-test hooks ---- */
+ORACLE_API void oracle_kat_rng(uint32_t seed, int n, uint32_t* states, float* floats)
+{
+    UmRandom a; a.Init(seed);
+    UmRandom b; b.Init(seed);
+    for (int i = 0; i < n; i++) { states[i] = a.NextState(); floats[i] = b.NextFloat(); }
+}
+ORACLE_API uint32_t oracle_kat_pixel_seed(uint32_t seed, int index) { return (seed * 0x8C4CA03Fu) ^ ((uint32_t)index * 0x7383ED49u); }
+ORACLE_API void oracle_kat_sincos(int n, const float* x, float* s, float* c) { for (int i = 0; i < n; i++) dm_sincosf(x[i], &s[i], &c[i]); }
+ORACLE_API void oracle_kat_log(int n, const float* x, float* y) { for (int i = 0; i < n; i++) y[i] = dm_logf(x[i]); }
+ORACLE_API void oracle_kat_pow(int n, const float* x, const float* e, float* y) { for (int i = 0; i < n; i++) y[i] = dm_powf(x[i], e[i]); }
+ORACLE_API float oracle_kat_schlick(float cosine, float ior) { return Material::Schlick(cosine, ior); }
+ORACLE_API int oracle_kat_refract(const float* v, const float* n, float niOverNt, float* out)
+{
+    float3 r;
+    const bool ok = Material::Refract(f3(v[0], v[1], v[2]), f3(n[0], n[1], n[2]), niOverNt, &r);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+    return ok ? 1 : 0;
+}
+ORACLE_API float oracle_kat_lambda(const float* w, const float* n, float roughness) { return Lambda(f3(w[0], w[1], w[2]), f3(n[0], n[1], n[2]), roughness); }
+ORACLE_API float oracle_kat_roughness_to_alpha(float roughness) { return RoughnessToAlpha(roughness); }
+ORACLE_API float oracle_kat_linear_to_gamma(float v) { return LinearToGamma1(v); }
+ORACLE_API void oracle_kat_basis(const float* n, float* tangent, float* bitangent)
+{
+    float3 t, b;
+    GetOrthonormalBasis(f3(n[0], n[1], n[2]), &t, &b);
+    tangent[0] = t.x; tangent[1] = t.y; tangent[2] = t.z;
+    bitangent[0] = b.x; bitangent[1] = b.y; bitangent[2] = b.z;
+}
+ORACLE_API int oracle_kat_aabb_hit(const float* mn, const float* mx, const float* ro, const float* rd)
+{
+    float3 inv = f3(um_rcp(rd[0]), um_rcp(rd[1]), um_rcp(rd[2]));
+    if (um_isnan(inv.x)) inv.x = INFINITY;
+    if (um_isnan(inv.y)) inv.y = INFINITY;
+    if (um_isnan(inv.z)) inv.z = INFINITY;
+    return HitAabb(AABB{f3(mn[0], mn[1], mn[2]), f3(mx[0], mx[1], mx[2])}, f3(ro[0], ro[1], ro[2]), inv) ? 1 : 0;
+}
+/* Entity.Hit for one RtowEntity (sphere), world-space ray; out = {distance, point[3], normal[3]} */
+ORACLE_API int oracle_kat_entity_hit(const RtowEntity* ent, const float* ro, const float* rd, float time, float tMin, float tMax, float* out)
+{
+    Entity e{};
+    e.Type = ent->type;
+    e.Moving = ent->moving != 0;
+    e.OriginTransform = RigidTransform{f4(ent->rotation), f3(ent->position)};
+    e.DestinationOffset = f3(ent->destinationOffset);
+    e.TimeRange = float2{ent->timeRange.x, ent->timeRange.y};
+    e.SphereContent = Sphere{ent->size.x * ent->size.x, ent->size.x};
+    if (!e.Moving) e.InverseTransform = um_inverse(e.OriginTransform);
+    HitRecord rec;
+    const bool hit = e.Hit(Ray(f3(ro[0], ro[1], ro[2]), f3(rd[0], rd[1], rd[2]), time), tMin, tMax, &rec);
+    out[0] = rec.Distance;
+    out[1] = rec.Point.x; out[2] = rec.Point.y; out[3] = rec.Point.z;
+    out[4] = rec.Normal.x; out[5] = rec.Normal.y; out[6] = rec.Normal.z;
+    return hit ? 1 : 0;
+}
+/* One Material.Scatter call. io: rngState (in/out). out = {reflectance[3], origin[3], dir[3], time, randomEvents, draws, isPerfectSpecular, emission[3]} */
+ORACLE_API void oracle_kat_scatter(const RtowMaterial* m, const float* ro, const float* rd, float time,
+                                   const float* point, const float* normal, float distance, uint32_t* rngState, float* out)
+{
+    auto tex = [](const RtowTexture& t) { return Texture{t.type, f3(t.mainColor), t.parameter, t.scalarValueChannel}; };
+    float parameter = 0;
+    if (m->type == RTOW_MATERIAL_DIELECTRIC || m->type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) parameter = m->parameter;
+    const Material mat{m->type, tex(m->albedo), tex(m->glossiness), tex(m->emission), tex(m->metallic), parameter};
+    RandomSource rng;
+    rng.whiteNoise.state = *rngState;
+    rng.RandomEvents = 0;
+    rng.draws = 0;
+    HitRecord rec{};
+    rec.Distance = distance;
+    rec.Point = f3(point[0], point[1], point[2]);
+    rec.Normal = f3(normal[0], normal[1], normal[2]);
+    float3 reflectance;
+    Ray scattered;
+    mat.Scatter(Ray(f3(ro[0], ro[1], ro[2]), f3(rd[0], rd[1], rd[2]), time), rec, rng, &reflectance, &scattered);
+    const float3 em = mat.Emit();
+    *rngState = rng.whiteNoise.state;
+    out[0] = reflectance.x; out[1] = reflectance.y; out[2] = reflectance.z;
+    out[3] = scattered.Origin.x; out[4] = scattered.Origin.y; out[5] = scattered.Origin.z;
+    out[6] = scattered.Direction.x; out[7] = scattered.Direction.y; out[8] = scattered.Direction.z;
+    out[9] = scattered.Time;
+    out[10] = rng.RandomEvents;
+    out[11] = (float)rng.draws;
+    out[12] = mat.IsPerfectSpecular() ? 1.0f : 0.0f;
+    out[13] = em.x; out[14] = em.y; out[15] = em.z;
+}
+/* View.GetRay for one normalized coordinate. out = {origin[3], dir[3], time, draws} */
+ORACLE_API void oracle_kat_get_ray(const RtowView* v, float u, float w, uint32_t* rngState, float* out)
+{
+    const View view = MakeView(*v);
+    RandomSource rng;
+    rng.whiteNoise.state = *rngState;
+    rng.RandomEvents = 0;
+    rng.draws = 0;
+    const Ray r = view.GetRay(float2{u, w}, rng);
+    *rngState = rng.whiteNoise.state;
+    out[0] = r.Origin.x; out[1] = r.Origin.y; out[2] = r.Origin.z;
+    out[3] = r.Direction.x; out[4] = r.Direction.y; out[5] = r.Direction.z;
+    out[6] = r.Time;
+    out[7] = (float)rng.draws;
+}
+/* Nearest hit along a ray through the reference-shaped pipeline (FindHitCandidates + FindHits, element 0);
+ * used for the auto-focus probe (UNITY/Raytracer.cs:608-609) and first-hit KATs.
+ * out = {distance, point[3], normal[3], entityIndex}; returns the number of hits found. */
+ORACLE_API int oracle_kat_nearest_hit(void* scenePtr, const float* ro, const float* rd, float time, float* out)
+{
+    const OracleScene* scene = (const OracleScene*)scenePtr;
+    Job job;
+    job.scene = scene;
+    Job::Scratch s;
+    Diagnostics d{0, 0, 0, 0};
+    const Ray ray(f3(ro[0], ro[1], ro[2]), f3(rd[0], rd[1], rd[2]), time);
+    job.FindHitCandidates(ray, s, d);
+    job.FindHits(ray, s);
+    if (s.hitRecordBuffer.empty()) return 0;
+    const HitRecord& r = s.hitRecordBuffer[0];
+    out[0] = r.Distance;
+    out[1] = r.Point.x; out[2] = r.Point.y; out[3] = r.Point.z;
+    out[4] = r.Normal.x; out[5] = r.Normal.y; out[6] = r.Normal.z;
+    out[7] = (float)r.EntityPtr->SourceIndex;
+    return (int)s.hitRecordBuffer.size();
+}

@@ -1,0 +1,15 @@
+"""MI355X-native sample-batch path for renaudbedard/raytracing-in-one-weekend.
+
+Package layout:
+  abi.py     ctypes mirror of include/rtow.h
+  lib.py     loader for csrc/librtow_hip.so (the C-ABI product library; fails loudly if missing)
+  host.py    host-side mirror of the reference's job structs (SampleBatchJob, CombineJob, ...)
+  scenes.py  synthetic benchmark scenes (input preparation, shared by product and tests)
+  csrc/      hand-written HIP (gfx950) kernels + the C ABI implementation
+
+The directory name contains '-' so it is loaded with importlib (see tests/conftest.py, bench.py):
+    rtow = importlib.import_module("raytracing-in-one-weekend_amd")
+"""
+from . import abi, scenes  # noqa: F401
+
+__all__ = ["abi", "scenes"]

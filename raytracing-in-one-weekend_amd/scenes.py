@@ -1,0 +1,420 @@
+"""Synthetic benchmark scenes for the sample-batch path (host side, float32 numpy).
+
+The book-cover scene exists in the reference only as data
+(`Assets/Scenes/Legacy/Final Scene (Book 1).asset`) plus a commented-out generator
+(`Assets/Scripts/Unity/Raytracer.cs:1355-1506`, `CollectActiveEntities`).  This module restates that
+generator - dart throwing driven by Unity.Mathematics.Random (xorshift32) - and emits the flat
+`RtowSceneDesc` arrays of include/rtow.h.  It is input preparation for BOTH the product and the
+oracle; it contains no part of the sample path itself.
+
+Frozen build decisions:
+ * fixed-sphere materials dangle in the asset (unresolved GUIDs, asset lines 33,48,63,78) -> the book's:
+   ground lambert 0.5 grey, centre glass ior 1.5, left lambert (0.4,0.2,0.1), right metal (0.7,0.6,0.5) fuzz 0;
+ * legacy material kinds map onto the reference's current model (RT/Material.cs:9-14):
+     lambert      -> Standard{metallic 0, glossiness 0}
+     metal(fuzz)  -> Standard{metallic 1, glossiness 1 - fuzz}
+     glass(ior)   -> Dielectric{ior, glossiness 1, albedo 1}
+ * the asset's 1000 tentatives give 4 + N random spheres with N != 482; BASELINE.json labels the scene
+   "486-sphere", so `cover_scene()` keeps throwing darts from the same stream until exactly 486 entities
+   exist and records how many tentatives that took (`tentatives_used`).
+"""
+import math
+
+import numpy as np
+
+from . import abi
+
+f32 = np.float32
+_M32 = 0xFFFFFFFF
+UM_PI = f32(3.14159265)
+
+
+class UnityRandom:
+    """Unity.Mathematics.Random 1.2.5 (assumed published semantics; package not vendored in the reference).
+
+    Random(seed): state = seed; NextState().   NextState(): returns the PRE-update state.
+    NextFloat(): asfloat(0x3f800000 | (NextState() >> 9)) - 1.
+    """
+
+    def __init__(self, seed):
+        self.state = seed & _M32
+        self.next_state()
+
+    def next_state(self):
+        t = self.state
+        s = t
+        s ^= (s << 13) & _M32
+        s ^= s >> 17
+        s ^= (s << 5) & _M32
+        self.state = s
+        return t
+
+    def next_float(self):
+        bits = np.array([0x3F800000 | (self.next_state() >> 9)], dtype=np.uint32)
+        return f32(bits.view(np.float32)[0] - f32(1.0))
+
+    def next_float_range(self, lo, hi):
+        lo, hi = f32(lo), f32(hi)
+        return f32(f32(self.next_float() * f32(hi - lo)) + lo)
+
+    def next_float3(self):
+        x = self.next_float()
+        y = self.next_float()
+        z = self.next_float()
+        return np.array([x, y, z], dtype=np.float32)
+
+    def next_float3_range(self, lo, hi):
+        lo = np.asarray(lo, dtype=np.float32)
+        hi = np.asarray(hi, dtype=np.float32)
+        return (self.next_float3() * (hi - lo) + lo).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# material helpers (legacy MaterialData.Lambertian / Metal / Dielectric -> RtowMaterial)
+# ---------------------------------------------------------------------------------------------------
+def _const_tex(v):
+    if np.isscalar(v):
+        v = (v, v, v)
+    return abi.Texture(abi.TEXTURE_CONSTANT, abi.Float3(*[float(f32(c)) for c in v]), 0.0, 0)
+
+
+def _none_tex():
+    return abi.Texture(abi.TEXTURE_NONE, abi.Float3(0, 0, 0), 0.0, 0)
+
+
+def lambertian(color):
+    return abi.Material(abi.MATERIAL_STANDARD, _const_tex(color), _const_tex(0.0), _none_tex(), _const_tex(0.0), 0.0)
+
+
+def metal(color, fuzz):
+    gloss = f32(f32(1.0) - f32(fuzz))
+    return abi.Material(abi.MATERIAL_STANDARD, _const_tex(color), _const_tex(gloss), _none_tex(), _const_tex(1.0), 0.0)
+
+
+def dielectric(ior, gloss=1.0, albedo=1.0):
+    return abi.Material(abi.MATERIAL_DIELECTRIC, _const_tex(albedo), _const_tex(gloss), _none_tex(), _none_tex(), float(f32(ior)))
+
+
+def standard(color, metallic, gloss, emission=None):
+    em = _none_tex() if emission is None else _const_tex(emission)
+    return abi.Material(abi.MATERIAL_STANDARD, _const_tex(color), _const_tex(gloss), em, _const_tex(metallic), 0.0)
+
+
+class Scene:
+    """Flat scene: parallel Python lists that `desc()` packs into an RtowSceneDesc."""
+
+    def __init__(self, name):
+        self.name = name
+        self.positions = []      # float32[3]
+        self.radii = []          # float32 (signed)
+        self.moving = []         # bool
+        self.dest_offsets = []   # float32[3]
+        self.time_ranges = []    # (t0, t1)
+        self.material_index = []
+        self.exclude_from_overlap = []
+        self.materials = []      # abi.Material
+        self.camera = {}
+        self.sky_bottom = (1.0, 1.0, 1.0)
+        self.sky_top = (0.5, 0.7, 1.0)
+        self.meta = {}
+        self._keepalive = None
+
+    @property
+    def entity_count(self):
+        return len(self.radii)
+
+    def add_sphere(self, pos, radius, material, moving=False, dest_offset=(0, 0, 0), time_range=(0, 0), exclude=False):
+        self.materials.append(material)
+        self.positions.append(np.asarray(pos, dtype=np.float32))
+        self.radii.append(f32(radius))
+        self.moving.append(bool(moving))
+        self.dest_offsets.append(np.asarray(dest_offset, dtype=np.float32))
+        self.time_ranges.append((f32(time_range[0]), f32(time_range[1])))
+        self.material_index.append(len(self.materials) - 1)
+        self.exclude_from_overlap.append(bool(exclude))
+
+    def desc(self, max_bvh_depth=32):
+        n = self.entity_count
+        ents = (abi.Entity * n)()
+        for i in range(n):
+            e = ents[i]
+            e.type = abi.ENTITY_SPHERE
+            e.moving = 1 if self.moving[i] else 0
+            e.rotation = abi.Float4(0.0, 0.0, 0.0, 1.0)  # quaternion.Euler(0,0,0)
+            e.position = abi.Float3(*[float(c) for c in self.positions[i]])
+            e.destinationOffset = abi.Float3(*[float(c) for c in self.dest_offsets[i]])
+            e.timeRange = abi.Float2(float(self.time_ranges[i][0]), float(self.time_ranges[i][1]))
+            e.materialIndex = self.material_index[i]
+            e.size = abi.Float3(float(self.radii[i]), 0.0, 0.0)
+            e.contentIndex = 0
+        mats = (abi.Material * len(self.materials))(*self.materials)
+        d = abi.SceneDesc(ents, n, mats, len(self.materials), max_bvh_depth)
+        self._keepalive = (ents, mats)
+        return d
+
+    # -- reproducible serialisation for tests/golden ------------------------------------------------
+    def to_dict(self):
+        def tex(t):
+            return [int(t.type), float(t.mainColor.x), float(t.mainColor.y), float(t.mainColor.z), float(t.parameter), int(t.scalarValueChannel)]
+
+        return {
+            "name": self.name,
+            "positions": [[float(c) for c in p] for p in self.positions],
+            "radii": [float(r) for r in self.radii],
+            "moving": [int(m) for m in self.moving],
+            "dest_offsets": [[float(c) for c in p] for p in self.dest_offsets],
+            "time_ranges": [[float(a), float(b)] for a, b in self.time_ranges],
+            "material_index": list(self.material_index),
+            "materials": [[int(m.type), tex(m.albedo), tex(m.glossiness), tex(m.emission), tex(m.metallic), float(m.parameter)] for m in self.materials],
+            "camera": self.camera,
+            "sky_bottom": list(self.sky_bottom),
+            "sky_top": list(self.sky_top),
+            "meta": self.meta,
+        }
+
+    @staticmethod
+    def from_dict(d):
+        s = Scene(d["name"])
+
+        def tex(t):
+            return abi.Texture(t[0], abi.Float3(t[1], t[2], t[3]), t[4], t[5])
+
+        s.materials = [abi.Material(m[0], tex(m[1]), tex(m[2]), tex(m[3]), tex(m[4]), m[5]) for m in d["materials"]]
+        s.positions = [np.asarray(p, dtype=np.float32) for p in d["positions"]]
+        s.radii = [f32(r) for r in d["radii"]]
+        s.moving = [bool(m) for m in d["moving"]]
+        s.dest_offsets = [np.asarray(p, dtype=np.float32) for p in d["dest_offsets"]]
+        s.time_ranges = [(f32(a), f32(b)) for a, b in d["time_ranges"]]
+        s.material_index = list(d["material_index"])
+        s.exclude_from_overlap = [False] * len(s.radii)
+        s.camera = d["camera"]
+        s.sky_bottom = tuple(d["sky_bottom"])
+        s.sky_top = tuple(d["sky_top"])
+        s.meta = d.get("meta", {})
+        return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# RandomEntityGroup dart throwing (UNITY/Raytracer.cs:1357-1505, commented-out generator)
+# ---------------------------------------------------------------------------------------------------
+def _throw_darts(scene, rng, *, tentative_count, spread, offset, radius_range, min_distance,
+                 chances, diffuse_range, double_sample, metal_range, fuzz_range, ior_range,
+                 movement_chance, movement_lo, movement_hi, stop_at_entity_count=None):
+    lambert_c, metal_c, diel_c, light_c = [f32(c) for c in chances]
+    total = f32(f32(f32(lambert_c + metal_c) + diel_c) + light_c)          # :1371
+    metal_c = f32(metal_c + lambert_c)                                      # :1372-1374
+    diel_c = f32(diel_c + metal_c)
+    light_c = f32(light_c + diel_c)
+    p_lambert, p_metal, p_diel = f32(lambert_c / total), f32(metal_c / total), f32(diel_c / total)  # :1375-1378
+
+    offset = np.asarray(offset, dtype=np.float32)
+    half = np.asarray(spread, dtype=np.float32) / f32(2)
+    used = 0
+
+    def get_material():                                                    # :1363-1413
+        v = rng.next_float()
+        if v < p_lambert:
+            color = rng.next_float3_range(diffuse_range[0], diffuse_range[1])
+            if double_sample:
+                color = (color * rng.next_float3_range(diffuse_range[0], diffuse_range[1])).astype(np.float32)
+            return lambertian(color)
+        if v < p_metal:
+            color = rng.next_float3_range(metal_range[0], metal_range[1])
+            fuzz = rng.next_float_range(fuzz_range[0], fuzz_range[1])
+            return metal(color, fuzz)
+        if v < p_diel:
+            return dielectric(rng.next_float_range(ior_range[0], ior_range[1]))
+        return None
+
+    for _ in range(tentative_count):
+        if stop_at_entity_count is not None and scene.entity_count >= stop_at_entity_count:
+            break
+        used += 1
+        center = rng.next_float3_range(-half, half)                        # :1456-1458
+        center = (center + offset).astype(np.float32)                      # :1460
+        radius = rng.next_float_range(radius_range[0], radius_range[1])    # :1462
+
+        # AnyOverlap (:1416-1419): distance(x.Position, center) < x.Radius + radius + MinDistance
+        if scene.entity_count:
+            pos = np.stack(scene.positions).astype(np.float32)
+            rad = np.asarray(scene.radii, dtype=np.float32)
+            excl = np.asarray(scene.exclude_from_overlap, dtype=bool)
+            d = (center[None, :] - pos).astype(np.float32)
+            dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+            limit = ((rad + radius).astype(np.float32) + f32(min_distance)).astype(np.float32)
+            if np.any(~excl & (dist < limit)):
+                continue
+
+        # GetEntity (:1421-1451)
+        moving = bool(rng.next_float() < f32(movement_chance))
+        position = ((center - offset).astype(np.float32) + offset).astype(np.float32)  # rotate(identity, c - o) + o
+        material = get_material()
+        dest = np.zeros(3, dtype=np.float32)
+        time_range = (0.0, 0.0)
+        if moving:
+            dest = rng.next_float3_range(movement_lo, movement_hi)
+            time_range = (0.0, 1.0)
+        if material is None:
+            continue
+        scene.add_sphere(position, radius, material, moving=moving, dest_offset=dest, time_range=time_range)
+    return used
+
+
+_BOOK_CAMERA = {"position": [12.3, 1.98, -2.99], "target": [11.342338, 1.8494737, -2.7333953], "up": [0.0, 1.0, 0.0], "vfov": 20.0}
+
+
+def _book_fixed_spheres(scene):
+    # `Final Scene (Book 1).asset`:19-83
+    scene.add_sphere((0, -1000, 0), 1000, lambertian((0.5, 0.5, 0.5)), exclude=True)
+    scene.add_sphere((0, 1, 0), 1, dielectric(1.5))
+    scene.add_sphere((-4, 1, 0), 1, lambertian((0.4, 0.2, 0.1)))
+    scene.add_sphere((4, 1, 0), 1, metal((0.7, 0.6, 0.5), 0.0))
+
+
+def cover_scene(target_entity_count=486, max_tentatives=4000):
+    """Book-1 cover scene (`Final Scene (Book 1).asset`): 4 fixed spheres + dart-thrown r=0.2 spheres, seed 700."""
+    s = Scene("cover")
+    _book_fixed_spheres(s)
+    rng = UnityRandom(700)                                                  # asset :84
+    used = _throw_darts(
+        s, rng, tentative_count=max_tentatives, spread=(22, 0, 22), offset=(0, 0.2, 0), radius_range=(0.2, 0.2),
+        min_distance=0.15, chances=(0.8, 0.15, 0.05, 0.0), diffuse_range=((0, 0, 0), (1, 1, 1)), double_sample=True,
+        metal_range=((0.5, 0.5, 0.5), (1, 1, 1)), fuzz_range=(0, 0.5), ior_range=(1.5, 1.5),
+        movement_chance=0.0, movement_lo=(0, 0, 0), movement_hi=(0, 0, 0), stop_at_entity_count=target_entity_count)
+    s.camera = dict(_BOOK_CAMERA, aperture=0.0)
+    s.meta = {"seed": 700, "tentatives_used": used, "asset_tentative_count": 1000, "target_entity_count": target_entity_count}
+    return s
+
+
+def moving_scene(tentative_count=1000):
+    """`Random With Movement (Book 2).asset`: cover layout, MovementChance 0.8, Y offset in [0, 0.5], aperture 0.05."""
+    s = Scene("moving")
+    _book_fixed_spheres(s)
+    rng = UnityRandom(700)
+    used = _throw_darts(
+        s, rng, tentative_count=tentative_count, spread=(22, 0, 22), offset=(0, 0.2, 0), radius_range=(0.2, 0.2),
+        min_distance=0.15, chances=(0.8, 0.15, 0.05, 0.0), diffuse_range=((0, 0, 0), (1, 1, 1)), double_sample=True,
+        metal_range=((0.5, 0.5, 0.5), (1, 1, 1)), fuzz_range=(0, 0.5), ior_range=(1.5, 1.5),
+        movement_chance=0.8, movement_lo=(0, 0, 0), movement_hi=(0, 0.5, 0))
+    s.camera = dict(_BOOK_CAMERA, aperture=0.05)
+    s.meta = {"seed": 700, "tentatives_used": used}
+    return s
+
+
+def stress_scene(count=10000, seed=10000, spread=100.0, max_tentatives=60000):
+    """Synthetic deep-BVH stress scene (BASELINE.json config 4): `count` r in [0.05, 0.2] spheres dart-thrown on a
+    spread x spread area with the cover scene's material mix.  Nothing like it exists in the reference."""
+    s = Scene("stress%d" % count)
+    _book_fixed_spheres(s)
+    rng = UnityRandom(seed)
+    used = _throw_darts(
+        s, rng, tentative_count=max_tentatives, spread=(spread, 0, spread), offset=(0, 0.2, 0), radius_range=(0.05, 0.2),
+        min_distance=0.05, chances=(0.8, 0.15, 0.05, 0.0), diffuse_range=((0, 0, 0), (1, 1, 1)), double_sample=True,
+        metal_range=((0.5, 0.5, 0.5), (1, 1, 1)), fuzz_range=(0, 0.5), ior_range=(1.5, 1.5),
+        movement_chance=0.0, movement_lo=(0, 0, 0), movement_hi=(0, 0, 0), stop_at_entity_count=count)
+    s.camera = dict(_BOOK_CAMERA, aperture=0.0)
+    s.meta = {"seed": seed, "tentatives_used": used}
+    return s
+
+
+def tiny_scene():
+    """Five spheres, one of each material branch + a negative-radius hollow glass shell; for fast unit tests."""
+    s = Scene("tiny")
+    s.add_sphere((0, -100.5, -1), 100, lambertian((0.8, 0.8, 0.0)))
+    s.add_sphere((0, 0, -1), 0.5, lambertian((0.1, 0.2, 0.5)))
+    s.add_sphere((-1, 0, -1), 0.5, dielectric(1.5))
+    s.add_sphere((-1, 0, -1), -0.45, dielectric(1.5))
+    s.add_sphere((1, 0, -1), 0.5, metal((0.8, 0.6, 0.2), 0.3))
+    s.add_sphere((0.3, 0.9, -1.2), 0.3, standard((0.9, 0.3, 0.3), 0.4, 0.6, emission=(0.2, 0.1, 0.0)))
+    s.add_sphere((-0.4, 0.6, -0.6), 0.15, metal((0.9, 0.9, 0.9), 0.0), moving=True, dest_offset=(0.0, 0.3, 0.1), time_range=(0.0, 1.0))
+    s.camera = {"position": [-2.0, 2.0, 1.0], "target": [0.0, 0.0, -1.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": 0.1}
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# camera: RT/View.cs:16-36 + the auto-focus probe of UNITY/Raytracer.cs:608-609
+# ---------------------------------------------------------------------------------------------------
+def _normalize(v):
+    v = v.astype(np.float32)
+    d = f32(f32(f32(v[0] * v[0]) + f32(v[1] * v[1])) + f32(v[2] * v[2]))
+    return (f32(f32(1.0) / np.sqrt(d, dtype=np.float32)) * v).astype(np.float32)
+
+
+def _cross(a, b):
+    return np.array([f32(a[1] * b[2]) - f32(a[2] * b[1]), f32(a[2] * b[0]) - f32(a[0] * b[2]), f32(a[0] * b[1]) - f32(a[1] * b[0])], dtype=np.float32)
+
+
+def focus_distance(scene, origin, direction):
+    """Nearest sphere hit along the view axis (HitWorld, UNITY/Raytracer.cs:608-609,1353) in float32 numpy."""
+    o = np.asarray(origin, dtype=np.float32)
+    d = np.asarray(direction, dtype=np.float32)
+    pos = np.stack(scene.positions).astype(np.float32)
+    rad = np.asarray(scene.radii, dtype=np.float32)
+    oc = (o[None, :] - pos).astype(np.float32)
+    a = f32(d @ d)
+    b = (oc @ d).astype(np.float32)
+    c = ((oc * oc).sum(axis=1).astype(np.float32) - rad * rad).astype(np.float32)
+    disc = (b * b - a * c).astype(np.float32)
+    best = None
+    for i in np.nonzero(disc > 0)[0]:
+        sq = np.sqrt(disc[i], dtype=np.float32)
+        for t in (f32((-b[i] - sq) / a), f32((-b[i] + sq) / a)):
+            if t > 0:
+                if best is None or t < best:
+                    best = t
+                break
+    return float(best) if best is not None else 1.0
+
+
+def make_view(scene, width, height, focus=None):
+    """View ctor (RT/View.cs:16-36) -> abi.View.  aspect = width / height (TargetCamera.aspect)."""
+    cam = scene.camera
+    origin = np.asarray(cam["position"], dtype=np.float32)
+    look_at = np.asarray(cam["target"], dtype=np.float32)
+    up = np.asarray(cam["up"], dtype=np.float32)
+    aperture = f32(cam.get("aperture", 0.0))
+    if focus is None:
+        fwd = _normalize(look_at - origin)
+        focus = focus_distance(scene, origin, fwd)
+    focus = f32(focus)
+    aspect = f32(f32(width) / f32(height))
+
+    lens_radius = f32(aperture / f32(2))
+    theta = f32(f32(f32(cam["vfov"]) * UM_PI) / f32(180))
+    half_height = f32(math.tan(float(f32(theta / f32(2)))))
+    half_width = f32(aspect * half_height)
+
+    forward = _normalize(origin - look_at)
+    right = _normalize(_cross(forward, up))
+    up_v = _cross(right, forward)
+
+    llc = ((f32(half_width * focus) * -right).astype(np.float32) + (f32(half_height * focus) * -up_v).astype(np.float32)).astype(np.float32)
+    llc = (llc + (focus * -forward).astype(np.float32)).astype(np.float32)
+    horizontal = (f32(f32(f32(2) * half_width) * focus) * right).astype(np.float32)
+    vertical = (f32(f32(f32(2) * half_height) * focus) * up_v).astype(np.float32)
+
+    def v3(a):
+        return abi.Float3(float(a[0]), float(a[1]), float(a[2]))
+
+    return abi.View(v3(origin), v3(llc), v3(horizontal), v3(vertical), v3(forward), v3(up_v), v3(right), float(lens_radius))
+
+
+def make_params(scene, width, height, spp, trace_depth, seed=1, jitter=True, slice_offset=0, slice_divider=1,
+                spp_max=None, extrema=(0.0, 0.0), diagnostics_stride=4, focus=None):
+    """SampleBatchJob parameter block with the benchmark defaults of SURVEY.md section 8(d)."""
+    p = abi.SampleParams()
+    p.size = abi.Float2(float(width), float(height))
+    p.sliceOffset = slice_offset
+    p.sliceDivider = slice_divider
+    p.seed = seed
+    p.view = make_view(scene, width, height, focus)
+    p.environment = abi.Environment(abi.SKY_GRADIENT, abi.Float3(*scene.sky_bottom), abi.Float3(*scene.sky_top))
+    p.sampleCountRange[0] = spp
+    p.sampleCountRange[1] = spp if spp_max is None else spp_max
+    p.traceDepth = trace_depth
+    p.subPixelJitter = 1 if jitter else 0
+    p.noiseColor = abi.NOISE_WHITE
+    p.sampleCountWeightExtrema = abi.Float2(float(extrema[0]), float(extrema[1]))
+    p.diagnosticsStride = diagnostics_stride
+    p.reserved = 0
+    return p
