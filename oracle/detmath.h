@@ -106,14 +106,14 @@ static inline float dm_exp2f(float t)
 
 /*
  * pow(x, y).  Spec:
- *  - y integral with 0 <= y <= 64: binary exponentiation, low bit first
+ *  - y integral with 0 <= y <= 1024: binary exponentiation, low bit first
  *      (result = 1; base = x; while n: if (n&1) result *= base; n >>= 1; if (n) base *= base;)
  *    so pow(x,2) == x*x, pow(x,5) == x*((x*x)*(x*x)), pow(2,depth) exact.
  *  - otherwise: x < 0 -> NaN; x == 0 -> (y > 0 ? 0 : +inf); else exp2(y * (log(x) * log2(e))).
  */
 static inline float dm_powf(float x, float y)
 {
-    if (y >= 0.0f && y <= 64.0f && y == rintf(y)) {
+    if (y >= 0.0f && y <= 1024.0f && y == rintf(y)) {
         unsigned n = (unsigned)y;
         float result = 1.0f, base = x;
         while (n) {

@@ -10,6 +10,9 @@ Package layout:
 The directory name contains '-' so it is loaded with importlib (see tests/conftest.py, bench.py):
     rtow = importlib.import_module("raytracing-in-one-weekend_amd")
 """
-from . import abi, scenes  # noqa: F401
+from . import abi, host, lib, scenes  # noqa: F401
+from .host import (CombineJob, Context, DeviceBuffer, FinalizeTexturesJob, ReduceMetricsJob, SampleBatchJob,  # noqa: F401
+                   sample_batch_host)
 
-__all__ = ["abi", "scenes"]
+__all__ = ["abi", "host", "lib", "scenes", "Context", "DeviceBuffer", "SampleBatchJob", "CombineJob", "FinalizeTexturesJob",
+           "ReduceMetricsJob", "sample_batch_host"]

@@ -1,0 +1,488 @@
+// rtow_api.hip - implementation of the C ABI declared in include/rtow.h (librtow_hip.so).
+//
+// Host-side runtime of the path: context / device selection, scene compilation + upload, grow-only device staging
+// for the host-buffer entry point, kernel launch on a HIP stream with HIP-event timing, cooperative cancellation,
+// and the post passes.  There is no CPU implementation behind any entry point: without a usable HIP device
+// rtowCreateContext fails with RTOW_ERROR_NO_DEVICE and nothing else can be called.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rtow.h"
+#include "rtow_bvh.h"
+#include "rtow_kernels.h"
+
+using namespace rtow;
+
+struct RtowContext_t {
+    int device = 0;
+    int cuCount = 0;
+    RtowLogCallback logCb = nullptr;
+    void* logData = nullptr;
+    int logLevel = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool haveTiming = false;
+
+    // scene
+    bool haveScene = false;
+    CompiledScene scene;
+    uint8_t* dScene = nullptr;
+    size_t dSceneCapacity = 0;
+    uint32_t ldsSceneBytes = 0, ldsNodeCount = 0;
+
+    // work distribution / cancellation
+    unsigned int* dWorkCounter = nullptr;
+    volatile uint32_t* hCancel = nullptr; // pinned, device-visible
+
+    // grow-only staging for rtowSampleBatch (host buffers) - like CudaBuffer.EnsureCapacity (OptixApi.cs:240-251)
+    float *dColor = nullptr, *dNormal = nullptr, *dAlbedo = nullptr, *dScw = nullptr;
+    uint8_t* dDiag = nullptr;
+    size_t stagingPixels = 0, stagingDiagBytes = 0;
+
+    MetricsPartial* dPartials = nullptr;
+    std::mutex mu;
+};
+
+namespace {
+
+void logf(RtowContext ctx, int level, const char* tag, const char* fmt, ...)
+{
+    if (!ctx || !ctx->logCb || level > ctx->logLevel) return;
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ctx->logCb(level, tag, buf, ctx->logData);
+}
+
+#define HIP_TRY(ctx, expr, result)                                                                    \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            logf(ctx, 2, "hip", "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (result);                                                                          \
+        }                                                                                             \
+    } while (0)
+
+int validateParams(const RtowSampleParams* p)
+{
+    if (!p) return RTOW_ERROR_INVALID_VALUE;
+    const int w = (int)p->size.x, h = (int)p->size.y;
+    if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return RTOW_ERROR_INVALID_VALUE;
+    if (p->sliceDivider < 1 || p->sliceOffset < 0 || p->sliceOffset >= p->sliceDivider) return RTOW_ERROR_INVALID_VALUE;
+    if (p->traceDepth < 1 || p->traceDepth > 64) return p->traceDepth < 1 ? RTOW_ERROR_INVALID_VALUE : RTOW_ERROR_CAPACITY;
+    if (p->noiseColor != RTOW_NOISE_WHITE) return RTOW_ERROR_UNSUPPORTED;
+    if (p->environment.skyType == RTOW_SKY_CUBEMAP) return RTOW_ERROR_UNSUPPORTED;
+    if (p->diagnosticsStride != 4 && p->diagnosticsStride != 16) return RTOW_ERROR_INVALID_VALUE;
+    return RTOW_SUCCESS;
+}
+
+int ownedRows(const RtowSampleParams* p)
+{
+    const int h = (int)p->size.y;
+    if (p->sliceOffset >= h) return 0;
+    return (h - p->sliceOffset + p->sliceDivider - 1) / p->sliceDivider;
+}
+
+int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuffers* in, const RtowAccumBuffers* out, void* diag,
+                 hipStream_t stream, bool useCancelFlag)
+{
+    SampleKernelArgs a{};
+    a.inColor = in->color; a.inNormal = in->normal; a.inAlbedo = in->albedo; a.inScw = in->sampleCountWeight;
+    a.outColor = out->color; a.outNormal = out->normal; a.outAlbedo = out->albedo; a.outScw = out->sampleCountWeight;
+    a.diagnostics = (uint8_t*)diag;
+    a.diagnosticsStride = p->diagnosticsStride;
+    a.sceneBlob = ctx->dScene;
+    a.layout = ctx->scene.layout;
+    a.ldsSceneBytes = ctx->ldsSceneBytes;
+    a.ldsNodeCount = ctx->ldsNodeCount;
+    a.workCounter = ctx->dWorkCounter;
+    a.cancelFlag = useCancelFlag ? ctx->hCancel : nullptr;
+    a.width = (int)p->size.x;
+    a.height = (int)p->size.y;
+    a.totalWork = (uint32_t)ownedRows(p) * (uint32_t)a.width;
+    a.sizeX = p->size.x; a.sizeY = p->size.y;
+    a.sliceOffset = p->sliceOffset; a.sliceDivider = p->sliceDivider;
+    a.seed = p->seed;
+    a.view = p->view;
+    a.environment = p->environment;
+    a.sampleCountMin = p->sampleCountRange[0];
+    a.sampleCountMax = p->sampleCountRange[1];
+    a.traceDepth = p->traceDepth;
+    a.subPixelJitter = p->subPixelJitter;
+    a.extremaX = p->sampleCountWeightExtrema.x;
+    a.extremaY = p->sampleCountWeightExtrema.y;
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
+    int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
+    if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
+    if (blocks < 1) blocks = 1;
+    HIP_TRY(ctx, hipEventRecord(ctx->evStart, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    ctx->haveTiming = true;
+    return RTOW_SUCCESS;
+}
+
+// Block until the stop event completes while mirroring the caller's cancellation byte into the device-visible flag.
+int waitWithCancel(RtowContext ctx, const volatile uint8_t* cancel)
+{
+    bool cancelled = false;
+    for (;;) {
+        const hipError_t q = hipEventQuery(ctx->evStop);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+            logf(ctx, 2, "hip", "sample kernel failed: %s", hipGetErrorString(q));
+            return RTOW_ERROR_LAUNCH_FAILURE;
+        }
+        if (cancel && *cancel && !cancelled) {
+            *ctx->hCancel = 1u;
+            cancelled = true;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (cancel && *cancel) cancelled = true;
+    return cancelled ? RTOW_ERROR_CANCELLED : RTOW_SUCCESS;
+}
+
+int ensureStaging(RtowContext ctx, size_t pixels, size_t diagBytes)
+{
+    if (pixels > ctx->stagingPixels) {
+        if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
+        ctx->dColor = ctx->dNormal = ctx->dAlbedo = ctx->dScw = nullptr;
+        ctx->stagingPixels = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->dColor, pixels * 16), RTOW_ERROR_MEMORY_ALLOCATION);
+        HIP_TRY(ctx, hipMalloc(&ctx->dNormal, pixels * 12), RTOW_ERROR_MEMORY_ALLOCATION);
+        HIP_TRY(ctx, hipMalloc(&ctx->dAlbedo, pixels * 12), RTOW_ERROR_MEMORY_ALLOCATION);
+        HIP_TRY(ctx, hipMalloc(&ctx->dScw, pixels * 4), RTOW_ERROR_MEMORY_ALLOCATION);
+        ctx->stagingPixels = pixels;
+    }
+    if (diagBytes > ctx->stagingDiagBytes) {
+        if (ctx->dDiag) (void)hipFree(ctx->dDiag);
+        ctx->dDiag = nullptr;
+        ctx->stagingDiagBytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->dDiag, diagBytes), RTOW_ERROR_MEMORY_ALLOCATION);
+        ctx->stagingDiagBytes = diagBytes;
+    }
+    return RTOW_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+RTOW_API int rtowGetApiVersion(void) { return RTOW_API_VERSION; }
+
+RTOW_API const char* rtowErrorString(int result)
+{
+    switch (result) {
+        case RTOW_SUCCESS: return "success";
+        case RTOW_ERROR_INVALID_VALUE: return "invalid value";
+        case RTOW_ERROR_MEMORY_ALLOCATION: return "memory allocation failed";
+        case RTOW_ERROR_NO_DEVICE: return "no usable HIP device (gfx950 required; there is no CPU fallback)";
+        case RTOW_ERROR_NO_SCENE: return "no scene uploaded";
+        case RTOW_ERROR_UNSUPPORTED: return "feature not built yet";
+        case RTOW_ERROR_LAUNCH_FAILURE: return "kernel launch or stream failure";
+        case RTOW_ERROR_CANCELLED: return "cancelled";
+        case RTOW_ERROR_CAPACITY: return "compiled-in capacity exceeded";
+        case RTOW_ERROR_INTERNAL: return "internal error";
+    }
+    return "unknown error";
+}
+
+RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* outContext)
+{
+    if (!outContext) return RTOW_ERROR_INVALID_VALUE;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RTOW_ERROR_NO_DEVICE;
+    const int ordinal = options ? options->deviceOrdinal : 0;
+    if (ordinal < 0 || ordinal >= count) return RTOW_ERROR_INVALID_VALUE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) return RTOW_ERROR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RTOW_ERROR_NO_DEVICE; // the code object is gfx950 only
+    if (hipSetDevice(ordinal) != hipSuccess) return RTOW_ERROR_NO_DEVICE;
+
+    RtowContext ctx = new (std::nothrow) RtowContext_t();
+    if (!ctx) return RTOW_ERROR_MEMORY_ALLOCATION;
+    ctx->device = ordinal;
+    ctx->cuCount = prop.multiProcessorCount;
+    if (options) { ctx->logCb = options->logCallback; ctx->logData = options->logCallbackData; ctx->logLevel = options->logCallbackLevel; }
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx->evStart) == hipSuccess && hipEventCreate(&ctx->evStop) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->dWorkCounter, sizeof(unsigned int)) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->dPartials, sizeof(MetricsPartial) * kMetricsBlocks) == hipSuccess;
+    void* pinned = nullptr;
+    ok = ok && hipHostMalloc(&pinned, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (!ok) { rtowDestroyContext(ctx); return RTOW_ERROR_MEMORY_ALLOCATION; }
+    ctx->hCancel = (volatile uint32_t*)pinned;
+    *ctx->hCancel = 0u;
+    logf(ctx, 4, "rtow", "context on device %d (%s, %d CUs)", ordinal, prop.gcnArchName, ctx->cuCount);
+    *outContext = ctx;
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowDestroyContext(RtowContext ctx)
+{
+    if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->dScene) (void)hipFree(ctx->dScene);
+    if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
+    if (ctx->dPartials) (void)hipFree(ctx->dPartials);
+    if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
+    if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
+    if (ctx->dDiag) (void)hipFree(ctx->dDiag);
+    if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
+    if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
+{
+    if (!ctx || !scene) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    CompiledScene compiled;
+    std::string err;
+    const int rc = compileScene(scene, scene->maxBvhDepth, &compiled, &err);
+    if (rc != RTOW_SUCCESS) {
+        logf(ctx, 2, "scene", "%s", err.c_str());
+        return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    if (compiled.blob.size() > ctx->dSceneCapacity) {
+        if (ctx->dScene) (void)hipFree(ctx->dScene);
+        ctx->dScene = nullptr;
+        ctx->dSceneCapacity = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->dScene, compiled.blob.size()), RTOW_ERROR_MEMORY_ALLOCATION);
+        ctx->dSceneCapacity = compiled.blob.size();
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->dScene, compiled.blob.data(), compiled.blob.size(), hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    ctx->scene = std::move(compiled);
+    const uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes);
+    if (ctx->scene.layout.totalBytes <= budget) {
+        ctx->ldsSceneBytes = ctx->scene.layout.totalBytes;
+        ctx->ldsNodeCount = ctx->scene.layout.nodeCount;
+    } else {
+        // too large for LDS: stage the top of the (breadth-first) node array, read the rest through L2
+        uint32_t nodes = budget / (uint32_t)sizeof(GpuNode);
+        if (nodes > ctx->scene.layout.nodeCount) nodes = ctx->scene.layout.nodeCount;
+        ctx->ldsNodeCount = nodes;
+        ctx->ldsSceneBytes = nodes * (uint32_t)sizeof(GpuNode);
+    }
+    ctx->haveScene = true;
+    logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
+         ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
+{
+    if (!ctx || !info) return RTOW_ERROR_INVALID_VALUE;
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    info->entityCount = ctx->scene.entityCount;
+    info->materialCount = ctx->scene.materialCount;
+    info->bvhNodeCount = (int32_t)ctx->scene.layout.nodeCount;
+    info->bvhDepth = (int32_t)ctx->scene.layout.bvhDepth;
+    info->ldsBytesScene = (int32_t)ctx->ldsSceneBytes;
+    info->sceneInLds = ctx->ldsSceneBytes == ctx->scene.layout.totalBytes ? 1 : 0;
+    info->sceneBytesDevice = ctx->scene.layout.totalBytes;
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowSampleBatchDevice(RtowContext ctx, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                                   void* diagnostics, void* stream, const volatile uint8_t* cancel)
+{
+    if (!ctx || !in || !out) return RTOW_ERROR_INVALID_VALUE;
+    const int v = validateParams(params);
+    if (v != RTOW_SUCCESS) return v;
+    if (!in->color || !in->normal || !in->albedo || !in->sampleCountWeight || !out->color || !out->normal || !out->albedo || !out->sampleCountWeight)
+        return RTOW_ERROR_INVALID_VALUE;
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE); // called from a different worker thread each time
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    *ctx->hCancel = 0u;
+    const int rc = launchSample(ctx, params, in, out, diagnostics, s, cancel != nullptr);
+    if (rc != RTOW_SUCCESS) return rc;
+    if (cancel) return waitWithCancel(ctx, cancel);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                             void* diagnostics, const volatile uint8_t* cancel)
+{
+    if (!ctx || !in || !out) return RTOW_ERROR_INVALID_VALUE;
+    const int v = validateParams(params);
+    if (v != RTOW_SUCCESS) return v;
+    if (!in->color || !in->normal || !in->albedo || !in->sampleCountWeight || !out->color || !out->normal || !out->albedo || !out->sampleCountWeight)
+        return RTOW_ERROR_INVALID_VALUE;
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    const int w = (int)params->size.x, h = (int)params->size.y;
+    const size_t n = (size_t)w * (size_t)h;
+    const size_t diagBytes = diagnostics ? n * (size_t)params->diagnosticsStride : 0;
+    int rc = ensureStaging(ctx, n, diagBytes);
+    if (rc != RTOW_SUCCESS) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dColor, in->color, n * 16, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dNormal, in->normal, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dAlbedo, in->albedo, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dScw, in->sampleCountWeight, n * 4, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+
+    RtowAccumBuffers dev{ctx->dColor, ctx->dNormal, ctx->dAlbedo, ctx->dScw}; // in place: each lane reads its pixel before writing it
+    *ctx->hCancel = 0u;
+    rc = launchSample(ctx, params, &dev, &dev, diagnostics ? ctx->dDiag : nullptr, s, cancel != nullptr);
+    if (rc != RTOW_SUCCESS) return rc;
+    rc = waitWithCancel(ctx, cancel);
+    if (rc != RTOW_SUCCESS) return rc;
+
+    // copy back ONLY the rows this slice owns: skipped pixels write nothing (JOBS/SampleBatchJob.cs:69-70)
+    const int rows = ownedRows(params);
+    if (rows > 0) {
+        const size_t D = (size_t)params->sliceDivider, O = (size_t)params->sliceOffset;
+        auto copyRows = [&](void* dst, const void* src, size_t bytesPerPixel) -> hipError_t {
+            const size_t rowBytes = (size_t)w * bytesPerPixel;
+            return hipMemcpy2DAsync((uint8_t*)dst + O * rowBytes, D * rowBytes, (const uint8_t*)src + O * rowBytes, D * rowBytes, rowBytes, (size_t)rows,
+                                    hipMemcpyDeviceToHost, s);
+        };
+        HIP_TRY(ctx, copyRows(out->color, ctx->dColor, 16), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, copyRows(out->normal, ctx->dNormal, 12), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, copyRows(out->albedo, ctx->dAlbedo, 12), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, copyRows(out->sampleCountWeight, ctx->dScw, 4), RTOW_ERROR_LAUNCH_FAILURE);
+        if (diagnostics) HIP_TRY(ctx, copyRows(diagnostics, ctx->dDiag, (size_t)params->diagnosticsStride), RTOW_ERROR_LAUNCH_FAILURE);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowGetLastSampleKernelMs(RtowContext ctx, float* outMs)
+{
+    if (!ctx || !outMs) return RTOW_ERROR_INVALID_VALUE;
+    if (!ctx->haveTiming) return RTOW_ERROR_INVALID_VALUE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->evStop), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipEventElapsedTime(outMs, ctx->evStart, ctx->evStop), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowReduceMetricsDevice(RtowContext ctx, int32_t pixelCount, const void* diagnostics, int32_t diagnosticsStride, const float* color,
+                                     const float* sampleCountWeight, void* stream, RtowMetrics* outMetrics)
+{
+    if (!ctx || !diagnostics || !color || !sampleCountWeight || !outMetrics || pixelCount <= 0) return RTOW_ERROR_INVALID_VALUE;
+    if (diagnosticsStride != 4 && diagnosticsStride != 16) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(ctx, launchReduceMetrics(pixelCount, (const uint8_t*)diagnostics, diagnosticsStride, color, sampleCountWeight, ctx->dPartials, s),
+            RTOW_ERROR_LAUNCH_FAILURE);
+    std::vector<MetricsPartial> parts(kMetricsBlocks);
+    HIP_TRY(ctx, hipMemcpyAsync(parts.data(), ctx->dPartials, sizeof(MetricsPartial) * kMetricsBlocks, hipMemcpyDeviceToHost, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
+    long long rays = 0, samples = 0;
+    float minW = INFINITY, maxW = -INFINITY, minS = INFINITY, maxS = -INFINITY;
+    auto fmin1 = [](float x, float y) { return (y != y || x < y) ? x : y; };
+    auto fmax1 = [](float x, float y) { return (y != y || x > y) ? x : y; };
+    for (const MetricsPartial& p : parts) {
+        rays += p.rays; samples += p.samples;
+        minW = fmin1(minW, p.minW); maxW = fmax1(maxW, p.maxW);
+        minS = fmin1(minS, p.minS); maxS = fmax1(maxS, p.maxS);
+    }
+    outMetrics->totalRayCount = (int32_t)(uint32_t)(uint64_t)rays;   // the reference accumulates in int32 (wraps)
+    outMetrics->totalSamples = (int32_t)(uint32_t)(uint64_t)samples;
+    outMetrics->sampleCountWeightExtrema = RtowFloat2{minW, maxW};
+    outMetrics->sampleCountExtrema[0] = (int32_t)minS;
+    outMetrics->sampleCountExtrema[1] = (int32_t)maxS;
+    outMetrics->totalRayCount64 = rays;
+    outMetrics->totalSamples64 = samples;
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowCombineDevice(RtowContext ctx, const RtowCombineParams* params, const float* inColor, const float* inNormal, const float* inAlbedo,
+                               float* outColor, float* outNormal, float* outAlbedo, void* stream)
+{
+    if (!ctx || !params || !inColor || !inNormal || !inAlbedo || !outColor || !outNormal || !outAlbedo) return RTOW_ERROR_INVALID_VALUE;
+    if (params->width <= 0 || params->height <= 0) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(ctx, launchCombine(*params, inColor, inNormal, inAlbedo, outColor, outNormal, outAlbedo, s), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowFinalizeDevice(RtowContext ctx, int32_t pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
+                                uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, void* stream)
+{
+    if (!ctx || pixelCount <= 0 || !inColor || !inNormal || !inAlbedo || !outColor || !outNormal || !outAlbedo) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(ctx, launchFinalize(pixelCount, inColor, inNormal, inAlbedo, outColor, outNormal, outAlbedo, s), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowDeviceAlloc(RtowContext ctx, size_t sizeInBytes, void** outPointer)
+{
+    if (!ctx || !outPointer || sizeInBytes == 0) return RTOW_ERROR_INVALID_VALUE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipMalloc(outPointer, sizeInBytes), RTOW_ERROR_MEMORY_ALLOCATION);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowDeviceFree(RtowContext ctx, void* pointer)
+{
+    if (!ctx || !pointer) return RTOW_ERROR_INVALID_VALUE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipFree(pointer), RTOW_ERROR_INVALID_VALUE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowDeviceCopy(RtowContext ctx, const void* source, void* destination, size_t sizeInBytes, int kind)
+{
+    if (!ctx || !source || !destination) return RTOW_ERROR_INVALID_VALUE;
+    hipMemcpyKind k;
+    switch (kind) {
+        case RTOW_MEMCPY_HOST_TO_HOST: k = hipMemcpyHostToHost; break;
+        case RTOW_MEMCPY_HOST_TO_DEVICE: k = hipMemcpyHostToDevice; break;
+        case RTOW_MEMCPY_DEVICE_TO_HOST: k = hipMemcpyDeviceToHost; break;
+        case RTOW_MEMCPY_DEVICE_TO_DEVICE: k = hipMemcpyDeviceToDevice; break;
+        default: return RTOW_ERROR_INVALID_VALUE;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpy(destination, source, sizeInBytes, k), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowDeviceMemset(RtowContext ctx, void* pointer, int value, size_t sizeInBytes)
+{
+    if (!ctx || !pointer) return RTOW_ERROR_INVALID_VALUE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipMemsetAsync(pointer, value, sizeInBytes, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowSynchronize(RtowContext ctx)
+{
+    if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+} // extern "C"

@@ -1,0 +1,283 @@
+// rtow_bvh.cpp - native scene compiler: RtowSceneDesc -> flat LDS-sized GPU layout (rtow_scene.h).
+//
+// Replaces, for this path, RebuildEntityBuffers' Entity/Material packing (UNITY/Raytracer.cs:1185-1304) and
+// RebuildBvh (UNITY/Raytracer.cs:1306-1351 -> UNITY/BvhNodeData.cs:122-213 -> JOBS/BuildRuntimeBvhJob.cs:20-39).
+// The reference builder (sort on the largest axis, half-extent split) exists to feed a CPU walk that collects
+// every overlapped leaf; here the tree feeds a 64-wide closest-hit traversal whose cost is LDS traffic and
+// divergence, so the builder is a full-sweep SAH with a hard depth bound (the traversal stack lives in LDS and is
+// sized by it).  The choice of tree is results-neutral: the nearest hit of a ray does not depend on it.
+#include "rtow_bvh.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <queue>
+
+namespace rtow {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; a++) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    double area() const
+    {
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct TmpNode {
+    Box box[2];
+    int child[2]; // >= 0: TmpNode index, < 0: ~primitive
+};
+
+struct Builder {
+    std::vector<Box> primBox;
+    std::vector<float> centroid[3];
+    std::vector<TmpNode> nodes;
+    int maxDepthSeen = 0;
+
+    // returns child code; box receives the subtree bounds. depthLeft = inner-node levels still allowed.
+    int build(std::vector<int>& idx, int begin, int end, int depthLeft, int depth, Box* outBox)
+    {
+        const int n = end - begin;
+        if (n == 1) {
+            *outBox = primBox[idx[begin]];
+            return ~idx[begin];
+        }
+        maxDepthSeen = std::max(maxDepthSeen, depth + 1);
+        const long long cap = depthLeft - 1 >= 30 ? (1LL << 30) : (1LL << std::max(depthLeft - 1, 0));
+
+        double bestCost = DBL_MAX;
+        int bestAxis = -1, bestSplit = -1;
+        std::vector<int> order(n), bestOrder;
+        std::vector<double> rightArea(n);
+        for (int axis = 0; axis < 3; axis++) {
+            std::copy(idx.begin() + begin, idx.begin() + end, order.begin());
+            const std::vector<float>& c = centroid[axis];
+            std::sort(order.begin(), order.end(), [&c](int a, int b) { return c[a] < c[b] || (c[a] == c[b] && a < b); });
+            Box acc;
+            acc.reset();
+            for (int i = n - 1; i >= 1; i--) { acc.grow(primBox[order[i]]); rightArea[i] = acc.area(); }
+            acc.reset();
+            for (int i = 1; i < n; i++) {
+                acc.grow(primBox[order[i - 1]]);
+                if (i > cap || (n - i) > cap) continue; // keep both subtrees buildable within the depth bound
+                const double cost = acc.area() * i + rightArea[i] * (n - i);
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = i; bestOrder = order; }
+            }
+        }
+        if (bestAxis < 0) { // cannot happen while n <= 2^depthLeft; defensive median split
+            bestOrder.assign(idx.begin() + begin, idx.begin() + end);
+            bestSplit = n / 2;
+        }
+        std::copy(bestOrder.begin(), bestOrder.end(), idx.begin() + begin);
+
+        const int self = (int)nodes.size();
+        nodes.push_back(TmpNode{});
+        Box b0, b1;
+        const int c0 = build(idx, begin, begin + bestSplit, depthLeft - 1, depth + 1, &b0);
+        const int c1 = build(idx, begin + bestSplit, end, depthLeft - 1, depth + 1, &b1);
+        nodes[self].box[0] = b0; nodes[self].box[1] = b1;
+        nodes[self].child[0] = c0; nodes[self].child[1] = c1;
+        *outBox = b0;
+        outBox->grow(b1);
+        return self;
+    }
+};
+
+float texColor(const RtowTexture& t, int c)
+{
+    switch (t.type) {
+        case RTOW_TEXTURE_CONSTANT: return c == 0 ? t.mainColor.x : c == 1 ? t.mainColor.y : t.mainColor.z; // RT/Texture.cs:55-56
+        case RTOW_TEXTURE_CONSTANT_SCALAR: return t.parameter;                                             // :58-59
+    }
+    return 0.0f; // TextureType.None samples as 0 (:92)
+}
+float texScalar(const RtowTexture& t)
+{
+    switch (t.type) {
+        case RTOW_TEXTURE_CONSTANT: return texColor(t, t.scalarValueChannel); // RT/Texture.cs:100-101
+        case RTOW_TEXTURE_CONSTANT_SCALAR: return t.parameter;               // :103-104
+    }
+    return 0.0f;
+}
+bool texSupported(const RtowTexture& t)
+{
+    return t.type == RTOW_TEXTURE_NONE || t.type == RTOW_TEXTURE_CONSTANT || t.type == RTOW_TEXTURE_CONSTANT_SCALAR;
+}
+bool almostOne(float v) { return std::fabs(1.0f - v) < 1e-6f; } // UTIL/MathExtensions.cs:24-27 with rhs = 1
+
+uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+} // namespace
+
+int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, std::string* err)
+{
+    if (!desc || !out || !desc->entities || !desc->materials || desc->entityCount <= 0 || desc->materialCount <= 0) {
+        *err = "null or empty scene description";
+        return RTOW_ERROR_INVALID_VALUE;
+    }
+    const int n = desc->entityCount;
+    if (n > 32767 || desc->materialCount > 32767) {
+        *err = "scene exceeds 32767 entities/materials (16-bit traversal-stack and path-history codes)";
+        return RTOW_ERROR_CAPACITY;
+    }
+    if (maxDepth <= 0) maxDepth = RTOW_DEFAULT_MAX_BVH_DEPTH;
+    if (maxDepth > RTOW_STACK_CAPACITY) maxDepth = RTOW_STACK_CAPACITY;
+    if ((1LL << std::min(maxDepth, 30)) < n) {
+        *err = "maxBvhDepth too small for the entity count";
+        return RTOW_ERROR_CAPACITY;
+    }
+
+    // ---- materials (RT/Material.cs:28-46, constant textures folded) ----
+    std::vector<GpuMaterial> mats(desc->materialCount);
+    for (int i = 0; i < desc->materialCount; i++) {
+        const RtowMaterial& m = desc->materials[i];
+        if (m.type != RTOW_MATERIAL_STANDARD && m.type != RTOW_MATERIAL_DIELECTRIC) {
+            *err = "material type not built yet (ProbabilisticVolume is a next row)";
+            return RTOW_ERROR_UNSUPPORTED;
+        }
+        if (!texSupported(m.albedo) || !texSupported(m.glossiness) || !texSupported(m.emission) || !texSupported(m.metallic)) {
+            *err = "texture type not built yet (only None / Constant / ConstantScalar)";
+            return RTOW_ERROR_UNSUPPORTED;
+        }
+        GpuMaterial g{};
+        for (int c = 0; c < 3; c++) { g.albedo[c] = texColor(m.albedo, c); g.emission[c] = texColor(m.emission, c); }
+        g.type = m.type;
+        g.metallic = texScalar(m.metallic);
+        g.glossiness = texScalar(m.glossiness);
+        g.parameter = (m.type == RTOW_MATERIAL_DIELECTRIC) ? m.parameter : 0.0f; // ctor stores it only for Dielectric/Volume
+        g.flags = 0;
+        bool spec = false;
+        if (m.type == RTOW_MATERIAL_DIELECTRIC) spec = true; // RT/Material.cs:187-188
+        else spec = m.metallic.type == RTOW_TEXTURE_CONSTANT && almostOne(m.metallic.mainColor.x) && almostOne(m.metallic.mainColor.y) &&
+                    almostOne(m.metallic.mainColor.z) && m.glossiness.type == RTOW_TEXTURE_CONSTANT && almostOne(m.glossiness.mainColor.x) &&
+                    almostOne(m.glossiness.mainColor.y) && almostOne(m.glossiness.mainColor.z); // :190-192
+        if (spec) g.flags |= MAT_FLAG_PERFECT_SPECULAR;
+        mats[i] = g;
+    }
+
+    // ---- entities -> spheres ----
+    std::vector<GpuSphere> spheres(n);
+    std::vector<GpuMotion> motion(n);
+    std::vector<uint32_t> matIndex(n);
+    bool hasMotion = false;
+    Builder b;
+    b.primBox.resize(n);
+    for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
+    for (int i = 0; i < n; i++) {
+        const RtowEntity& e = desc->entities[i];
+        if (e.type != RTOW_ENTITY_SPHERE) {
+            *err = "entity type not built yet (Rect / Box / Triangle are next rows)";
+            return RTOW_ERROR_UNSUPPORTED;
+        }
+        if (!(e.rotation.x == 0.0f && e.rotation.y == 0.0f && e.rotation.z == 0.0f && e.rotation.w == 1.0f)) {
+            *err = "rotated sphere entities not built yet (identity rotation only)";
+            return RTOW_ERROR_UNSUPPORTED;
+        }
+        if (e.materialIndex < 0 || e.materialIndex >= desc->materialCount) {
+            *err = "materialIndex out of range";
+            return RTOW_ERROR_INVALID_VALUE;
+        }
+        if (e.moving && e.timeRange.x == e.timeRange.y) { // RT/Entity.cs:53-54
+            *err = "time range cannot be empty for moving entities";
+            return RTOW_ERROR_INVALID_VALUE;
+        }
+        spheres[i] = GpuSphere{e.position.x, e.position.y, e.position.z, e.size.x};
+        motion[i] = GpuMotion{e.destinationOffset.x, e.destinationOffset.y, e.destinationOffset.z, e.timeRange.x, e.timeRange.y, e.moving ? 1 : 0, {0, 0}};
+        matIndex[i] = (uint32_t)e.materialIndex;
+        hasMotion |= e.moving != 0;
+
+        // world bounds (UNITY/BvhNodeData.cs:23-81): |radius| box, union of start/end positions when moving,
+        // padded so that the kernel's slab test (different rounding from the exact sphere test) stays conservative.
+        const float r = std::fabs(e.size.x);
+        const float p0[3] = {e.position.x, e.position.y, e.position.z};
+        const float d[3] = {e.moving ? e.destinationOffset.x : 0.0f, e.moving ? e.destinationOffset.y : 0.0f, e.moving ? e.destinationOffset.z : 0.0f};
+        Box bx;
+        for (int a = 0; a < 3; a++) {
+            const float c0 = p0[a], c1 = p0[a] + d[a];
+            float lo = std::min(c0, c1) - r, hi = std::max(c0, c1) + r;
+            const float pad = 1e-5f * std::max(std::max(std::fabs(lo), std::fabs(hi)), 1.0f) + 1e-5f * r;
+            bx.lo[a] = lo - pad;
+            bx.hi[a] = hi + pad;
+            b.centroid[a][i] = 0.5f * (lo + hi);
+        }
+        b.primBox[i] = bx;
+    }
+
+    // ---- SAH build, then breadth-first renumbering ----
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    Box rootBox;
+    std::vector<GpuNode> gnodes;
+    int depthSeen = 0;
+    if (n == 1) {
+        GpuNode g{};
+        for (int a = 0; a < 3; a++) { g.lo0[a] = b.primBox[0].lo[a]; g.hi0[a] = b.primBox[0].hi[a]; g.lo1[a] = FLT_MAX; g.hi1[a] = -FLT_MAX; }
+        g.child0 = ~0; g.child1 = ~0;
+        gnodes.push_back(g);
+        depthSeen = 1;
+    } else {
+        b.nodes.reserve(n);
+        const int root = b.build(idx, 0, n, maxDepth, 0, &rootBox);
+        depthSeen = b.maxDepthSeen;
+        std::vector<int> newIndex(b.nodes.size(), -1);
+        std::vector<int> bfs;
+        bfs.reserve(b.nodes.size());
+        std::queue<int> q;
+        q.push(root);
+        while (!q.empty()) {
+            const int t = q.front();
+            q.pop();
+            newIndex[t] = (int)bfs.size();
+            bfs.push_back(t);
+            for (int c = 0; c < 2; c++) if (b.nodes[t].child[c] >= 0) q.push(b.nodes[t].child[c]);
+        }
+        gnodes.resize(bfs.size());
+        for (size_t i = 0; i < bfs.size(); i++) {
+            const TmpNode& t = b.nodes[bfs[i]];
+            GpuNode g{};
+            for (int a = 0; a < 3; a++) {
+                g.lo0[a] = t.box[0].lo[a]; g.hi0[a] = t.box[0].hi[a];
+                g.lo1[a] = t.box[1].lo[a]; g.hi1[a] = t.box[1].hi[a];
+            }
+            g.child0 = t.child[0] >= 0 ? newIndex[t.child[0]] : t.child[0];
+            g.child1 = t.child[1] >= 0 ? newIndex[t.child[1]] : t.child[1];
+            gnodes[i] = g;
+        }
+    }
+    if (gnodes.size() > 65535) {
+        *err = "more than 65535 BVH nodes";
+        return RTOW_ERROR_CAPACITY;
+    }
+
+    // ---- pack the blob ----
+    SceneLayout L{};
+    uint32_t off = 0;
+    L.nodeOffset = off; L.nodeCount = (uint32_t)gnodes.size(); off = align16(off + L.nodeCount * (uint32_t)sizeof(GpuNode));
+    L.sphereOffset = off; L.sphereCount = (uint32_t)n; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuSphere));
+    L.hasMotion = hasMotion ? 1u : 0u;
+    L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
+    L.matIndexOffset = off; off = align16(off + (uint32_t)n * 4u);
+    L.materialOffset = off; L.materialCount = (uint32_t)mats.size(); off = align16(off + L.materialCount * (uint32_t)sizeof(GpuMaterial));
+    L.totalBytes = off;
+    L.bvhDepth = (uint32_t)depthSeen;
+
+    out->blob.assign(off, 0);
+    memcpy(out->blob.data() + L.nodeOffset, gnodes.data(), gnodes.size() * sizeof(GpuNode));
+    memcpy(out->blob.data() + L.sphereOffset, spheres.data(), spheres.size() * sizeof(GpuSphere));
+    if (hasMotion) memcpy(out->blob.data() + L.motionOffset, motion.data(), motion.size() * sizeof(GpuMotion));
+    memcpy(out->blob.data() + L.matIndexOffset, matIndex.data(), matIndex.size() * 4u);
+    memcpy(out->blob.data() + L.materialOffset, mats.data(), mats.size() * sizeof(GpuMaterial));
+    out->layout = L;
+    out->entityCount = n;
+    out->materialCount = desc->materialCount;
+    return RTOW_SUCCESS;
+}
+
+} // namespace rtow

@@ -1,0 +1,28 @@
+// rtow_bvh.h - host-side scene compiler interface (see rtow_bvh.cpp).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rtow.h"
+#include "rtow_scene.h"
+
+// Upper bound on the number of inner nodes along any root->leaf path; equals the per-lane traversal stack depth the
+// kernels reserve in LDS (16-bit entries).  2^24 leaves is far above the 32767-entity cap.
+#define RTOW_STACK_CAPACITY 24
+#define RTOW_DEFAULT_MAX_BVH_DEPTH 24
+
+namespace rtow {
+
+struct CompiledScene {
+    std::vector<uint8_t> blob; // device image, see SceneLayout
+    SceneLayout layout;
+    int entityCount = 0;
+    int materialCount = 0;
+};
+
+// Returns an RtowResult; *err describes failures.
+int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, std::string* err);
+
+} // namespace rtow

@@ -1,0 +1,77 @@
+// rtow_kernels.h - launch interface between the C-ABI layer (rtow_api.hip) and the gfx950 kernels (rtow_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtow.h"
+#include "rtow_bvh.h"
+#include "rtow_scene.h"
+
+namespace rtow {
+
+// One persistent workgroup per CU: 1024 lanes (16 wavefronts, 4 per SIMD, <= 128 VGPRs) share one LDS image of the scene.
+constexpr int kBlockThreads = 1024;
+constexpr int kLdsBytesMax = 160 * 1024;
+constexpr int kStackBytes = RTOW_STACK_CAPACITY * kBlockThreads * 2; // 16-bit entries, [level][lane]
+
+// Everything the sample kernel needs, passed by value (kernarg segment).
+struct SampleKernelArgs {
+    // accumulators (JOBS/SampleBatchJob.cs:41-51)
+    const float* inColor;   // float4[N]
+    const float* inNormal;  // float3[N]
+    const float* inAlbedo;  // float3[N]
+    const float* inScw;     // float [N]
+    float* outColor;
+    float* outNormal;
+    float* outAlbedo;
+    float* outScw;
+    uint8_t* diagnostics;   // may be null
+    int32_t diagnosticsStride;
+
+    // scene
+    const uint8_t* sceneBlob;
+    SceneLayout layout;
+    uint32_t ldsSceneBytes;  // bytes of the blob staged into LDS (whole blob, or a node prefix)
+    uint32_t ldsNodeCount;   // nodes [0, ldsNodeCount) are LDS resident
+
+    // work distribution
+    unsigned int* workCounter;            // zeroed before the launch
+    const volatile uint32_t* cancelFlag;  // host-pinned, may be null
+    uint32_t totalWork;                   // owned pixels = ownedRows * width
+    int32_t width, height;
+
+    // SampleBatchJob parameter block (:25-39)
+    float sizeX, sizeY;
+    int32_t sliceOffset, sliceDivider;
+    uint32_t seed;
+    RtowView view;
+    RtowEnvironment environment;
+    uint32_t sampleCountMin, sampleCountMax;
+    int32_t traceDepth;
+    int32_t subPixelJitter;
+    float extremaX, extremaY;
+};
+
+struct KernelInfo {
+    int numRegs;          // VGPRs per lane
+    int sharedSizeBytes;  // static LDS
+    int maxDynamicLds;
+};
+
+// launchers (defined in rtow_kernels.hip)
+hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
+hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
+                         float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream);
+hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
+                          uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, hipStream_t stream);
+
+// Per-block partial results of the metrics reduction; the host folds them in block order.
+struct MetricsPartial {
+    long long rays, samples;
+    float minW, maxW, minS, maxS;
+};
+constexpr int kMetricsBlocks = 256;
+hipError_t launchReduceMetrics(int pixelCount, const uint8_t* diagnostics, int stride, const float* color, const float* scw,
+                               MetricsPartial* partials, hipStream_t stream);
+
+} // namespace rtow

@@ -1,0 +1,756 @@
+// rtow_kernels.hip - hand-written gfx950 (CDNA4) kernels of the sample-batch path.
+//
+// sample_batch_kernel replaces SampleBatchJob.Execute + Sample + FindHitCandidates + FindHits + Entity.Hit +
+// Sphere.Hit + Material.Scatter + View.GetRay + RandomSource (JOBS/SampleBatchJob.cs:59-475, RT/*.cs).
+//
+// Shape of the kernel (see DESIGN.md "Kernel"):
+//  * persistent: one 1024-lane workgroup per CU; the whole scene image (BVH nodes, spheres, materials) is staged
+//    once into LDS with coalesced 16-byte loads, next to a [level][lane] 16-bit traversal stack;
+//  * one lane = one PIXEL (the reference seeds its xorshift32 once per pixel and runs it through all of that
+//    pixel's samples, JOBS/SampleBatchJob.cs:91,132-157, so samples of a pixel are inherently sequential);
+//  * per-lane state machine with path regeneration: every trip of the main loop advances every live lane by
+//    exactly one path segment (traverse + shade); a lane whose path ended starts its next sample - or pulls its
+//    next pixel from a global ticket counter (wave-aggregated atomic) - in the same trip, so lanes never idle on
+//    a finished path;
+//  * closest-hit traversal, near child first, with t-pruning: equivalent to the reference's collect-all /
+//    sort / take [0] (JOBS/SampleBatchJob.cs:403-475, 205-209) because only element 0 is consumed when no
+//    ProbabilisticVolume exists;
+//  * the per-depth emission/attenuation stacks (JOBS/SampleBatchJob.cs:103-104,311,330) are kept as 16-bit
+//    material codes packed in VGPRs and re-expanded when the path is folded tail -> head (:384-396), which keeps the
+//    colour bit-identical to the reference's fold order without 2 x TraceDepth float3 of per-lane storage.
+//
+// Numerics: compiled with -ffp-contract=off; every expression below is written in the evaluation order of the C#
+// source (left to right, no fusion), with IEEE division and square root, and the deterministic transcendental
+// functions of rtow_detmath.hip.h.  No MFMA: there is no dense contraction anywhere on this path.
+#include "rtow_kernels.h"
+
+#include "rtow_detmath.hip.h"
+
+namespace rtow {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// small float3 helpers; each spells out the reference's evaluation order
+// ------------------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 v3(const RtowFloat3& a) { return v3(a.x, a.y, a.z); }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 scale(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// math.normalize(v) = rsqrt(dot(v, v)) * v with rsqrt(x) = 1 / sqrt(x)
+__device__ __forceinline__ V3 normalize(V3 v) { const float r = 1.0f / __builtin_sqrtf(dot(v, v)); return scale(r, v); }
+// math.reflect(i, n) = i - 2f * n * dot(i, n)
+__device__ __forceinline__ V3 reflect(V3 i, V3 n)
+{
+    const float d = dot(i, n);
+    return v3(i.x - (2.0f * n.x) * d, i.y - (2.0f * n.y) * d, i.z - (2.0f * n.z) * d);
+}
+// math.min / math.max return the FIRST operand when the second is NaN
+__device__ __forceinline__ float um_min(float x, float y) { return (y != y || x < y) ? x : y; }
+__device__ __forceinline__ float um_max(float x, float y) { return (y != y || x > y) ? x : y; }
+__device__ __forceinline__ float um_saturate(float x) { return um_max(0.0f, um_min(1.0f, x)); }
+
+constexpr float kPi = 3.14159265f; // math.PI
+
+// x / pow(2, depth) == x * 2^-depth exactly (scaling by a power of two), including the subnormal end of the range;
+// pow(2, depth) overflows to +inf from depth 128 on, where the quotient is 0.
+__device__ __forceinline__ float inv_pow2(int depth)
+{
+    if (depth <= 126) return __uint_as_float((unsigned)(127 - depth) << 23);
+    if (depth == 127) return __uint_as_float(0x00400000u);
+    return 0.0f;
+}
+
+// Unity.Mathematics.Random: NextState returns the pre-update state; NextFloat = asfloat(0x3f800000 | (s >> 9)) - 1
+__device__ __forceinline__ float rng_next(unsigned& state)
+{
+    const unsigned t = state;
+    unsigned s = t;
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    state = s;
+    return __uint_as_float(0x3f800000u | (t >> 9)) - 1.0f;
+}
+
+// RandomSource.OnCosineWeightedHemisphere (RT/RandomSource.cs:63-89) + Tools.TangentToWorldSpace (UTIL/Tools.cs:19-37)
+__device__ __forceinline__ V3 cosine_hemisphere(unsigned& rng, V3 n)
+{
+    const float u = rng_next(rng);
+    const float v = rng_next(rng);
+    const float radius = __builtin_sqrtf(u);
+    const float theta = v * 2 * kPi;
+    float sinT, cosT;
+    det_sincos(theta, sinT, cosT);
+    const float tx = radius * cosT, tz = radius * sinT;
+    const float ty = __builtin_sqrtf(1 - u);
+
+    const float s = n.z >= 0 ? 1.0f : -1.0f;
+    const float a = -1 / (s + n.z);
+    const float b = n.x * n.y * a;
+    const V3 tangent = v3(1 + s * n.x * n.x * a, s * b, -s * n.x);
+    const V3 bitangent = v3(b, s + n.y * n.y * a, -n.y);
+    const V3 r = v3(tangent.x * tx + n.x * ty + bitangent.x * tz,
+                    tangent.y * tx + n.y * ty + bitangent.y * tz,
+                    tangent.z * tx + n.z * ty + bitangent.z * tz);
+    return normalize(r);
+}
+
+// Material.Schlick (RT/Material.cs:212-217)
+__device__ __forceinline__ float schlick(float cosine, float ior)
+{
+    float r0 = (1 - ior) / (1 + ior);
+    r0 *= r0;
+    return r0 + (1 - r0) * det_pow5(1 - cosine);
+}
+
+// Microfacet.TrowbridgeReitz.RoughnessToAlpha / Lambda, SmithMaskingShadowing (RT/Microfacet.cs:9-12,53-80)
+__device__ __forceinline__ float roughness_to_alpha(float roughness)
+{
+    roughness = um_max(roughness, 1e-3f);
+    const float x = det_log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+__device__ __forceinline__ float smith_g1(V3 w, V3 n, float roughness)
+{
+    const float cosTheta = dot(n, w);
+    const float sqCos = cosTheta * cosTheta;
+    const float sqSin = um_max(0.0f, 1 - sqCos);
+    const float sinTheta = __builtin_sqrtf(sqSin);
+    const float tanTheta = sinTheta / cosTheta;
+    const float absTan = __builtin_fabsf(tanTheta);
+    float lambda;
+    if (__builtin_isinf(absTan)) {
+        lambda = 0;
+    } else {
+        const float alpha = roughness_to_alpha(roughness);
+        const float a2t2 = (alpha * absTan) * (alpha * absTan);
+        lambda = (-1 + __builtin_sqrtf(1 + a2t2)) / 2;
+    }
+    return 1 / (1 + lambda);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// scene access: LDS image first, HBM/L2 for whatever did not fit
+// ------------------------------------------------------------------------------------------------------------
+struct SceneRefs {
+    const uint8_t* lds;     // LDS copy of the blob prefix
+    const uint8_t* glob;    // full blob in HBM
+    uint32_t ldsNodeCount;
+};
+
+template <bool ALL_LDS>
+__device__ __forceinline__ void load_node(const SceneRefs& sc, const SceneLayout& L, int idx, float4& q0, float4& q1, float4& q2, int& c0, int& c1)
+{
+    const uint32_t off = L.nodeOffset + (uint32_t)idx * 64u;
+    const uint8_t* base = (ALL_LDS || (uint32_t)idx < sc.ldsNodeCount) ? sc.lds : sc.glob;
+    const float4* p = reinterpret_cast<const float4*>(base + off);
+    q0 = p[0];
+    q1 = p[1];
+    q2 = p[2];
+    const int2 c = *reinterpret_cast<const int2*>(base + off + 48);
+    c0 = c.x;
+    c1 = c.y;
+}
+
+template <bool ALL_LDS>
+__device__ __forceinline__ const uint8_t* section(const SceneRefs& sc, uint32_t offset)
+{
+    return (ALL_LDS ? sc.lds : sc.glob) + offset;
+}
+
+// centre of primitive `i` at ray time `time` (Entity.TransformAtTime, RT/Entity.cs:124-127) and its signed radius
+template <bool ALL_LDS, bool HAS_MOTION>
+__device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout& L, int i, float time, V3& c, float& radius)
+{
+    const float4 s = *reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.sphereOffset) + (uint32_t)i * 16u);
+    c = v3(s.x, s.y, s.z);
+    radius = s.w;
+    if (HAS_MOTION) {
+        const uint8_t* mp = section<ALL_LDS>(sc, L.motionOffset) + (uint32_t)i * 32u;
+        const float4 m0 = *reinterpret_cast<const float4*>(mp);      // dx dy dz t0
+        const float2 m1 = *reinterpret_cast<const float2*>(mp + 16); // t1 moving
+        if (__float_as_int(m1.y) != 0) {
+            const float f = um_max(0.0f, um_min(1.0f, (time - m0.w) / (m1.x - m0.w))); // clamp(unlerp(t0, t1, t), 0, 1)
+            c = v3(c.x + m0.x * f, c.y + m0.y * f, c.z + m0.z * f);
+        }
+    }
+}
+
+// HitTests.Hit(Sphere) (RT/HitTests.cs:23-60) in entity space (oc = origin - centre), tMin = 0, tMax = +inf
+__device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, float& tOut)
+{
+    const float b = dot(oc, d);
+    const float c = dot(oc, oc) - radius * radius;
+    const float disc = b * b - a * c;
+    if (disc > 0) {
+        const float sq = __builtin_sqrtf(disc);
+        float t = (-b - sq) / a;
+        if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
+        t = (-b + sq) / a;
+        if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
+    }
+    return false;
+}
+
+__device__ __forceinline__ void slab(float4 qa, float4 qb, bool second, V3 o, V3 inv, float best, float& tmin, float& tmax)
+{
+    // second == false: box0 = (qa.x qa.y qa.z | qa.w qb.x qb.y); second == true is handled by the caller's argument shuffle
+    (void)second;
+    const float t0x = (qa.x - o.x) * inv.x, t1x = (qa.w - o.x) * inv.x;
+    const float t0y = (qa.y - o.y) * inv.y, t1y = (qb.x - o.y) * inv.y;
+    const float t0z = (qa.z - o.z) * inv.z, t1z = (qb.y - o.z) * inv.z;
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fminf(__builtin_fmaxf(t0z, t1z), best));
+}
+
+// Closest hit of one ray.  Replaces FindHitCandidates + FindHits + "take hit[0]" (JOBS/SampleBatchJob.cs:403-475,205-209).
+template <bool ALL_LDS, bool HAS_MOTION>
+__device__ __forceinline__ void closest_hit(const SceneRefs& sc, const SceneLayout& L, unsigned short* stack /* + lane */, V3 o, V3 d, float time,
+                                            float& bestT, int& bestPrim, float& boundsHits, float& candidates)
+{
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float a = dot(d, d);
+    float best = __builtin_inff();
+    int prim = -1;
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        float4 q0, q1, q2;
+        int c0, c1;
+        load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
+        float tmin0, tmax0, tmin1, tmax1;
+        slab(q0, q1, false, o, inv, best, tmin0, tmax0);
+        // box1 = (q1.z q1.w q2.x | q2.y q2.z q2.w)
+        slab(make_float4(q1.z, q1.w, q2.x, q2.y), make_float4(q2.z, q2.w, 0.f, 0.f), true, o, inv, best, tmin1, tmax1);
+        bool hit0 = tmin0 <= tmax0;
+        bool hit1 = tmin1 <= tmax1;
+        boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
+
+        if (hit0 && c0 < 0) {
+            const int i = ~c0;
+            V3 c; float r, t;
+            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, time, c, r);
+            candidates += 1.0f;
+            if (sphere_hit(sub(o, c), d, a, r, t) && t < best) { best = t; prim = i; }
+            hit0 = false;
+        }
+        if (hit1 && c1 < 0) {
+            const int i = ~c1;
+            V3 c; float r, t;
+            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, time, c, r);
+            candidates += 1.0f;
+            if (sphere_hit(sub(o, c), d, a, r, t) && t < best) { best = t; prim = i; }
+            hit1 = false;
+        }
+        hit0 = hit0 && tmin0 <= best;
+        hit1 = hit1 && tmin1 <= best;
+        if (hit0 || hit1) {
+            if (hit0 && hit1) {
+                const bool swap = tmin1 < tmin0;
+                const int nearC = swap ? c1 : c0;
+                const int farC = swap ? c0 : c1;
+                stack[sp * kBlockThreads] = (unsigned short)farC;
+                sp++;
+                cur = nearC;
+            } else {
+                cur = hit0 ? c0 : c1;
+            }
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * kBlockThreads];
+        }
+    }
+    bestT = best;
+    bestPrim = prim;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// path history: one 16-bit code per surface hit (bit 15 = "reflectance was overridden to 1", bits 0..14 = material)
+// ------------------------------------------------------------------------------------------------------------
+template <int HW>
+__device__ __forceinline__ void hist_set(unsigned (&h)[HW], int depth, unsigned code)
+{
+    const int w = depth >> 1;
+    const unsigned sh = (unsigned)(depth & 1) * 16u;
+#pragma unroll
+    for (int i = 0; i < HW; i++)
+        if (i == w) h[i] |= code << sh;
+}
+template <int HW>
+__device__ __forceinline__ unsigned hist_get(const unsigned (&h)[HW], int depth)
+{
+    const int w = depth >> 1;
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < HW; i++)
+        if (i == w) v = h[i];
+    return (v >> ((unsigned)(depth & 1) * 16u)) & 0xffffu;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the megakernel
+// ------------------------------------------------------------------------------------------------------------
+template <bool ALL_LDS, bool HAS_MOTION, int HW>
+__global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = (int)threadIdx.x;
+
+    // ---- stage the scene image into LDS: coalesced 16 B per lane ----
+    unsigned short* const stackBase = reinterpret_cast<unsigned short*>(smem) + tid;
+    uint8_t* const ldsScene = smem + kStackBytes;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(A.sceneBlob);
+        uint4* dst = reinterpret_cast<uint4*>(ldsScene);
+        const uint32_t n16 = A.ldsSceneBytes >> 4;
+        for (uint32_t i = (uint32_t)tid; i < n16; i += kBlockThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    SceneRefs sc;
+    sc.lds = ldsScene;
+    sc.glob = A.sceneBlob;
+    sc.ldsNodeCount = A.ldsNodeCount;
+    const SceneLayout L = A.layout;
+
+    const V3 viewOrigin = v3(A.view.origin), viewLLC = v3(A.view.lowerLeftCorner);
+    const V3 viewH = v3(A.view.horizontal), viewV = v3(A.view.vertical);
+    const V3 viewRight = v3(A.view.right), viewUp = v3(A.view.up);
+    const float lensRadius = A.view.lensRadius;
+    const int traceDepth = A.traceDepth;
+
+    // ---- per-lane persistent state ----
+    int pix = -1;               // current pixel index (global), -1 = none yet
+    bool alive = true;          // false once the ticket counter is exhausted
+    bool needRay = true;        // no active path
+    unsigned rng = 0;
+    unsigned smp = 0, nsamp = 0;
+    int cx = 0, cy = 0;
+    V3 colorAcc = v3(0, 0, 0), normalAcc = v3(0, 0, 0), albedoAcc = v3(0, 0, 0);
+    float scwAcc = 0, scw0 = 0;
+    int sampleCount = 0;
+    float rayCount = 0, boundsHits = 0, candidates = 0;
+
+    // per-path state
+    V3 ro = v3(0, 0, 0), rd = v3(0, 0, 1);
+    float rtime = 0;
+    int depth = 0;
+    unsigned hist[HW];
+    V3 sampleNormal = v3(0, 0, 0), sampleAlbedo = v3(0, 0, 0);
+    bool firstNonSpecular = false;
+    float randomEventsLocal = 0;
+
+    for (;;) {
+        // ================= 1. regenerate: next sample of this pixel, or next pixel =================
+        if (alive && needRay) {
+            while (smp >= nsamp) {
+                if (pix >= 0) {
+                    // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
+                    reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
+                    if (sampleCount != 0) {
+                        A.outNormal[3 * (size_t)pix + 0] = normalAcc.x; A.outNormal[3 * (size_t)pix + 1] = normalAcc.y; A.outNormal[3 * (size_t)pix + 2] = normalAcc.z;
+                        A.outAlbedo[3 * (size_t)pix + 0] = albedoAcc.x; A.outAlbedo[3 * (size_t)pix + 1] = albedoAcc.y; A.outAlbedo[3 * (size_t)pix + 2] = albedoAcc.z;
+                    } else if (nsamp == 0) {
+                        // no sample ran: the fallbacks keep their default (0) value (:115)
+                        A.outNormal[3 * (size_t)pix + 0] = 0; A.outNormal[3 * (size_t)pix + 1] = 0; A.outNormal[3 * (size_t)pix + 2] = 0;
+                        A.outAlbedo[3 * (size_t)pix + 0] = 0; A.outAlbedo[3 * (size_t)pix + 1] = 0; A.outAlbedo[3 * (size_t)pix + 2] = 0;
+                    } // else: sample 0's AOVs were stored as the fallback when that sample ended (:152-156,160-161)
+                    A.outScw[pix] = scwAcc;
+                    if (A.diagnostics) {
+                        if (A.diagnosticsStride >= 16)
+                            *reinterpret_cast<float4*>(A.diagnostics + (size_t)pix * (size_t)A.diagnosticsStride) = make_float4(rayCount, boundsHits, candidates, scw0);
+                        else
+                            *reinterpret_cast<float*>(A.diagnostics + (size_t)pix * (size_t)A.diagnosticsStride) = rayCount;
+                    }
+                    pix = -1;
+                }
+                // ---- pull the next owned pixel (ticket counter; the compiler aggregates this per wave) ----
+                bool cancelled = false;
+                if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
+                const unsigned ticket = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
+                if (ticket >= A.totalWork) { alive = false; break; }
+                const int ownedRow = (int)(ticket / (unsigned)A.width);
+                cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
+                cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
+                pix = cy * A.width + cx;
+
+                const float4 last = reinterpret_cast<const float4*>(A.inColor)[pix];                  // :72-78
+                colorAcc = v3(last.x, last.y, last.z);
+                normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
+                albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
+                scwAcc = A.inScw[pix];
+                sampleCount = (int)last.w;
+
+                // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
+                rng = (A.seed * 0x8C4CA03Fu) ^ ((unsigned)pix * 0x7383ED49u);
+                (void)rng_next(rng);
+
+                // :118-126
+                const float w = scwAcc / (float)sampleCount;
+                if (w == 0) {
+                    nsamp = A.sampleCountMin;
+                } else {
+                    const float nw = um_saturate((w - A.extremaX) / (A.extremaY - A.extremaX));
+                    const float lo = (float)A.sampleCountMin, hi = (float)A.sampleCountMax;
+                    nsamp = (unsigned)__builtin_rintf(lo + nw * (hi - lo));
+                }
+                scw0 = w;
+                smp = 0;
+                rayCount = 0; boundsHits = 0; candidates = 0;
+            }
+            if (alive) {
+                // ---- camera ray (:134-135, RT/View.cs:38-48) ----
+                float jx = 0.5f, jy = 0.5f;
+                if (A.subPixelJitter) { jx = rng_next(rng); jy = rng_next(rng); }
+                const float u = ((float)cx + jx) / A.sizeX;
+                const float v = ((float)cy + jy) / A.sizeY;
+                float rdx = 0, rdy = 0;
+                if (lensRadius != 0) {
+                    // RandomSource.InUnitDisk (RT/RandomSource.cs:40-61): theta = NextFloat(0, 2*PI), radius = sqrt(NextFloat())
+                    const float theta = rng_next(rng) * (2.0f * kPi - 0.0f) + 0.0f;
+                    const float radius = __builtin_sqrtf(rng_next(rng));
+                    float sinT, cosT;
+                    det_sincos(theta, sinT, cosT);
+                    rdx = lensRadius * (radius * cosT);
+                    rdy = lensRadius * (radius * sinT);
+                }
+                const V3 offset = v3(viewRight.x * rdx + viewUp.x * rdy, viewRight.y * rdx + viewUp.y * rdy, viewRight.z * rdx + viewUp.z * rdy);
+                ro = add(viewOrigin, offset);
+                rd = normalize(v3(viewLLC.x - offset.x + u * viewH.x + v * viewV.x,
+                                  viewLLC.y - offset.y + u * viewH.y + v * viewV.y,
+                                  viewLLC.z - offset.z + u * viewH.z + v * viewV.z));
+                rtime = rng_next(rng);
+
+                depth = 0;
+#pragma unroll
+                for (int i = 0; i < HW; i++) hist[i] = 0;
+                sampleNormal = v3(0, 0, 0);
+                sampleAlbedo = v3(0, 0, 0);
+                firstNonSpecular = false;
+                randomEventsLocal = 0;
+                needRay = false;
+            }
+        }
+        if (!__any(alive)) break;
+
+        if (alive) {
+            // ================= 2. one path segment: closest hit =================
+            float t;
+            int prim;
+            closest_hit<ALL_LDS, HAS_MOTION>(sc, L, stackBase, ro, rd, rtime, t, prim, boundsHits, candidates);
+            rayCount += 1.0f;                                                               // :203
+
+            bool sampleEnded = false, sampleOk = false;
+            V3 sampleColor = v3(0, 0, 0);
+
+            if (prim >= 0) {
+                // ================= 3a. surface hit: Entity.Hit record + Material.Scatter =================
+                V3 c; float radius;
+                sphere_at<ALL_LDS, HAS_MOTION>(sc, L, prim, rtime, c, radius);
+                const V3 oc = sub(ro, c);
+                const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
+                const V3 nLocal = v3((oc.x + t * rd.x) / radius, (oc.y + t * rd.y) / radius, (oc.z + t * rd.z) / radius); // r.GetPoint(t) / radius
+                const V3 N = normalize(nLocal);                                               // RT/Entity.cs:65
+
+                const unsigned matIdx = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
+                const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + matIdx * 48u;
+                const float4 m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
+                const float4 m1 = *reinterpret_cast<const float4*>(mp + 16);  // emission.yz type metallic
+                const float4 m2 = *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags pad
+                V3 reflectance = v3(m0.x, m0.y, m0.z);
+                const V3 emission = v3(m0.w, m1.x, m1.y);
+                const int mtype = __float_as_int(m1.z);
+                const unsigned mflags = __float_as_uint(m2.z);
+                bool white = false;
+                V3 sdir;
+                float randomEvents = 0;
+
+                if (mtype == RTOW_MATERIAL_STANDARD) {                                        // RT/Material.cs:75-119
+                    const float metallic = m1.w;
+                    const float glossiness = m2.x;
+                    const float roughness = det_sq(1 - glossiness);
+                    V3 roughN = N;
+                    if (roughness > 0) {
+                        const V3 h = cosine_hemisphere(rng, N);
+                        roughN = normalize(v3(N.x + roughness * (h.x - N.x), N.y + roughness * (h.y - N.y), N.z + roughness * (h.z - N.z)));
+                    }
+                    const float incidentCosine = -dot(rd, roughN);
+                    const float ior = 1.5f + metallic * (1.1f - 1.5f);
+                    const float fresnel = schlick(incidentCosine, ior);
+                    const float g1 = smith_g1(rd, N, roughness);
+                    const float reflectionChance = um_saturate(fresnel * glossiness * g1);
+
+                    if (reflectionChance > 0 && rng_next(rng) < reflectionChance) {
+                        sdir = reflect(rd, roughN);
+                        reflectance = v3(1, 1, 1);
+                        white = true;
+                    } else if (metallic > 0 && rng_next(rng) < metallic) {
+                        sdir = reflect(rd, roughN);
+                    } else {
+                        sdir = cosine_hemisphere(rng, N);
+                    }
+                    if (reflectionChance > 0 && reflectionChance < 1) randomEvents++;
+                    if (metallic > 0 && metallic < 1) randomEvents++;
+                    randomEvents += roughness * (reflectionChance + (1 - reflectionChance) * metallic);
+                    randomEvents += (1 - reflectionChance) * (1 - metallic);
+                } else {                                                                      // Dielectric, RT/Material.cs:121-161
+                    const float ior = m2.y;
+                    const float roughness = 1 - m2.x;
+                    // RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128)
+                    const float r0 = rng_next(rng);
+                    const float r1 = rng_next(rng);
+                    const float z = r0 * 2.0f - 1.0f;
+                    const float rr = __builtin_sqrtf(um_max(1.0f - z * z, 0.0f));
+                    const float angle = r1 * kPi * 2.0f;
+                    float sn, cs;
+                    det_sincos(angle, sn, cs);
+                    const V3 rdir = v3(cs * rr, sn * rr, z);
+                    const V3 roughN = normalize(v3(N.x + roughness * rdir.x, N.y + roughness * rdir.y, N.z + roughness * rdir.z));
+
+                    float niOverNt, cosine;
+                    V3 outwardN;
+                    const float dDotN = dot(rd, roughN);
+                    if (dDotN > 0) { outwardN = neg(roughN); niOverNt = ior; cosine = ior * dDotN; }
+                    else { outwardN = roughN; niOverNt = 1 / ior; cosine = -dDotN; }
+
+                    // Refract (:198-210)
+                    const float dt = dot(rd, outwardN);
+                    const float disc = 1 - niOverNt * niOverNt * (1 - dt * dt);
+                    bool refractOk = false;
+                    if (disc > 0) {
+                        const float sq = __builtin_sqrtf(disc);
+                        const V3 refracted = v3(niOverNt * (rd.x - outwardN.x * dt) - outwardN.x * sq,
+                                                niOverNt * (rd.y - outwardN.y * dt) - outwardN.y * sq,
+                                                niOverNt * (rd.z - outwardN.z * dt) - outwardN.z * sq);
+                        if (rng_next(rng) > schlick(cosine, ior)) { sdir = refracted; refractOk = true; }
+                    }
+                    if (!refractOk) {
+                        sdir = reflect(rd, roughN);
+                        reflectance = v3(1, 1, 1);
+                        white = true;
+                    }
+                    randomEvents++;
+                    randomEvents += roughness;
+                }
+
+                hist_set<HW>(hist, depth, (white ? 0x8000u : 0u) | matIdx);                   // :311,330 (re-expanded at the fold)
+                if (depth == 0) sampleNormal = N;                                             // :313-314
+                if (!firstNonSpecular && !(mflags & MAT_FLAG_PERFECT_SPECULAR)) {             // :316-328
+                    sampleAlbedo = add(emission, reflectance);
+                    sampleNormal = N;
+                    firstNonSpecular = true;
+                }
+                randomEventsLocal += randomEvents * inv_pow2(depth);                                   // RandomEvents / pow(2, depth), :332
+
+                // ray = scattered.OffsetTowards(dot(dir, N) >= 0 ? N : -N)  (:335-336, RT/Ray.cs:18)
+                const V3 offN = dot(sdir, N) >= 0 ? N : neg(N);
+                ro = v3(P.x + 0.001f * offN.x, P.y + 0.001f * offN.y, P.z + 0.001f * offN.z);
+                rd = sdir;
+                depth++;
+                if (depth == traceDepth) { sampleEnded = true; sampleOk = false; }            // :379-381
+            } else {
+                // ================= 3b. sky (:341-374), then fold tail -> head (:384-396) =================
+                V3 sky = v3(0, 0, 0);
+                if (A.environment.skyType == RTOW_SKY_GRADIENT) {
+                    const float s = 0.5f * (rd.y + 1);
+                    const V3 b = v3(A.environment.skyBottomColor), tp = v3(A.environment.skyTopColor);
+                    sky = v3(b.x + s * (tp.x - b.x), b.y + s * (tp.y - b.y), b.z + s * (tp.z - b.z));
+                }
+                // randomEventsLocalAcc += rng.RandomEvents / pow(2, depth) with RandomEvents == 0 here (:363): adds +0
+                if (!firstNonSpecular) { sampleAlbedo = sky; sampleNormal = neg(rd); }
+
+                V3 col = sky; // 0 * 1 + sky
+                for (int i = depth - 1; i >= 0; i--) {
+                    const unsigned code = hist_get<HW>(hist, i);
+                    const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + (code & 0x7fffu) * 48u;
+                    const float4 m0 = *reinterpret_cast<const float4*>(mp);
+                    const float2 m1 = *reinterpret_cast<const float2*>(mp + 16);
+                    const bool white = (code & 0x8000u) != 0;
+                    const V3 att = white ? v3(1, 1, 1) : v3(m0.x, m0.y, m0.z);
+                    col = v3(col.x * att.x + m0.w, col.y * att.y + m1.x, col.z * att.z + m1.y);
+                }
+                sampleColor = col;
+                sampleEnded = true;
+                sampleOk = true;
+            }
+
+            if (sampleEnded) {
+                if (sampleOk) {                                                               // :145-149, :398
+                    scwAcc += randomEventsLocal;
+                    colorAcc = add(colorAcc, sampleColor);
+                    normalAcc = add(normalAcc, sampleNormal);
+                    albedoAcc = add(albedoAcc, sampleAlbedo);
+                    sampleCount++;
+                }
+                if (smp == 0) {                                                               // :152-156 -> stored now, kept if sampleCount stays 0
+                    A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
+                    A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
+                }
+                smp++;
+                needRay = true;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// post passes
+// ------------------------------------------------------------------------------------------------------------
+
+// CombineJob.Execute (JOBS/CombineJob.cs:29-71)
+__global__ void __launch_bounds__(256) combine_kernel(RtowCombineParams p, const float4* __restrict__ inColor, const float* __restrict__ inNormal,
+                                                      const float* __restrict__ inAlbedo, float* __restrict__ outColor, float* __restrict__ outNormal,
+                                                      float* __restrict__ outAlbedo)
+{
+    const int n = p.width * p.height;
+    for (int index = (int)(blockIdx.x * blockDim.x + threadIdx.x); index < n; index += (int)(gridDim.x * blockDim.x)) {
+        float4 c = inColor[index];
+        int count = (int)c.w;
+        if (!p.debugMode && count == 0) {
+            int tentative = index;
+            while (count == 0 && (tentative -= p.width) >= 0) { // look-around for interlaced buffers (:40-50)
+                c = inColor[tentative];
+                count = (int)c.w;
+            }
+        }
+        const bool anyNan = (c.x != c.x) || (c.y != c.y) || (c.z != c.z) || (c.w != c.w);
+        V3 finalColor;
+        if (count == 0) finalColor = p.debugMode ? v3(1, 0, 1) : v3(0, 0, 0);
+        else if (anyNan) finalColor = p.debugMode ? v3(0, 1, 1) : v3(0, 0, 0);
+        else finalColor = v3(c.x / (float)count, c.y / (float)count, c.z / (float)count);
+
+        const float denom = (float)(count > 1 ? count : 1);
+        V3 alb = v3(inAlbedo[3 * (size_t)index] / denom, inAlbedo[3 * (size_t)index + 1] / denom, inAlbedo[3 * (size_t)index + 2] / denom);
+        if (p.ldrAlbedo) alb = v3(um_min(alb.x, 1.0f), um_min(alb.y, 1.0f), um_min(alb.z, 1.0f));
+        const V3 nv = v3(inNormal[3 * (size_t)index] / denom, inNormal[3 * (size_t)index + 1] / denom, inNormal[3 * (size_t)index + 2] / denom);
+        const float len = dot(nv, nv);
+        V3 nn = v3(0, 0, 0);
+        if (len > 1.175494351e-38f) { const float r = 1.0f / __builtin_sqrtf(len); nn = v3(nv.x * r, nv.y * r, nv.z * r); } // normalizesafe
+        outColor[3 * (size_t)index] = finalColor.x; outColor[3 * (size_t)index + 1] = finalColor.y; outColor[3 * (size_t)index + 2] = finalColor.z;
+        outNormal[3 * (size_t)index] = nn.x; outNormal[3 * (size_t)index + 1] = nn.y; outNormal[3 * (size_t)index + 2] = nn.z;
+        outAlbedo[3 * (size_t)index] = alb.x; outAlbedo[3 * (size_t)index + 1] = alb.y; outAlbedo[3 * (size_t)index + 2] = alb.z;
+    }
+}
+
+// LinearToGamma (UTIL/MathExtensions.cs:17-21) -> saturate -> * 255 -> (byte)
+__device__ __forceinline__ unsigned to_byte(float v)
+{
+    v = um_max(v, 0.0f);
+    const float g = um_max(1.055f * det_pow(v, 0.416666667f) - 0.055f, 0.0f);
+    return (unsigned)(um_saturate(g) * 255);
+}
+
+// FinalizeTexturesJob.Execute (JOBS/FinalizeTexturesJob.cs:23-55)
+__global__ void __launch_bounds__(256) finalize_kernel(int n, const float* __restrict__ inColor, const float* __restrict__ inNormal,
+                                                       const float* __restrict__ inAlbedo, uchar4* __restrict__ outColor, uchar4* __restrict__ outNormal,
+                                                       uchar4* __restrict__ outAlbedo)
+{
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
+        const size_t b = 3 * (size_t)i;
+        outColor[i] = make_uchar4((unsigned char)to_byte(inColor[b]), (unsigned char)to_byte(inColor[b + 1]), (unsigned char)to_byte(inColor[b + 2]), 255);
+        outNormal[i] = make_uchar4((unsigned char)to_byte(inNormal[b] * 0.5f + 0.5f), (unsigned char)to_byte(inNormal[b + 1] * 0.5f + 0.5f),
+                                   (unsigned char)to_byte(inNormal[b + 2] * 0.5f + 0.5f), 255);
+        outAlbedo[i] = make_uchar4((unsigned char)to_byte(inAlbedo[b]), (unsigned char)to_byte(inAlbedo[b + 1]), (unsigned char)to_byte(inAlbedo[b + 2]), 255);
+    }
+}
+
+// ReduceMetricsJob.Execute (JOBS/ReduceMetricsJob.cs:22-45) as a two-level reduction; integer sums and float min/max are
+// order independent (math.min/max skip a NaN second operand), so the result equals the reference's serial loop.
+__global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_t* __restrict__ diag, int stride, const float4* __restrict__ color,
+                                                             const float* __restrict__ scw, MetricsPartial* __restrict__ partials)
+{
+    long long rays = 0, samples = 0;
+    float minW = __builtin_inff(), maxW = -__builtin_inff(), minS = __builtin_inff(), maxS = -__builtin_inff();
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
+        const float rc = *reinterpret_cast<const float*>(diag + (size_t)i * (size_t)stride);
+        rays += (int)rc;
+        const int sc = (int)color[i].w;
+        samples += sc;
+        const float w = scw[i] / (float)sc;
+        minW = um_min(minW, w); maxW = um_max(maxW, w);
+        minS = um_min(minS, (float)sc); maxS = um_max(maxS, (float)sc);
+    }
+    __shared__ MetricsPartial sh[256];
+    MetricsPartial mine;
+    mine.rays = rays; mine.samples = samples; mine.minW = minW; mine.maxW = maxW; mine.minS = minS; mine.maxS = maxS;
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            MetricsPartial a = sh[threadIdx.x];
+            const MetricsPartial b = sh[threadIdx.x + s];
+            a.rays += b.rays; a.samples += b.samples;
+            a.minW = um_min(a.minW, b.minW); a.maxW = um_max(a.maxW, b.maxW);
+            a.minS = um_min(a.minS, b.minS); a.maxS = um_max(a.maxS, b.maxS);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+template <bool ALL_LDS, bool HAS_MOTION, int HW>
+hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
+{
+    auto k = sample_batch_kernel<ALL_LDS, HAS_MOTION, HW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(numBlocks), dim3(kBlockThreads), ldsBytes, stream, args);
+    return hipGetLastError();
+}
+
+template <bool ALL_LDS, bool HAS_MOTION>
+hipError_t launchByDepth(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
+{
+    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, HAS_MOTION, 4>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, HAS_MOTION, 8>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 32) return launchVariant<ALL_LDS, HAS_MOTION, 16>(args, numBlocks, ldsBytes, stream);
+    return launchVariant<ALL_LDS, HAS_MOTION, 32>(args, numBlocks, ldsBytes, stream);
+}
+
+} // namespace
+
+hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
+{
+    const size_t ldsBytes = (size_t)kStackBytes + args.ldsSceneBytes;
+    const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
+    const bool motion = args.layout.hasMotion != 0;
+    if (allLds) return motion ? launchByDepth<true, true>(args, numBlocks, ldsBytes, stream) : launchByDepth<true, false>(args, numBlocks, ldsBytes, stream);
+    return motion ? launchByDepth<false, true>(args, numBlocks, ldsBytes, stream) : launchByDepth<false, false>(args, numBlocks, ldsBytes, stream);
+}
+
+hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
+                         float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream)
+{
+    const int n = p.width * p.height;
+    const int blocks = n < 256 * 2048 ? (n + 255) / 256 : 2048;
+    hipLaunchKernelGGL(combine_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, p, reinterpret_cast<const float4*>(inColor), inNormal, inAlbedo,
+                       outColor, outNormal, outAlbedo);
+    return hipGetLastError();
+}
+
+hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
+                          uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, hipStream_t stream)
+{
+    const int blocks = pixelCount < 256 * 2048 ? (pixelCount + 255) / 256 : 2048;
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, pixelCount, inColor, inNormal, inAlbedo,
+                       reinterpret_cast<uchar4*>(outColor), reinterpret_cast<uchar4*>(outNormal), reinterpret_cast<uchar4*>(outAlbedo));
+    return hipGetLastError();
+}
+
+hipError_t launchReduceMetrics(int pixelCount, const uint8_t* diagnostics, int stride, const float* color, const float* scw,
+                               MetricsPartial* partials, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reduce_metrics_kernel, dim3(kMetricsBlocks), dim3(256), 0, stream, pixelCount, diagnostics, stride,
+                       reinterpret_cast<const float4*>(color), scw, partials);
+    return hipGetLastError();
+}
+
+} // namespace rtow

@@ -1,0 +1,72 @@
+// rtow_scene.h - flat GPU scene layout shared by the host-side builder (rtow_bvh.cpp) and the kernels.
+//
+// The reference's runtime scene is a pointer graph (RT/BvhNode.cs:7-10: AABB + Left/Right/EntitiesStart pointers,
+// RT/Entity.cs:27-37: 104-byte Entity with two RigidTransforms, Material*, void* Content).  None of that can live
+// in LDS or be chased efficiently by 64-wide wavefronts, so the native layout is index based and sized for LDS:
+//
+//   GpuNode   64 B  one INNER node holding the boxes of BOTH children (one 64-byte fetch decides both subtrees,
+//                   near child first).  child >= 0: inner node index; child < 0: leaf, primitive index = ~child.
+//                   Nodes are stored breadth-first, so "the first K nodes" == "the top levels" when a scene
+//                   is too large for LDS and only a prefix is staged.
+//   GpuSphere 16 B  centre + signed radius (RT/EntityTypes/Sphere.cs:8; the centre is Entity.OriginTransform.pos).
+//   GpuMotion 32 B  only for scenes with moving entities: DestinationOffset + TimeRange (RT/Entity.cs:33-34).
+//   GpuMaterial 48 B constant-texture material (RT/Material.cs:16-47 with RT/Texture.cs constant branches folded).
+//
+// Everything is packed into ONE device blob (16-byte aligned sections) so a workgroup stages it into LDS with a
+// single coalesced 16-byte-per-lane copy.
+#pragma once
+#include <stdint.h>
+
+namespace rtow {
+
+struct GpuNode {
+    // q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)  q3 = (c0 c1 - -)
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t pad[2];
+};
+static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 bytes");
+
+struct GpuSphere {
+    float cx, cy, cz, radius;
+};
+static_assert(sizeof(GpuSphere) == 16, "GpuSphere must be 16 bytes");
+
+struct GpuMotion {
+    float dx, dy, dz;   // DestinationOffset
+    float t0, t1;       // TimeRange
+    int32_t moving;     // Entity.Moving
+    int32_t pad[2];
+};
+static_assert(sizeof(GpuMotion) == 32, "GpuMotion must be 32 bytes");
+
+enum : uint32_t {
+    MAT_FLAG_PERFECT_SPECULAR = 1u, // Material.IsPerfectSpecular (RT/Material.cs:181-196)
+};
+
+struct GpuMaterial {
+    float albedo[3];     // Albedo.SampleColor
+    float emission[3];   // Emission.SampleColor
+    int32_t type;        // RtowMaterialType
+    float metallic;      // Metallic.SampleScalar
+    float glossiness;    // Glossiness.SampleScalar
+    float parameter;     // IndexOfRefraction / Density
+    uint32_t flags;
+    int32_t pad;
+};
+static_assert(sizeof(GpuMaterial) == 48, "GpuMaterial must be 48 bytes");
+
+// Byte offsets of the sections inside the scene blob (all multiples of 16).
+struct SceneLayout {
+    uint32_t nodeOffset, nodeCount;         // GpuNode[nodeCount]
+    uint32_t sphereOffset, sphereCount;     // GpuSphere[sphereCount]
+    uint32_t motionOffset, hasMotion;       // GpuMotion[sphereCount] when hasMotion
+    uint32_t matIndexOffset;                // uint32 materialIndex[sphereCount]
+    uint32_t materialOffset, materialCount; // GpuMaterial[materialCount]
+    uint32_t totalBytes;                    // size of the blob
+    uint32_t bvhDepth;                      // max number of inner nodes on a root->leaf path == stack bound
+    uint32_t pad;
+};
+
+} // namespace rtow
