@@ -1295,3 +1295,12 @@ ORACLE_API int oracle_kat_nearest_hit(void* scenePtr, const float* ro, const flo
     out[7] = (float)r.EntityPtr->SourceIndex;
     return (int)s.hitRecordBuffer.size();
 }
+
+/* sizeof() of every boundary struct as the C++ compiler sees include/rtow.h; tests compare them with the ctypes mirror. */
+ORACLE_API void oracle_abi_sizes(int* out)
+{
+    out[0] = (int)sizeof(RtowTexture); out[1] = (int)sizeof(RtowMaterial); out[2] = (int)sizeof(RtowEntity);
+    out[3] = (int)sizeof(RtowSceneDesc); out[4] = (int)sizeof(RtowSceneInfo); out[5] = (int)sizeof(RtowView);
+    out[6] = (int)sizeof(RtowEnvironment); out[7] = (int)sizeof(RtowSampleParams); out[8] = (int)sizeof(RtowAccumBuffers);
+    out[9] = (int)sizeof(RtowContextOptions); out[10] = (int)sizeof(RtowMetrics); out[11] = (int)sizeof(RtowCombineParams);
+}

@@ -1,0 +1,85 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/rtow.h declares, the
+ctypes mirror matches the C struct layouts, and - with no GPU - the product fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol(rt):
+    lib = rt.lib.load()
+    header = open(os.path.join(ROOT, "include", "rtow.h")).read()
+    declared = sorted(set(re.findall(r"RTOW_API\s+[\w\s\*]+?\b(rtow\w+)\s*\(", header)))
+    assert declared == sorted(rt.abi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.rtowGetApiVersion() == rt.abi.RTOW_API_VERSION
+    for code in (0, 1, 2, 3, 4, 5, 6, 7, 8, 99):
+        assert len(lib.rtowErrorString(code)) > 0
+
+
+def test_ctypes_mirror_matches_c_layout(rt, oracle):
+    sizes = (C.c_int * 12)()
+    oracle.load().oracle_abi_sizes(sizes)  # sizeof() as g++ sees include/rtow.h
+    a = rt.abi
+    mirror = [a.Texture, a.Material, a.Entity, a.SceneDesc, a.SceneInfo, a.View, a.Environment, a.SampleParams, a.AccumBuffers,
+              a.ContextOptions, a.Metrics, a.CombineParams]
+    assert [C.sizeof(t) for t in mirror] == list(sizes)
+    assert C.sizeof(a.View) == 88  # 7 x float3 + float (RT/View.cs:8-14)
+
+
+def test_product_does_not_import_or_link_the_oracle():
+    """Nothing under the product package may reference oracle/ (the oracle is test infrastructure)."""
+    pkg = os.path.join(ROOT, "raytracing-in-one-weekend_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "oracle/" not in text and "import oracle" not in text and "from oracle" not in text, f
+    import subprocess
+    out = subprocess.run(["ldd", rt_lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def rt_lib_path():
+    return os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc", "librtow_hip.so")
+
+
+def _gpu_present(rt):
+    h = C.c_void_p()
+    rc = rt.lib.load().rtowCreateContext(None, C.byref(h))
+    if rc == 0:
+        rt.lib.load().rtowDestroyContext(h)
+    return rc == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback(rt):
+    if _gpu_present(rt):
+        pytest.skip("GPU present: the no-device path cannot be exercised here")
+    h = C.c_void_p()
+    assert rt.lib.load().rtowCreateContext(None, C.byref(h)) == rt.abi.RTOW_ERROR_NO_DEVICE
+    with pytest.raises(rt.lib.RtowError) as e:
+        rt.Context(0)
+    assert e.value.code == rt.abi.RTOW_ERROR_NO_DEVICE
+
+
+def test_null_arguments_are_rejected_without_a_device(rt):
+    lib = rt.lib.load()
+    assert lib.rtowCreateContext(None, None) == rt.abi.RTOW_ERROR_INVALID_VALUE
+    assert lib.rtowDestroyContext(None) == rt.abi.RTOW_ERROR_INVALID_VALUE
+    assert lib.rtowUploadScene(None, None) == rt.abi.RTOW_ERROR_INVALID_VALUE
+    assert lib.rtowSampleBatch(None, None, None, None, None, None) == rt.abi.RTOW_ERROR_INVALID_VALUE
+    assert lib.rtowSynchronize(None) == rt.abi.RTOW_ERROR_INVALID_VALUE
+
+
+def test_missing_library_raises(rt, monkeypatch, tmp_path):
+    monkeypatch.setattr(rt.lib, "_lib", None)
+    monkeypatch.setattr(rt.lib, "LIB_PATH", str(tmp_path / "librtow_hip.so"))
+    with pytest.raises(FileNotFoundError):
+        rt.lib.load()

@@ -1,0 +1,217 @@
+"""GPU tests of the rest of the boundary: device-resident form, post passes, error behaviour, cancellation, big scenes."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(rt, ctx, arr):
+    return rt.DeviceBuffer(ctx).upload(arr)
+
+
+def test_device_resident_form_matches_host_form(rt, oracle, gpu_context):
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 80, 45
+    n = w * h
+    p = rt.scenes.make_params(scene, w, h, spp=4, trace_depth=8, diagnostics_stride=16)
+    host = rt.sample_batch_host(ctx, p)
+    ins = [rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)]
+    outs = [rt.DeviceBuffer(ctx, n * k * 4) for k in (4, 3, 3, 1)]
+    diag = rt.DeviceBuffer(ctx, n * 16)
+    job = rt.SampleBatchJob(ctx, p)
+    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = ins
+    job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = outs
+    job.OutputDiagnostics = diag
+    assert job.Schedule(n, 1).Complete() == 0
+    ctx.synchronize()
+    assert ctx.last_sample_kernel_ms() > 0
+    for key, buf, k in zip(("color", "normal", "albedo", "scw"), outs, (4, 3, 3, 1)):
+        got = buf.download(np.float32, (n, k) if k > 1 else (n,))
+        assert np.array_equal(got.view(np.uint32), host[key].view(np.uint32)), key
+    assert np.array_equal(diag.download(np.float32, (n, 4))[:, 0], host["diag"][:, 0])
+
+    # in-place accumulation (in == out) over two more batches equals ping-pong accumulation in the oracle
+    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = outs
+    ref = {k: host[k] for k in ("color", "normal", "albedo", "scw")}
+    osc = oracle.OracleScene(scene.desc())
+    for seed in (2, 3):
+        job.Seed = seed
+        assert job.Schedule().Complete() == 0
+        p2 = rt.scenes.make_params(scene, w, h, spp=4, trace_depth=8, seed=seed)
+        ref = osc.sample_batch(p2, {k: ref[k] for k in ("color", "normal", "albedo", "scw")})
+    osc.close()
+    ctx.synchronize()
+    got = outs[0].download(np.float32, (n, 4))
+    assert np.array_equal(got.view(np.uint32), ref["color"].view(np.uint32))
+
+    # post passes on the resident buffers
+    c3, n3, a3 = (rt.DeviceBuffer(ctx, n * 12) for _ in range(3))
+    cj = rt.CombineJob(ctx, (w, h), DebugMode=False, LdrAlbedo=True)
+    cj.InputColor, cj.InputNormal, cj.InputAlbedo = outs[0], outs[1], outs[2]
+    cj.OutputColor, cj.OutputNormal, cj.OutputAlbedo = c3, n3, a3
+    assert cj.Schedule().Complete() == 0
+    r8 = [rt.DeviceBuffer(ctx, n * 4) for _ in range(3)]
+    fj = rt.FinalizeTexturesJob(ctx, n)
+    fj.InputColor, fj.InputNormal, fj.InputAlbedo = c3, n3, a3
+    fj.OutputColor, fj.OutputNormal, fj.OutputAlbedo = r8
+    assert fj.Schedule().Complete() == 0
+    ctx.synchronize()
+    oc, on, oa = oracle.combine(w, h, ref["color"], outs[1].download(np.float32, (n, 3)), outs[2].download(np.float32, (n, 3)), False, True)
+    assert np.array_equal(c3.download(np.float32, (n, 3)).view(np.uint32), oc.view(np.uint32))
+    assert np.array_equal(n3.download(np.float32, (n, 3)).view(np.uint32), on.view(np.uint32))
+    assert np.array_equal(a3.download(np.float32, (n, 3)).view(np.uint32), oa.view(np.uint32))
+    fc, fn, fa = oracle.finalize(oc, on, oa)
+    assert np.array_equal(r8[0].download(np.uint8, (n, 4)), fc)
+    assert np.array_equal(r8[1].download(np.uint8, (n, 4)), fn)
+    assert np.array_equal(r8[2].download(np.uint8, (n, 4)), fa)
+
+    rj = rt.ReduceMetricsJob(ctx, n, 16)
+    rj.Diagnostics, rj.AccumulatedColor, rj.AccumulatedSampleCountWeight = diag, outs[0], outs[3]
+    assert rj.Schedule().Complete() == 0
+    m = oracle.reduce_metrics(diag.download(np.float32, (n, 4)), ref["color"], outs[3].download(np.float32, (n,)))
+    assert (rj.TotalRayCount, rj.TotalSamples) == (m.totalRayCount, m.totalSamples)
+    assert rj.SampleCountExtrema == (m.sampleCountExtrema[0], m.sampleCountExtrema[1])
+    assert rj.SampleCountWeightExtrema == (m.sampleCountWeightExtrema.x, m.sampleCountWeightExtrema.y)
+
+
+def test_combine_interlace_lookaround_and_debug_colours(rt, oracle, gpu_context):
+    ctx = gpu_context
+    rng = np.random.default_rng(0)
+    w, h = 40, 30
+    n = w * h
+    color = np.concatenate([rng.uniform(0, 40, (n, 3)), rng.integers(0, 6, (n, 1))], axis=1).astype(np.float32)
+    color[np.repeat(np.arange(h) % 3 != 0, w), 3] = 0      # interlaced buffer: two of three rows have no samples yet
+    color[7, 1] = np.nan
+    normal = rng.normal(size=(n, 3)).astype(np.float32)
+    albedo = rng.uniform(0, 3, (n, 3)).astype(np.float32)
+    for debug in (False, True):
+        ins = [_dev(rt, ctx, a) for a in (color, normal, albedo)]
+        outs = [rt.DeviceBuffer(ctx, n * 12) for _ in range(3)]
+        cj = rt.CombineJob(ctx, (w, h), DebugMode=debug)
+        cj.InputColor, cj.InputNormal, cj.InputAlbedo = ins
+        cj.OutputColor, cj.OutputNormal, cj.OutputAlbedo = outs
+        assert cj.Schedule().Complete() == 0
+        ctx.synchronize()
+        want = oracle.combine(w, h, color, normal, albedo, debug, False)
+        for o, wv in zip(outs, want):
+            assert np.array_equal(o.download(np.float32, (n, 3)).view(np.uint32), wv.view(np.uint32))
+
+
+def test_error_codes(rt, gpu_context):
+    lib = rt.lib.load()
+    a = rt.abi
+    fresh = rt.Context(0)
+    scene = rt.scenes.tiny_scene()
+    p = rt.scenes.make_params(scene, 8, 8, spp=1, trace_depth=4)
+    z = {k: np.zeros((64, c), np.float32) for k, c in (("color", 4), ("normal", 3), ("albedo", 3))}
+    z["scw"] = np.zeros(64, np.float32)
+    with pytest.raises(rt.lib.RtowError) as e:
+        rt.sample_batch_host(fresh, p, z)
+    assert e.value.code == a.RTOW_ERROR_NO_SCENE
+    info = a.SceneInfo()
+    assert lib.rtowGetSceneInfo(fresh.handle, C.byref(info)) == a.RTOW_ERROR_NO_SCENE
+
+    fresh.upload_scene(scene.desc())
+    for field, value, code in (("traceDepth", 0, a.RTOW_ERROR_INVALID_VALUE), ("traceDepth", 65, a.RTOW_ERROR_CAPACITY),
+                               ("sliceDivider", 0, a.RTOW_ERROR_INVALID_VALUE), ("noiseColor", a.NOISE_BLUE, a.RTOW_ERROR_UNSUPPORTED),
+                               ("diagnosticsStride", 8, a.RTOW_ERROR_INVALID_VALUE)):
+        q = rt.scenes.make_params(scene, 8, 8, spp=1, trace_depth=4)
+        setattr(q, field, value)
+        with pytest.raises(rt.lib.RtowError) as e:
+            rt.sample_batch_host(fresh, q, z)
+        assert e.value.code == code, field
+
+    bad = scene.desc()
+    bad.entities[0].type = a.ENTITY_BOX
+    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_UNSUPPORTED
+    bad = scene.desc()
+    bad.entities[0].materialIndex = 99
+    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE
+    bad = scene.desc()
+    bad.materials[0].type = a.MATERIAL_PROBABILISTIC_VOLUME
+    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_UNSUPPORTED
+    # a failed upload leaves the previous scene usable
+    out = rt.sample_batch_host(fresh, p, z)
+    assert out["color"][:, 3].sum() > 0
+    fresh.close()
+
+
+def test_cancellation_token(rt, gpu_context):
+    """NativeReference<bool> CancellationToken (JOBS/SampleBatchJob.cs:23,61-62): set mid-batch -> RTOW_ERROR_CANCELLED, promptly."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 1920, 1080
+    n = w * h
+    p = rt.scenes.make_params(scene, w, h, spp=2048, trace_depth=8)     # ~1.4 s of GPU work if not cancelled
+    bufs = [rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)]
+    job = rt.SampleBatchJob(ctx, p)
+    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = bufs
+    job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = bufs
+    token = C.c_uint8(0)
+    job.CancellationToken = token
+    threading.Timer(0.05, lambda: setattr(token, "value", 1)).start()
+    t = time.perf_counter()
+    rc = job.Schedule().Complete()
+    dt = time.perf_counter() - t
+    assert rc == rt.abi.RTOW_ERROR_CANCELLED
+    full = None
+    token.value = 0
+    t = time.perf_counter()
+    assert job.Schedule().Complete() == 0
+    full = time.perf_counter() - t
+    assert dt < 0.6 * full, "cancelled batch took %.3f s, a full one %.3f s" % (dt, full)
+
+
+def test_stress_scene_too_large_for_lds(rt, oracle, gpu_context):
+    """BASELINE.json configs[3] at a reduced size: a scene whose image exceeds LDS (BVH top levels staged, rest through L2)."""
+    ctx = gpu_context
+    scene = rt.scenes.stress_scene(count=3000, max_tentatives=12000)
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    info = ctx.scene_info()
+    assert info.sceneInLds == 0 and info.bvhNodeCount == scene.entity_count - 1 and 0 < info.ldsBytesScene < info.sceneBytesDevice
+    p = rt.scenes.make_params(scene, 96, 54, spp=4, trace_depth=8)
+    gpu = rt.sample_batch_host(ctx, p)
+    osc = oracle.OracleScene(desc)
+    ref = osc.sample_batch(p)
+    osc.close()
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), k
+    assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0])
+
+
+def test_deep_trace_depths_use_wider_history(rt, oracle, gpu_context):
+    ctx = gpu_context
+    scene = rt.scenes.tiny_scene()
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    osc = oracle.OracleScene(desc)
+    for depth in (9, 16, 17, 33, 64):
+        p = rt.scenes.make_params(scene, 48, 27, spp=3, trace_depth=depth)
+        gpu = rt.sample_batch_host(ctx, p)
+        ref = osc.sample_batch(p)
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (depth, k)
+    osc.close()
+
+
+def test_single_sphere_scene(rt, oracle, gpu_context):
+    scene = rt.scenes.Scene("one")
+    scene.add_sphere((0, 0, -3), 1.0, rt.scenes.lambertian((0.7, 0.3, 0.3)))
+    scene.camera = {"position": [0, 0, 0], "target": [0, 0, -1], "up": [0, 1, 0], "vfov": 60.0, "aperture": 0.0}
+    desc = scene.desc()
+    gpu_context.upload_scene(desc)
+    p = rt.scenes.make_params(scene, 32, 32, spp=4, trace_depth=5)
+    gpu = rt.sample_batch_host(gpu_context, p)
+    osc = oracle.OracleScene(desc)
+    ref = osc.sample_batch(p)
+    osc.close()
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), k
