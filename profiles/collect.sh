@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   gpurun -- 'bash profiles/collect.sh r01'
+# Pass 1: --kernel-trace --stats (per-kernel time).  Passes 2..: one --pmc run each (counters are never combined
+# with tracing domains; FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# Raw output goes to gpurun_out/prof_<tag>/ (scratch); profiles/summarize.py turns it into the committed summary.
+TAG=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+ONE="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $ONE > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $ONE > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq1 -o bench -- $ONE > $OUT/pmc_sq1.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq2 -o bench -- $ONE > $OUT/pmc_sq2.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq3 -o bench -- $ONE > $OUT/pmc_sq3.log 2>&1
+grep -h '^{' $OUT/*.log | tail -1 > $OUT/bench_line.json
+find $OUT -name '*.csv' | head -40

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (raw rocprofv3 CSV) into the committed profiles/<tag>_* summary files.
+
+  python profiles/summarize.py r01
+writes profiles/<tag>_kernel_stats.csv   (the rocprofv3 --kernel-trace --stats kernel table, verbatim)
+       profiles/<tag>_pmc_summary.json   (per-launch counter sums for sample_batch_kernel + derived figures)
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
+KERNEL = "sample_batch_kernel"
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    stats = find("trace/**/*kernel_stats.csv")
+    if stats:
+        shutil.copy(stats, os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv"))
+    summary = {"tag": TAG, "kernel": KERNEL, "counters_per_launch": {}}
+    if stats:
+        for row in csv.DictReader(open(stats)):
+            if KERNEL in row["Name"]:
+                summary["kernel_trace"] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "total_ns": float(row["TotalDurationNs"]),
+                                           "percentage": float(row["Percentage"])}
+    trace = find("trace/**/*kernel_trace.csv")
+    if trace:
+        for row in csv.DictReader(open(trace)):
+            if KERNEL in row["Kernel_Name"]:
+                summary["dispatch"] = {k: row[k] for k in ("Kernel_Name", "Workgroup_Size_X", "Grid_Size_X", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
+                break
+    for f in glob.glob(os.path.join(SRC, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        sums, launches = {}, set()
+        for row in csv.DictReader(open(f)):
+            if KERNEL in row["Kernel_Name"]:
+                sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                launches.add(row["Dispatch_Id"])
+        for k, v in sums.items():
+            summary["counters_per_launch"][k] = v / max(len(launches), 1)
+    c = summary["counters_per_launch"]
+    d = {}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced stream
+        # (MI355X_MICROARCH.md "HBM"), so the read side is doubled as that guide prescribes (upper bound for narrow reads).
+        d["hbm_read_bytes_corrected"] = c["FETCH_SIZE"] * 1024 * 2
+        d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+        d["hbm_traffic_bytes"] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+        d["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64)
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8  # 8 XCDs
+        d["gpu_cycles_per_launch"] = cycles
+        d["valu_issue_utilisation"] = c["SQ_INSTS_VALU"] * 2 / (cycles * 1024)  # wave64 on SIMD32: 2 cycles/instr, 1024 SIMDs
+    if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
+        d["lds_busy_fraction"] = c["SQ_LDS_IDX_ACTIVE"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256)
+    if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:
+        d["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    summary["derived"] = d
+    bl = os.path.join(SRC, "bench_line.json")
+    if os.path.exists(bl) and os.path.getsize(bl):
+        summary["bench_line_under_profiler"] = json.loads(open(bl).read())
+    json.dump(summary, open(os.path.join(ROOT, "profiles", TAG + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(summary["derived"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
