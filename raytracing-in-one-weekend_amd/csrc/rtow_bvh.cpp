@@ -114,6 +114,12 @@ bool almostOne(float v) { return std::fabs(1.0f - v) < 1e-6f; } // UTIL/MathExte
 
 uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
+void setBoxes(GpuNode& g, const Box& b0, const Box& b1)
+{
+    g.lox[0] = b0.lo[0]; g.lox[1] = b1.lo[0]; g.loy[0] = b0.lo[1]; g.loy[1] = b1.lo[1]; g.loz[0] = b0.lo[2]; g.loz[1] = b1.lo[2];
+    g.hix[0] = b0.hi[0]; g.hix[1] = b1.hi[0]; g.hiy[0] = b0.hi[1]; g.hiy[1] = b1.hi[1]; g.hiz[0] = b0.hi[2]; g.hiz[1] = b1.hi[2];
+}
+
 } // namespace
 
 int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, std::string* err)
@@ -218,7 +224,9 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     int depthSeen = 0;
     if (n == 1) {
         GpuNode g{};
-        for (int a = 0; a < 3; a++) { g.lo0[a] = b.primBox[0].lo[a]; g.hi0[a] = b.primBox[0].hi[a]; g.lo1[a] = FLT_MAX; g.hi1[a] = -FLT_MAX; }
+        Box empty;
+        empty.reset(); // lo = +FLT_MAX, hi = -FLT_MAX: never hit
+        setBoxes(g, b.primBox[0], empty);
         g.child0 = ~0; g.child1 = ~0;
         gnodes.push_back(g);
         depthSeen = 1;
@@ -242,10 +250,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         for (size_t i = 0; i < bfs.size(); i++) {
             const TmpNode& t = b.nodes[bfs[i]];
             GpuNode g{};
-            for (int a = 0; a < 3; a++) {
-                g.lo0[a] = t.box[0].lo[a]; g.hi0[a] = t.box[0].hi[a];
-                g.lo1[a] = t.box[1].lo[a]; g.hi1[a] = t.box[1].hi[a];
-            }
+            setBoxes(g, t.box[0], t.box[1]);
             g.child0 = t.child[0] >= 0 ? newIndex[t.child[0]] : t.child[0];
             g.child1 = t.child[1] >= 0 ? newIndex[t.child[1]] : t.child[1];
             gnodes[i] = g;

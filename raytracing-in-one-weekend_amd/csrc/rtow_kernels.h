@@ -12,7 +12,8 @@ namespace rtow {
 // One persistent workgroup per CU: 1024 lanes (16 wavefronts, 4 per SIMD, <= 128 VGPRs) share one LDS image of the scene.
 constexpr int kBlockThreads = 1024;
 constexpr int kLdsBytesMax = 160 * 1024;
-constexpr int kStackBytes = RTOW_STACK_CAPACITY * kBlockThreads * 2; // 16-bit entries, [level][lane]
+constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting their exact test (flushed when full)
+constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane]
 
 // Everything the sample kernel needs, passed by value (kernarg segment).
 struct SampleKernelArgs {

@@ -198,74 +198,76 @@ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, f
     return false;
 }
 
-__device__ __forceinline__ void slab(float4 qa, float4 qb, bool second, V3 o, V3 inv, float best, float& tmin, float& tmax)
-{
-    // second == false: box0 = (qa.x qa.y qa.z | qa.w qb.x qb.y); second == true is handled by the caller's argument shuffle
-    (void)second;
-    const float t0x = (qa.x - o.x) * inv.x, t1x = (qa.w - o.x) * inv.x;
-    const float t0y = (qa.y - o.y) * inv.y, t1y = (qb.x - o.y) * inv.y;
-    const float t0z = (qa.z - o.z) * inv.z, t1z = (qb.y - o.z) * inv.z;
-    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
-    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fminf(__builtin_fmaxf(t0z, t1z), best));
-}
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Closest hit of one ray.  Replaces FindHitCandidates + FindHits + "take hit[0]" (JOBS/SampleBatchJob.cs:403-475,205-209).
+//
+// Two alternating phases, like the reference's own split into FindHitCandidates / FindHits, so that the cheap box walk
+// and the expensive exact sphere test (IEEE sqrt + divide) each run in a tight loop of their own instead of the sphere
+// code being dragged through every box iteration by whichever lane happens to sit on a leaf:
+//   A  walk inner nodes (both child boxes per 64-byte node, tested as packed pairs); children that are leaves are
+//      appended to a small per-lane candidate list in LDS; stops when the node stack is empty or the list is full;
+//   B  exact sphere tests of the listed candidates, nearest t kept; phase A then resumes with that t as a prune bound.
+// `stack` = this lane's column of the [level][lane] uint16 LDS array: levels [0, RTOW_STACK_CAPACITY) hold inner nodes,
+// levels [RTOW_STACK_CAPACITY, +kCandCapacity) hold candidates.
 template <bool ALL_LDS, bool HAS_MOTION>
 __device__ __forceinline__ void closest_hit(const SceneRefs& sc, const SceneLayout& L, unsigned short* stack /* + lane */, V3 o, V3 d, float time,
                                             float& bestT, int& bestPrim, float& boundsHits, float& candidates)
 {
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f2 invx = {1.0f / d.x, 1.0f / d.x}, invy = {1.0f / d.y, 1.0f / d.y}, invz = {1.0f / d.z, 1.0f / d.z};
+    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const float a = dot(d, d);
     float best = __builtin_inff();
     int prim = -1;
-    int sp = 0;
-    int cur = 0;
+    int sp = 0;       // inner-node stack height
+    int nc = 0;       // candidates listed
+    int cur = 0;      // node to visit, -1 = walk finished
+    unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;
     for (;;) {
-        float4 q0, q1, q2;
-        int c0, c1;
-        load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
-        float tmin0, tmax0, tmin1, tmax1;
-        slab(q0, q1, false, o, inv, best, tmin0, tmax0);
-        // box1 = (q1.z q1.w q2.x | q2.y q2.z q2.w)
-        slab(make_float4(q1.z, q1.w, q2.x, q2.y), make_float4(q2.z, q2.w, 0.f, 0.f), true, o, inv, best, tmin1, tmax1);
-        bool hit0 = tmin0 <= tmax0;
-        bool hit1 = tmin1 <= tmax1;
-        boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
-
-        if (hit0 && c0 < 0) {
-            const int i = ~c0;
-            V3 c; float r, t;
-            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, time, c, r);
-            candidates += 1.0f;
-            if (sphere_hit(sub(o, c), d, a, r, t) && t < best) { best = t; prim = i; }
-            hit0 = false;
-        }
-        if (hit1 && c1 < 0) {
-            const int i = ~c1;
-            V3 c; float r, t;
-            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, time, c, r);
-            candidates += 1.0f;
-            if (sphere_hit(sub(o, c), d, a, r, t) && t < best) { best = t; prim = i; }
-            hit1 = false;
-        }
-        hit0 = hit0 && tmin0 <= best;
-        hit1 = hit1 && tmin1 <= best;
-        if (hit0 || hit1) {
-            if (hit0 && hit1) {
-                const bool swap = tmin1 < tmin0;
-                const int nearC = swap ? c1 : c0;
-                const int farC = swap ? c0 : c1;
-                stack[sp * kBlockThreads] = (unsigned short)farC;
+        // ---- phase A: boxes ----
+        while (cur >= 0 && nc <= kCandCapacity - 2) {
+            float4 q0, q1, q2;
+            int c0, c1;
+            load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
+            // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
+            const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
+            const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
+            const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
+            const float tmin0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tlx.x, thx.x), __builtin_fminf(tly.x, thy.x)), __builtin_fmaxf(__builtin_fminf(tlz.x, thz.x), 0.0f));
+            const float tmax0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tlx.x, thx.x), __builtin_fmaxf(tly.x, thy.x)), __builtin_fminf(__builtin_fmaxf(tlz.x, thz.x), best));
+            const float tmin1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tlx.y, thx.y), __builtin_fminf(tly.y, thy.y)), __builtin_fmaxf(__builtin_fminf(tlz.y, thz.y), 0.0f));
+            const float tmax1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tlx.y, thx.y), __builtin_fmaxf(tly.y, thy.y)), __builtin_fminf(__builtin_fmaxf(tlz.y, thz.y), best));
+            const bool hit0 = tmin0 <= tmax0;
+            const bool hit1 = tmin1 <= tmax1;
+            boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
+            if (hit0 && c0 < 0) { cand[nc * kBlockThreads] = (unsigned short)~c0; nc++; }
+            if (hit1 && c1 < 0) { cand[nc * kBlockThreads] = (unsigned short)~c1; nc++; }
+            const bool in0 = hit0 && c0 >= 0;
+            const bool in1 = hit1 && c1 >= 0;
+            if (in0 && in1) {
+                const bool swap = tmin1 < tmin0;                    // near child first
+                stack[sp * kBlockThreads] = (unsigned short)(swap ? c0 : c1);
                 sp++;
-                cur = nearC;
+                cur = swap ? c1 : c0;
+            } else if (in0 || in1) {
+                cur = in0 ? c0 : c1;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack[sp * kBlockThreads];
             } else {
-                cur = hit0 ? c0 : c1;
+                cur = -1;
             }
-        } else {
-            if (sp == 0) break;
-            sp--;
-            cur = stack[sp * kBlockThreads];
         }
+        // ---- phase B: exact sphere tests ----
+        candidates += (float)nc;
+        while (nc > 0) {
+            nc--;
+            const int i = cand[nc * kBlockThreads];
+            V3 c; float r, t;
+            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, time, c, r);
+            if (sphere_hit(sub(o, c), d, a, r, t) && t < best) { best = t; prim = i; }
+        }
+        if (cur < 0) break;
     }
     bestT = best;
     bestPrim = prim;

@@ -20,9 +20,11 @@
 namespace rtow {
 
 struct GpuNode {
-    // q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)  q3 = (c0 c1 - -)
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
+    // bounds interleaved as (child0, child1) pairs so both boxes are tested with packed fp32 math:
+    // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z)  q3 = (c0 c1 - -)
+    float lox[2], loy[2];
+    float loz[2], hix[2];
+    float hiy[2], hiz[2];
     int32_t child0, child1;
     int32_t pad[2];
 };
