@@ -20,6 +20,12 @@
 #include "rtow_bvh.h"
 #include "rtow_kernels.h"
 
+// minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: any
+// threshold above 1 loses (waiting lanes cost more than the skipped stage saves); slicing the walk at 16 wins ~5 %.
+#ifndef RTOW_DEFAULT_TUNE
+#define RTOW_DEFAULT_TUNE 1, 1, 1, 1, 1, 1, 1, 1, 16
+#endif
+
 using namespace rtow;
 
 struct RtowContext_t {
@@ -124,6 +130,23 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.extremaX = p->sampleCountWeightExtrema.x;
     a.extremaY = p->sampleCountWeightExtrema.y;
 
+    // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice; RTOW_TUNE overrides for experiments
+    static const int kDefaultTune[9] = {RTOW_DEFAULT_TUNE};
+    int tune[9];
+    memcpy(tune, kDefaultTune, sizeof(tune));
+    if (const char* env = getenv("RTOW_TUNE")) {
+        int v[9];
+        if (sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[8]) == 8) { v[7] = 1; memcpy(tune, v, sizeof(tune)); }
+    }
+    for (int i = 0; i < 8; i++) a.tune[i] = tune[i] < 1 ? 1 : tune[i];
+    a.travSlice = tune[8] < 1 ? 1 : tune[8];
+    a.stats = nullptr;
+#ifdef RTOW_STATS
+    static unsigned long long* dStats = nullptr;
+    if (!dStats) (void)hipMalloc(&dStats, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dStats, 0, 16 * sizeof(unsigned long long), stream);
+    a.stats = dStats;
+#endif
     HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
     int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
@@ -131,6 +154,16 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     HIP_TRY(ctx, hipEventRecord(ctx->evStart, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
+#ifdef RTOW_STATS
+    {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, a.stats, sizeof(h), hipMemcpyDeviceToHost);
+        static const char* names[16] = {"trips*64", "regen runs*64", "regen lanes", "walk iters", "walk lanes", "test iters", "test lanes", "hit runs*64", "hit lanes",
+                                        "lambert runs", "lambert lanes", "general runs", "general lanes", "diel runs", "diel lanes", "sky runs*lanes"};
+        for (int i = 0; i < 16; i++) fprintf(stderr, "[stats] %-16s %llu\n", names[i], h[i]);
+    }
+#endif
     ctx->haveTiming = true;
     return RTOW_SUCCESS;
 }
@@ -271,6 +304,8 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         ctx->dSceneCapacity = compiled.blob.size();
     }
     HIP_TRY(ctx, hipMemcpy(ctx->dScene, compiled.blob.data(), compiled.blob.size(), hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     ctx->scene = std::move(compiled);
     const uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes);
     if (ctx->scene.layout.totalBytes <= budget) {

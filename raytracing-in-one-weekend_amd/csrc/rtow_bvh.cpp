@@ -142,6 +142,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
 
     // ---- materials (RT/Material.cs:28-46, constant textures folded) ----
     std::vector<GpuMaterial> mats(desc->materialCount);
+    std::vector<uint32_t> matClass(desc->materialCount);
     for (int i = 0; i < desc->materialCount; i++) {
         const RtowMaterial& m = desc->materials[i];
         if (m.type != RTOW_MATERIAL_STANDARD && m.type != RTOW_MATERIAL_DIELECTRIC) {
@@ -166,6 +167,8 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
                     almostOne(m.glossiness.mainColor.y) && almostOne(m.glossiness.mainColor.z); // :190-192
         if (spec) g.flags |= MAT_FLAG_PERFECT_SPECULAR;
         mats[i] = g;
+        matClass[i] = m.type == RTOW_MATERIAL_DIELECTRIC ? MAT_CLASS_DIELECTRIC
+                      : (g.glossiness == 0.0f && g.metallic == 0.0f) ? MAT_CLASS_LAMBERT : MAT_CLASS_GENERAL;
     }
 
     // ---- entities -> spheres ----
@@ -196,7 +199,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         }
         spheres[i] = GpuSphere{e.position.x, e.position.y, e.position.z, e.size.x};
         motion[i] = GpuMotion{e.destinationOffset.x, e.destinationOffset.y, e.destinationOffset.z, e.timeRange.x, e.timeRange.y, e.moving ? 1 : 0, {0, 0}};
-        matIndex[i] = (uint32_t)e.materialIndex;
+        matIndex[i] = (uint32_t)e.materialIndex | (matClass[e.materialIndex] << 16);
         hasMotion |= e.moving != 0;
 
         // world bounds (UNITY/BvhNodeData.cs:23-81): |radius| box, union of start/end positions when moving,

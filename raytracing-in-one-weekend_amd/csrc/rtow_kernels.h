@@ -12,6 +12,9 @@ namespace rtow {
 // One persistent workgroup per CU: 1024 lanes (16 wavefronts, 4 per SIMD, <= 128 VGPRs) share one LDS image of the scene.
 constexpr int kBlockThreads = 1024;
 constexpr int kLdsBytesMax = 160 * 1024;
+#ifndef RTOW_TRAV_SLICE
+#define RTOW_TRAV_SLICE 8   // box-walk node visits per scheduler trip
+#endif
 constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting their exact test (flushed when full)
 constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane]
 
@@ -51,6 +54,11 @@ struct SampleKernelArgs {
     int32_t traceDepth;
     int32_t subPixelJitter;
     float extremaX, extremaY;
+
+    // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice
+    int32_t tune[8];
+    int32_t travSlice;
+    unsigned long long* stats; // development statistics (RTOW_STATS builds only), may be null
 };
 
 struct KernelInfo {
@@ -61,6 +69,7 @@ struct KernelInfo {
 
 // launchers (defined in rtow_kernels.hip)
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
+hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
                          float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream);
 hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,

@@ -101,14 +101,6 @@ __device__ __forceinline__ V3 cosine_hemisphere(unsigned& rng, V3 n)
     return normalize(r);
 }
 
-// Material.Schlick (RT/Material.cs:212-217)
-__device__ __forceinline__ float schlick(float cosine, float ior)
-{
-    float r0 = (1 - ior) / (1 + ior);
-    r0 *= r0;
-    return r0 + (1 - r0) * det_pow5(1 - cosine);
-}
-
 // Microfacet.TrowbridgeReitz.RoughnessToAlpha / Lambda, SmithMaskingShadowing (RT/Microfacet.cs:9-12,53-80)
 __device__ __forceinline__ float roughness_to_alpha(float roughness)
 {
@@ -116,7 +108,7 @@ __device__ __forceinline__ float roughness_to_alpha(float roughness)
     const float x = det_log(roughness);
     return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
 }
-__device__ __forceinline__ float smith_g1(V3 w, V3 n, float roughness)
+__device__ __forceinline__ float smith_g1(V3 w, V3 n, float alpha /* = RoughnessToAlpha(roughness), per material */)
 {
     const float cosTheta = dot(n, w);
     const float sqCos = cosTheta * cosTheta;
@@ -128,7 +120,6 @@ __device__ __forceinline__ float smith_g1(V3 w, V3 n, float roughness)
     if (__builtin_isinf(absTan)) {
         lambda = 0;
     } else {
-        const float alpha = roughness_to_alpha(roughness);
         const float a2t2 = (alpha * absTan) * (alpha * absTan);
         lambda = (-1 + __builtin_sqrtf(1 + a2t2)) / 2;
     }
@@ -200,113 +191,90 @@ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, f
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Closest hit of one ray.  Replaces FindHitCandidates + FindHits + "take hit[0]" (JOBS/SampleBatchJob.cs:403-475,205-209).
-//
-// Two alternating phases, like the reference's own split into FindHitCandidates / FindHits, so that the cheap box walk
-// and the expensive exact sphere test (IEEE sqrt + divide) each run in a tight loop of their own instead of the sphere
-// code being dragged through every box iteration by whichever lane happens to sit on a leaf:
-//   A  walk inner nodes (both child boxes per 64-byte node, tested as packed pairs); children that are leaves are
-//      appended to a small per-lane candidate list in LDS; stops when the node stack is empty or the list is full;
-//   B  exact sphere tests of the listed candidates, nearest t kept; phase A then resumes with that t as a prune bound.
-// `stack` = this lane's column of the [level][lane] uint16 LDS array: levels [0, RTOW_STACK_CAPACITY) hold inner nodes,
-// levels [RTOW_STACK_CAPACITY, +kCandCapacity) hold candidates.
-template <bool ALL_LDS, bool HAS_MOTION>
-__device__ __forceinline__ void closest_hit(const SceneRefs& sc, const SceneLayout& L, unsigned short* stack /* + lane */, V3 o, V3 d, float time,
-                                            float& bestT, int& bestPrim, float& boundsHits, float& candidates)
-{
-    const f2 invx = {1.0f / d.x, 1.0f / d.x}, invy = {1.0f / d.y, 1.0f / d.y}, invz = {1.0f / d.z, 1.0f / d.z};
-    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const float a = dot(d, d);
-    float best = __builtin_inff();
-    int prim = -1;
-    int sp = 0;       // inner-node stack height
-    int nc = 0;       // candidates listed
-    int cur = 0;      // node to visit, -1 = walk finished
-    unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;
-    for (;;) {
-        // ---- phase A: boxes ----
-        while (cur >= 0 && nc <= kCandCapacity - 2) {
-            float4 q0, q1, q2;
-            int c0, c1;
-            load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
-            // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
-            const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
-            const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
-            const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
-            const float tmin0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tlx.x, thx.x), __builtin_fminf(tly.x, thy.x)), __builtin_fmaxf(__builtin_fminf(tlz.x, thz.x), 0.0f));
-            const float tmax0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tlx.x, thx.x), __builtin_fmaxf(tly.x, thy.x)), __builtin_fminf(__builtin_fmaxf(tlz.x, thz.x), best));
-            const float tmin1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tlx.y, thx.y), __builtin_fminf(tly.y, thy.y)), __builtin_fmaxf(__builtin_fminf(tlz.y, thz.y), 0.0f));
-            const float tmax1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tlx.y, thx.y), __builtin_fmaxf(tly.y, thy.y)), __builtin_fminf(__builtin_fmaxf(tlz.y, thz.y), best));
-            const bool hit0 = tmin0 <= tmax0;
-            const bool hit1 = tmin1 <= tmax1;
-            boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
-            if (hit0 && c0 < 0) { cand[nc * kBlockThreads] = (unsigned short)~c0; nc++; }
-            if (hit1 && c1 < 0) { cand[nc * kBlockThreads] = (unsigned short)~c1; nc++; }
-            const bool in0 = hit0 && c0 >= 0;
-            const bool in1 = hit1 && c1 >= 0;
-            if (in0 && in1) {
-                const bool swap = tmin1 < tmin0;                    // near child first
-                stack[sp * kBlockThreads] = (unsigned short)(swap ? c0 : c1);
-                sp++;
-                cur = swap ? c1 : c0;
-            } else if (in0 || in1) {
-                cur = in0 ? c0 : c1;
-            } else if (sp > 0) {
-                sp--;
-                cur = stack[sp * kBlockThreads];
-            } else {
-                cur = -1;
-            }
-        }
-        // ---- phase B: exact sphere tests ----
-        candidates += (float)nc;
-        while (nc > 0) {
-            nc--;
-            const int i = cand[nc * kBlockThreads];
-            V3 c; float r, t;
-            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, time, c, r);
-            if (sphere_hit(sub(o, c), d, a, r, t) && t < best) { best = t; prim = i; }
-        }
-        if (cur < 0) break;
-    }
-    bestT = best;
-    bestPrim = prim;
-}
+// Raw VALU min/max (IEEE mode: a NaN operand yields the other operand).  __builtin_fminf/fmaxf would first canonicalise
+// both inputs (v_max_f32 x, x), which doubles the instruction count of the slab test for nothing.
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Development-only wave-level statistics (make stats -> librtow_hip_stats.so): how often each stage runs and with how
+// many lanes.  Compiled out of the product build.
+#ifdef RTOW_STATS
+#define STAT_DECL unsigned long long stat[16] = {0}
+#define STAT_ADD(i, v) stat[i] += (unsigned long long)(v)
+#define STAT_LANES(i) stat[i] += 1ull
+#else
+#define STAT_DECL
+#define STAT_ADD(i, v)
+#define STAT_LANES(i)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
-// path history: one 16-bit code per surface hit (bit 15 = "reflectance was overridden to 1", bits 0..14 = material)
+// path history: one 16-bit code per surface hit (bit 15 = "reflectance was overridden to 1", bits 0..14 = material).
+// The reference keeps float3 emission / attenuation stacks (JOBS/SampleBatchJob.cs:103-104,311,330) and folds them
+// tail -> head (:384-396); the codes are re-expanded at the fold, which reproduces the fold order bit for bit.
+// Depth <= 8 and <= 16 keep the codes in named 64-bit registers (an indexed array would be demoted to scratch).
 // ------------------------------------------------------------------------------------------------------------
-template <int HW>
-__device__ __forceinline__ void hist_set(unsigned (&h)[HW], int depth, unsigned code)
-{
-    const int w = depth >> 1;
-    const unsigned sh = (unsigned)(depth & 1) * 16u;
-#pragma unroll
-    for (int i = 0; i < HW; i++)
-        if (i == w) h[i] |= code << sh;
-}
-template <int HW>
-__device__ __forceinline__ unsigned hist_get(const unsigned (&h)[HW], int depth)
-{
-    const int w = depth >> 1;
-    unsigned v = 0;
-#pragma unroll
-    for (int i = 0; i < HW; i++)
-        if (i == w) v = h[i];
-    return (v >> ((unsigned)(depth & 1) * 16u)) & 0xffffu;
-}
+template <int HW> struct Hist {
+    unsigned w[HW];
+    __device__ __forceinline__ void clear() { for (int i = 0; i < HW; i++) w[i] = 0; }
+    __device__ __forceinline__ void set(int depth, unsigned code) { w[depth >> 1] |= code << ((unsigned)(depth & 1) * 16u); }
+    __device__ __forceinline__ unsigned get(int depth) const { return (w[depth >> 1] >> ((unsigned)(depth & 1) * 16u)) & 0xffffu; }
+};
+template <> struct Hist<4> {
+    unsigned long long a, b;
+    __device__ __forceinline__ void clear() { a = 0; b = 0; }
+    __device__ __forceinline__ void set(int depth, unsigned code)
+    {
+        const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
+        if (depth < 4) a |= v; else b |= v;
+    }
+    __device__ __forceinline__ unsigned get(int depth) const { return (unsigned)((depth < 4 ? a : b) >> ((unsigned)(depth & 3) * 16u)) & 0xffffu; }
+};
+template <> struct Hist<8> {
+    unsigned long long a, b, c, d;
+    __device__ __forceinline__ void clear() { a = 0; b = 0; c = 0; d = 0; }
+    __device__ __forceinline__ void set(int depth, unsigned code)
+    {
+        const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
+        const int q = depth >> 2;
+        if (q == 0) a |= v; else if (q == 1) b |= v; else if (q == 2) c |= v; else d |= v;
+    }
+    __device__ __forceinline__ unsigned get(int depth) const
+    {
+        const int q = depth >> 2;
+        const unsigned long long v = q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
+        return (unsigned)(v >> ((unsigned)(depth & 3) * 16u)) & 0xffffu;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------------------
 // the megakernel
 // ------------------------------------------------------------------------------------------------------------
-template <bool ALL_LDS, bool HAS_MOTION, int HW>
+// Lane states.  Every trip of the main loop the wavefront takes a population vote (__ballot + popcount per state) and
+// runs ONLY the stage with the most lanes waiting; the other lanes keep their state and wait.  Rare, expensive stages
+// (glass, rough metal) therefore execute with many lanes batched up instead of being dragged through every trip by
+// one straggler, and the box walk never waits for the slowest ray: this is what replaces per-bounce compaction.
+enum : int {
+    ST_REGEN = 0,    // needs its next sample (or next pixel)
+    ST_TRAV = 1,     // walking BVH boxes (resumable; at most A.travSlice node visits per trip)
+    ST_TEST = 2,     // has leaf candidates awaiting the exact sphere test
+    ST_HIT = 3,      // nearest hit known: shade
+    ST_SKY = 4,      // missed everything: sky + fold
+    ST_DEAD = 5,
+    ST_COUNT = 5
+};
+
+template <bool ALL_LDS, bool HAS_MOTION, int HW, bool FULL_DIAG>
 __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = (int)threadIdx.x;
 
     // ---- stage the scene image into LDS: coalesced 16 B per lane ----
-    unsigned short* const stackBase = reinterpret_cast<unsigned short*>(smem) + tid;
+    unsigned short* const stack = reinterpret_cast<unsigned short*>(smem) + tid;             // [level][lane] inner nodes
+    unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;                // [slot][lane] leaf candidates
     uint8_t* const ldsScene = smem + kStackBytes;
     {
         const uint4* src = reinterpret_cast<const uint4*>(A.sceneBlob);
@@ -321,17 +289,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     sc.glob = A.sceneBlob;
     sc.ldsNodeCount = A.ldsNodeCount;
     const SceneLayout L = A.layout;
-
-    const V3 viewOrigin = v3(A.view.origin), viewLLC = v3(A.view.lowerLeftCorner);
-    const V3 viewH = v3(A.view.horizontal), viewV = v3(A.view.vertical);
-    const V3 viewRight = v3(A.view.right), viewUp = v3(A.view.up);
-    const float lensRadius = A.view.lensRadius;
     const int traceDepth = A.traceDepth;
 
     // ---- per-lane persistent state ----
-    int pix = -1;               // current pixel index (global), -1 = none yet
-    bool alive = true;          // false once the ticket counter is exhausted
-    bool needRay = true;        // no active path
+    int st = ST_REGEN;
+    int pix = -1;
     unsigned rng = 0;
     unsigned smp = 0, nsamp = 0;
     int cx = 0, cy = 0;
@@ -344,149 +306,273 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     V3 ro = v3(0, 0, 0), rd = v3(0, 0, 1);
     float rtime = 0;
     int depth = 0;
-    unsigned hist[HW];
+    Hist<HW> hist;
+    hist.clear();
     V3 sampleNormal = v3(0, 0, 0), sampleAlbedo = v3(0, 0, 0);
     bool firstNonSpecular = false;
     float randomEventsLocal = 0;
 
+    // per-ray traversal state (resumable across trips)
+    V3 inv = v3(0, 0, 0);
+    int cur = 0, sp = 0, nc = 0, prim = -1;
+    float best = 0;
+
+    // end of a sample (JOBS/SampleBatchJob.cs:137-156)
+    auto endSample = [&](bool ok, V3 sampleColor) {
+        if (ok) {                                                                         // :145-149, :398
+            scwAcc += randomEventsLocal;
+            colorAcc = add(colorAcc, sampleColor);
+            normalAcc = add(normalAcc, sampleNormal);
+            albedoAcc = add(albedoAcc, sampleAlbedo);
+            sampleCount++;
+        } else if (smp == 0) {
+            // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
+            // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
+            A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
+            A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
+        }
+        smp++;
+        st = ST_REGEN;
+    };
+    // a new ray segment starts: reset the traversal state
+    auto startRay = [&]() {
+        inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        cur = 0; sp = 0; nc = 0; prim = -1;
+        best = __builtin_inff();
+        st = ST_TRAV;
+    };
+    // traversal finished: classify the result
+    auto classify = [&]() {
+        rayCount += 1.0f;                                                                  // :203
+        st = prim < 0 ? ST_SKY : ST_HIT;
+    };
+
+    int force = -1;
+    STAT_DECL;
     for (;;) {
-        // ================= 1. regenerate: next sample of this pixel, or next pixel =================
-        if (alive && needRay) {
-            while (smp >= nsamp) {
-                if (pix >= 0) {
-                    // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
-                    reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
-                    if (sampleCount != 0) {
-                        A.outNormal[3 * (size_t)pix + 0] = normalAcc.x; A.outNormal[3 * (size_t)pix + 1] = normalAcc.y; A.outNormal[3 * (size_t)pix + 2] = normalAcc.z;
-                        A.outAlbedo[3 * (size_t)pix + 0] = albedoAcc.x; A.outAlbedo[3 * (size_t)pix + 1] = albedoAcc.y; A.outAlbedo[3 * (size_t)pix + 2] = albedoAcc.z;
-                    } else if (nsamp == 0) {
-                        // no sample ran: the fallbacks keep their default (0) value (:115)
-                        A.outNormal[3 * (size_t)pix + 0] = 0; A.outNormal[3 * (size_t)pix + 1] = 0; A.outNormal[3 * (size_t)pix + 2] = 0;
-                        A.outAlbedo[3 * (size_t)pix + 0] = 0; A.outAlbedo[3 * (size_t)pix + 1] = 0; A.outAlbedo[3 * (size_t)pix + 2] = 0;
-                    } // else: sample 0's AOVs were stored as the fallback when that sample ended (:152-156,160-161)
-                    A.outScw[pix] = scwAcc;
-                    if (A.diagnostics) {
-                        if (A.diagnosticsStride >= 16)
-                            *reinterpret_cast<float4*>(A.diagnostics + (size_t)pix * (size_t)A.diagnosticsStride) = make_float4(rayCount, boundsHits, candidates, scw0);
-                        else
-                            *reinterpret_cast<float*>(A.diagnostics + (size_t)pix * (size_t)A.diagnosticsStride) = rayCount;
+        STAT_ADD(0, 1);
+        // Stages run in pipeline order; each one only if enough lanes wait in it (thresholds in A.tune), so a lane can
+        // still advance a whole path segment per trip when the wave is dense, while sparse stages batch up.
+        bool ran = false;
+        if ((int)__popcll(__ballot(st == ST_REGEN)) >= (force == ST_REGEN ? 1 : A.tune[0])) {
+            ran = true;
+            // ================= next sample of this pixel, or next pixel =================
+            STAT_ADD(1, 1);
+            if (st == ST_REGEN) {
+                STAT_LANES(2);
+                while (smp >= nsamp) {
+                    if (pix >= 0) {
+                        // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
+                        reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
+                        if (sampleCount != 0) {
+                            A.outNormal[3 * (size_t)pix + 0] = normalAcc.x; A.outNormal[3 * (size_t)pix + 1] = normalAcc.y; A.outNormal[3 * (size_t)pix + 2] = normalAcc.z;
+                            A.outAlbedo[3 * (size_t)pix + 0] = albedoAcc.x; A.outAlbedo[3 * (size_t)pix + 1] = albedoAcc.y; A.outAlbedo[3 * (size_t)pix + 2] = albedoAcc.z;
+                        } else if (nsamp == 0) {
+                            // no sample ran: the fallbacks keep their default (0) value (:115)
+                            A.outNormal[3 * (size_t)pix + 0] = 0; A.outNormal[3 * (size_t)pix + 1] = 0; A.outNormal[3 * (size_t)pix + 2] = 0;
+                            A.outAlbedo[3 * (size_t)pix + 0] = 0; A.outAlbedo[3 * (size_t)pix + 1] = 0; A.outAlbedo[3 * (size_t)pix + 2] = 0;
+                        } // else: sample 0 failed and its AOVs were stored as the fallback by endSample
+                        A.outScw[pix] = scwAcc;
+                        if (A.diagnostics) {
+                            if (FULL_DIAG)
+                                *reinterpret_cast<float4*>(A.diagnostics + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
+                            else
+                                *reinterpret_cast<float*>(A.diagnostics + (size_t)pix * 4u) = rayCount;
+                        }
+                        pix = -1;
                     }
-                    pix = -1;
+                    // ---- pull the next owned pixel (ticket counter; the compiler aggregates the atomic per wave) ----
+                    bool cancelled = false;
+                    if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
+                    const unsigned ticket = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
+                    if (ticket >= A.totalWork) { st = ST_DEAD; break; }
+                    const int ownedRow = (int)(ticket / (unsigned)A.width);
+                    cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
+                    cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
+                    pix = cy * A.width + cx;
+
+                    const float4 last = reinterpret_cast<const float4*>(A.inColor)[pix];                  // :72-78
+                    colorAcc = v3(last.x, last.y, last.z);
+                    normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
+                    albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
+                    scwAcc = A.inScw[pix];
+                    sampleCount = (int)last.w;
+
+                    // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
+                    rng = (A.seed * 0x8C4CA03Fu) ^ ((unsigned)pix * 0x7383ED49u);
+                    (void)rng_next(rng);
+
+                    // :118-126
+                    const float w = scwAcc / (float)sampleCount;
+                    if (w == 0) {
+                        nsamp = A.sampleCountMin;
+                    } else {
+                        const float nw = um_saturate((w - A.extremaX) / (A.extremaY - A.extremaX));
+                        const float lo = (float)A.sampleCountMin, hi = (float)A.sampleCountMax;
+                        nsamp = (unsigned)__builtin_rintf(lo + nw * (hi - lo));
+                    }
+                    scw0 = w;
+                    smp = 0;
+                    rayCount = 0; boundsHits = 0; candidates = 0;
                 }
-                // ---- pull the next owned pixel (ticket counter; the compiler aggregates this per wave) ----
-                bool cancelled = false;
-                if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
-                const unsigned ticket = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
-                if (ticket >= A.totalWork) { alive = false; break; }
-                const int ownedRow = (int)(ticket / (unsigned)A.width);
-                cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
-                cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
-                pix = cy * A.width + cx;
+                if (st != ST_DEAD) {
+                    // ---- camera ray (:134-135, RT/View.cs:38-48) ----
+                    const V3 viewRight = v3(A.view.right), viewUp = v3(A.view.up);
+                    const V3 viewLLC = v3(A.view.lowerLeftCorner), viewH = v3(A.view.horizontal), viewV = v3(A.view.vertical);
+                    const float lensRadius = A.view.lensRadius;
+                    float jx = 0.5f, jy = 0.5f;
+                    if (A.subPixelJitter) { jx = rng_next(rng); jy = rng_next(rng); }
+                    const float u = ((float)cx + jx) / A.sizeX;
+                    const float v = ((float)cy + jy) / A.sizeY;
+                    float rdx = 0, rdy = 0;
+                    if (lensRadius != 0) {
+                        // RandomSource.InUnitDisk (RT/RandomSource.cs:40-61): theta = NextFloat(0, 2*PI), radius = sqrt(NextFloat())
+                        const float theta = rng_next(rng) * (2.0f * kPi - 0.0f) + 0.0f;
+                        const float radius = __builtin_sqrtf(rng_next(rng));
+                        float sinT, cosT;
+                        det_sincos(theta, sinT, cosT);
+                        rdx = lensRadius * (radius * cosT);
+                        rdy = lensRadius * (radius * sinT);
+                    }
+                    const V3 offset = v3(viewRight.x * rdx + viewUp.x * rdy, viewRight.y * rdx + viewUp.y * rdy, viewRight.z * rdx + viewUp.z * rdy);
+                    ro = add(v3(A.view.origin), offset);
+                    rd = normalize(v3(viewLLC.x - offset.x + u * viewH.x + v * viewV.x,
+                                      viewLLC.y - offset.y + u * viewH.y + v * viewV.y,
+                                      viewLLC.z - offset.z + u * viewH.z + v * viewV.z));
+                    rtime = rng_next(rng);
 
-                const float4 last = reinterpret_cast<const float4*>(A.inColor)[pix];                  // :72-78
-                colorAcc = v3(last.x, last.y, last.z);
-                normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
-                albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
-                scwAcc = A.inScw[pix];
-                sampleCount = (int)last.w;
-
-                // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
-                rng = (A.seed * 0x8C4CA03Fu) ^ ((unsigned)pix * 0x7383ED49u);
-                (void)rng_next(rng);
-
-                // :118-126
-                const float w = scwAcc / (float)sampleCount;
-                if (w == 0) {
-                    nsamp = A.sampleCountMin;
-                } else {
-                    const float nw = um_saturate((w - A.extremaX) / (A.extremaY - A.extremaX));
-                    const float lo = (float)A.sampleCountMin, hi = (float)A.sampleCountMax;
-                    nsamp = (unsigned)__builtin_rintf(lo + nw * (hi - lo));
+                    depth = 0;
+                    hist.clear();
+                    sampleNormal = v3(0, 0, 0);
+                    sampleAlbedo = v3(0, 0, 0);
+                    firstNonSpecular = false;
+                    randomEventsLocal = 0;
+                    startRay();
                 }
-                scw0 = w;
-                smp = 0;
-                rayCount = 0; boundsHits = 0; candidates = 0;
-            }
-            if (alive) {
-                // ---- camera ray (:134-135, RT/View.cs:38-48) ----
-                float jx = 0.5f, jy = 0.5f;
-                if (A.subPixelJitter) { jx = rng_next(rng); jy = rng_next(rng); }
-                const float u = ((float)cx + jx) / A.sizeX;
-                const float v = ((float)cy + jy) / A.sizeY;
-                float rdx = 0, rdy = 0;
-                if (lensRadius != 0) {
-                    // RandomSource.InUnitDisk (RT/RandomSource.cs:40-61): theta = NextFloat(0, 2*PI), radius = sqrt(NextFloat())
-                    const float theta = rng_next(rng) * (2.0f * kPi - 0.0f) + 0.0f;
-                    const float radius = __builtin_sqrtf(rng_next(rng));
-                    float sinT, cosT;
-                    det_sincos(theta, sinT, cosT);
-                    rdx = lensRadius * (radius * cosT);
-                    rdy = lensRadius * (radius * sinT);
-                }
-                const V3 offset = v3(viewRight.x * rdx + viewUp.x * rdy, viewRight.y * rdx + viewUp.y * rdy, viewRight.z * rdx + viewUp.z * rdy);
-                ro = add(viewOrigin, offset);
-                rd = normalize(v3(viewLLC.x - offset.x + u * viewH.x + v * viewV.x,
-                                  viewLLC.y - offset.y + u * viewH.y + v * viewV.y,
-                                  viewLLC.z - offset.z + u * viewH.z + v * viewV.z));
-                rtime = rng_next(rng);
-
-                depth = 0;
-#pragma unroll
-                for (int i = 0; i < HW; i++) hist[i] = 0;
-                sampleNormal = v3(0, 0, 0);
-                sampleAlbedo = v3(0, 0, 0);
-                firstNonSpecular = false;
-                randomEventsLocal = 0;
-                needRay = false;
             }
         }
-        if (!__any(alive)) break;
-
-        if (alive) {
-            // ================= 2. one path segment: closest hit =================
-            float t;
-            int prim;
-            closest_hit<ALL_LDS, HAS_MOTION>(sc, L, stackBase, ro, rd, rtime, t, prim, boundsHits, candidates);
-            rayCount += 1.0f;                                                               // :203
-
-            bool sampleEnded = false, sampleOk = false;
-            V3 sampleColor = v3(0, 0, 0);
-
-            if (prim >= 0) {
-                // ================= 3a. surface hit: Entity.Hit record + Material.Scatter =================
+        if ((int)__popcll(__ballot(st == ST_TRAV)) >= (force == ST_TRAV ? 1 : A.tune[1])) {
+            ran = true;
+            // ================= box walk: FindHitCandidates (JOBS/SampleBatchJob.cs:403-448), resumable =================
+            if (st == ST_TRAV) {
+                const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
+                const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
+                int budget = A.travSlice;
+                // Branch-free node visit: every LDS access of the iteration is issued up front (node, plus the stack slot a
+                // pop would need), candidate / stack slots are written unconditionally and only the counters are predicated,
+                // so the wave's EXEC mask changes only at the loop test.
+                while (budget > 0 && cur >= 0 && nc <= kCandCapacity - 2) {
+                    budget--;
+                    STAT_ADD(3, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0);
+                    STAT_LANES(4);
+                    float4 q0, q1, q2;
+                    int c0, c1;
+                    load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
+                    const int spm1 = sp > 0 ? sp - 1 : 0;
+                    const int popped = stack[spm1 * kBlockThreads];
+                    // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
+                    const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
+                    const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
+                    const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
+                    const float tmin0 = vmax3(vmin(tlx.x, thx.x), vmin(tly.x, thy.x), vmax(vmin(tlz.x, thz.x), 0.0f));
+                    const float tmax0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmin(vmax(tlz.x, thz.x), best));
+                    const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
+                    const float tmax1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmin(vmax(tlz.y, thz.y), best));
+                    const bool hit0 = tmin0 <= tmax0;
+                    const bool hit1 = tmin1 <= tmax1;
+                    if (FULL_DIAG) boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
+                    const bool leaf0 = hit0 && c0 < 0, leaf1 = hit1 && c1 < 0;
+                    cand[nc * kBlockThreads] = (unsigned short)~c0;
+                    nc += leaf0 ? 1 : 0;
+                    cand[nc * kBlockThreads] = (unsigned short)~c1;
+                    nc += leaf1 ? 1 : 0;
+                    const bool in0 = hit0 && c0 >= 0;
+                    const bool in1 = hit1 && c1 >= 0;
+                    const bool both = in0 && in1;
+                    const bool swap = tmin1 < tmin0;                         // near child first
+                    stack[sp * kBlockThreads] = (unsigned short)(swap ? c0 : c1);
+                    const int next = both ? (swap ? c1 : c0) : (in0 ? c0 : c1);
+                    const bool any = in0 || in1;
+                    cur = any ? next : (sp > 0 ? popped : -1);
+                    sp = any ? sp + (both ? 1 : 0) : spm1;
+                }
+                if (cur < 0 || nc > kCandCapacity - 2) {
+                    if (nc > 0) st = ST_TEST;      // exact tests pending (walk finished, or the list is full)
+                    else classify();               // walk finished with nothing left to test
+                }
+            }
+        }
+        if ((int)__popcll(__ballot(st == ST_TEST)) >= (force == ST_TEST ? 1 : A.tune[2])) {
+            ran = true;
+            // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
+            if (st == ST_TEST) {
+                const float a = dot(rd, rd);
+                if (FULL_DIAG) candidates += (float)nc;
+                while (nc > 0) {
+                    STAT_ADD(5, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0);
+                    STAT_LANES(6);
+                    nc--;
+                    const int i = cand[nc * kBlockThreads];
+                    V3 c; float r, t;
+                    sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
+                    if (sphere_hit(sub(ro, c), rd, a, r, t) && t < best) { best = t; prim = i; }
+                }
+                if (cur >= 0) st = ST_TRAV;        // the list was full: resume the walk, now pruned by `best`
+                else classify();
+            }
+        }
+        if ((int)__popcll(__ballot(st == ST_HIT)) >= (force == ST_HIT ? 1 : A.tune[3])) {
+            ran = true;
+            // ================= surface hit: Entity.Hit record + Material.Scatter =================
+            STAT_ADD(7, 1);
+            if (st == ST_HIT) {
+                STAT_LANES(8);
                 V3 c; float radius;
                 sphere_at<ALL_LDS, HAS_MOTION>(sc, L, prim, rtime, c, radius);
+                const float t = best;
                 const V3 oc = sub(ro, c);
                 const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
                 const V3 nLocal = v3((oc.x + t * rd.x) / radius, (oc.y + t * rd.y) / radius, (oc.z + t * rd.z) / radius); // r.GetPoint(t) / radius
                 const V3 N = normalize(nLocal);                                               // RT/Entity.cs:65
 
-                const unsigned matIdx = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
-                const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + matIdx * 48u;
+                const unsigned mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
+                const unsigned matIdx = mi & 0xffffu;
+                const unsigned cls = mi >> 16;                                 // shading class packed by the scene compiler
+                const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + matIdx * 64u;
                 const float4 m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
                 const float4 m1 = *reinterpret_cast<const float4*>(mp + 16);  // emission.yz type metallic
-                const float4 m2 = *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags pad
                 V3 reflectance = v3(m0.x, m0.y, m0.z);
                 const V3 emission = v3(m0.w, m1.x, m1.y);
-                const int mtype = __float_as_int(m1.z);
-                const unsigned mflags = __float_as_uint(m2.z);
                 bool white = false;
+                bool perfectSpecular = false;
                 V3 sdir;
                 float randomEvents = 0;
 
-                if (mtype == RTOW_MATERIAL_STANDARD) {                                        // RT/Material.cs:75-119
+                if (cls == MAT_CLASS_LAMBERT) {
+                    STAT_ADD(9, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(10);
+                    // Standard with glossiness == 0 and metallic == 0 (RT/Material.cs:75-119): roughness = 1, so the rough normal
+                    // costs two draws whose result is never used (reflectionChance = saturate(fresnel * 0 * g1) = 0, and the
+                    // rough-metal branch needs metallic > 0); RandomEvents = 0 + 0 + 1 * 0 + 1 * 1.
+                    (void)rng_next(rng);
+                    (void)rng_next(rng);
+                    sdir = cosine_hemisphere(rng, N);
+                    randomEvents = 1.0f;
+                } else if (cls == MAT_CLASS_GENERAL) {                                        // RT/Material.cs:75-119
+                    STAT_ADD(11, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(12);
+                    const float4 m2 = *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags roughness
+                    const float4 m3 = *reinterpret_cast<const float4*>(mp + 48);  // alpha ior r0 1/ior
                     const float metallic = m1.w;
                     const float glossiness = m2.x;
-                    const float roughness = det_sq(1 - glossiness);
+                    const float roughness = m2.w;                                 // pow(1 - glossiness, 2)
+                    perfectSpecular = (__float_as_uint(m2.z) & MAT_FLAG_PERFECT_SPECULAR) != 0;
                     V3 roughN = N;
                     if (roughness > 0) {
                         const V3 h = cosine_hemisphere(rng, N);
                         roughN = normalize(v3(N.x + roughness * (h.x - N.x), N.y + roughness * (h.y - N.y), N.z + roughness * (h.z - N.z)));
                     }
                     const float incidentCosine = -dot(rd, roughN);
-                    const float ior = 1.5f + metallic * (1.1f - 1.5f);
-                    const float fresnel = schlick(incidentCosine, ior);
-                    const float g1 = smith_g1(rd, N, roughness);
+                    const float fresnel = m3.z + (1 - m3.z) * det_pow5(1 - incidentCosine);   // Schlick, r0 from lerp(1.5, 1.1, metallic)
+                    const float g1 = smith_g1(rd, N, m3.x);
                     const float reflectionChance = um_saturate(fresnel * glossiness * g1);
 
                     if (reflectionChance > 0 && rng_next(rng) < reflectionChance) {
@@ -503,8 +589,12 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     randomEvents += roughness * (reflectionChance + (1 - reflectionChance) * metallic);
                     randomEvents += (1 - reflectionChance) * (1 - metallic);
                 } else {                                                                      // Dielectric, RT/Material.cs:121-161
+                    const float4 m2 = *reinterpret_cast<const float4*>(mp + 32);
+                    const float4 m3 = *reinterpret_cast<const float4*>(mp + 48);
+                    STAT_ADD(13, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(14);
+                    perfectSpecular = true;
                     const float ior = m2.y;
-                    const float roughness = 1 - m2.x;
+                    const float roughness = m2.w;                                 // 1 - glossiness
                     // RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128)
                     const float r0 = rng_next(rng);
                     const float r1 = rng_next(rng);
@@ -520,7 +610,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     V3 outwardN;
                     const float dDotN = dot(rd, roughN);
                     if (dDotN > 0) { outwardN = neg(roughN); niOverNt = ior; cosine = ior * dDotN; }
-                    else { outwardN = roughN; niOverNt = 1 / ior; cosine = -dDotN; }
+                    else { outwardN = roughN; niOverNt = m3.w; cosine = -dDotN; }
 
                     // Refract (:198-210)
                     const float dt = dot(rd, outwardN);
@@ -531,7 +621,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         const V3 refracted = v3(niOverNt * (rd.x - outwardN.x * dt) - outwardN.x * sq,
                                                 niOverNt * (rd.y - outwardN.y * dt) - outwardN.y * sq,
                                                 niOverNt * (rd.z - outwardN.z * dt) - outwardN.z * sq);
-                        if (rng_next(rng) > schlick(cosine, ior)) { sdir = refracted; refractOk = true; }
+                        const float schlickV = m3.z + (1 - m3.z) * det_pow5(1 - cosine);
+                        if (rng_next(rng) > schlickV) { sdir = refracted; refractOk = true; }
                     }
                     if (!refractOk) {
                         sdir = reflect(rd, roughN);
@@ -542,23 +633,29 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     randomEvents += roughness;
                 }
 
-                hist_set<HW>(hist, depth, (white ? 0x8000u : 0u) | matIdx);                   // :311,330 (re-expanded at the fold)
+                hist.set(depth, (white ? 0x8000u : 0u) | matIdx);                             // :311,330 (re-expanded at the fold)
                 if (depth == 0) sampleNormal = N;                                             // :313-314
-                if (!firstNonSpecular && !(mflags & MAT_FLAG_PERFECT_SPECULAR)) {             // :316-328
+                if (!firstNonSpecular && !perfectSpecular) {                                  // :316-328
                     sampleAlbedo = add(emission, reflectance);
                     sampleNormal = N;
                     firstNonSpecular = true;
                 }
-                randomEventsLocal += randomEvents * inv_pow2(depth);                                   // RandomEvents / pow(2, depth), :332
+                randomEventsLocal += randomEvents * inv_pow2(depth);                          // RandomEvents / pow(2, depth), :332
 
                 // ray = scattered.OffsetTowards(dot(dir, N) >= 0 ? N : -N)  (:335-336, RT/Ray.cs:18)
                 const V3 offN = dot(sdir, N) >= 0 ? N : neg(N);
                 ro = v3(P.x + 0.001f * offN.x, P.y + 0.001f * offN.y, P.z + 0.001f * offN.z);
                 rd = sdir;
                 depth++;
-                if (depth == traceDepth) { sampleEnded = true; sampleOk = false; }            // :379-381
-            } else {
-                // ================= 3b. sky (:341-374), then fold tail -> head (:384-396) =================
+                if (depth == traceDepth) endSample(false, v3(0, 0, 0));                       // :379-381
+                else startRay();
+            }
+        }
+        if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : A.tune[4])) {
+            ran = true;
+            // ================= sky (:341-374), then fold tail -> head (:384-396) =================
+            STAT_ADD(15, 1);
+            if (st == ST_SKY) {
                 V3 sky = v3(0, 0, 0);
                 if (A.environment.skyType == RTOW_SKY_GRADIENT) {
                     const float s = 0.5f * (rd.y + 1);
@@ -570,36 +667,61 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 
                 V3 col = sky; // 0 * 1 + sky
                 for (int i = depth - 1; i >= 0; i--) {
-                    const unsigned code = hist_get<HW>(hist, i);
-                    const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + (code & 0x7fffu) * 48u;
+                    const unsigned code = hist.get(i);
+                    const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + (code & 0x7fffu) * 64u;
                     const float4 m0 = *reinterpret_cast<const float4*>(mp);
                     const float2 m1 = *reinterpret_cast<const float2*>(mp + 16);
                     const bool white = (code & 0x8000u) != 0;
                     const V3 att = white ? v3(1, 1, 1) : v3(m0.x, m0.y, m0.z);
                     col = v3(col.x * att.x + m0.w, col.y * att.y + m1.x, col.z * att.z + m1.y);
                 }
-                sampleColor = col;
-                sampleEnded = true;
-                sampleOk = true;
-            }
-
-            if (sampleEnded) {
-                if (sampleOk) {                                                               // :145-149, :398
-                    scwAcc += randomEventsLocal;
-                    colorAcc = add(colorAcc, sampleColor);
-                    normalAcc = add(normalAcc, sampleNormal);
-                    albedoAcc = add(albedoAcc, sampleAlbedo);
-                    sampleCount++;
-                }
-                if (smp == 0) {                                                               // :152-156 -> stored now, kept if sampleCount stays 0
-                    A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
-                    A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
-                }
-                smp++;
-                needRay = true;
+                endSample(true, col);
             }
         }
+        // nothing met its threshold: force the most populated stage next trip (or stop when every lane is dead)
+        if (ran) {
+            force = -1;
+        } else {
+            int top = 0;
+            force = -1;
+            for (int k = ST_REGEN; k < ST_COUNT; k++) {
+                const int n = (int)__popcll(__ballot(st == k));
+                if (n > top) { top = n; force = k; }
+            }
+            if (top == 0) break;
+        }
     }
+#ifdef RTOW_STATS
+    // every lane counted the same wave-level events for 'per-run' slots; lane-population slots were added by all active lanes.
+    if (A.stats) for (int i = 0; i < 16; i++) atomicAdd(&A.stats[i], stat[i]);
+#endif
+}
+
+// Derived per-material constants, computed ON THE DEVICE with the same float program the per-hit code would run
+// (pow(1 - glossiness, 2), RoughnessToAlpha, lerp(PlasticIor, MetalIor, metallic), Schlick's r0, 1 / ior), so hoisting
+// them out of the bounce loop cannot change a bit of the result.
+__global__ void prepare_materials_kernel(uint8_t* blob, SceneLayout L)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.materialCount) return;
+    GpuMaterial* m = reinterpret_cast<GpuMaterial*>(blob + L.materialOffset) + i;
+    float roughness, ior, invIor = 0.0f, alpha = 0.0f;
+    if (m->type == RTOW_MATERIAL_STANDARD) {
+        roughness = det_sq(1 - m->glossiness);                  // RT/Material.cs:80
+        ior = 1.5f + m->metallic * (1.1f - 1.5f);               // :84 lerp(PlasticIor, MetalIor, metallic)
+        alpha = roughness_to_alpha(roughness);                  // RT/Microfacet.cs:72 (inside Lambda)
+    } else {
+        roughness = 1 - m->glossiness;                          // RT/Material.cs:123
+        ior = m->parameter;
+        invIor = 1 / ior;                                       // :137
+    }
+    float r0 = (1 - ior) / (1 + ior);                           // Schlick, :214-215
+    r0 *= r0;
+    m->roughness = roughness;
+    m->alpha = alpha;
+    m->ior = ior;
+    m->r0 = r0;
+    m->invIor = invIor;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -698,23 +820,29 @@ __global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-template <bool ALL_LDS, bool HAS_MOTION, int HW>
+template <bool ALL_LDS, bool HAS_MOTION, int HW, bool FULL_DIAG>
 hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    auto k = sample_batch_kernel<ALL_LDS, HAS_MOTION, HW>;
+    auto k = sample_batch_kernel<ALL_LDS, HAS_MOTION, HW, FULL_DIAG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(numBlocks), dim3(kBlockThreads), ldsBytes, stream, args);
     return hipGetLastError();
 }
 
-template <bool ALL_LDS, bool HAS_MOTION>
+template <bool ALL_LDS, bool HAS_MOTION, bool FULL_DIAG>
 hipError_t launchByDepth(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, HAS_MOTION, 4>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, HAS_MOTION, 8>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 32) return launchVariant<ALL_LDS, HAS_MOTION, 16>(args, numBlocks, ldsBytes, stream);
-    return launchVariant<ALL_LDS, HAS_MOTION, 32>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, HAS_MOTION, 4, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, HAS_MOTION, 8, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
+    return launchVariant<ALL_LDS, HAS_MOTION, 32, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
+}
+
+template <bool ALL_LDS, bool HAS_MOTION>
+hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
+{
+    if (args.diagnostics && args.diagnosticsStride >= 16) return launchByDepth<ALL_LDS, HAS_MOTION, true>(args, numBlocks, ldsBytes, stream);
+    return launchByDepth<ALL_LDS, HAS_MOTION, false>(args, numBlocks, ldsBytes, stream);
 }
 
 } // namespace
@@ -724,8 +852,15 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     const size_t ldsBytes = (size_t)kStackBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
     const bool motion = args.layout.hasMotion != 0;
-    if (allLds) return motion ? launchByDepth<true, true>(args, numBlocks, ldsBytes, stream) : launchByDepth<true, false>(args, numBlocks, ldsBytes, stream);
-    return motion ? launchByDepth<false, true>(args, numBlocks, ldsBytes, stream) : launchByDepth<false, false>(args, numBlocks, ldsBytes, stream);
+    if (allLds) return motion ? launchByDiag<true, true>(args, numBlocks, ldsBytes, stream) : launchByDiag<true, false>(args, numBlocks, ldsBytes, stream);
+    return motion ? launchByDiag<false, true>(args, numBlocks, ldsBytes, stream) : launchByDiag<false, false>(args, numBlocks, ldsBytes, stream);
+}
+
+hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream)
+{
+    const unsigned blocks = (layout.materialCount + 127u) / 128u;
+    hipLaunchKernelGGL(prepare_materials_kernel, dim3(blocks ? blocks : 1), dim3(128), 0, stream, blob, layout);
+    return hipGetLastError();
 }
 
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,

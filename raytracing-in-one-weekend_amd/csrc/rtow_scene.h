@@ -10,7 +10,7 @@
 //                   is too large for LDS and only a prefix is staged.
 //   GpuSphere 16 B  centre + signed radius (RT/EntityTypes/Sphere.cs:8; the centre is Entity.OriginTransform.pos).
 //   GpuMotion 32 B  only for scenes with moving entities: DestinationOffset + TimeRange (RT/Entity.cs:33-34).
-//   GpuMaterial 48 B constant-texture material (RT/Material.cs:16-47 with RT/Texture.cs constant branches folded).
+//   GpuMaterial 64 B constant-texture material + per-material derived constants (RT/Material.cs:16-47 with RT/Texture.cs constant branches folded).
 //
 // Everything is packed into ONE device blob (16-byte aligned sections) so a workgroup stages it into LDS with a
 // single coalesced 16-byte-per-lane copy.
@@ -46,6 +46,13 @@ static_assert(sizeof(GpuMotion) == 32, "GpuMotion must be 32 bytes");
 enum : uint32_t {
     MAT_FLAG_PERFECT_SPECULAR = 1u, // Material.IsPerfectSpecular (RT/Material.cs:181-196)
 };
+// Shading class of a material; the scene compiler packs it into bits 16.. of materialIndex[] so the kernel can sort a
+// hit into its scheduler stage with one LDS read.
+enum : uint32_t {
+    MAT_CLASS_LAMBERT = 0, // Standard, glossiness == 0 and metallic == 0
+    MAT_CLASS_GENERAL = 1, // any other Standard
+    MAT_CLASS_DIELECTRIC = 2,
+};
 
 struct GpuMaterial {
     float albedo[3];     // Albedo.SampleColor
@@ -55,9 +62,14 @@ struct GpuMaterial {
     float glossiness;    // Glossiness.SampleScalar
     float parameter;     // IndexOfRefraction / Density
     uint32_t flags;
-    int32_t pad;
+    // derived on the device by prepare_materials_kernel (same float program as the per-hit code):
+    float roughness;     // Standard: pow(1 - glossiness, 2); Dielectric: 1 - glossiness
+    float alpha;         // Standard: RoughnessToAlpha(roughness)
+    float ior;           // Standard: lerp(1.5, 1.1, metallic); Dielectric: parameter
+    float r0;            // Schlick r0 = ((1 - ior) / (1 + ior))^2
+    float invIor;        // Dielectric: 1 / ior
 };
-static_assert(sizeof(GpuMaterial) == 48, "GpuMaterial must be 48 bytes");
+static_assert(sizeof(GpuMaterial) == 64, "GpuMaterial must be 64 bytes");
 
 // Byte offsets of the sections inside the scene blob (all multiples of 16).
 struct SceneLayout {

@@ -9,7 +9,7 @@ import subprocess
 from . import abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "librtow_hip.so")
+LIB_PATH = os.environ.get("RTOW_LIB_PATH") or os.path.join(_CSRC, "librtow_hip.so")  # override: development builds only
 _lib = None
 
 
