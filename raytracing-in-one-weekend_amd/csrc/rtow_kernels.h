@@ -10,7 +10,10 @@
 namespace rtow {
 
 // One persistent workgroup per CU: 1024 lanes (16 wavefronts, 4 per SIMD, <= 128 VGPRs) share one LDS image of the scene.
-constexpr int kBlockThreads = 1024;
+#ifndef RTOW_BLOCK_THREADS
+#define RTOW_BLOCK_THREADS 1024
+#endif
+constexpr int kBlockThreads = RTOW_BLOCK_THREADS;
 constexpr int kLdsBytesMax = 160 * 1024;
 #ifndef RTOW_TRAV_SLICE
 #define RTOW_TRAV_SLICE 8   // box-walk node visits per scheduler trip

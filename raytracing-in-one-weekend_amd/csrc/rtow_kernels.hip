@@ -273,7 +273,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     const int tid = (int)threadIdx.x;
 
     // ---- stage the scene image into LDS: coalesced 16 B per lane ----
-    unsigned short* const stack = reinterpret_cast<unsigned short*>(smem) + tid;             // [level][lane] inner nodes
+    // [level][lane] uint16 arrays; within a wave lane l sits at 2*(l&31) + (l>>5), so the 32 lanes the LDS services together
+    // touch 32 different dwords (= banks) whatever level each of them is at
+    unsigned short* const stack = reinterpret_cast<unsigned short*>(smem) + (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
     unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;                // [slot][lane] leaf candidates
     uint8_t* const ldsScene = smem + kStackBytes;
     {
@@ -336,7 +338,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     };
     // a new ray segment starts: reset the traversal state
     auto startRay = [&]() {
-        inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        // reciprocal direction for the box walk only: v_rcp_f32 (<= 1 ulp) is enough there, the boxes are padded by 1e-5
+        inv = v3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
         cur = 0; sp = 0; nc = 0; prim = -1;
         best = __builtin_inff();
         st = ST_TRAV;
