@@ -30,6 +30,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def measured_hbm_traffic():
+    """HBM bytes per launch of the sample kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
+    FETCH_SIZE and WRITE_SIZE from separate --pmc passes of this same bench command, KiB -> bytes, read side doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            return float(d["derived"]["hbm_traffic_bytes"]), os.path.basename(f)
+        except (KeyError, ValueError, OSError):
+            continue
+    return None, None
+
+
 def usable_cores():
     """Logical cores this process may actually use: affinity mask capped by the cgroup CPU quota (cpu.max)."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -184,6 +199,7 @@ def main():
         owned_pixels = len(range(rank, H, world)) * W
         alg_bytes = owned_pixels * 92 + int(info.sceneBytesDevice)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_hbm_traffic() if world == 1 else (None, None)
         out = {
             "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce",
             "value": round(total_samples / elapsed / 1e6, 2),
@@ -214,7 +230,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 8),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "sample_batch_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "graph-traversal path: algorithmic HBM traffic is 92 B/pixel per launch, so the HBM fraction is tiny by construction; "

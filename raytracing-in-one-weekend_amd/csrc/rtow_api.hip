@@ -307,7 +307,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     ctx->scene = std::move(compiled);
-    const uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes);
+    const uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);
     if (ctx->scene.layout.totalBytes <= budget) {
         ctx->ldsSceneBytes = ctx->scene.layout.totalBytes;
         ctx->ldsNodeCount = ctx->scene.layout.nodeCount;

@@ -20,6 +20,7 @@ constexpr int kLdsBytesMax = 160 * 1024;
 #endif
 constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting their exact test (flushed when full)
 constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane]
+constexpr int kQueueBytes = 256;   // per-wave {next, end} pixel-ticket chunk (16 waves x 8 B, padded)
 
 // Everything the sample kernel needs, passed by value (kernarg segment).
 struct SampleKernelArgs {

@@ -277,7 +277,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     // touch 32 different dwords (= banks) whatever level each of them is at
     unsigned short* const stack = reinterpret_cast<unsigned short*>(smem) + (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
     unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;                // [slot][lane] leaf candidates
-    uint8_t* const ldsScene = smem + kStackBytes;
+    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytes) + (tid >> 6) * 2;  // {next, end} ticket chunk of this wave
+    uint8_t* const ldsScene = smem + kStackBytes + kQueueBytes;
+    if ((tid & 63) == 0) { waveQueue[0] = 0; waveQueue[1] = 0; }
     {
         const uint4* src = reinterpret_cast<const uint4*>(A.sceneBlob);
         uint4* dst = reinterpret_cast<uint4*>(ldsScene);
@@ -384,11 +386,34 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         }
                         pix = -1;
                     }
-                    // ---- pull the next owned pixel (ticket counter; the compiler aggregates the atomic per wave) ----
-                    bool cancelled = false;
-                    if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
-                    const unsigned ticket = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
-                    if (ticket >= A.totalWork) { st = ST_DEAD; break; }
+                    // ---- pull the next owned pixel ----
+                    // Tickets are handed to WAVES in chunks of 64 consecutive pixels (one global atomic per chunk) and to lanes
+                    // from the wave's chunk by ballot rank, so every 64-byte line of the accumulator arrays is read and written
+                    // by a single CU within about one pixel-time and coalesces in that XCD's L2 instead of being fetched and
+                    // written back once per pixel from eight different L2s.
+                    unsigned ticket = 0xffffffffu;
+                    for (bool got = false; !got;) {
+                        const unsigned long long need = __ballot(1);                  // lanes asking right now (all still in this loop)
+                        const int lane = tid & 63;
+                        const int leader = __builtin_ctzll(need);
+                        const int rank = __popcll(need & ((1ull << lane) - 1ull));
+                        const unsigned next = waveQueue[0], end = waveQueue[1];      // wave-private: same value in every lane
+                        if (next == 0xffffffffu) break;                               // queue exhausted (or cancelled)
+                        if (next == end) {
+                            if (lane == leader) {
+                                bool cancelled = false;
+                                if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
+                                const unsigned base = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 64u);
+                                if (base >= A.totalWork) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
+                                else { waveQueue[0] = base; waveQueue[1] = (A.totalWork - base < 64u) ? A.totalWork : base + 64u; }
+                            }
+                            continue;
+                        }
+                        const unsigned take = (unsigned)__popcll(need) < end - next ? (unsigned)__popcll(need) : end - next;
+                        if ((unsigned)rank < take) { ticket = next + (unsigned)rank; got = true; }
+                        if (lane == leader) waveQueue[0] = next + take;
+                    }
+                    if (ticket == 0xffffffffu) { st = ST_DEAD; break; }
                     const int ownedRow = (int)(ticket / (unsigned)A.width);
                     cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
                     cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
@@ -852,7 +877,7 @@ hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, size_t ldsB
 
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
-    const size_t ldsBytes = (size_t)kStackBytes + args.ldsSceneBytes;
+    const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
     const bool motion = args.layout.hasMotion != 0;
     if (allLds) return motion ? launchByDiag<true, true>(args, numBlocks, ldsBytes, stream) : launchByDiag<true, false>(args, numBlocks, ldsBytes, stream);
