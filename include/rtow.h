@@ -122,7 +122,9 @@ typedef struct RtowMaterial {
 
 /* RT/Entity.cs:27-56 + the Content struct it points to (RT/EntityTypes/Sphere.cs:6-24 ...).
  * `size`: Sphere -> (radius, -, -)  [signed radius, Sphere.cs:8-14]
- *         Rect   -> (sizeX, sizeY, -), Box -> (sizeX, sizeY, sizeZ); Triangle -> contentIndex. */
+ *         Rect   -> (sizeX, sizeY, -)   [RT/EntityTypes/Rect.cs:12-16: From = -size/2, To = size/2]
+ *         Box    -> (sizeX, sizeY, sizeZ) [RT/EntityTypes/Box.cs:11-15: Extents = size/2]
+ *         Triangle -> `contentIndex` selects RtowSceneDesc.triangles[contentIndex]. */
 typedef struct RtowEntity {
     int32_t type;                   /* RtowEntityType */
     int32_t moving;                 /* Entity.Moving (0/1) */
@@ -132,8 +134,17 @@ typedef struct RtowEntity {
     RtowFloat2 timeRange;           /* Entity.TimeRange */
     int32_t materialIndex;          /* index into RtowSceneDesc.materials (Entity.Material) */
     RtowFloat3 size;                /* content parameters, see above */
-    int32_t contentIndex;           /* reserved for triangle payloads */
+    int32_t contentIndex;           /* triangle payload index (RTOW_ENTITY_TRIANGLE only) */
 } RtowEntity;
+
+/* RT/EntityTypes/Triangle.cs:8-12, byte for byte (float3x3 Data, float3x3 Normals, float2x3 TextureCoordinates = 96 bytes),
+ * so the host can pass its NativeList<Triangle> buffer (UNITY/Raytracer.cs:1198,1290-1300) without conversion.
+ * data[0] = v2 - v0, data[1] = v1 - v0, data[2] = v0 (world space: triangles are never transformed, RT/Entity.cs:91-93). */
+typedef struct RtowTriangle {
+    RtowFloat3 data[3];
+    RtowFloat3 normals[3];
+    RtowFloat2 textureCoordinates[3];
+} RtowTriangle;
 
 typedef struct RtowSceneDesc {
     const RtowEntity* entities;
@@ -141,6 +152,8 @@ typedef struct RtowSceneDesc {
     const RtowMaterial* materials;
     int32_t materialCount;
     int32_t maxBvhDepth;            /* UNITY/Raytracer.cs:88 (prefab default 32); 0 = builder default */
+    const RtowTriangle* triangles;  /* payloads of RTOW_ENTITY_TRIANGLE entities (RtowEntity.contentIndex); may be NULL */
+    int32_t triangleCount;
 } RtowSceneDesc;
 
 typedef struct RtowSceneInfo {

@@ -67,7 +67,8 @@ def load(kind="strict"):
     lib.oracle_kat_linear_to_gamma.argtypes = [C.c_float]
     lib.oracle_kat_basis.argtypes = [fp, fp, fp]
     lib.oracle_kat_aabb_hit.argtypes = [fp, fp, fp, fp]
-    lib.oracle_kat_entity_hit.argtypes = [C.POINTER(abi.Entity), fp, fp, C.c_float, C.c_float, C.c_float, fp]
+    lib.oracle_kat_entity_hit.argtypes = [C.POINTER(abi.Entity), C.POINTER(abi.Triangle), C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, fp]
+    lib.oracle_kat_entity_bounds.argtypes = [C.POINTER(abi.Entity), C.POINTER(abi.Triangle), C.c_int, fp]
     lib.oracle_kat_scatter.argtypes = [C.POINTER(abi.Material), fp, fp, C.c_float, fp, fp, C.c_float, C.POINTER(C.c_uint32), fp]
     lib.oracle_kat_get_ray.argtypes = [C.POINTER(abi.View), C.c_float, C.c_float, C.POINTER(C.c_uint32), fp]
     lib.oracle_kat_nearest_hit.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]

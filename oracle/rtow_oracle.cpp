@@ -484,6 +484,106 @@ inline bool HitSphere(const Sphere& s, const Ray& r, float tMin, float tMax, flo
     return false;
 }
 
+/* RT/EntityTypes/Rect.cs:7-20: an axis-aligned rectangle in the XY plane */
+struct Rect {
+    float2 From, To;
+    static Rect Make(float2 size) { return Rect{float2{-size.x / 2, -size.y / 2}, float2{size.x / 2, size.y / 2}}; }
+    AABB Bounds() const { return AABB{f3(From.x, From.y, -0.001f), f3(To.x, To.y, 0.001f)}; }
+};
+/* RT/EntityTypes/Box.cs:6-18 */
+struct Box {
+    float3 InverseExtents, Extents;
+    static Box Make(float3 size) { Box b; b.Extents = size / 2; b.InverseExtents = f3(1 / b.Extents.x, 1 / b.Extents.y, 1 / b.Extents.z); return b; }
+    AABB Bounds() const { return AABB{-Extents, Extents}; }
+};
+/* RT/EntityTypes/Triangle.cs:6-51: Data = {v2 - v0, v1 - v0, v0}, per-vertex normals, per-vertex uv */
+struct Triangle {
+    float3 Data[3];
+    float3 Normals[3];
+    float2 TextureCoordinates[3];
+    AABB Bounds() const                                                                   /* :37-49 */
+    {
+        const float3 vertices[3] = {Data[2], Data[1] + Data[2], Data[0] + Data[2]};
+        float3 negativeOffset[3], positiveOffset[3];
+        for (int i = 0; i < 3; i++) {
+            const float3 absN = f3(fabsf(Normals[i].x), fabsf(Normals[i].y), fabsf(Normals[i].z));
+            negativeOffset[i] = vertices[i] - absN * 0.001f;
+            positiveOffset[i] = vertices[i] + absN * 0.001f;
+        }
+        return AABB{um_min(um_min(negativeOffset[0], negativeOffset[1]), negativeOffset[2]),
+                    um_max(um_max(positiveOffset[0], positiveOffset[1]), positiveOffset[2])};
+    }
+};
+
+inline float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); } /* math.sign */
+
+/* RT/HitTests.cs:62-78 */
+inline bool HitRect(const Rect& rect, const Ray& r, float tMin, float tMax, float* distance, float3* normal)
+{
+    *distance = 0;
+    *normal = f3(0);
+    if (r.Direction.z >= 0) return false;
+    const float t = -r.Origin.z / r.Direction.z;
+    if (t < tMin || t > tMax) return false;
+    const float2 xy = float2{r.Origin.x + t * r.Direction.x, r.Origin.y + t * r.Direction.y};
+    if (xy.x < rect.From.x || xy.y < rect.From.y || xy.x > rect.To.x || xy.y > rect.To.y) return false;
+    *distance = t;
+    *normal = f3(0, 0, 1);
+    return true;
+}
+
+/* RT/HitTests.cs:80-113 (Majercik et al. ray-box); ray direction is assumed to be normalized */
+inline bool HitBox(const Box& box, Ray r, float tMin, float tMax, float* distance, float3* normal)
+{
+    r = Ray(r.Origin + r.Direction * tMin, r.Direction, r.Time);
+    *distance = 0;
+    *normal = f3(0);
+    const float3 rayDirection = r.Direction;
+    const float3 ao = f3(fabsf(r.Origin.x), fabsf(r.Origin.y), fabsf(r.Origin.z)) * box.InverseExtents;
+    const float winding = um_cmax(ao) < 1 ? -1.0f : 1.0f;
+    float3 sgn = -f3(um_sign(rayDirection.x), um_sign(rayDirection.y), um_sign(rayDirection.z));
+    const float3 distanceToPlane = (box.Extents * winding * sgn - r.Origin) / rayDirection;
+    const bool tx = distanceToPlane.x >= 0 &&
+                    fabsf(r.Origin.y + rayDirection.y * distanceToPlane.x) < box.Extents.y && fabsf(r.Origin.z + rayDirection.z * distanceToPlane.x) < box.Extents.z;
+    const bool ty = distanceToPlane.y >= 0 &&
+                    fabsf(r.Origin.z + rayDirection.z * distanceToPlane.y) < box.Extents.z && fabsf(r.Origin.x + rayDirection.x * distanceToPlane.y) < box.Extents.x;
+    const bool tz = distanceToPlane.z >= 0 &&
+                    fabsf(r.Origin.x + rayDirection.x * distanceToPlane.z) < box.Extents.x && fabsf(r.Origin.y + rayDirection.y * distanceToPlane.z) < box.Extents.y;
+    sgn = tx ? f3(sgn.x, 0, 0) : ty ? f3(0, sgn.y, 0) : f3(0, 0, tz ? sgn.z : 0);
+    const bool nzx = sgn.x != 0, nzy = sgn.y != 0, nzz = sgn.z != 0;
+    if (!(nzx || nzy || nzz)) return false;
+    *distance = nzx ? distanceToPlane.x : nzy ? distanceToPlane.y : distanceToPlane.z;
+    *distance += tMin;
+    if (*distance > tMax) return false;
+    *normal = sgn;
+    return true;
+}
+
+/* RT/HitTests.cs:115-150 (Moeller-Trumbore, no back-face culling) */
+inline bool HitTriangle(const Triangle& tri, const Ray& r, float tMin, float tMax, float* distance, float3* normal, float2* texCoord)
+{
+    *distance = 0;
+    *normal = f3(0);
+    *texCoord = float2{0, 0};
+    const float3 pvec = um_cross(r.Direction, tri.Data[0]);
+    const float det = um_dot(tri.Data[1], pvec);
+    if (det == 0) return false;
+    const float invDet = 1 / det;
+    const float3 tvec = r.Origin - tri.Data[2];
+    const float u = um_dot(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    const float3 qvec = um_cross(tvec, tri.Data[1]);
+    const float v = um_dot(r.Direction, qvec) * invDet;
+    if (v < 0 || u + v > 1) return false;
+    *distance = um_dot(tri.Data[0], qvec) * invDet;
+    if (*distance < tMin || *distance > tMax) return false;
+    const float3 bary = f3(1 - u - v, u, v);
+    *normal = tri.Normals[0] * bary.x + tri.Normals[1] * bary.y + tri.Normals[2] * bary.z;
+    const float2 t0 = tri.TextureCoordinates[0], t1 = tri.TextureCoordinates[1], t2 = tri.TextureCoordinates[2];
+    *texCoord = float2{t0.x * bary.x + t1.x * bary.y + t2.x * bary.z, t0.y * bary.x + t1.y * bary.y + t2.y * bary.z};
+    return true;
+}
+
 /* RT/Entity.cs:27-127 */
 struct Entity {
     int Type;
@@ -492,7 +592,10 @@ struct Entity {
     float3 DestinationOffset;
     float2 TimeRange;
     const Material* MaterialPtr;
-    Sphere SphereContent;
+    Sphere SphereContent;   /* void* Content (RT/Entity.cs:37), one of: */
+    Rect RectContent;
+    Box BoxContent;
+    Triangle TriangleContent;
     int SourceIndex; /* oracle-only: index in the caller's entity array */
 
     /* :124-127 */
@@ -508,6 +611,9 @@ struct Entity {
         *texCoord = float2{0, 0};
         switch (Type) {
             case RTOW_ENTITY_SPHERE: return HitSphere(SphereContent, r, tMin, tMax, distance, normal);
+            case RTOW_ENTITY_RECT: return HitRect(RectContent, r, tMin, tMax, distance, normal);
+            case RTOW_ENTITY_BOX: return HitBox(BoxContent, r, tMin, tMax, distance, normal);
+            case RTOW_ENTITY_TRIANGLE: return HitTriangle(TriangleContent, r, tMin, tMax, distance, normal, texCoord);
             default:
                 *distance = 0;
                 *normal = f3(0);
@@ -598,7 +704,10 @@ struct OracleScene {
     /* UNITY/BvhNodeData.cs:23-81 : world-space bounds of an entity (moving: union of start/end boxes) */
     static AABB EntityBounds(const Entity& e)
     {
-        AABB Bounds = e.SphereContent.Bounds();
+        AABB Bounds = e.Type == RTOW_ENTITY_RECT ? e.RectContent.Bounds()
+                    : e.Type == RTOW_ENTITY_BOX ? e.BoxContent.Bounds()
+                    : e.Type == RTOW_ENTITY_TRIANGLE ? e.TriangleContent.Bounds()
+                    : e.SphereContent.Bounds();                                     /* :32-39 */
         const float3 corners[8] = {
             f3(Bounds.Min.x, Bounds.Min.y, Bounds.Min.z), f3(Bounds.Min.x, Bounds.Min.y, Bounds.Max.z),
             f3(Bounds.Min.x, Bounds.Max.y, Bounds.Min.z), f3(Bounds.Max.x, Bounds.Min.y, Bounds.Min.z),
@@ -621,6 +730,37 @@ struct OracleScene {
             }
         }
         return AABB{minimum, maximum};
+    }
+
+    /* `new Entity(type, content, originTransform, material, moving, destinationOffset, timeRange)` (RT/Entity.cs:39-56)
+     * with the Content struct built from the flat description. */
+    static bool MakeEntity(const RtowEntity& s, const RtowTriangle* triangles, int triangleCount, Entity* out)
+    {
+        Entity e{};
+        e.Type = s.type;
+        e.Moving = s.moving != 0;
+        e.OriginTransform = RigidTransform{f4(s.rotation), f3(s.position)};
+        e.DestinationOffset = f3(s.destinationOffset);
+        e.TimeRange = float2{s.timeRange.x, s.timeRange.y};
+        bool ok = true;
+        switch (s.type) {
+            case RTOW_ENTITY_SPHERE: e.SphereContent = Sphere{s.size.x * s.size.x, s.size.x}; break;          /* Sphere.cs:10-14 */
+            case RTOW_ENTITY_RECT: e.RectContent = Rect::Make(float2{s.size.x, s.size.y}); break;            /* Rect.cs:12-16 */
+            case RTOW_ENTITY_BOX: e.BoxContent = Box::Make(f3(s.size)); break;                               /* Box.cs:11-15 */
+            case RTOW_ENTITY_TRIANGLE:
+                if (!triangles || s.contentIndex < 0 || s.contentIndex >= triangleCount) { ok = false; break; }
+                for (int k = 0; k < 3; k++) {
+                    e.TriangleContent.Data[k] = f3(triangles[s.contentIndex].data[k]);
+                    e.TriangleContent.Normals[k] = f3(triangles[s.contentIndex].normals[k]);
+                    e.TriangleContent.TextureCoordinates[k] = float2{triangles[s.contentIndex].textureCoordinates[k].x, triangles[s.contentIndex].textureCoordinates[k].y};
+                }
+                break;
+            default: ok = false;
+        }
+        if (!e.Moving) e.InverseTransform = um_inverse(e.OriginTransform);                                  /* Entity.cs:51-52 */
+        else e.InverseTransform = RigidTransform{float4{0, 0, 0, 0}, f3(0)};
+        *out = e;
+        return ok;
     }
 
     static float axisOf(float3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
@@ -708,17 +848,9 @@ struct OracleScene {
         for (int i = 0; i < d->entityCount; i++) {
             const RtowEntity& s = d->entities[i];
             Entity e{};
-            e.Type = s.type;
-            e.Moving = s.moving != 0;
-            e.OriginTransform = RigidTransform{f4(s.rotation), f3(s.position)};
-            e.DestinationOffset = f3(s.destinationOffset);
-            e.TimeRange = float2{s.timeRange.x, s.timeRange.y};
+            if (!MakeEntity(s, d->triangles, d->triangleCount, &e)) unsupported = true;
             e.MaterialPtr = &materials[s.materialIndex];
-            e.SphereContent = Sphere{s.size.x * s.size.x, s.size.x}; /* Sphere.cs:10-14 */
             e.SourceIndex = i;
-            if (!e.Moving) e.InverseTransform = um_inverse(e.OriginTransform); /* Entity.cs:51-52 */
-            else e.InverseTransform = RigidTransform{float4{0, 0, 0, 0}, f3(0)};
-            if (s.type != RTOW_ENTITY_SPHERE) unsupported = true; /* Rect/Box/Triangle: next row, SURVEY 8(f)#3 */
             entities[i] = e;
         }
         /* UNITY/Raytracer.cs:1306-1351 */
@@ -1211,23 +1343,28 @@ ORACLE_API int oracle_kat_aabb_hit(const float* mn, const float* mx, const float
     if (um_isnan(inv.z)) inv.z = INFINITY;
     return HitAabb(AABB{f3(mn[0], mn[1], mn[2]), f3(mx[0], mx[1], mx[2])}, f3(ro[0], ro[1], ro[2]), inv) ? 1 : 0;
 }
-/* Entity.Hit for one RtowEntity (sphere), world-space ray; out = {distance, point[3], normal[3]} */
-ORACLE_API int oracle_kat_entity_hit(const RtowEntity* ent, const float* ro, const float* rd, float time, float tMin, float tMax, float* out)
+/* Entity.Hit for one RtowEntity, world-space ray; out = {distance, point[3], normal[3], uv[2]} */
+ORACLE_API int oracle_kat_entity_hit(const RtowEntity* ent, const RtowTriangle* triangles, int triangleCount, const float* ro, const float* rd,
+                                     float time, float tMin, float tMax, float* out)
 {
     Entity e{};
-    e.Type = ent->type;
-    e.Moving = ent->moving != 0;
-    e.OriginTransform = RigidTransform{f4(ent->rotation), f3(ent->position)};
-    e.DestinationOffset = f3(ent->destinationOffset);
-    e.TimeRange = float2{ent->timeRange.x, ent->timeRange.y};
-    e.SphereContent = Sphere{ent->size.x * ent->size.x, ent->size.x};
-    if (!e.Moving) e.InverseTransform = um_inverse(e.OriginTransform);
+    if (!OracleScene::MakeEntity(*ent, triangles, triangleCount, &e)) return -1;
     HitRecord rec;
     const bool hit = e.Hit(Ray(f3(ro[0], ro[1], ro[2]), f3(rd[0], rd[1], rd[2]), time), tMin, tMax, &rec);
     out[0] = rec.Distance;
     out[1] = rec.Point.x; out[2] = rec.Point.y; out[3] = rec.Point.z;
     out[4] = rec.Normal.x; out[5] = rec.Normal.y; out[6] = rec.Normal.z;
+    out[7] = rec.TexCoords.x; out[8] = rec.TexCoords.y;
     return hit ? 1 : 0;
+}
+/* world-space bounds of one entity (BvhBuildingEntity ctor, UNITY/BvhNodeData.cs:23-81); out = {min[3], max[3]} */
+ORACLE_API int oracle_kat_entity_bounds(const RtowEntity* ent, const RtowTriangle* triangles, int triangleCount, float* out)
+{
+    Entity e{};
+    if (!OracleScene::MakeEntity(*ent, triangles, triangleCount, &e)) return -1;
+    const AABB b = OracleScene::EntityBounds(e);
+    out[0] = b.Min.x; out[1] = b.Min.y; out[2] = b.Min.z; out[3] = b.Max.x; out[4] = b.Max.y; out[5] = b.Max.z;
+    return 0;
 }
 /* One Material.Scatter call. io: rngState (in/out). out = {reflectance[3], origin[3], dir[3], time, randomEvents, draws, isPerfectSpecular, emission[3]} */
 ORACLE_API void oracle_kat_scatter(const RtowMaterial* m, const float* ro, const float* rd, float time,
@@ -1303,4 +1440,5 @@ ORACLE_API void oracle_abi_sizes(int* out)
     out[3] = (int)sizeof(RtowSceneDesc); out[4] = (int)sizeof(RtowSceneInfo); out[5] = (int)sizeof(RtowView);
     out[6] = (int)sizeof(RtowEnvironment); out[7] = (int)sizeof(RtowSampleParams); out[8] = (int)sizeof(RtowAccumBuffers);
     out[9] = (int)sizeof(RtowContextOptions); out[10] = (int)sizeof(RtowMetrics); out[11] = (int)sizeof(RtowCombineParams);
+    out[12] = (int)sizeof(RtowTriangle);
 }

@@ -68,10 +68,15 @@ class Entity(C.Structure):
                 ("size", Float3), ("contentIndex", C.c_int32)]
 
 
+class Triangle(C.Structure):
+    """RT/EntityTypes/Triangle.cs:8-12 byte for byte (96 bytes): Data {v2-v0, v1-v0, v0}, Normals, TextureCoordinates."""
+    _fields_ = [("data", Float3 * 3), ("normals", Float3 * 3), ("textureCoordinates", Float2 * 3)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("entities", C.POINTER(Entity)), ("entityCount", C.c_int32),
                 ("materials", C.POINTER(Material)), ("materialCount", C.c_int32),
-                ("maxBvhDepth", C.c_int32)]
+                ("maxBvhDepth", C.c_int32), ("triangles", C.POINTER(Triangle)), ("triangleCount", C.c_int32)]
 
 
 class SceneInfo(C.Structure):

@@ -305,6 +305,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     }
     HIP_TRY(ctx, hipMemcpy(ctx->dScene, compiled.blob.data(), compiled.blob.size(), hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchPrepareEntities(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     ctx->scene = std::move(compiled);
     const uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);

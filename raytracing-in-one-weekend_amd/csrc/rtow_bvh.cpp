@@ -129,8 +129,8 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         return RTOW_ERROR_INVALID_VALUE;
     }
     const int n = desc->entityCount;
-    if (n > 32767 || desc->materialCount > 32767) {
-        *err = "scene exceeds 32767 entities/materials (16-bit traversal-stack and path-history codes)";
+    if (n > 65535 || desc->materialCount > 32767) {
+        *err = "scene exceeds 65535 entities or 32767 materials (16-bit candidate and path-history codes)";
         return RTOW_ERROR_CAPACITY;
     }
     if (maxDepth <= 0) maxDepth = RTOW_DEFAULT_MAX_BVH_DEPTH;
@@ -171,23 +171,26 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
                       : (g.glossiness == 0.0f && g.metallic == 0.0f) ? MAT_CLASS_LAMBERT : MAT_CLASS_GENERAL;
     }
 
-    // ---- entities -> spheres ----
+    // ---- entities -> primitives ----
     std::vector<GpuSphere> spheres(n);
     std::vector<GpuMotion> motion(n);
+    std::vector<GpuPrim> prims;
     std::vector<uint32_t> matIndex(n);
-    bool hasMotion = false;
+    bool hasMotion = false, general = false;
+    for (int i = 0; i < n; i++) {
+        const RtowEntity& e = desc->entities[i];
+        const bool identity = e.rotation.x == 0.0f && e.rotation.y == 0.0f && e.rotation.z == 0.0f && e.rotation.w == 1.0f;
+        if (e.type != RTOW_ENTITY_SPHERE || !identity) general = true;
+    }
+    if (general) prims.resize(n);
     Builder b;
     b.primBox.resize(n);
     for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
     for (int i = 0; i < n; i++) {
         const RtowEntity& e = desc->entities[i];
-        if (e.type != RTOW_ENTITY_SPHERE) {
-            *err = "entity type not built yet (Rect / Box / Triangle are next rows)";
-            return RTOW_ERROR_UNSUPPORTED;
-        }
-        if (!(e.rotation.x == 0.0f && e.rotation.y == 0.0f && e.rotation.z == 0.0f && e.rotation.w == 1.0f)) {
-            *err = "rotated sphere entities not built yet (identity rotation only)";
-            return RTOW_ERROR_UNSUPPORTED;
+        if (e.type != RTOW_ENTITY_SPHERE && e.type != RTOW_ENTITY_RECT && e.type != RTOW_ENTITY_BOX && e.type != RTOW_ENTITY_TRIANGLE) {
+            *err = "unknown entity type";
+            return RTOW_ERROR_INVALID_VALUE;
         }
         if (e.materialIndex < 0 || e.materialIndex >= desc->materialCount) {
             *err = "materialIndex out of range";
@@ -197,26 +200,87 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
             *err = "time range cannot be empty for moving entities";
             return RTOW_ERROR_INVALID_VALUE;
         }
+        if (e.type == RTOW_ENTITY_TRIANGLE && (!desc->triangles || e.contentIndex < 0 || e.contentIndex >= desc->triangleCount)) {
+            *err = "triangle contentIndex out of range";
+            return RTOW_ERROR_INVALID_VALUE;
+        }
         spheres[i] = GpuSphere{e.position.x, e.position.y, e.position.z, e.size.x};
         motion[i] = GpuMotion{e.destinationOffset.x, e.destinationOffset.y, e.destinationOffset.z, e.timeRange.x, e.timeRange.y, e.moving ? 1 : 0, {0, 0}};
-        matIndex[i] = (uint32_t)e.materialIndex | (matClass[e.materialIndex] << 16);
+        matIndex[i] = (uint32_t)e.materialIndex | (matClass[e.materialIndex] << 16) | ((uint32_t)e.type << kPrimTypeShift);
         hasMotion |= e.moving != 0;
 
-        // world bounds (UNITY/BvhNodeData.cs:23-81): |radius| box, union of start/end positions when moving,
-        // padded so that the kernel's slab test (different rounding from the exact sphere test) stays conservative.
-        const float r = std::fabs(e.size.x);
-        const float p0[3] = {e.position.x, e.position.y, e.position.z};
-        const float d[3] = {e.moving ? e.destinationOffset.x : 0.0f, e.moving ? e.destinationOffset.y : 0.0f, e.moving ? e.destinationOffset.z : 0.0f};
+        // local (content) bounds: Sphere.cs:16-23, Rect.cs:17-19, Box.cs:17, Triangle.cs:37-49
+        float lo[3], hi[3];
+        if (e.type == RTOW_ENTITY_SPHERE) {
+            const float r = std::fabs(e.size.x);
+            for (int a = 0; a < 3; a++) { lo[a] = -r; hi[a] = r; }
+        } else if (e.type == RTOW_ENTITY_RECT) {
+            lo[0] = -e.size.x / 2; hi[0] = e.size.x / 2; lo[1] = -e.size.y / 2; hi[1] = e.size.y / 2; lo[2] = -0.001f; hi[2] = 0.001f;
+        } else if (e.type == RTOW_ENTITY_BOX) {
+            lo[0] = -e.size.x / 2; hi[0] = e.size.x / 2; lo[1] = -e.size.y / 2; hi[1] = e.size.y / 2; lo[2] = -e.size.z / 2; hi[2] = e.size.z / 2;
+        } else {
+            const RtowTriangle& t = desc->triangles[e.contentIndex];
+            const float v[3][3] = {{t.data[2].x, t.data[2].y, t.data[2].z},
+                                   {t.data[1].x + t.data[2].x, t.data[1].y + t.data[2].y, t.data[1].z + t.data[2].z},
+                                   {t.data[0].x + t.data[2].x, t.data[0].y + t.data[2].y, t.data[0].z + t.data[2].z}};
+            const float nn[3][3] = {{t.normals[0].x, t.normals[0].y, t.normals[0].z}, {t.normals[1].x, t.normals[1].y, t.normals[1].z}, {t.normals[2].x, t.normals[2].y, t.normals[2].z}};
+            for (int a = 0; a < 3; a++) {
+                lo[a] = FLT_MAX; hi[a] = -FLT_MAX;
+                for (int k = 0; k < 3; k++) {
+                    lo[a] = std::min(lo[a], v[k][a] - std::fabs(nn[k][a]) * 0.001f);
+                    hi[a] = std::max(hi[a], v[k][a] + std::fabs(nn[k][a]) * 0.001f);
+                }
+            }
+        }
+        // world bounds (UNITY/BvhNodeData.cs:41-80): the 8 corners through the entity transform; moving entities take the union of
+        // the start and end positions.  Padded so that the kernel's slab test (own rounding) stays conservative.
+        const double qx = e.rotation.x, qy = e.rotation.y, qz = e.rotation.z, qw = e.rotation.w;
         Box bx;
+        bx.reset();
+        for (int c = 0; c < 8; c++) {
+            const double vx = (c & 1) ? hi[0] : lo[0], vy = (c & 2) ? hi[1] : lo[1], vz = (c & 4) ? hi[2] : lo[2];
+            // rotate(q, v) = v + q.w * t + cross(q.xyz, t), t = 2 * cross(q.xyz, v)
+            const double tx = 2 * (qy * vz - qz * vy), ty = 2 * (qz * vx - qx * vz), tz = 2 * (qx * vy - qy * vx);
+            const double rx = vx + qw * tx + (qy * tz - qz * ty), ry = vy + qw * ty + (qz * tx - qx * tz), rz = vz + qw * tz + (qx * ty - qy * tx);
+            const double w[3] = {rx + e.position.x, ry + e.position.y, rz + e.position.z};
+            const double d[3] = {e.moving ? e.destinationOffset.x : 0.0, e.moving ? e.destinationOffset.y : 0.0, e.moving ? e.destinationOffset.z : 0.0};
+            for (int a = 0; a < 3; a++) {
+                bx.lo[a] = std::min(bx.lo[a], (float)std::min(w[a], w[a] + d[a]));
+                bx.hi[a] = std::max(bx.hi[a], (float)std::max(w[a], w[a] + d[a]));
+            }
+        }
         for (int a = 0; a < 3; a++) {
-            const float c0 = p0[a], c1 = p0[a] + d[a];
-            float lo = std::min(c0, c1) - r, hi = std::max(c0, c1) + r;
-            const float pad = 1e-5f * std::max(std::max(std::fabs(lo), std::fabs(hi)), 1.0f) + 1e-5f * r;
-            bx.lo[a] = lo - pad;
-            bx.hi[a] = hi + pad;
-            b.centroid[a][i] = 0.5f * (lo + hi);
+            const float ext = bx.hi[a] - bx.lo[a];
+            const float pad = 1e-5f * std::max(std::max(std::fabs(bx.lo[a]), std::fabs(bx.hi[a])), 1.0f) + 1e-5f * ext;
+            b.centroid[a][i] = 0.5f * (bx.lo[a] + bx.hi[a]);
+            bx.lo[a] -= pad;
+            bx.hi[a] += pad;
         }
         b.primBox[i] = bx;
+
+        if (general) {
+            GpuPrim g{};
+            if (e.type == RTOW_ENTITY_TRIANGLE) {
+                memcpy(g.q, &desc->triangles[e.contentIndex], sizeof(RtowTriangle));   // q0..q5
+                g.q[24] = e.rotation.x; g.q[25] = e.rotation.y; g.q[26] = e.rotation.z; g.q[27] = e.rotation.w;
+            } else {
+                g.q[0] = e.rotation.x; g.q[1] = e.rotation.y; g.q[2] = e.rotation.z; g.q[3] = e.rotation.w;
+                g.q[8] = e.position.x; g.q[9] = e.position.y; g.q[10] = e.position.z;
+                const int32_t mv = e.moving ? 1 : 0;
+                memcpy(&g.q[11], &mv, 4);
+                g.q[12] = e.destinationOffset.x; g.q[13] = e.destinationOffset.y; g.q[14] = e.destinationOffset.z; g.q[15] = e.timeRange.x;
+                g.q[16] = e.timeRange.y;
+                if (e.type == RTOW_ENTITY_SPHERE) {
+                    g.q[20] = e.size.x;
+                } else if (e.type == RTOW_ENTITY_RECT) {                 // Rect.cs:12-16: From = -size / 2, To = size / 2
+                    g.q[20] = -e.size.x / 2; g.q[21] = -e.size.y / 2; g.q[22] = e.size.x / 2; g.q[23] = e.size.y / 2;
+                } else {                                                  // Box.cs:11-15: Extents = size / 2, InverseExtents = 1 / Extents
+                    g.q[20] = e.size.x / 2; g.q[21] = e.size.y / 2; g.q[22] = e.size.z / 2;
+                    g.q[23] = 1 / g.q[20]; g.q[24] = 1 / g.q[21]; g.q[25] = 1 / g.q[22];
+                }
+            }
+            prims[i] = g;
+        }
     }
 
     // ---- SAH build, then breadth-first renumbering ----
@@ -271,6 +335,8 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.sphereOffset = off; L.sphereCount = (uint32_t)n; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuSphere));
     L.hasMotion = hasMotion ? 1u : 0u;
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
+    L.sceneKind = general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
+    L.primOffset = off; if (general) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuPrim));
     L.matIndexOffset = off; off = align16(off + (uint32_t)n * 4u);
     L.materialOffset = off; L.materialCount = (uint32_t)mats.size(); off = align16(off + L.materialCount * (uint32_t)sizeof(GpuMaterial));
     L.totalBytes = off;
@@ -280,6 +346,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     memcpy(out->blob.data() + L.nodeOffset, gnodes.data(), gnodes.size() * sizeof(GpuNode));
     memcpy(out->blob.data() + L.sphereOffset, spheres.data(), spheres.size() * sizeof(GpuSphere));
     if (hasMotion) memcpy(out->blob.data() + L.motionOffset, motion.data(), motion.size() * sizeof(GpuMotion));
+    if (general) memcpy(out->blob.data() + L.primOffset, prims.data(), prims.size() * sizeof(GpuPrim));
     memcpy(out->blob.data() + L.matIndexOffset, matIndex.data(), matIndex.size() * 4u);
     memcpy(out->blob.data() + L.materialOffset, mats.data(), mats.size() * sizeof(GpuMaterial));
     out->layout = L;

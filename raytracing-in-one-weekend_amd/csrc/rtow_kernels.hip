@@ -189,6 +189,99 @@ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, f
     return false;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// general entities (SCENE_KIND_GENERAL): Rect / Box / Triangle and rotated or moving transforms, RT/Entity.cs:58-127
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// math.mul(quaternion q, float3 v): t = 2 * cross(q.xyz, v); v + q.w * t + cross(q.xyz, t)
+__device__ __forceinline__ V3 rotate(float4 q, V3 v)
+{
+    const V3 qv = v3(q.x, q.y, q.z);
+    const V3 t = scale(2.0f, cross(qv, v));
+    const V3 c = cross(qv, t);
+    return v3(v.x + q.w * t.x + c.x, v.y + q.w * t.y + c.y, v.z + q.w * t.z + c.z);
+}
+__device__ __forceinline__ float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); }
+
+// Entity.HitInternal + HitContent for primitive `i` (RT/Entity.cs:74-122) with tMin = 0, tMax = +inf.
+// Returns the distance, the entity-space normal and the rotation that takes it to world space.
+template <bool ALL_LDS>
+__device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time,
+                                            float& tOut, V3& nLocal, float4& rot)
+{
+    const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)i * 128u);
+    if (type == RTOW_ENTITY_TRIANGLE) {
+        // HitTests.Hit(Triangle) (RT/HitTests.cs:115-150); triangles are tested in world space (RT/Entity.cs:91-93)
+        const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
+        rot = p[6];
+        const V3 e0 = v3(a0.x, a0.y, a0.z), e1 = v3(a0.w, a1.x, a1.y), v0 = v3(a1.z, a1.w, a2.x);
+        const V3 pvec = cross(rd, e0);
+        const float det = dot(e1, pvec);
+        if (det == 0) return false;
+        const float invDet = 1 / det;
+        const V3 tvec = sub(ro, v0);
+        const float u = dot(tvec, pvec) * invDet;
+        if (u < 0 || u > 1) return false;
+        const V3 qvec = cross(tvec, e1);
+        const float v = dot(rd, qvec) * invDet;
+        if (v < 0 || u + v > 1) return false;
+        const float dist = dot(e0, qvec) * invDet;
+        if (dist < 0 || dist > __builtin_inff()) return false;
+        const float b0 = 1 - u - v;
+        const V3 n0 = v3(a2.y, a2.z, a2.w), n1 = v3(a3.x, a3.y, a3.z), n2 = v3(a3.w, a4.x, a4.y);
+        nLocal = v3(n0.x * b0 + n1.x * u + n2.x * v, n0.y * b0 + n1.y * u + n2.y * v, n0.z * b0 + n1.z * u + n2.z * v);
+        tOut = dist;
+        return true;
+    }
+    rot = p[0];
+    const float4 invRot = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+    V3 invT = v3(q4.y, q4.z, q4.w);
+    if (__float_as_int(q2.w) != 0) {
+        // TransformAtTime (RT/Entity.cs:124-127) and its inverse (:87-88): invTranslation = mul(invRot, -pos(t))
+        const float f = um_max(0.0f, um_min(1.0f, (time - q3.w) / (q4.x - q3.w)));
+        const V3 pt = v3(q2.x + q3.x * f, q2.y + q3.y * f, q2.z + q3.z * f);
+        invT = rotate(invRot, neg(pt));
+    }
+    const V3 oL = add(rotate(invRot, ro), invT);     // transform(inverseTransform, ray.Origin)
+    const V3 dL = rotate(invRot, rd);                // rotate(inverseTransform, ray.Direction)
+    if (type == RTOW_ENTITY_SPHERE) {
+        float t;
+        if (!sphere_hit(oL, dL, dot(dL, dL), q5.x, t)) return false;
+        nLocal = v3((oL.x + t * dL.x) / q5.x, (oL.y + t * dL.y) / q5.x, (oL.z + t * dL.z) / q5.x);
+        tOut = t;
+        return true;
+    }
+    if (type == RTOW_ENTITY_RECT) {
+        // HitTests.Hit(Rect) (RT/HitTests.cs:62-78)
+        if (dL.z >= 0) return false;
+        const float t = -oL.z / dL.z;
+        if (t < 0 || t > __builtin_inff()) return false;
+        const float x = oL.x + t * dL.x, y = oL.y + t * dL.y;
+        if (x < q5.x || y < q5.y || x > q5.z || y > q5.w) return false;
+        nLocal = v3(0, 0, 1);
+        tOut = t;
+        return true;
+    }
+    // HitTests.Hit(Box) (RT/HitTests.cs:80-113), tMin = 0 so the origin offset is origin + direction * 0
+    const float4 q6 = p[6];
+    const V3 ext = v3(q5.x, q5.y, q5.z), invExt = v3(q5.w, q6.x, q6.y);
+    const V3 o = v3(oL.x + dL.x * 0.0f, oL.y + dL.y * 0.0f, oL.z + dL.z * 0.0f);
+    const float winding = um_max(um_max(__builtin_fabsf(o.x) * invExt.x, __builtin_fabsf(o.y) * invExt.y), __builtin_fabsf(o.z) * invExt.z) < 1 ? -1.0f : 1.0f;
+    V3 sgn = v3(-um_sign(dL.x), -um_sign(dL.y), -um_sign(dL.z));
+    const V3 dtp = v3((ext.x * winding * sgn.x - o.x) / dL.x, (ext.y * winding * sgn.y - o.y) / dL.y, (ext.z * winding * sgn.z - o.z) / dL.z);
+    const bool tx = dtp.x >= 0 && __builtin_fabsf(o.y + dL.y * dtp.x) < ext.y && __builtin_fabsf(o.z + dL.z * dtp.x) < ext.z;
+    const bool ty = dtp.y >= 0 && __builtin_fabsf(o.z + dL.z * dtp.y) < ext.z && __builtin_fabsf(o.x + dL.x * dtp.y) < ext.x;
+    const bool tz = dtp.z >= 0 && __builtin_fabsf(o.x + dL.x * dtp.z) < ext.x && __builtin_fabsf(o.y + dL.y * dtp.z) < ext.y;
+    sgn = tx ? v3(sgn.x, 0, 0) : ty ? v3(0, sgn.y, 0) : v3(0, 0, tz ? sgn.z : 0);
+    if (!(sgn.x != 0 || sgn.y != 0 || sgn.z != 0)) return false;
+    float dist = sgn.x != 0 ? dtp.x : sgn.y != 0 ? dtp.y : dtp.z;
+    dist += 0.0f;
+    if (dist > __builtin_inff()) return false;
+    nLocal = sgn;
+    tOut = dist;
+    return true;
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Raw VALU min/max (IEEE mode: a NaN operand yields the other operand).  __builtin_fminf/fmaxf would first canonicalise
@@ -266,7 +359,7 @@ enum : int {
     ST_COUNT = 5
 };
 
-template <bool ALL_LDS, bool HAS_MOTION, int HW, bool FULL_DIAG>
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG>
 __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -294,6 +387,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     sc.ldsNodeCount = A.ldsNodeCount;
     const SceneLayout L = A.layout;
     const int traceDepth = A.traceDepth;
+    constexpr bool HAS_MOTION = KIND == SCENE_KIND_SPHERES_MOTION;
+    constexpr bool GENERAL = KIND == SCENE_KIND_GENERAL;
 
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
@@ -541,9 +636,15 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     STAT_LANES(6);
                     nc--;
                     const int i = cand[nc * kBlockThreads];
-                    V3 c; float r, t;
-                    sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
-                    if (sphere_hit(sub(ro, c), rd, a, r, t) && t < best) { best = t; prim = i; }
+                    if (GENERAL) {
+                        const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
+                        float t; V3 nl; float4 rq;
+                        if (general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, t, nl, rq) && t < best) { best = t; prim = i; }
+                    } else {
+                        V3 c; float r, t;
+                        sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
+                        if (sphere_hit(sub(ro, c), rd, a, r, t) && t < best) { best = t; prim = i; }
+                    }
                 }
                 if (cur >= 0) st = ST_TRAV;        // the list was full: resume the walk, now pruned by `best`
                 else classify();
@@ -555,17 +656,24 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             STAT_ADD(7, 1);
             if (st == ST_HIT) {
                 STAT_LANES(8);
-                V3 c; float radius;
-                sphere_at<ALL_LDS, HAS_MOTION>(sc, L, prim, rtime, c, radius);
-                const float t = best;
-                const V3 oc = sub(ro, c);
-                const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
-                const V3 nLocal = v3((oc.x + t * rd.x) / radius, (oc.y + t * rd.y) / radius, (oc.z + t * rd.z) / radius); // r.GetPoint(t) / radius
-                const V3 N = normalize(nLocal);                                               // RT/Entity.cs:65
-
                 const unsigned mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
                 const unsigned matIdx = mi & 0xffffu;
-                const unsigned cls = mi >> 16;                                 // shading class packed by the scene compiler
+                const unsigned cls = (mi >> 16) & 3u;                          // shading class packed by the scene compiler
+                const float t = best;
+                const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
+                V3 N;
+                if (GENERAL) {
+                    // re-run the winning primitive's test for its entity-space normal, then rotate it out (RT/Entity.cs:62-66)
+                    float t2; V3 nLocal; float4 rq;
+                    (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, t2, nLocal, rq);
+                    N = normalize(rotate(rq, nLocal));
+                } else {
+                    V3 c; float radius;
+                    sphere_at<ALL_LDS, HAS_MOTION>(sc, L, prim, rtime, c, radius);
+                    const V3 oc = sub(ro, c);
+                    const V3 nLocal = v3((oc.x + t * rd.x) / radius, (oc.y + t * rd.y) / radius, (oc.z + t * rd.z) / radius); // r.GetPoint(t) / radius
+                    N = normalize(nLocal);                                                    // RT/Entity.cs:65
+                }
                 const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + matIdx * 64u;
                 const float4 m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
                 const float4 m1 = *reinterpret_cast<const float4*>(mp + 16);  // emission.yz type metallic
@@ -725,6 +833,27 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 #endif
 }
 
+// Derived per-entity transform data for SCENE_KIND_GENERAL, on the device: InverseTransform = inverse(OriginTransform)
+// (RT/Entity.cs:51-52; math.inverse(RigidTransform): invRot = inverse(rot), invTranslation = mul(invRot, -pos);
+// math.inverse(quaternion q) = rcp(dot(q, q)) * q * float4(-1, -1, -1, 1)).
+__global__ void prepare_entities_kernel(uint8_t* blob, SceneLayout L)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.sphereCount) return;
+    const unsigned type = reinterpret_cast<const unsigned*>(blob + L.matIndexOffset)[i] >> kPrimTypeShift;
+    if (type == RTOW_ENTITY_TRIANGLE) return;
+    float4* p = reinterpret_cast<float4*>(blob + L.primOffset + (size_t)i * 128u);
+    const float4 q = p[0];
+    const float r = 1.0f / (q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float4 inv = make_float4(r * q.x * -1.0f, r * q.y * -1.0f, r * q.z * -1.0f, r * q.w * 1.0f);
+    p[1] = inv;
+    const float4 q2 = p[2];
+    const V3 it = rotate(inv, v3(-q2.x, -q2.y, -q2.z));
+    float4 q4 = p[4];
+    q4.y = it.x; q4.z = it.y; q4.w = it.z;
+    p[4] = q4;
+}
+
 // Derived per-material constants, computed ON THE DEVICE with the same float program the per-hit code would run
 // (pow(1 - glossiness, 2), RoughnessToAlpha, lerp(PlasticIor, MetalIor, metallic), Schlick's r0, 1 / ior), so hoisting
 // them out of the bounce loop cannot change a bit of the result.
@@ -848,29 +977,39 @@ __global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-template <bool ALL_LDS, bool HAS_MOTION, int HW, bool FULL_DIAG>
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG>
 hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    auto k = sample_batch_kernel<ALL_LDS, HAS_MOTION, HW, FULL_DIAG>;
+    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(numBlocks), dim3(kBlockThreads), ldsBytes, stream, args);
     return hipGetLastError();
 }
 
-template <bool ALL_LDS, bool HAS_MOTION, bool FULL_DIAG>
+template <bool ALL_LDS, int KIND, bool FULL_DIAG>
 hipError_t launchByDepth(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, HAS_MOTION, 4, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, HAS_MOTION, 8, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
-    return launchVariant<ALL_LDS, HAS_MOTION, 32, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
+    return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
 }
 
-template <bool ALL_LDS, bool HAS_MOTION>
+template <bool ALL_LDS, int KIND>
 hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    if (args.diagnostics && args.diagnosticsStride >= 16) return launchByDepth<ALL_LDS, HAS_MOTION, true>(args, numBlocks, ldsBytes, stream);
-    return launchByDepth<ALL_LDS, HAS_MOTION, false>(args, numBlocks, ldsBytes, stream);
+    if (args.diagnostics && args.diagnosticsStride >= 16) return launchByDepth<ALL_LDS, KIND, true>(args, numBlocks, ldsBytes, stream);
+    return launchByDepth<ALL_LDS, KIND, false>(args, numBlocks, ldsBytes, stream);
+}
+
+template <bool ALL_LDS>
+hipError_t launchByKind(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
+{
+    switch (args.layout.sceneKind) {
+        case SCENE_KIND_SPHERES: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES>(args, numBlocks, ldsBytes, stream);
+        case SCENE_KIND_SPHERES_MOTION: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES_MOTION>(args, numBlocks, ldsBytes, stream);
+        default: return launchByDiag<ALL_LDS, SCENE_KIND_GENERAL>(args, numBlocks, ldsBytes, stream);
+    }
 }
 
 } // namespace
@@ -879,9 +1018,15 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
 {
     const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
-    const bool motion = args.layout.hasMotion != 0;
-    if (allLds) return motion ? launchByDiag<true, true>(args, numBlocks, ldsBytes, stream) : launchByDiag<true, false>(args, numBlocks, ldsBytes, stream);
-    return motion ? launchByDiag<false, true>(args, numBlocks, ldsBytes, stream) : launchByDiag<false, false>(args, numBlocks, ldsBytes, stream);
+    return allLds ? launchByKind<true>(args, numBlocks, ldsBytes, stream) : launchByKind<false>(args, numBlocks, ldsBytes, stream);
+}
+
+hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream)
+{
+    if (layout.sceneKind != SCENE_KIND_GENERAL) return hipSuccess;
+    const unsigned blocks = (layout.sphereCount + 127u) / 128u;
+    hipLaunchKernelGGL(prepare_entities_kernel, dim3(blocks ? blocks : 1), dim3(128), 0, stream, blob, layout);
+    return hipGetLastError();
 }
 
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream)

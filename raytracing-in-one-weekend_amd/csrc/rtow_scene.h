@@ -71,6 +71,26 @@ struct GpuMaterial {
 };
 static_assert(sizeof(GpuMaterial) == 64, "GpuMaterial must be 64 bytes");
 
+// General primitive record (128 B) for scenes that are not identity-rotation spheres: Rect / Box / Triangle entities,
+// rotated entities (RT/Entity.cs:27-127).  One fixed-stride array so a leaf code indexes it directly.
+//   transformed entity (sphere / rect / box):
+//     q0 rot  q1 inverse(rot)*  q2 (pos.xyz, moving)  q3 (DestinationOffset.xyz, t0)  q4 (t1, inverse translation*.xyz)
+//     q5 (p0 p1 p2 p3)  q6 (p4 p5 p6 -)      sphere: p0 = radius; rect: From.xy To.xy; box: Extents.xyz, InverseExtents.xyz (p3..p5)
+//   triangle: q0..q5 = RtowTriangle verbatim (Data, Normals, TextureCoordinates), q6 = rot
+//   (* derived on the device by prepare_entities_kernel with the path's own float program)
+struct GpuPrim {
+    float q[32];
+};
+static_assert(sizeof(GpuPrim) == 128, "GpuPrim must be 128 bytes");
+
+enum : uint32_t {
+    SCENE_KIND_SPHERES = 0,        // identity-rotation static spheres: GpuSphere only
+    SCENE_KIND_SPHERES_MOTION = 1, // identity-rotation spheres, some moving: GpuSphere + GpuMotion
+    SCENE_KIND_GENERAL = 2,        // anything else: GpuPrim
+};
+// materialIndex[] word: bits 0..15 material, 16..17 shading class, 18..20 RtowEntityType
+constexpr uint32_t kPrimTypeShift = 18;
+
 // Byte offsets of the sections inside the scene blob (all multiples of 16).
 struct SceneLayout {
     uint32_t nodeOffset, nodeCount;         // GpuNode[nodeCount]
@@ -80,7 +100,9 @@ struct SceneLayout {
     uint32_t materialOffset, materialCount; // GpuMaterial[materialCount]
     uint32_t totalBytes;                    // size of the blob
     uint32_t bvhDepth;                      // max number of inner nodes on a root->leaf path == stack bound
-    uint32_t pad;
+    uint32_t sceneKind;                     // SCENE_KIND_*
+    uint32_t primOffset;                    // GpuPrim[sphereCount] when sceneKind == SCENE_KIND_GENERAL
+    uint32_t pad[3];
 };
 
 } // namespace rtow

@@ -112,6 +112,11 @@ class Scene:
         self.time_ranges = []    # (t0, t1)
         self.material_index = []
         self.exclude_from_overlap = []
+        self.types = []          # abi.ENTITY_*
+        self.rotations = []      # quaternion (x, y, z, w)
+        self.sizes = []          # float32[3]: sphere (r,-,-), rect (sx,sy,-), box (sx,sy,sz)
+        self.tri_index = []      # index into self.triangles, -1 for non-triangles
+        self.triangles = []      # abi.Triangle payloads
         self.materials = []      # abi.Material
         self.camera = {}
         self.sky_bottom = (1.0, 1.0, 1.0)
@@ -123,33 +128,72 @@ class Scene:
     def entity_count(self):
         return len(self.radii)
 
-    def add_sphere(self, pos, radius, material, moving=False, dest_offset=(0, 0, 0), time_range=(0, 0), exclude=False):
-        self.materials.append(material)
+    def _add(self, etype, pos, size, material, rotation, moving, dest_offset, time_range, exclude, tri=-1):
+        if isinstance(material, int):
+            mi = material
+        else:
+            self.materials.append(material)
+            mi = len(self.materials) - 1
+        self.types.append(etype)
         self.positions.append(np.asarray(pos, dtype=np.float32))
-        self.radii.append(f32(radius))
+        self.sizes.append(np.asarray(size, dtype=np.float32))
+        self.radii.append(f32(size[0]))
+        self.rotations.append(tuple(float(f32(c)) for c in rotation))
         self.moving.append(bool(moving))
         self.dest_offsets.append(np.asarray(dest_offset, dtype=np.float32))
         self.time_ranges.append((f32(time_range[0]), f32(time_range[1])))
-        self.material_index.append(len(self.materials) - 1)
+        self.material_index.append(mi)
         self.exclude_from_overlap.append(bool(exclude))
+        self.tri_index.append(tri)
+
+    def add_sphere(self, pos, radius, material, moving=False, dest_offset=(0, 0, 0), time_range=(0, 0), exclude=False, rotation=(0, 0, 0, 1)):
+        self._add(abi.ENTITY_SPHERE, pos, (radius, 0, 0), material, rotation, moving, dest_offset, time_range, exclude)
+
+    def add_rect(self, pos, size_xy, material, rotation=(0, 0, 0, 1), moving=False, dest_offset=(0, 0, 0), time_range=(0, 0)):
+        """Rect in the entity's XY plane, facing +Z (RT/EntityTypes/Rect.cs); only hit by rays with local direction.z < 0."""
+        self._add(abi.ENTITY_RECT, pos, (size_xy[0], size_xy[1], 0), material, rotation, moving, dest_offset, time_range, True)
+
+    def add_box(self, pos, size, material, rotation=(0, 0, 0, 1), moving=False, dest_offset=(0, 0, 0), time_range=(0, 0)):
+        self._add(abi.ENTITY_BOX, pos, size, material, rotation, moving, dest_offset, time_range, True)
+
+    def add_triangle(self, v1, v2, v3, material, normals=None, uvs=((0, 0), (1, 0), (0, 1)), moving=False, dest_offset=(0, 0, 0), time_range=(0, 0)):
+        """World-space triangle; Triangle ctor of RT/EntityTypes/Triangle.cs:15-30 (face normal when `normals` is None).
+        The entity carries the `default` RigidTransform (zero quaternion), as AddMeshRuntimeEntitiesJob creates it (:83-85)."""
+        v1, v2, v3 = (np.asarray(v, dtype=np.float32) for v in (v1, v2, v3))
+        d0, d1 = (v3 - v1).astype(np.float32), (v2 - v1).astype(np.float32)
+        if normals is None:
+            fn = _normalize(_cross(d1, d0))
+            ns = (fn, fn, fn)
+        else:
+            ns = tuple(_normalize(np.asarray(n, dtype=np.float32)) for n in normals)
+        t = abi.Triangle()
+        for k, v in enumerate((d0, d1, v1)):
+            t.data[k] = abi.Float3(*[float(c) for c in v])
+        for k, v in enumerate(ns):
+            t.normals[k] = abi.Float3(*[float(c) for c in v])
+        for k, v in enumerate(uvs):
+            t.textureCoordinates[k] = abi.Float2(float(v[0]), float(v[1]))
+        self.triangles.append(t)
+        self._add(abi.ENTITY_TRIANGLE, (0, 0, 0), (0, 0, 0), material, (0, 0, 0, 0), moving, dest_offset, time_range, True, tri=len(self.triangles) - 1)
 
     def desc(self, max_bvh_depth=32):
         n = self.entity_count
         ents = (abi.Entity * n)()
         for i in range(n):
             e = ents[i]
-            e.type = abi.ENTITY_SPHERE
+            e.type = self.types[i]
             e.moving = 1 if self.moving[i] else 0
-            e.rotation = abi.Float4(0.0, 0.0, 0.0, 1.0)  # quaternion.Euler(0,0,0)
+            e.rotation = abi.Float4(*self.rotations[i])  # quaternion.Euler(0,0,0) = (0,0,0,1) for the book scenes
             e.position = abi.Float3(*[float(c) for c in self.positions[i]])
             e.destinationOffset = abi.Float3(*[float(c) for c in self.dest_offsets[i]])
             e.timeRange = abi.Float2(float(self.time_ranges[i][0]), float(self.time_ranges[i][1]))
             e.materialIndex = self.material_index[i]
-            e.size = abi.Float3(float(self.radii[i]), 0.0, 0.0)
-            e.contentIndex = 0
+            e.size = abi.Float3(*[float(c) for c in self.sizes[i]])
+            e.contentIndex = max(self.tri_index[i], 0)
         mats = (abi.Material * len(self.materials))(*self.materials)
-        d = abi.SceneDesc(ents, n, mats, len(self.materials), max_bvh_depth)
-        self._keepalive = (ents, mats)
+        tris = (abi.Triangle * max(len(self.triangles), 1))(*self.triangles)
+        d = abi.SceneDesc(ents, n, mats, len(self.materials), max_bvh_depth, tris if self.triangles else None, len(self.triangles))
+        self._keepalive = (ents, mats, tris)
         return d
 
     # -- reproducible serialisation for tests/golden ------------------------------------------------
@@ -187,6 +231,10 @@ class Scene:
         s.time_ranges = [(f32(a), f32(b)) for a, b in d["time_ranges"]]
         s.material_index = list(d["material_index"])
         s.exclude_from_overlap = [False] * len(s.radii)
+        s.types = [abi.ENTITY_SPHERE] * len(s.radii)
+        s.rotations = [(0.0, 0.0, 0.0, 1.0)] * len(s.radii)
+        s.sizes = [np.array([r, 0, 0], dtype=np.float32) for r in s.radii]
+        s.tri_index = [-1] * len(s.radii)
         s.camera = d["camera"]
         s.sky_bottom = tuple(d["sky_bottom"])
         s.sky_top = tuple(d["sky_top"])
@@ -317,6 +365,48 @@ def stress_scene(count=10000, seed=10000, spread=100.0, max_tentatives=60000):
     return s
 
 
+def quat_axis_angle(axis, degrees):
+    """quaternion.AxisAngle(axis, radians) = (sin(a/2) * axis, cos(a/2)) in float32."""
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    h = math.radians(degrees) / 2
+    q = np.array([a[0] * math.sin(h), a[1] * math.sin(h), a[2] * math.sin(h), math.cos(h)], dtype=np.float32)
+    return tuple(float(c) for c in q)
+
+
+def mixed_scene():
+    """Cornell-like room exercising every primitive kind and the general entity transform: rects (walls, light), rotated
+    and moving boxes, a rotated sphere, a small triangle mesh (pyramid, face normals + one smooth-shaded face)."""
+    s = Scene("mixed")
+    white, red, green = lambertian((0.73, 0.73, 0.73)), lambertian((0.65, 0.05, 0.05)), lambertian((0.12, 0.45, 0.15))
+    light = standard((0.0, 0.0, 0.0), 0.0, 0.0, emission=(7.0, 7.0, 7.0))
+    up90, dn90 = quat_axis_angle((1, 0, 0), -90), quat_axis_angle((1, 0, 0), 90)
+    s.add_rect((0, 0, -2), (4, 4), white)                                          # back wall, faces +Z
+    s.add_rect((0, -2, 0), (4, 4), white, rotation=up90)                           # floor, faces +Y
+    s.add_rect((0, 2, 0), (4, 4), white, rotation=dn90)                            # ceiling, faces -Y
+    s.add_rect((-2, 0, 0), (4, 4), red, rotation=quat_axis_angle((0, 1, 0), 90))   # left wall, faces +X
+    s.add_rect((2, 0, 0), (4, 4), green, rotation=quat_axis_angle((0, 1, 0), -90)) # right wall, faces -X
+    s.add_rect((0, 1.99, 0), (1.2, 1.2), light, rotation=dn90)                     # area light
+    s.add_box((-0.7, -1.2, -0.6), (1.1, 1.6, 1.1), white, rotation=quat_axis_angle((0, 1, 0), 20))
+    s.add_box((0.8, -1.5, 0.3), (1.0, 1.0, 1.0), metal((0.8, 0.85, 0.9), 0.1), rotation=quat_axis_angle((0, 1, 0), -17),
+              moving=True, dest_offset=(0.0, 0.3, 0.0), time_range=(0.0, 1.0))
+    s.add_sphere((0.7, -0.6, 0.3), 0.4, dielectric(1.5), rotation=quat_axis_angle((1, 1, 0), 33))
+    s.add_sphere((-0.7, 0.0, -0.6), 0.35, metal((0.9, 0.6, 0.2), 0.0), rotation=quat_axis_angle((0, 0, 1), 75),
+                 moving=True, dest_offset=(0.2, 0.0, 0.0), time_range=(0.2, 0.9))
+    apex = (0.0, -0.9, 1.0)
+    base = [(-0.4, -2.0, 0.6), (0.4, -2.0, 0.6), (0.4, -2.0, 1.4), (-0.4, -2.0, 1.4)]
+    blue = lambertian((0.2, 0.3, 0.8))
+    for k in range(4):
+        a, b = base[k], base[(k + 1) % 4]
+        if k == 0:
+            s.add_triangle(a, apex, b, blue, normals=((-0.5, 0.3, -1), (0, 1, 0), (0.5, 0.3, -1)))   # smooth-shaded face
+        else:
+            s.add_triangle(a, apex, b, blue)
+    s.camera = {"position": [0.0, 0.0, 6.5], "target": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 38.0, "aperture": 0.0}
+    s.sky_bottom, s.sky_top = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)
+    return s
+
+
 def tiny_scene():
     """Five spheres, one of each material branch + a negative-radius hollow glass shell; for fast unit tests."""
     s = Scene("tiny")
@@ -348,8 +438,11 @@ def focus_distance(scene, origin, direction):
     """Nearest sphere hit along the view axis (HitWorld, UNITY/Raytracer.cs:608-609,1353) in float32 numpy."""
     o = np.asarray(origin, dtype=np.float32)
     d = np.asarray(direction, dtype=np.float32)
-    pos = np.stack(scene.positions).astype(np.float32)
-    rad = np.asarray(scene.radii, dtype=np.float32)
+    sph = [i for i, t in enumerate(scene.types) if t == abi.ENTITY_SPHERE]
+    if not sph:
+        return 1.0
+    pos = np.stack([scene.positions[i] for i in sph]).astype(np.float32)
+    rad = np.asarray([scene.radii[i] for i in sph], dtype=np.float32)
     oc = (o[None, :] - pos).astype(np.float32)
     a = f32(d @ d)
     b = (oc @ d).astype(np.float32)

@@ -128,8 +128,11 @@ def test_error_codes(rt, gpu_context):
         assert e.value.code == code, field
 
     bad = scene.desc()
-    bad.entities[0].type = a.ENTITY_BOX
-    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_UNSUPPORTED
+    bad.entities[0].type = 9
+    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE
+    bad = scene.desc()
+    bad.entities[0].type = a.ENTITY_TRIANGLE           # no triangle payloads supplied
+    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE
     bad = scene.desc()
     bad.entities[0].materialIndex = 99
     assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE

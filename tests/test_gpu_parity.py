@@ -104,3 +104,37 @@ def test_slices_partition_the_frame(rt, oracle, gpu_context):
             parts[k][mask] = marker[k][mask]
     for k in parts:
         assert np.array_equal(parts[k], full[k])
+
+
+def test_mixed_primitives_rotated_and_moving(rt, oracle, gpu_context):
+    """Rect / Box / Triangle / rotated + moving entities through the general Entity transform (RT/Entity.cs:58-127)."""
+    scene = rt.scenes.mixed_scene()
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 120, 120, 8, 8, focus=6.5, diagnostics_stride=16)
+    _compare(gpu, ref)
+    assert gpu["color"][:, 3].sum() > 0
+
+
+def test_triangle_mesh_scene(rt, oracle, gpu_context):
+    """The reference's live host only ingests triangle meshes (UNITY/Raytracer.cs:1185-1304): a tessellated sphere over a quad."""
+    import numpy as np
+    scene = rt.scenes.Scene("mesh")
+    grey = scene.materials.append(rt.scenes.lambertian((0.6, 0.6, 0.6))) or 0
+    gold = scene.materials.append(rt.scenes.metal((0.9, 0.7, 0.3), 0.15)) or 1
+    scene.add_triangle((-3, 0, -3), (3, 0, 3), (3, 0, -3), grey)
+    scene.add_triangle((-3, 0, -3), (-3, 0, 3), (3, 0, 3), grey)
+    nu, nv, r, c = 12, 8, 0.8, np.array([0.0, 0.9, 0.0])
+
+    def pt(i, j):
+        th, ph = 2 * np.pi * i / nu, np.pi * j / nv
+        return c + r * np.array([np.sin(ph) * np.cos(th), np.cos(ph), np.sin(ph) * np.sin(th)])
+
+    for i in range(nu):
+        for j in range(nv):
+            a, b, cc, d = pt(i, j), pt(i + 1, j), pt(i + 1, j + 1), pt(i, j + 1)
+            if j > 0:
+                scene.add_triangle(a, b, cc, gold, normals=(a - c, b - c, cc - c))      # vertex normals: smooth shading
+            if j < nv - 1:
+                scene.add_triangle(a, cc, d, gold, normals=(a - c, cc - c, d - c))
+    scene.camera = {"position": [2.5, 1.8, 3.0], "target": [0.0, 0.7, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 35.0, "aperture": 0.0}
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 72, 6, 8, focus=4.0)
+    _compare(gpu, ref)
