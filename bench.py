@@ -11,9 +11,15 @@ ping-pong buffers with a fresh seed, exactly like the reference's successive bat
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; the frame is row-interleaved across ranks with the reference's own slice contract
-(SliceOffset = rank, SliceDivider = N, JOBS/SampleBatchJob.cs:69-70), no data-path collective inside the batch, and
-ONE RCCL gather of each rank's colour rows to rank 0 per batch.  The frame is fixed, so scaling is "strong".
+N > 1: one process per GPU, no data-path collective inside a batch, ONE RCCL gather per batch.  The total work is fixed
+(same frame, same spp), so scaling is "strong".  Two partitions (raytracing-in-one-weekend_amd/multigpu.py):
+  --partition batches (default)  every rank renders the whole frame with spp/N samples and its own seed from zeroed
+                                 accumulators; rank 0 gathers the partial accumulators and folds them in rank order
+                                 (the reference's batch accumulation, Raytracer.cs:656-661,798-802, run concurrently);
+  --partition tiles              the frame is row-interleaved with the reference's slice contract (SliceOffset = rank,
+                                 SliceDivider = N, JOBS/SampleBatchJob.cs:69-70) and the colour rows are gathered;
+                                 bit-identical to the single-GPU frame but limited by lane-per-pixel granularity
+                                 (measured 3.2x at 8 slices of 1080p), which is why it is not the default.
 
 Rank 0 prints ONE JSON line (see the task contract) that also carries `roofline` and `cpu_baseline`.
 """
@@ -105,6 +111,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--partition", choices=("batches", "tiles"), default="batches", help="how N > 1 GPUs split a batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,30 +144,64 @@ def main():
     ctx.upload_scene(scene.desc())
     info = ctx.scene_info()
 
-    # accumulators resident in HBM (torch tensors are only the allocation + stream plumbing)
-    def bufs():
-        return [torch.zeros(n, 4, device=dev), torch.zeros(n, 3, device=dev), torch.zeros(n, 3, device=dev), torch.zeros(n, device=dev)]
-
-    ping, pong = bufs(), bufs()
-    diag = torch.zeros(n, device=dev)
+    # accumulators resident in HBM (torch tensors are only the allocation + stream plumbing); each set of four buffers is a
+    # view of one flat [11 * n] tensor so that a rank's partial result can travel in one collective
     mg = importlib.import_module("raytracing-in-one-weekend_amd.multigpu")
+    batches = world > 1 and args.partition == "batches"
+
+    def flat():
+        return torch.zeros(mg.ACCUM_FLOATS * n, device=dev)
+
+    ping_flat, pong_flat = flat(), flat()
+    ping, pong = mg.accum_views(ping_flat, n), mg.accum_views(pong_flat, n)
+    zero_flat = flat() if batches else None           # never written: the input of every rank's sub-batch
+    gather_bufs = [flat() for _ in range(world)] if (batches and rank == 0) else None
+    diag = torch.zeros(n, device=dev)
+    # parameter block built once (View ctor + auto-focus probe are host work outside the path); only Seed changes per step
+    if batches:
+        base = rt.scenes.make_params(scene, W, H, spp=mg.batch_split(spp, rank, world), trace_depth=depth)
+    else:
+        base = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, slice_offset=rank, slice_divider=world)
+
+    def params_for(seed):
+        p = abi.SampleParams.from_buffer_copy(base)
+        p.seed = seed
+        return p
 
     import ctypes as C
     lib = rt.lib.load()
     stream = torch.cuda.current_stream(dev)
     kernel_ms = []
 
+    def add_fn(dst_views, src_views):
+        d = abi.AccumBuffers(*[t.data_ptr() for t in dst_views])
+        s_ = abi.AccumBuffers(*[t.data_ptr() for t in src_views])
+        rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, n, C.byref(d), C.byref(s_), stream.cuda_stream), "rtowAddAccumDevice")
+
+    def launch(p, src, dst):
+        bi = abi.AccumBuffers(*[t.data_ptr() for t in src])
+        bo = abi.AccumBuffers(*[t.data_ptr() for t in dst])
+        rt.lib.check(lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(bi), C.byref(bo), diag.data_ptr(), stream.cuda_stream, None),
+                     "rtowSampleBatchDevice")
+
     def step(i, record=False):
-        nonlocal ping, pong
-        p = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, seed=i + 1, slice_offset=rank, slice_divider=world)
-        bi = abi.AccumBuffers(*[t.data_ptr() for t in ping])
-        bo = abi.AccumBuffers(*[t.data_ptr() for t in pong])
-        rc = lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(bi), C.byref(bo), diag.data_ptr(), stream.cuda_stream, None)
-        rt.lib.check(rc, "rtowSampleBatchDevice")
-        if world > 1:
-            # the one collective of the multi-GPU path: colour rows of every rank -> rank 0 (RCCL gather)
-            mg.gather_frame(mg.pack_owned(pong[0].view(H, W, 4), rank, world), H, rank, world)
-        ping, pong = pong, ping
+        nonlocal ping, pong, ping_flat, pong_flat
+        if batches:
+            # every rank: whole frame, its share of the samples, its own seed, zeroed inputs; one gather; ordered fold on rank 0
+            p = params_for(mg.batch_seed(i + 1, rank, world))
+
+            def render_full():
+                launch(p, mg.accum_views(zero_flat, n), pong)
+                return pong_flat
+
+            mg.render_batches(render_full, ping_flat, n, rank, world, add_fn, gather_list=gather_bufs)   # ping = running accumulation (rank 0)
+        else:
+            p = params_for(i + 1)
+            launch(p, ping, pong)
+            if world > 1:
+                # the one collective of the tile path: colour rows of every rank -> rank 0 (RCCL gather)
+                mg.gather_frame(mg.pack_owned(pong[0].view(H, W, 4), rank, world), H, rank, world)
+            ping, pong, ping_flat, pong_flat = pong, ping, pong_flat, ping_flat
         if record:
             kernel_ms.append(ctx.last_sample_kernel_ms())  # HIP events on the launch stream (synchronises)
 
@@ -193,10 +234,11 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # metrics of the last batch (rays per sample, success ratio) - outside the timed region
         last = ping
-        rays = float(diag.sum().item()) * (world if world > 1 else 1)  # every rank traces a statistically equal slice
+        rays = float(diag.sum().item()) * (world if world > 1 else 1)  # every rank traces a statistically equal share
         # algorithmic HBM bytes per launch of the sample kernel: 44 B read + 44 B write + 4 B diagnostics per
         # owned pixel, plus the scene image once
-        owned_pixels = len(range(rank, H, world)) * W
+        owned_pixels = n if (batches or world == 1) else len(range(rank, H, world)) * W
+        rank_spp = mg.batch_split(spp, rank, world) if batches else spp
         alg_bytes = owned_pixels * 92 + int(info.sceneBytesDevice)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_hbm_traffic() if world == 1 else (None, None)
@@ -216,11 +258,13 @@ def main():
             "config": {
                 "workload": "cover scene (486 spheres, generated per Final Scene (Book 1).asset, seed 700), %dx%d, %d spp per batch, "
                             "%d bounces, white noise, jitter on, reference RNG stream (lane per pixel)" % (W, H, spp, depth),
-                "partition": "row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch" % world if world > 1 else "single GPU",
+                "partition": ("single GPU" if world == 1 else
+                              "batches: every rank renders the whole frame with spp/%d samples and its own seed, one RCCL gather of the partial accumulators, ordered fold on rank 0" % world
+                              if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch" % world),
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds),
             },
             "kernel_ms_per_step": round(avg_kernel_ms, 3),
-            "msamples_per_s_kernel_only": round(owned_pixels * spp * world / (avg_kernel_ms * 1e-3) / 1e6, 2),
+            "msamples_per_s_kernel_only": round(owned_pixels * rank_spp * world / (avg_kernel_ms * 1e-3) / 1e6, 2),
             "mrays_per_s": round(rays / (avg_kernel_ms * 1e-3) / 1e6, 1),
             "rays_per_sample": round(rays / (float(n) * spp), 4),
             "successful_sample_ratio": round(float(last[0][:, 3].sum().item()) * (world if world > 1 else 1) / (float(n) * spp * (args.steps + args.warmup)), 4) if world == 1 else None,

@@ -290,6 +290,12 @@ RTOW_API int rtowFinalizeDevice(RtowContext context, int32_t pixelCount,
                                 const float* inColor /*float3*/, const float* inNormal, const float* inAlbedo,
                                 uint8_t* outColor /*RGBA32*/, uint8_t* outNormal, uint8_t* outAlbedo, void* stream);
 
+/* dst += src for the four accumulation buffers (device pointers, `pixelCount` elements each).  The reference accumulates
+ * successive batches by feeding a batch's outputs to the next one as inputs (UNITY/Raytracer.cs:798-802); when batches run
+ * CONCURRENTLY on several GPUs (each from zeroed accumulators, its own Seed) their partial sums are folded with this, in
+ * a fixed order, on the root.  color.w (the success count) adds like the other channels. */
+RTOW_API int rtowAddAccumDevice(RtowContext context, int32_t pixelCount, const RtowAccumBuffers* dst, const RtowAccumBuffers* src, void* stream);
+
 /* replaces: allocateCudaBuffer / copyCudaBuffer / deallocateCudaBuffer (OptixDenoiser.h:57-64). kind: RtowMemcpyKind. */
 typedef enum RtowMemcpyKind {       /* CudaMemcpyKind, OptixApi.cs:33-40 */
     RTOW_MEMCPY_HOST_TO_HOST = 0,

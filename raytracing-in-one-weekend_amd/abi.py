@@ -127,6 +127,6 @@ class CombineParams(C.Structure):
 EXPORTED_SYMBOLS = [
     "rtowGetApiVersion", "rtowErrorString", "rtowCreateContext", "rtowDestroyContext", "rtowUploadScene",
     "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
-    "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowDeviceAlloc", "rtowDeviceFree",
+    "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize",
 ]

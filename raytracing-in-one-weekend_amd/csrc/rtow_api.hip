@@ -471,6 +471,22 @@ RTOW_API int rtowFinalizeDevice(RtowContext ctx, int32_t pixelCount, const float
     return RTOW_SUCCESS;
 }
 
+RTOW_API int rtowAddAccumDevice(RtowContext ctx, int32_t pixelCount, const RtowAccumBuffers* dst, const RtowAccumBuffers* src, void* stream)
+{
+    if (!ctx || !dst || !src || pixelCount <= 0) return RTOW_ERROR_INVALID_VALUE;
+    if (!dst->color || !dst->normal || !dst->albedo || !dst->sampleCountWeight || !src->color || !src->normal || !src->albedo || !src->sampleCountWeight)
+        return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const size_t n = (size_t)pixelCount;
+    HIP_TRY(ctx, launchAdd(n * 4, dst->color, src->color, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchAdd(n * 3, dst->normal, src->normal, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchAdd(n * 3, dst->albedo, src->albedo, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchAdd(n, dst->sampleCountWeight, src->sampleCountWeight, s), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
 RTOW_API int rtowDeviceAlloc(RtowContext ctx, size_t sizeInBytes, void** outPointer)
 {
     if (!ctx || !outPointer || sizeInBytes == 0) return RTOW_ERROR_INVALID_VALUE;

@@ -80,6 +80,8 @@ hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const
 hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
                           uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, hipStream_t stream);
 
+hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t stream); // dst += src
+
 // Per-block partial results of the metrics reduction; the host folds them in block order.
 struct MetricsPartial {
     long long rays, samples;

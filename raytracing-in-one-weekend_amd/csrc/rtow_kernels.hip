@@ -920,6 +920,20 @@ __global__ void __launch_bounds__(256) combine_kernel(RtowCombineParams p, const
     }
 }
 
+// dst += src over a flat float array (the four accumulators are added as 16 B / 4 B streams; HBM bound: 8 B read + 4 B written per float)
+__global__ void __launch_bounds__(256) add_kernel(size_t n4, float4* __restrict__ dst, const float4* __restrict__ src, size_t tailStart, size_t n, float* __restrict__ dstS,
+                                                  const float* __restrict__ srcS)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = dst[i];
+        const float4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+    for (size_t i = tailStart + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dstS[i] += srcS[i];
+}
+
 // LinearToGamma (UTIL/MathExtensions.cs:17-21) -> saturate -> * 255 -> (byte)
 __device__ __forceinline__ unsigned to_byte(float v)
 {
@@ -1052,6 +1066,18 @@ hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inN
     const int blocks = pixelCount < 256 * 2048 ? (pixelCount + 255) / 256 : 2048;
     hipLaunchKernelGGL(finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, pixelCount, inColor, inNormal, inAlbedo,
                        reinterpret_cast<uchar4*>(outColor), reinterpret_cast<uchar4*>(outNormal), reinterpret_cast<uchar4*>(outAlbedo));
+    return hipGetLastError();
+}
+
+hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t stream)
+{
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0;
+    const size_t n4 = aligned ? floats / 4 : 0;
+    const size_t work = n4 + (floats - n4 * 4);
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n4, reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(src), n4 * 4, floats, dst, src);
     return hipGetLastError();
 }
 

@@ -1,4 +1,14 @@
-"""Multi-GPU host logic: one process per GPU, the frame row-interleaved across ranks, one gather per sample batch.
+"""Multi-GPU host logic: one process per GPU, ONE collective per sample batch, two ways to split a batch.
+
+"tiles"   (`render_partitioned`): the frame is row-interleaved across ranks; bit-identical to the single-GPU frame.
+"batches" (`render_batches`): every rank renders the WHOLE frame with spp / world samples and its own Seed, from zeroed
+          accumulators; rank 0 gathers the partial accumulators and folds them in rank order.  This is the reference's own
+          notion of accumulation - successive batches with fresh seeds summed into the same buffers
+          (Assets/Scripts/Unity/Raytracer.cs:656-661,798-802) - run concurrently instead of back to back.
+
+Why both: the reference RNG stream makes a pixel's samples sequential (one lane per pixel), so with tiles a GPU that owns
+about one pixel per resident lane (1080p over 8 GPUs) finishes only when its slowest pixel does: measured 1.5x / 2.5x /
+3.2x at 2 / 4 / 8 slices of the 1080p cover scene.  Splitting the SAMPLES keeps ~8 pixels per lane on every GPU.
 
 Pixels are independent given (params, scene, Seed, global pixel index) - the per-pixel RNG seed is a function of the
 GLOBAL index (JOBS/SampleBatchJob.cs:91) - so any partition reproduces the single-GPU frame bit for bit.  The partition
@@ -64,3 +74,48 @@ def render_partitioned(render_slice, params, height, width, rank, world, group=N
     color = render_slice(params)
     mine = pack_owned(color.view(height, width, 4), rank, world)
     return gather_frame(mine, height, rank, world, group)
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch-parallel: split the samples of a batch, not the pixels
+# ---------------------------------------------------------------------------------------------------
+ACCUM_FLOATS = 11  # float4 colour + float3 normal + float3 albedo + float sample-count weight per pixel
+
+
+def accum_views(flat, n):
+    """The four accumulation buffers as views of ONE contiguous [11 * n] tensor (so a rank's partial result travels in a
+    single collective): colour [n,4] | normal [n,3] | albedo [n,3] | sampleCountWeight [n]."""
+    return [flat[0:4 * n].view(n, 4), flat[4 * n:7 * n].view(n, 3), flat[7 * n:10 * n].view(n, 3), flat[10 * n:11 * n]]
+
+
+def batch_split(spp, rank, world):
+    """Samples per pixel rank `rank` takes of a `spp`-sample batch (remainder to the low ranks)."""
+    return spp // world + (1 if rank < spp % world else 0)
+
+
+def batch_seed(seed, rank, world):
+    """Seed of rank `rank`'s sub-batch: batches of one step get consecutive seeds, like consecutive frames do in the host
+    (frameSeed = Time.frameCount + 1, UNITY/Raytracer.cs:660)."""
+    return (seed - 1) * world + rank + 1
+
+
+def fold_partials(acc_flat, partials, n, add_fn):
+    """acc += partial_0 + partial_1 + ... in RANK ORDER (deterministic, so the result can be reproduced bit for bit)."""
+    for part in partials:
+        add_fn(accum_views(acc_flat, n), accum_views(part, n))
+    return acc_flat
+
+
+def render_batches(render_full, acc_flat, n, rank, world, add_fn, group=None, dst=0, gather_list=None):
+    """One sample batch, batch-parallel.  `render_full()` returns this rank's partial accumulators (from ZERO inputs, its own
+    seed and sample share) as one flat [11 * n] tensor; the partials are gathered on `dst` with ONE collective and folded
+    into `acc_flat` there (ignored on the other ranks)."""
+    part = render_full()
+    if world == 1:
+        return fold_partials(acc_flat, [part], n, add_fn)
+    if rank == dst and gather_list is None:
+        gather_list = [torch.empty_like(part) for _ in range(world)]   # callers on a hot path pass a preallocated list
+    dist.gather(part, gather_list if rank == dst else None, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return fold_partials(acc_flat, gather_list, n, add_fn)

@@ -218,3 +218,42 @@ def test_single_sphere_scene(rt, oracle, gpu_context):
     osc.close()
     for k in ("color", "normal", "albedo", "scw"):
         assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), k
+
+
+def test_add_accum_device(rt, gpu_context):
+    """rtowAddAccumDevice: dst += src on the four accumulators (the fold step of the batch-parallel multi-GPU path)."""
+    ctx = gpu_context
+    rng = np.random.default_rng(4)
+    n = 12345                                            # not a multiple of 4: exercises the scalar tail of the float3 arrays
+    dst = [rng.normal(size=(n, k)).astype(np.float32) for k in (4, 3, 3, 1)]
+    src = [rng.normal(size=(n, k)).astype(np.float32) for k in (4, 3, 3, 1)]
+    dd = [_dev(rt, ctx, a) for a in dst]
+    ds = [_dev(rt, ctx, a) for a in src]
+    bd = rt.abi.AccumBuffers(*[b.ptr for b in dd])
+    bs = rt.abi.AccumBuffers(*[b.ptr for b in ds])
+    assert rt.lib.load().rtowAddAccumDevice(ctx.handle, n, C.byref(bd), C.byref(bs), None) == 0
+    ctx.synchronize()
+    for a, b, buf, k in zip(dst, src, dd, (4, 3, 3, 1)):
+        assert np.array_equal(buf.download(np.float32, (n, k)), a + b)
+    assert rt.lib.load().rtowAddAccumDevice(ctx.handle, 0, C.byref(bd), C.byref(bs), None) == rt.abi.RTOW_ERROR_INVALID_VALUE
+
+
+def test_adaptive_sample_counts_match_oracle(rt, oracle, gpu_context):
+    """SampleCountRange.x != .y with weight extrema (JOBS/SampleBatchJob.cs:118-126), first batch (0/0 -> max) and a second one."""
+    ctx = gpu_context
+    scene = rt.scenes.tiny_scene()
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    osc = oracle.OracleScene(desc)
+    p = rt.scenes.make_params(scene, 40, 24, spp=2, spp_max=7, trace_depth=5, extrema=(0.5, 1.5), diagnostics_stride=16)
+    g1, r1 = rt.sample_batch_host(ctx, p), osc.sample_batch(p)
+    ins = {k: r1[k] for k in ("color", "normal", "albedo", "scw")}
+    p.seed = 9
+    g2, r2 = rt.sample_batch_host(ctx, p, ins), osc.sample_batch(p, ins)
+    osc.close()
+    for g, r in ((g1, r1), (g2, r2)):
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(g[k].view(np.uint32), r[k].view(np.uint32)), k
+        assert np.array_equal(g["diag"][:, 0], r["diag"][:, 0])
+        assert np.array_equal(g["diag"][:, 3].view(np.uint32), r["diag"][:, 3].view(np.uint32))   # FULL_DIAGNOSTICS SampleCountWeight
+    assert len(np.unique(r2["diag"][:, 0])) > 3
