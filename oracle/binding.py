@@ -47,6 +47,8 @@ def load(kind="strict"):
     lib.oracle_scene_depth.argtypes = [C.c_void_p]
     lib.oracle_sample_batch.restype = C.c_int
     lib.oracle_sample_batch.argtypes = [C.c_void_p, C.POINTER(abi.SampleParams)] + [C.c_void_p] * 9 + [C.c_int, C.POINTER(CountersOut)]
+    lib.oracle_sample_pixels.restype = C.c_int
+    lib.oracle_sample_pixels.argtypes = [C.c_void_p, C.POINTER(abi.SampleParams)] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int]
     lib.oracle_combine.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6
     lib.oracle_finalize.argtypes = [C.c_int] + [C.c_void_p] * 6
     lib.oracle_reduce_metrics.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(abi.Metrics)]
@@ -128,6 +130,25 @@ class OracleScene:
         if want_counters:
             return out, counters
         return out
+
+    def sample_pixels(self, params, indices, inputs=None, nthreads=0):
+        """SampleBatchJob.Execute for the given pixel indices only; returns compact arrays ordered like `indices`."""
+        w, h = int(params.size.x), int(params.size.y)
+        n = w * h
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        ins = zero_buffers(n) if inputs is None else {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in inputs.items()}
+        out = {k: np.array(v, dtype=np.float32, copy=True) for k, v in ins.items()}
+        diag = np.zeros((n, max(params.diagnosticsStride, 4) // 4), dtype=np.float32)
+        rc = self.lib.oracle_sample_pixels(
+            self.handle, C.byref(params),
+            ins["color"].ctypes.data, ins["normal"].ctypes.data, ins["albedo"].ctypes.data, ins["scw"].ctypes.data,
+            out["color"].ctypes.data, out["normal"].ctypes.data, out["albedo"].ctypes.data, out["scw"].ctypes.data,
+            diag.ctypes.data, nthreads, idx.ctypes.data, len(idx))
+        if rc != 0:
+            raise RuntimeError("oracle_sample_pixels failed: %d" % rc)
+        res = {k: v[idx] for k, v in out.items()}
+        res["diag"] = diag[idx]
+        return res
 
     def nearest_hit(self, origin, direction, time=0.0):
         o = (C.c_float * 8)()

@@ -1165,10 +1165,34 @@ ORACLE_API int oracle_scene_node_count(void* scene) { return (int)((OracleScene*
 ORACLE_API int oracle_scene_depth(void* scene) { return ((OracleScene*)scene)->maxDepthSeen; }
 
 /* SampleBatchJob.Schedule(W*H, 1): one task per pixel index, dynamic hand-out (UNITY/Raytracer.cs:730). */
+static int sample_impl(void* scenePtr, const RtowSampleParams* params,
+                       const float* inColor, const float* inNormal, const float* inAlbedo, const float* inScw,
+                       float* outColor, float* outNormal, float* outAlbedo, float* outScw,
+                       void* diagnostics, int nthreads, OracleCountersOut* countersOut, const int* pixelIndices, int pixelCount);
+
 ORACLE_API int oracle_sample_batch(void* scenePtr, const RtowSampleParams* params,
                                    const float* inColor, const float* inNormal, const float* inAlbedo, const float* inScw,
                                    float* outColor, float* outNormal, float* outAlbedo, float* outScw,
                                    void* diagnostics, int nthreads, OracleCountersOut* countersOut)
+{
+    return sample_impl(scenePtr, params, inColor, inNormal, inAlbedo, inScw, outColor, outNormal, outAlbedo, outScw, diagnostics, nthreads, countersOut, nullptr, 0);
+}
+
+/* SampleBatchJob.Execute for a chosen subset of pixel indices only (pixels are independent): lets tests check a sparse sample
+ * of a full-size frame (BASELINE configs 2-5) in seconds.  Buffers are full-frame sized; other pixels are left untouched. */
+ORACLE_API int oracle_sample_pixels(void* scenePtr, const RtowSampleParams* params,
+                                    const float* inColor, const float* inNormal, const float* inAlbedo, const float* inScw,
+                                    float* outColor, float* outNormal, float* outAlbedo, float* outScw,
+                                    void* diagnostics, int nthreads, const int* pixelIndices, int pixelCount)
+{
+    if (!pixelIndices || pixelCount < 0) return 1;
+    return sample_impl(scenePtr, params, inColor, inNormal, inAlbedo, inScw, outColor, outNormal, outAlbedo, outScw, diagnostics, nthreads, nullptr, pixelIndices, pixelCount);
+}
+
+static int sample_impl(void* scenePtr, const RtowSampleParams* params,
+                       const float* inColor, const float* inNormal, const float* inAlbedo, const float* inScw,
+                       float* outColor, float* outNormal, float* outAlbedo, float* outScw,
+                       void* diagnostics, int nthreads, OracleCountersOut* countersOut, const int* pixelIndices, int pixelCount)
 {
     if (!scenePtr || !params) return 1;
     if (params->noiseColor != RTOW_NOISE_WHITE) return 5;
@@ -1182,7 +1206,7 @@ ORACLE_API int oracle_sample_batch(void* scenePtr, const RtowSampleParams* param
     job.OutputColor = outColor; job.OutputNormal = outNormal; job.OutputAlbedo = outAlbedo; job.OutputSampleCountWeight = outScw;
     job.OutputDiagnostics = (uint8_t*)diagnostics;
 
-    const int total = (int)params->size.x * (int)params->size.y;
+    const int total = pixelIndices ? pixelCount : (int)params->size.x * (int)params->size.y;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     if (nthreads <= 0) nthreads = 1;
     std::atomic<int> next{0};
@@ -1192,7 +1216,7 @@ ORACLE_API int oracle_sample_batch(void* scenePtr, const RtowSampleParams* param
         for (;;) {
             const int i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= total) break;
-            job.Execute(i, scratch);
+            job.Execute(pixelIndices ? pixelIndices[i] : i, scratch);
         }
         perThread[tid] = scratch.counters;
     };

@@ -1,0 +1,81 @@
+"""GPU parity at BASELINE.json's FULL sizes.  The CPU oracle cannot render whole frames of these configs in test time, but
+pixels are independent (the RNG seed depends only on Seed and the global pixel index), so a sparse sample of pixels of the
+full-size GPU frame is checked bit for bit against the oracle run on exactly those pixels, next to size-independent
+properties (every pixel written, sample counts bounded, ray counts bounded, partition == whole)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_render(rt, ctx, p, n, stride):
+    bufs = [rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)]
+    outs = [rt.DeviceBuffer(ctx, n * k * 4) for k in (4, 3, 3, 1)]
+    for o in outs:
+        check = rt.lib.load().rtowDeviceMemset(ctx.handle, o.handle, 0xFF, o.nbytes)   # NaN pattern: unwritten pixels would show
+        assert check == 0
+    diag = rt.DeviceBuffer(ctx, n * stride)
+    job = rt.SampleBatchJob(ctx, p)
+    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = bufs
+    job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = outs
+    job.OutputDiagnostics = diag
+    assert job.Schedule().Complete() == 0
+    ctx.synchronize()
+    res = {"color": outs[0].download(np.float32, (n, 4)), "normal": outs[1].download(np.float32, (n, 3)),
+           "albedo": outs[2].download(np.float32, (n, 3)), "scw": outs[3].download(np.float32, (n,)),
+           "diag": diag.download(np.float32, (n, stride // 4))}
+    for b in bufs + outs + [diag]:
+        b.free()
+    return res
+
+
+def _check_sparse(rt, oracle, ctx, scene, w, h, spp, depth, count, seed=1, stride=4, nthreads=0):
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    n = w * h
+    p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=seed, diagnostics_stride=stride)
+    gpu = _device_render(rt, ctx, p, n, stride)
+    # size-independent properties over the WHOLE frame
+    assert not np.isnan(gpu["color"]).any() and not np.isnan(gpu["scw"]).any(), "a pixel was not written"
+    cnt = gpu["color"][:, 3]
+    assert cnt.min() >= 0 and cnt.max() == spp and np.all(cnt == np.floor(cnt))
+    rays = gpu["diag"][:, 0]
+    assert rays.min() >= spp and rays.max() <= spp * depth
+    assert cnt.sum() > 0.9 * n * spp
+    # sparse bit-exact comparison
+    rng = np.random.default_rng(seed)
+    idx = np.unique(np.concatenate([rng.integers(0, n, count), [0, w - 1, n - w, n - 1, (h // 3) * w + w // 2]])).astype(np.int32)
+    osc = oracle.OracleScene(desc)
+    ref = osc.sample_pixels(p, idx, nthreads=nthreads)
+    osc.close()
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(gpu[k][idx].view(np.uint32), ref[k].view(np.uint32)), k
+    assert np.array_equal(gpu["diag"][idx, 0], ref["diag"][:, 0])
+    mean_g = gpu["color"][idx, :3] / np.maximum(gpu["color"][idx, 3:4], 1)
+    mean_r = ref["color"][:, :3] / np.maximum(ref["color"][:, 3:4], 1)
+    assert np.abs(mean_g - mean_r).max() <= 1e-4          # the north-star tolerance, on top of bit equality
+    return gpu
+
+
+def test_config2_cover_1080p_256spp(rt, oracle, gpu_context):
+    """BASELINE.json configs[1]: cover scene 1920x1080, 256 spp, 8 bounces (the bench workload)."""
+    _check_sparse(rt, oracle, gpu_context, rt.scenes.cover_scene(), 1920, 1080, 256, 8, count=600)
+
+
+def test_config3_cover_4k_16_bounces(rt, oracle, gpu_context):
+    """BASELINE.json configs[2] geometry (3840x2160, 16 bounces) at 64 spp per batch: exercises the 16-deep path history."""
+    _check_sparse(rt, oracle, gpu_context, rt.scenes.cover_scene(), 3840, 2160, 64, 16, count=500, seed=3)
+
+
+def test_config4_stress_10k_spheres(rt, oracle, gpu_context):
+    """BASELINE.json configs[3]: 10 000-sphere scene (deep BVH, image larger than LDS) at 1920x1080, 32 spp."""
+    scene = rt.scenes.stress_scene()
+    assert scene.entity_count == 10000
+    gpu = _check_sparse(rt, oracle, gpu_context, scene, 1920, 1080, 32, 8, count=500, seed=5)
+    info = gpu_context.scene_info()
+    assert info.sceneInLds == 0 and info.bvhNodeCount == 9999
+
+
+def test_config5_moving_defocus_1080p(rt, oracle, gpu_context):
+    """BASELINE.json configs[4]: moving spheres + aperture 0.05 at 1920x1080, 64 spp."""
+    _check_sparse(rt, oracle, gpu_context, rt.scenes.moving_scene(), 1920, 1080, 64, 8, count=500, seed=7, stride=16)
