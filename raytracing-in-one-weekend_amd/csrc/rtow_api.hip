@@ -48,6 +48,11 @@ struct RtowContext_t {
 
     // work distribution / cancellation
     unsigned int* dWorkCounter = nullptr;
+    // chunk cost map -> launch order (longest chunks first); valid for one (width, height, slice, scene) configuration
+    unsigned int *dChunkCost = nullptr, *dChunkOrder = nullptr;
+    uint32_t chunkCapacity = 0;
+    bool orderValid = false;
+    int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
     volatile uint32_t* hCancel = nullptr; // pinned, device-visible
 
     // grow-only staging for rtowSampleBatch (host buffers) - like CudaBuffer.EnsureCapacity (OptixApi.cs:240-251)
@@ -143,17 +148,52 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.stats = nullptr;
 #ifdef RTOW_STATS
     static unsigned long long* dStats = nullptr;
-    if (!dStats) (void)hipMalloc(&dStats, 16 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dStats, 0, 16 * sizeof(unsigned long long), stream);
+    if (!dStats) (void)hipMalloc(&dStats, 32 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dStats, 0, 32 * sizeof(unsigned long long), stream);
     a.stats = dStats;
 #endif
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
     int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
     if (blocks < 1) blocks = 1;
+
+    // ---- chunk order: most expensive 64-pixel chunks first, from the ray counts of the previous launch (or of a probe) ----
+    a.chunkCount = (a.totalWork + 63u) / 64u;
+    const bool wantOrder = a.chunkCount >= (uint32_t)(4 * ctx->cuCount) && !getenv("RTOW_NO_CHUNK_ORDER");   // tiny frames: not worth it
+    if (wantOrder) {
+        if (a.chunkCount > ctx->chunkCapacity) {
+            if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); }
+            ctx->dChunkCost = ctx->dChunkOrder = nullptr;
+            ctx->chunkCapacity = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dChunkCost, a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            HIP_TRY(ctx, hipMalloc(&ctx->dChunkOrder, a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->chunkCapacity = a.chunkCount;
+            ctx->orderValid = false;
+        }
+        if (ctx->orderW != a.width || ctx->orderH != a.height || ctx->orderOff != a.sliceOffset || ctx->orderDiv != a.sliceDivider) ctx->orderValid = false;
+        a.chunkCost = ctx->dChunkCost;
+        if (!ctx->orderValid) {
+            // no cost map yet for this frame configuration: a 1-sample-per-pixel probe of the same kernel (stores nothing)
+            SampleKernelArgs probe = a;
+            probe.probeOnly = 1;
+            probe.chunkOrder = nullptr;
+            probe.cancelFlag = nullptr;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+            HIP_TRY(ctx, launchSampleBatch(probe, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
+            HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, stream), RTOW_ERROR_LAUNCH_FAILURE);
+            ctx->orderValid = true;
+            ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider;
+        }
+        a.chunkOrder = ctx->dChunkOrder;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+    }
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStart, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
+    if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, stream), RTOW_ERROR_LAUNCH_FAILURE);
 #ifdef RTOW_STATS
     {
         unsigned long long h[16];
@@ -162,6 +202,10 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         static const char* names[16] = {"trips*64", "regen runs*64", "regen lanes", "walk iters", "walk lanes", "test iters", "test lanes", "hit runs*64", "hit lanes",
                                         "lambert runs", "lambert lanes", "general runs", "general lanes", "diel runs", "diel lanes", "sky runs*lanes"};
         for (int i = 0; i < 16; i++) fprintf(stderr, "[stats] %-16s %llu\n", names[i], h[i]);
+        unsigned long long w[3];
+        (void)hipMemcpy(w, a.stats + 16, sizeof(w), hipMemcpyDeviceToHost);
+        if (w[2]) fprintf(stderr, "[stats] wave residency: mean %.3f ms, max %.3f ms over %llu waves -> tail idle fraction %.3f\n", w[0] / (double)w[2] / 1e5, w[1] / 1e5, w[2],
+                          1.0 - (w[0] / (double)w[2]) / (double)w[1]);
     }
 #endif
     ctx->haveTiming = true;
@@ -272,6 +316,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->dScene) (void)hipFree(ctx->dScene);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
+    if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); }
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
@@ -320,6 +365,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         ctx->ldsSceneBytes = nodes * (uint32_t)sizeof(GpuNode);
     }
     ctx->haveScene = true;
+    ctx->orderValid = false;
     logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
          ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes);
     return RTOW_SUCCESS;

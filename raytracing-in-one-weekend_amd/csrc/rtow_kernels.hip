@@ -393,6 +393,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
     int pix = -1;
+    unsigned tick = 0;          // ticket (owned-pixel number) of the current pixel
     unsigned rng = 0;
     unsigned smp = 0, nsamp = 0;
     int cx = 0, cy = 0;
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             normalAcc = add(normalAcc, sampleNormal);
             albedoAcc = add(albedoAcc, sampleAlbedo);
             sampleCount++;
-        } else if (smp == 0) {
+        } else if (smp == 0 && !A.probeOnly) {
             // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
             // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
             A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
@@ -449,6 +450,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 
     int force = -1;
     STAT_DECL;
+#ifdef RTOW_STATS
+    const unsigned long long statT0 = wall_clock64();
+#endif
     for (;;) {
         STAT_ADD(0, 1);
         // Stages run in pipeline order; each one only if enough lanes wait in it (thresholds in A.tune), so a lane can
@@ -461,6 +465,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             if (st == ST_REGEN) {
                 STAT_LANES(2);
                 while (smp >= nsamp) {
+                    if (pix >= 0 && A.chunkCost) atomicAdd(&A.chunkCost[tick >> 6], (unsigned)rayCount);   // cost map for the next launch's order
+                    if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
                     if (pix >= 0) {
                         // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
                         reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
@@ -498,9 +504,15 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             if (lane == leader) {
                                 bool cancelled = false;
                                 if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
-                                const unsigned base = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 64u);
-                                if (base >= A.totalWork) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
-                                else { waveQueue[0] = base; waveQueue[1] = (A.totalWork - base < 64u) ? A.totalWork : base + 64u; }
+                                const unsigned slot = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
+                                if (slot >= A.chunkCount) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
+                                else {
+                                    // most expensive chunks first (cost map of the previous launch, or of a 1-spp probe), so that the
+                                    // chunks handed out last - the ones that decide when a wave can retire - are the cheap ones
+                                    const unsigned base = (A.chunkOrder ? A.chunkOrder[slot] : slot) * 64u;
+                                    waveQueue[0] = base;
+                                    waveQueue[1] = (A.totalWork - base < 64u) ? A.totalWork : base + 64u;
+                                }
                             }
                             continue;
                         }
@@ -509,16 +521,20 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         if (lane == leader) waveQueue[0] = next + take;
                     }
                     if (ticket == 0xffffffffu) { st = ST_DEAD; break; }
+                    tick = ticket;
                     const int ownedRow = (int)(ticket / (unsigned)A.width);
                     cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
                     cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
                     pix = cy * A.width + cx;
 
-                    const float4 last = reinterpret_cast<const float4*>(A.inColor)[pix];                  // :72-78
+                    float4 last = make_float4(0, 0, 0, 0);
+                    if (!A.probeOnly) {
+                        last = reinterpret_cast<const float4*>(A.inColor)[pix];                           // :72-78
+                        normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
+                        albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
+                        scwAcc = A.inScw[pix];
+                    }
                     colorAcc = v3(last.x, last.y, last.z);
-                    normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
-                    albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
-                    scwAcc = A.inScw[pix];
                     sampleCount = (int)last.w;
 
                     // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
@@ -534,6 +550,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         const float lo = (float)A.sampleCountMin, hi = (float)A.sampleCountMax;
                         nsamp = (unsigned)__builtin_rintf(lo + nw * (hi - lo));
                     }
+                    if (A.probeOnly) nsamp = 1;
                     scw0 = w;
                     smp = 0;
                     rayCount = 0; boundsHits = 0; candidates = 0;
@@ -830,7 +847,40 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 #ifdef RTOW_STATS
     // every lane counted the same wave-level events for 'per-run' slots; lane-population slots were added by all active lanes.
     if (A.stats) for (int i = 0; i < 16; i++) atomicAdd(&A.stats[i], stat[i]);
+    if (A.stats && (threadIdx.x & 63) == 0) {
+        const unsigned long long dt = wall_clock64() - statT0;   // 100 MHz ticks this wave was resident
+        atomicAdd(&A.stats[16], dt);
+        atomicMax(&A.stats[17], dt);
+        atomicAdd(&A.stats[18], 1ull);
+    }
 #endif
+}
+
+// Launch order of the 64-pixel ticket chunks: most expensive first (longest-processing-time-first), from the per-chunk ray
+// counts of the previous launch.  Counting sort on a 1024-bucket quantisation of the cost; the order inside a bucket is
+// arbitrary - it only changes which lane renders which pixel, never a result.
+constexpr int kOrderBuckets = 1024;
+__global__ void __launch_bounds__(1024) build_chunk_order_kernel(const unsigned* __restrict__ cost, unsigned n, unsigned* __restrict__ order)
+{
+    __shared__ unsigned hist[kOrderBuckets];
+    __shared__ unsigned maxCost;
+    const unsigned t = threadIdx.x;
+    hist[t] = 0;
+    if (t == 0) maxCost = 1;
+    __syncthreads();
+    unsigned m = 0;
+    for (unsigned i = t; i < n; i += 1024) m = cost[i] > m ? cost[i] : m;
+    atomicMax(&maxCost, m);
+    __syncthreads();
+    const float scale = (float)(kOrderBuckets - 1) / (float)maxCost;
+    for (unsigned i = t; i < n; i += 1024) atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)((float)cost[i] * scale)], 1u);   // bucket 0 = most expensive
+    __syncthreads();
+    if (t == 0) {
+        unsigned run = 0;
+        for (int b = 0; b < kOrderBuckets; b++) { const unsigned c = hist[b]; hist[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (unsigned i = t; i < n; i += 1024) order[atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)((float)cost[i] * scale)], 1u)] = i;
 }
 
 // Derived per-entity transform data for SCENE_KIND_GENERAL, on the device: InverseTransform = inverse(OriginTransform)
@@ -1033,6 +1083,12 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
     return allLds ? launchByKind<true>(args, numBlocks, ldsBytes, stream) : launchByKind<false>(args, numBlocks, ldsBytes, stream);
+}
+
+hipError_t launchBuildChunkOrder(const unsigned* cost, unsigned chunkCount, unsigned* order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(build_chunk_order_kernel, dim3(1), dim3(1024), 0, stream, cost, chunkCount, order);
+    return hipGetLastError();
 }
 
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream)
