@@ -6,6 +6,7 @@
 // rtowCreateContext fails with RTOW_ERROR_NO_DEVICE and nothing else can be called.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -148,8 +149,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.stats = nullptr;
 #ifdef RTOW_STATS
     static unsigned long long* dStats = nullptr;
-    if (!dStats) (void)hipMalloc(&dStats, 32 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dStats, 0, 32 * sizeof(unsigned long long), stream);
+    if (!dStats) (void)hipMalloc(&dStats, (32 + 8192) * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dStats, 0, (32 + 8192) * sizeof(unsigned long long), stream);
     a.stats = dStats;
 #endif
     int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
@@ -164,7 +165,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); }
             ctx->dChunkCost = ctx->dChunkOrder = nullptr;
             ctx->chunkCapacity = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dChunkCost, a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            HIP_TRY(ctx, hipMalloc(&ctx->dChunkCost, 2 * a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkOrder, a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             ctx->chunkCapacity = a.chunkCount;
             ctx->orderValid = false;
@@ -178,14 +179,14 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             probe.chunkOrder = nullptr;
             probe.cancelFlag = nullptr;
             HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, 2 * a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
             HIP_TRY(ctx, launchSampleBatch(probe, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
-            HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, stream), RTOW_ERROR_LAUNCH_FAILURE);
+            HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 0, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->orderValid = true;
             ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider;
         }
         a.chunkOrder = ctx->dChunkOrder;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, 2 * a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
     }
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
@@ -193,7 +194,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
     // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
-    if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
 #ifdef RTOW_STATS
     {
         unsigned long long h[16];
@@ -206,6 +207,13 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         (void)hipMemcpy(w, a.stats + 16, sizeof(w), hipMemcpyDeviceToHost);
         if (w[2]) fprintf(stderr, "[stats] wave residency: mean %.3f ms, max %.3f ms over %llu waves -> tail idle fraction %.3f\n", w[0] / (double)w[2] / 1e5, w[1] / 1e5, w[2],
                           1.0 - (w[0] / (double)w[2]) / (double)w[1]);
+        {
+            std::vector<unsigned long long> r(4096);
+            (void)hipMemcpy(r.data(), a.stats + 32, r.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            std::sort(r.begin(), r.end());
+            fprintf(stderr, "[stats] residency quantiles ms: min %.2f p10 %.2f p25 %.2f p50 %.2f p75 %.2f p90 %.2f p99 %.2f max %.2f\n", r[0] / 1e5, r[409] / 1e5, r[1024] / 1e5,
+                    r[2048] / 1e5, r[3072] / 1e5, r[3686] / 1e5, r[4055] / 1e5, r[4095] / 1e5);
+        }
     }
 #endif
     ctx->haveTiming = true;

@@ -465,7 +465,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             if (st == ST_REGEN) {
                 STAT_LANES(2);
                 while (smp >= nsamp) {
-                    if (pix >= 0 && A.chunkCost) atomicAdd(&A.chunkCost[tick >> 6], (unsigned)rayCount);   // cost map for the next launch's order
+                    if (pix >= 0 && A.chunkCost) {
+                        // cost map for the next launch's order: ray count of the chunk (sum) and of its most expensive pixel (max)
+                        atomicAdd(&A.chunkCost[tick >> 6], (unsigned)rayCount);
+                        atomicMax(&A.chunkCost[A.chunkCount + (tick >> 6)], (unsigned)rayCount);
+                    }
                     if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
                     if (pix >= 0) {
                         // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
@@ -852,6 +856,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         atomicAdd(&A.stats[16], dt);
         atomicMax(&A.stats[17], dt);
         atomicAdd(&A.stats[18], 1ull);
+        A.stats[32 + blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)] = dt;   // per-wave residency
     }
 #endif
 }
@@ -860,27 +865,34 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 // counts of the previous launch.  Counting sort on a 1024-bucket quantisation of the cost; the order inside a bucket is
 // arbitrary - it only changes which lane renders which pixel, never a result.
 constexpr int kOrderBuckets = 1024;
-__global__ void __launch_bounds__(1024) build_chunk_order_kernel(const unsigned* __restrict__ cost, unsigned n, unsigned* __restrict__ order)
+// cost[0..n) = ray count per chunk, cost[n..2n) = ray count of the chunk's most expensive pixel.  byMax: order by the most
+// expensive pixel first (what decides when the last lanes retire), ties by the chunk total; otherwise by the total (used for
+// the 1-sample probe, whose per-pixel counts are too noisy).
+__device__ __forceinline__ float chunk_key(const unsigned* cost, unsigned n, unsigned i, int byMax)
+{
+    return byMax ? (float)cost[n + i] * 64.0f + (float)cost[i] * (1.0f / 64.0f) : (float)cost[i];
+}
+__global__ void __launch_bounds__(1024) build_chunk_order_kernel(const unsigned* __restrict__ cost, unsigned n, unsigned* __restrict__ order, int byMax)
 {
     __shared__ unsigned hist[kOrderBuckets];
-    __shared__ unsigned maxCost;
+    __shared__ unsigned maxKeyBits;
     const unsigned t = threadIdx.x;
     hist[t] = 0;
-    if (t == 0) maxCost = 1;
+    if (t == 0) maxKeyBits = __float_as_uint(1.0f);
     __syncthreads();
-    unsigned m = 0;
-    for (unsigned i = t; i < n; i += 1024) m = cost[i] > m ? cost[i] : m;
-    atomicMax(&maxCost, m);
+    float m = 0;
+    for (unsigned i = t; i < n; i += 1024) m = fmaxf(m, chunk_key(cost, n, i, byMax));
+    atomicMax(&maxKeyBits, __float_as_uint(m));                     // non-negative floats order like their bit patterns
     __syncthreads();
-    const float scale = (float)(kOrderBuckets - 1) / (float)maxCost;
-    for (unsigned i = t; i < n; i += 1024) atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)((float)cost[i] * scale)], 1u);   // bucket 0 = most expensive
+    const float scale = (float)(kOrderBuckets - 1) / __uint_as_float(maxKeyBits);
+    for (unsigned i = t; i < n; i += 1024) atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)(chunk_key(cost, n, i, byMax) * scale)], 1u);   // bucket 0 = most expensive
     __syncthreads();
     if (t == 0) {
         unsigned run = 0;
         for (int b = 0; b < kOrderBuckets; b++) { const unsigned c = hist[b]; hist[b] = run; run += c; }
     }
     __syncthreads();
-    for (unsigned i = t; i < n; i += 1024) order[atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)((float)cost[i] * scale)], 1u)] = i;
+    for (unsigned i = t; i < n; i += 1024) order[atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)(chunk_key(cost, n, i, byMax) * scale)], 1u)] = i;
 }
 
 // Derived per-entity transform data for SCENE_KIND_GENERAL, on the device: InverseTransform = inverse(OriginTransform)
@@ -1085,9 +1097,9 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     return allLds ? launchByKind<true>(args, numBlocks, ldsBytes, stream) : launchByKind<false>(args, numBlocks, ldsBytes, stream);
 }
 
-hipError_t launchBuildChunkOrder(const unsigned* cost, unsigned chunkCount, unsigned* order, hipStream_t stream)
+hipError_t launchBuildChunkOrder(const unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream)
 {
-    hipLaunchKernelGGL(build_chunk_order_kernel, dim3(1), dim3(1024), 0, stream, cost, chunkCount, order);
+    hipLaunchKernelGGL(build_chunk_order_kernel, dim3(1), dim3(1024), 0, stream, cost, chunkCount, order, byMax);
     return hipGetLastError();
 }
 
