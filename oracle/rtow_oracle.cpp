@@ -31,6 +31,8 @@
  */
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -160,6 +162,101 @@ struct Ray {
 struct Entity;
 
 /* RT/HitRecord.cs:6-26 */
+/* ===================================================================================================
+ * NativeSortExtension.Sort (com.unity.collections 1.0.0-pre.6 - a package dependency of the reference,
+ * Packages/manifest.json:4, whose sources are NOT under /root/reference).  Restated from the published
+ * algorithm: the introsort of .NET Core's ArraySortHelper - partitions of <= 16 elements use a 2- and a
+ * 3-element compare-exchange network or a straight insertion sort, larger ones a median-of-three Hoare
+ * partition, with heap sort once 2*floor(log2(n)) levels are used up.  It is NOT stable, and the order it
+ * leaves equal keys in is part of the reference's behaviour (hits at bit-identical distances, entities
+ * with equal Bounds.Min on the split axis).  `cmp(a, b)` returns the IComparer<T>.Compare integer.
+ * =================================================================================================== */
+template <class T, class Cmp>
+struct UnitySort {
+    T* a;
+    Cmp cmp;
+    void SwapIfGreater(int l, int r) { if (l != r && cmp(a[l], a[r]) > 0) std::swap(a[l], a[r]); }
+    void InsertionSort(int lo, int hi)
+    {
+        for (int i = lo; i < hi; i++) {
+            int j = i;
+            const T t = a[i + 1];
+            while (j >= lo && cmp(t, a[j]) < 0) { a[j + 1] = a[j]; j--; }
+            a[j + 1] = t;
+        }
+    }
+    void Heapify(int i, int n, int lo)
+    {
+        const T val = a[lo + i - 1];
+        while (i <= n / 2) {
+            int child = 2 * i;
+            if (child < n && cmp(a[lo + child - 1], a[lo + child]) < 0) child++;
+            if (cmp(a[lo + child - 1], val) < 0) break;
+            a[lo + i - 1] = a[lo + child - 1];
+            i = child;
+        }
+        a[lo + i - 1] = val;
+    }
+    void HeapSort(int lo, int hi)
+    {
+        const int n = hi - lo + 1;
+        for (int i = n / 2; i >= 1; i--) Heapify(i, n, lo);
+        for (int i = n; i > 1; i--) { std::swap(a[lo], a[lo + i - 1]); Heapify(1, i - 1, lo); }
+    }
+    int Partition(int lo, int hi)
+    {
+        const int mid = lo + (hi - lo) / 2;
+        SwapIfGreater(lo, mid);
+        SwapIfGreater(lo, hi);
+        SwapIfGreater(mid, hi);
+        const T pivot = a[mid];
+        std::swap(a[mid], a[hi - 1]);
+        int left = lo, right = hi - 1;
+        while (left < right) {
+            while (cmp(pivot, a[++left]) > 0) {}
+            while (cmp(pivot, a[--right]) < 0) {}
+            if (left >= right) break;
+            std::swap(a[left], a[right]);
+        }
+        std::swap(a[left], a[hi - 1]);
+        return left;
+    }
+    void IntroSort(int lo, int hi, int depth)
+    {
+        while (hi > lo) {
+            const int partitionSize = hi - lo + 1;
+            if (partitionSize <= 16) {
+                if (partitionSize == 1) return;
+                if (partitionSize == 2) { SwapIfGreater(lo, hi); return; }
+                if (partitionSize == 3) { SwapIfGreater(lo, hi - 1); SwapIfGreater(lo, hi); SwapIfGreater(hi - 1, hi); return; }
+                InsertionSort(lo, hi);
+                return;
+            }
+            if (depth == 0) { HeapSort(lo, hi); return; }
+            depth--;
+            const int p = Partition(lo, hi);
+            IntroSort(p + 1, hi, depth);
+            hi = p - 1;
+        }
+    }
+};
+template <class T, class Cmp>
+inline void unity_sort(T* array, int length, Cmp cmp)
+{
+    if (length < 2) return;
+    int log2floor = 0;
+    while ((length >> (log2floor + 1)) != 0) log2floor++;
+    UnitySort<T, Cmp>{array, cmp}.IntroSort(0, length - 1, 2 * log2floor);
+}
+inline int float_compare_to(float x, float y) /* System.Single.CompareTo */
+{
+    if (x < y) return -1;
+    if (x > y) return 1;
+    if (x == y) return 0;
+    if (um_isnan(x)) return um_isnan(y) ? 0 : -1;
+    return 1;
+}
+
 struct HitRecord {
     float Distance;
     float3 Point, Normal;
@@ -766,8 +863,7 @@ struct OracleScene {
     static float axisOf(float3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
 
     /* UNITY/BvhNodeData.cs:122-213.  Returns the index of the node it filled.
-     * NativeSlice.Sort is an unstable sort in the reference; a stable sort is used here - only the leaf
-     * composition of ties can differ, never the set of hits (documented in DESIGN.md). */
+     * NativeSlice.Sort is the unstable introsort restated above (unity_sort). */
     int BuildNode(std::vector<BvhBuildingEntity>& ents, int begin, int end, int maxDepth, int depth, int sortAxis)
     {
         const int self = (int)nodes.size();
@@ -786,10 +882,10 @@ struct OracleScene {
         }
         if (sortAxis != biggestPartition && biggestPartition >= 0) {
             const int ax = biggestPartition;
-            std::stable_sort(ents.begin() + begin, ents.begin() + end,
-                             [ax](const BvhBuildingEntity& l, const BvhBuildingEntity& r) {
-                                 return axisOf(l.Bounds.Min, ax) - axisOf(r.Bounds.Min, ax) < 0; /* (int)sign(l - r) < 0 */
-                             });
+            unity_sort(ents.data() + begin, end - begin, [ax](const BvhBuildingEntity& l, const BvhBuildingEntity& r) {
+                const float d = axisOf(l.Bounds.Min, ax) - axisOf(r.Bounds.Min, ax);       /* (int) sign(lhs - rhs), :246-249 */
+                return d > 0 ? 1 : d < 0 ? -1 : 0;
+            });
         }
         const int biggestAxis = biggestPartition;
         const int length = end - begin;
@@ -841,7 +937,6 @@ struct OracleScene {
             /* RT/Material.cs:28-46: `parameter` only stored for Dielectric / ProbabilisticVolume */
             float parameter = 0;
             if (m.type == RTOW_MATERIAL_DIELECTRIC || m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) parameter = m.parameter;
-            if (m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) unsupported = true; /* next row, SURVEY 8(f)#3 */
             materials[i] = Material{m.type, tex(m.albedo), tex(m.glossiness), tex(m.emission), tex(m.metallic), parameter};
         }
         entities.resize(d->entityCount);
@@ -875,6 +970,7 @@ struct Counters {
 };
 
 struct Job {
+    mutable bool tracePixel = false;   /* ORACLE_TRACE_PIXEL=<index>: per-segment trace on stderr (debugging aid) */
     const OracleScene* scene;
     RtowSampleParams p;
     View view;
@@ -926,7 +1022,7 @@ struct Job {
         s.counters.maxCandidates = std::max<uint32_t>(s.counters.maxCandidates, (uint32_t)s.hitCandidateBuffer.size());
     }
 
-    /* :450-475 (volume exit-hit injection :463-469 is a next row; volumes are rejected at scene build) */
+    /* :450-475 */
     void FindHits(const Ray& ray, Scratch& s) const
     {
         s.hitRecordBuffer.clear();
@@ -937,15 +1033,53 @@ struct Job {
             if (hitCandidate->Hit(ray, 0, INFINITY, &thisRec)) {
                 thisRec.EntityPtr = hitCandidate;
                 s.hitRecordBuffer.push_back(thisRec);
+
+                /* Inject exit hits for probabilistic convex hulls (:462-469); IsConvexHull = Box || Sphere (RT/Entity.cs:22-25) */
+                HitRecord exitRec;
+                if (hitCandidate->MaterialPtr->Type == RTOW_MATERIAL_PROBABILISTIC_VOLUME &&
+                    (hitCandidate->Type == RTOW_ENTITY_BOX || hitCandidate->Type == RTOW_ENTITY_SPHERE) &&
+                    hitCandidate->Hit(ray, thisRec.Distance + 0.001f, INFINITY, &exitRec)) {
+                    exitRec.EntityPtr = hitCandidate;
+                    s.hitRecordBuffer.push_back(exitRec);
+                }
             }
         }
         s.counters.hits += s.hitRecordBuffer.size();
         s.counters.maxHits = std::max<uint32_t>(s.counters.maxHits, (uint32_t)s.hitRecordBuffer.size());
-        /* NativeSortExtension.Sort with HitRecord.DistanceComparer (RT/HitRecord.cs:22-25). Unstable in the
-         * reference; ties (two entities at the bit-identical distance) are left in candidate order here. */
-        if (s.hitRecordBuffer.size() > 1)
-            std::stable_sort(s.hitRecordBuffer.begin(), s.hitRecordBuffer.end(),
-                             [](const HitRecord& x, const HitRecord& y) { return x.Distance < y.Distance; });
+        /* hitBuffer.Sort(new HitRecord.DistanceComparer()) (:474, RT/HitRecord.cs:22-25) */
+        unity_sort(s.hitRecordBuffer.data(), (int)s.hitRecordBuffer.size(),
+                   [](const HitRecord& x, const HitRecord& y) { return float_compare_to(x.Distance, y.Distance); });
+    }
+
+    /* :510-524 */
+    static bool AnyBackwardsVolumeEntryHit(const Ray& backwardsRay, const Scratch& s)
+    {
+        for (size_t i = 0; i < s.hitCandidateBuffer.size(); i++) {
+            const Entity* hitCandidate = s.hitCandidateBuffer[i];
+            HitRecord hitRecord;
+            if (hitCandidate->MaterialPtr->Type == RTOW_MATERIAL_PROBABILISTIC_VOLUME &&
+                hitCandidate->Hit(backwardsRay, 0, INFINITY, &hitRecord) &&
+                um_dot(hitRecord.Normal, backwardsRay.Direction) > 0)
+                return true;
+        }
+        return false;
+    }
+
+    /* :477-508.  The backwards probe overwrites the node / candidate buffers; the hit list is untouched. */
+    const Material* DetermineVolumeContainment(const Ray& ray, Scratch& s, Diagnostics& diagnostics) const
+    {
+        for (size_t i = 0; i < s.hitRecordBuffer.size(); i++) {
+            const HitRecord& hit = s.hitRecordBuffer[i];
+            if (hit.EntityPtr->MaterialPtr->Type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) {
+                /* Entry hit, early out */
+                if (um_dot(hit.Normal, ray.Direction) < 0) break;
+                /* Exit hit before an entry hit, we are likely inside this volume; throw a ray backwards to make sure */
+                const Ray backwardsRay(ray.Origin, -ray.Direction, ray.Time);
+                FindHitCandidates(backwardsRay, s, diagnostics);
+                if (AnyBackwardsVolumeEntryHit(backwardsRay, s)) return hit.EntityPtr->MaterialPtr;
+            }
+        }
+        return nullptr;
     }
 
     /* :166-401 */
@@ -957,6 +1091,7 @@ struct Job {
         int depth = 0;
         bool firstNonSpecularHit = false;
         *sampleColor = *sampleNormal = *sampleAlbedo = f3(0);
+        const Material* currentProbabilisticVolumeMaterial = nullptr;                                /* :180 */
         const int TraceDepth = p.traceDepth;
 
         Ray ray = eyeRay;
@@ -964,18 +1099,88 @@ struct Job {
         for (; depth < TraceDepth; depth++) {
             FindHitCandidates(ray, s, diagnostics);
             FindHits(ray, s);
-            /* DetermineVolumeContainment (:194-201, :477-508) returns null unless a ProbabilisticVolume hit exists. */
+            if (currentProbabilisticVolumeMaterial == nullptr)                                        /* :194-201 */
+                currentProbabilisticVolumeMaterial = DetermineVolumeContainment(ray, s, diagnostics);
 
             diagnostics.RayCount++;
             s.counters.rays++;
+            if (tracePixel) { for (size_t i = 0; i < s.hitRecordBuffer.size(); i++) fprintf(stderr, "[otrace]   hit %zu prim %d t %.9g entry %d\n", i, s.hitRecordBuffer[i].EntityPtr->SourceIndex, s.hitRecordBuffer[i].Distance, um_dot(s.hitRecordBuffer[i].Normal, ray.Direction) < 0 ? 1 : 0);
+                fprintf(stderr, "[otrace]   contained %d o %.9g %.9g %.9g d %.9g %.9g %.9g\n", currentProbabilisticVolumeMaterial ? (int)(currentProbabilisticVolumeMaterial - &scene->materials[0]) : -1, ray.Origin.x, ray.Origin.y, ray.Origin.z, ray.Direction.x, ray.Direction.y, ray.Direction.z); }
 
             int hitIndex = 0;
-            const int hitCount = (int)s.hitRecordBuffer.size();
+            int hitCount = (int)s.hitRecordBuffer.size();
             while (hitIndex < hitCount) {
-                const HitRecord rec = s.hitRecordBuffer[hitIndex];
+                HitRecord rec = s.hitRecordBuffer[hitIndex];
                 const Material* material = rec.EntityPtr->MaterialPtr;
-                /* volume branch :212-303 not reachable: no ProbabilisticVolume materials */
 
+                if (currentProbabilisticVolumeMaterial != nullptr ||                                  /* Inside a volume */
+                    material->Type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) {                           /* Entering a volume (:212-303) */
+                    const bool isEntryHit = currentProbabilisticVolumeMaterial == nullptr;
+                    if (currentProbabilisticVolumeMaterial == nullptr) currentProbabilisticVolumeMaterial = material;
+
+                    /* Look for an obstacle or an exit hit */
+                    int exitHitIndex = hitIndex;
+                    int lastExitIndex = -1;
+                    int sameMaterialEntries = 0;
+                    while (exitHitIndex < hitCount) {
+                        const HitRecord& hit = s.hitRecordBuffer[exitHitIndex];
+                        if (hit.EntityPtr->MaterialPtr == currentProbabilisticVolumeMaterial) {
+                            if (um_dot(hit.Normal, ray.Direction) < 0)
+                                sameMaterialEntries++;
+                            else {
+                                sameMaterialEntries--;
+                                lastExitIndex = exitHitIndex;
+                            }
+                            if (sameMaterialEntries <= 0) break;
+                        } else
+                            break;
+                        exitHitIndex++;
+                    }
+                    if (sameMaterialEntries > 0 && lastExitIndex != -1) exitHitIndex = lastExitIndex;
+
+                    if (exitHitIndex < hitCount) {
+                        const HitRecord exitHitRecord = s.hitRecordBuffer[exitHitIndex];
+                        float distanceInProbabilisticVolume = exitHitRecord.Distance;
+                        float probabilisticVolumeEntryDistance = 0;
+                        if (isEntryHit) {
+                            /* Factor in entry distance */
+                            probabilisticVolumeEntryDistance = rec.Distance;
+                            distanceInProbabilisticVolume -= rec.Distance;
+                        }
+                        if (currentProbabilisticVolumeMaterial->ProbabilisticHit(&distanceInProbabilisticVolume, rng)) {
+                            /* We hit inside the volume; hijack the current hit record's distance and material */
+                            const float totalDistance = probabilisticVolumeEntryDistance + distanceInProbabilisticVolume;
+                            HitRecord inside{};
+                            inside.Distance = totalDistance;
+                            inside.Point = ray.GetPoint(totalDistance);
+                            inside.Normal = -ray.Direction;
+                            inside.TexCoords = float2{0, 0};
+                            inside.EntityPtr = nullptr;
+                            rec = inside;
+                            material = currentProbabilisticVolumeMaterial;
+                        } else {
+                            /* No hit inside the volume, exit it */
+                            currentProbabilisticVolumeMaterial = nullptr;
+                            if (exitHitRecord.EntityPtr->MaterialPtr->Type == RTOW_MATERIAL_PROBABILISTIC_VOLUME &&
+                                um_dot(exitHitRecord.Normal, ray.Direction) > 0) {
+                                /* Volume exit, move to next hit */
+                                hitIndex = exitHitIndex + 1;
+                                continue;
+                            }
+                            /* Obstacle, continue */
+                            rec = exitHitRecord;
+                            material = rec.EntityPtr->MaterialPtr;
+                        }
+                    } else {
+                        /* No more surfaces to hit (probabilistic volume has holes) */
+                        s.hitRecordBuffer.clear();
+                        hitCount = 0;
+                        break;
+                    }
+                }
+
+                if (tracePixel) fprintf(stderr, "[otrace] depth %d kind %d prim %d t %.9g curVol %d nHits %d rng %u\n", depth, rec.EntityPtr ? 0 : 1, rec.EntityPtr ? rec.EntityPtr->SourceIndex : 65535, rec.Distance,
+                                        currentProbabilisticVolumeMaterial ? (int)(currentProbabilisticVolumeMaterial - &scene->materials[0]) : -1, hitCount, rng.whiteNoise.state);
                 float3 albedo;
                 Ray scatteredRay;
                 material->Scatter(ray, rec, rng, &albedo, &scatteredRay);                    /* :308 */
@@ -1007,6 +1212,7 @@ struct Job {
 
             /* No hit? (:341-374) */
             if (hitIndex >= hitCount) {
+                if (tracePixel) fprintf(stderr, "[otrace] depth %d kind 2 sky curVol %d rng %u\n", depth, currentProbabilisticVolumeMaterial ? (int)(currentProbabilisticVolumeMaterial - &scene->materials[0]) : -1, rng.whiteNoise.state);
                 float3 hitSkyColor = f3(0);
                 switch (p.environment.skyType) {
                     case RTOW_SKY_GRADIENT:
@@ -1049,6 +1255,7 @@ struct Job {
     /* :59-164 */
     void Execute(int index, Scratch& s) const
     {
+        { static const int tracedPixel = getenv("ORACLE_TRACE_PIXEL") ? atoi(getenv("ORACLE_TRACE_PIXEL")) : -1; tracePixel = tracedPixel == index; }
         const int width = (int)p.size.x;
         const int cx = index % width; /* column */
         const int cy = index / width; /* row */
@@ -1090,6 +1297,7 @@ struct Job {
         diagnostics.SampleCountWeight = sampleCountWeight;                                   /* :128-130 */
 
         for (uint32_t smp = 0; smp < samplesToAccumulate; smp++) {                            /* :132-157 */
+            if (tracePixel) fprintf(stderr, "[otrace] sample %u\n", smp);
             float2 jitter;
             if (p.subPixelJitter) jitter = rng.NextFloat2();
             else jitter = float2{0.5f, 0.5f};
@@ -1366,6 +1574,30 @@ ORACLE_API int oracle_kat_aabb_hit(const float* mn, const float* mx, const float
     if (um_isnan(inv.y)) inv.y = INFINITY;
     if (um_isnan(inv.z)) inv.z = INFINITY;
     return HitAabb(AABB{f3(mn[0], mn[1], mn[2]), f3(mx[0], mx[1], mx[2])}, f3(ro[0], ro[1], ro[2]), inv) ? 1 : 0;
+}
+/* unity_sort on (key, id) pairs with the float comparer; ids carry the permutation out */
+ORACLE_API void oracle_kat_unity_sort(float* keys, int* ids, int n)
+{
+    struct KV { float k; int id; };
+    std::vector<KV> v(n);
+    for (int i = 0; i < n; i++) v[i] = KV{keys[i], ids[i]};
+    unity_sort(v.data(), n, [](const KV& x, const KV& y) { return float_compare_to(x.k, y.k); });
+    for (int i = 0; i < n; i++) { keys[i] = v[i].k; ids[i] = v[i].id; }
+}
+/* the order in which hits of equal distance start out: source indices of the re-ordered entity array, leaf by leaf, each
+ * leaf back to front (candidates are pushed front to back and popped from the end) */
+ORACLE_API int oracle_kat_hit_tie_order(const RtowSceneDesc* d, int* out)
+{
+    OracleScene sc;
+    sc.Build(d);
+    int k = 0;
+    /* leaves in left-to-right order == ascending EntitiesStart */
+    std::vector<const BvhNode*> leaves;
+    for (const BvhNode& n : sc.nodes) if (n.IsLeaf()) leaves.push_back(&n);
+    std::sort(leaves.begin(), leaves.end(), [](const BvhNode* a, const BvhNode* b) { return a->EntitiesStart < b->EntitiesStart; });
+    for (const BvhNode* n : leaves)
+        for (int i = n->EntityCount - 1; i >= 0; i--) out[k++] = sc.bvhEntities[n->EntitiesStart + i].SourceIndex;
+    return k;
 }
 /* Entity.Hit for one RtowEntity, world-space ray; out = {distance, point[3], normal[3], uv[2]} */
 ORACLE_API int oracle_kat_entity_hit(const RtowEntity* ent, const RtowTriangle* triangles, int triangleCount, const float* ro, const float* rd,

@@ -149,9 +149,10 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.stats = nullptr;
 #ifdef RTOW_STATS
     static unsigned long long* dStats = nullptr;
-    if (!dStats) (void)hipMalloc(&dStats, (32 + 8192) * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dStats, 0, (32 + 8192) * sizeof(unsigned long long), stream);
+    if (!dStats) (void)hipMalloc(&dStats, 16384 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dStats, 0, 16384 * sizeof(unsigned long long), stream);
     a.stats = dStats;
+    a.debugPixel = getenv("RTOW_DEBUG_PIXEL") ? atoi(getenv("RTOW_DEBUG_PIXEL")) : -2;
 #endif
     int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
@@ -205,6 +206,13 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         for (int i = 0; i < 16; i++) fprintf(stderr, "[stats] %-16s %llu\n", names[i], h[i]);
         unsigned long long w[3];
         (void)hipMemcpy(w, a.stats + 16, sizeof(w), hipMemcpyDeviceToHost);
+        if (getenv("RTOW_DEBUG_PIXEL")) {
+            std::vector<unsigned long long> t(8 * 500 + 8);
+            (void)hipMemcpy(t.data(), a.stats + 5000, 8 * 500 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            unsigned long long cnt = 0; (void)hipMemcpy(&cnt, a.stats + 20, 8, hipMemcpyDeviceToHost);
+            for (unsigned long long k = 0; k < cnt && k < 500; k++) { float tv; unsigned tb = (unsigned)t[k * 8 + 4]; memcpy(&tv, &tb, 4);
+                fprintf(stderr, "[trace] smp %llu depth %llu kind %llu prim %llu t %.9g curVol %d nHits %llu rng %llu\n", t[k*8], t[k*8+1], t[k*8+2], t[k*8+3], tv, (int)t[k*8+5], t[k*8+6], t[k*8+7]); }
+        }
         if (w[2]) fprintf(stderr, "[stats] wave residency: mean %.3f ms, max %.3f ms over %llu waves -> tail idle fraction %.3f\n", w[0] / (double)w[2] / 1e5, w[1] / 1e5, w[2],
                           1.0 - (w[0] / (double)w[2]) / (double)w[1]);
         {

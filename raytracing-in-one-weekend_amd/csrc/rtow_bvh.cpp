@@ -7,6 +7,7 @@
 // divergence, so the builder is a full-sweep SAH with a hard depth bound (the traversal stack lives in LDS and is
 // sized by it).  The choice of tree is results-neutral: the nearest hit of a ray does not depend on it.
 #include "rtow_bvh.h"
+#include "rtow_reforder.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -143,12 +144,14 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     // ---- materials (RT/Material.cs:28-46, constant textures folded) ----
     std::vector<GpuMaterial> mats(desc->materialCount);
     std::vector<uint32_t> matClass(desc->materialCount);
+    bool hasVolumes = false;
     for (int i = 0; i < desc->materialCount; i++) {
         const RtowMaterial& m = desc->materials[i];
-        if (m.type != RTOW_MATERIAL_STANDARD && m.type != RTOW_MATERIAL_DIELECTRIC) {
-            *err = "material type not built yet (ProbabilisticVolume is a next row)";
-            return RTOW_ERROR_UNSUPPORTED;
+        if (m.type != RTOW_MATERIAL_STANDARD && m.type != RTOW_MATERIAL_DIELECTRIC && m.type != RTOW_MATERIAL_PROBABILISTIC_VOLUME) {
+            *err = "unknown material type";
+            return RTOW_ERROR_INVALID_VALUE;
         }
+        hasVolumes |= m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME;
         if (!texSupported(m.albedo) || !texSupported(m.glossiness) || !texSupported(m.emission) || !texSupported(m.metallic)) {
             *err = "texture type not built yet (only None / Constant / ConstantScalar)";
             return RTOW_ERROR_UNSUPPORTED;
@@ -158,16 +161,17 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         g.type = m.type;
         g.metallic = texScalar(m.metallic);
         g.glossiness = texScalar(m.glossiness);
-        g.parameter = (m.type == RTOW_MATERIAL_DIELECTRIC) ? m.parameter : 0.0f; // ctor stores it only for Dielectric/Volume
+        g.parameter = (m.type == RTOW_MATERIAL_DIELECTRIC || m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME) ? m.parameter : 0.0f; // ctor stores it only for Dielectric/Volume
         g.flags = 0;
         bool spec = false;
         if (m.type == RTOW_MATERIAL_DIELECTRIC) spec = true; // RT/Material.cs:187-188
-        else spec = m.metallic.type == RTOW_TEXTURE_CONSTANT && almostOne(m.metallic.mainColor.x) && almostOne(m.metallic.mainColor.y) &&
+        else if (m.type == RTOW_MATERIAL_STANDARD)
+            spec = m.metallic.type == RTOW_TEXTURE_CONSTANT && almostOne(m.metallic.mainColor.x) && almostOne(m.metallic.mainColor.y) &&
                     almostOne(m.metallic.mainColor.z) && m.glossiness.type == RTOW_TEXTURE_CONSTANT && almostOne(m.glossiness.mainColor.x) &&
                     almostOne(m.glossiness.mainColor.y) && almostOne(m.glossiness.mainColor.z); // :190-192
         if (spec) g.flags |= MAT_FLAG_PERFECT_SPECULAR;
         mats[i] = g;
-        matClass[i] = m.type == RTOW_MATERIAL_DIELECTRIC ? MAT_CLASS_DIELECTRIC
+        matClass[i] = m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME ? MAT_CLASS_VOLUME : m.type == RTOW_MATERIAL_DIELECTRIC ? MAT_CLASS_DIELECTRIC
                       : (g.glossiness == 0.0f && g.metallic == 0.0f) ? MAT_CLASS_LAMBERT : MAT_CLASS_GENERAL;
     }
 
@@ -175,14 +179,16 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     std::vector<GpuSphere> spheres(n);
     std::vector<GpuMotion> motion(n);
     std::vector<GpuPrim> prims;
+    std::vector<float> cullBoxes;
     std::vector<uint32_t> matIndex(n);
-    bool hasMotion = false, general = false;
+    bool hasMotion = false, general = hasVolumes;   // volume scenes always take the general-entity path
     for (int i = 0; i < n; i++) {
         const RtowEntity& e = desc->entities[i];
         const bool identity = e.rotation.x == 0.0f && e.rotation.y == 0.0f && e.rotation.z == 0.0f && e.rotation.w == 1.0f;
         if (e.type != RTOW_ENTITY_SPHERE || !identity) general = true;
     }
     if (general) prims.resize(n);
+    if (hasVolumes) cullBoxes.assign((size_t)n * 8, 0.0f);
     Builder b;
     b.primBox.resize(n);
     for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
@@ -249,6 +255,32 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
                 bx.hi[a] = std::max(bx.hi[a], (float)std::max(w[a], w[a] + d[a]));
             }
         }
+        if (hasVolumes) {
+            // The box the reference's own tree gives this entity (BvhBuildingEntity, UNITY/BvhNodeData.cs:23-81), in its fp32 arithmetic.
+            // DetermineVolumeContainment's backwards probe (tMin = 0, origin ON a hull surface) is decided by the reference's
+            // slab test against exactly this box, so the kernel repeats that test before the exact hull test.
+            const float q[4] = {e.rotation.x, e.rotation.y, e.rotation.z, e.rotation.w};
+            const float p0[3] = {e.position.x, e.position.y, e.position.z};
+            float pMin[3], pMax[3];
+            for (int a = 0; a < 3; a++) {
+                const float dst = p0[a] + (&e.destinationOffset.x)[a];
+                pMin[a] = e.moving ? std::min(p0[a], dst) : p0[a];
+                pMax[a] = e.moving ? std::max(p0[a], dst) : p0[a];
+            }
+            float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int c = 0; c < 8; c++) {
+                const float v[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+                const float t[3] = {2.0f * (q[1] * v[2] - q[2] * v[1]), 2.0f * (q[2] * v[0] - q[0] * v[2]), 2.0f * (q[0] * v[1] - q[1] * v[0])};
+                const float u[3] = {q[1] * t[2] - q[2] * t[1], q[2] * t[0] - q[0] * t[2], q[0] * t[1] - q[1] * t[0]};
+                for (int a = 0; a < 3; a++) {
+                    const float r = v[a] + q[3] * t[a] + u[a];
+                    cl[a] = std::min(cl[a], r + pMin[a]);
+                    ch[a] = std::max(ch[a], r + pMax[a]);
+                }
+            }
+            cullBoxes[i * 8 + 0] = cl[0]; cullBoxes[i * 8 + 1] = cl[1]; cullBoxes[i * 8 + 2] = cl[2];
+            cullBoxes[i * 8 + 4] = ch[0]; cullBoxes[i * 8 + 5] = ch[1]; cullBoxes[i * 8 + 6] = ch[2];
+        }
         for (int a = 0; a < 3; a++) {
             const float ext = bx.hi[a] - bx.lo[a];
             const float pad = 1e-5f * std::max(std::max(std::fabs(bx.lo[a]), std::fabs(bx.hi[a])), 1.0f) + 1e-5f * ext;
@@ -281,6 +313,12 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
             }
             prims[i] = g;
         }
+    }
+
+    if (hasVolumes) {
+        // tie order of hits at bit-identical distances: the entity's place in the reference tree's leaf order (rtow_reforder.h)
+        const std::vector<uint32_t> ranks = referenceLeafRanks(cullBoxes, n, desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32 /* prefab default */);
+        for (int i = 0; i < n; i++) memcpy(&cullBoxes[(size_t)i * 8 + 3], &ranks[i], 4);
     }
 
     // ---- SAH build, then breadth-first renumbering ----
@@ -335,8 +373,9 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.sphereOffset = off; L.sphereCount = (uint32_t)n; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuSphere));
     L.hasMotion = hasMotion ? 1u : 0u;
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
-    L.sceneKind = general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
+    L.sceneKind = hasVolumes ? SCENE_KIND_VOLUMES : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     L.primOffset = off; if (general) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuPrim));
+    L.cullOffset = off; if (hasVolumes) off = align16(off + (uint32_t)n * 32u);
     L.matIndexOffset = off; off = align16(off + (uint32_t)n * 4u);
     L.materialOffset = off; L.materialCount = (uint32_t)mats.size(); off = align16(off + L.materialCount * (uint32_t)sizeof(GpuMaterial));
     L.totalBytes = off;
@@ -347,6 +386,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     memcpy(out->blob.data() + L.sphereOffset, spheres.data(), spheres.size() * sizeof(GpuSphere));
     if (hasMotion) memcpy(out->blob.data() + L.motionOffset, motion.data(), motion.size() * sizeof(GpuMotion));
     if (general) memcpy(out->blob.data() + L.primOffset, prims.data(), prims.size() * sizeof(GpuPrim));
+    if (hasVolumes) memcpy(out->blob.data() + L.cullOffset, cullBoxes.data(), cullBoxes.size() * 4u);
     memcpy(out->blob.data() + L.matIndexOffset, matIndex.data(), matIndex.size() * 4u);
     memcpy(out->blob.data() + L.materialOffset, mats.data(), mats.size() * sizeof(GpuMaterial));
     out->layout = L;

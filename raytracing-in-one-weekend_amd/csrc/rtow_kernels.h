@@ -67,6 +67,7 @@ struct SampleKernelArgs {
     int32_t tune[8];
     int32_t travSlice;
     unsigned long long* stats; // development statistics (RTOW_STATS builds only), may be null
+    int32_t debugPixel;        // RTOW_STATS builds: pixel whose path segments are traced
 };
 
 struct KernelInfo {

@@ -189,6 +189,22 @@ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, f
     return false;
 }
 
+// the same test with an arbitrary tMin (strict: t > tMin), RT/HitTests.cs:40,49
+__device__ __forceinline__ bool sphere_hit_tmin(V3 oc, V3 d, float a, float radius, float tMin, float& tOut)
+{
+    const float b = dot(oc, d);
+    const float c = dot(oc, oc) - radius * radius;
+    const float disc = b * b - a * c;
+    if (disc > 0) {
+        const float sq = __builtin_sqrtf(disc);
+        float t = (-b - sq) / a;
+        if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
+        t = (-b + sq) / a;
+        if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // general entities (SCENE_KIND_GENERAL): Rect / Box / Triangle and rotated or moving transforms, RT/Entity.cs:58-127
 // ------------------------------------------------------------------------------------------------------------
@@ -203,10 +219,11 @@ __device__ __forceinline__ V3 rotate(float4 q, V3 v)
 }
 __device__ __forceinline__ float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); }
 
-// Entity.HitInternal + HitContent for primitive `i` (RT/Entity.cs:74-122) with tMin = 0, tMax = +inf.
+// Entity.HitInternal + HitContent for primitive `i` (RT/Entity.cs:74-122) with tMax = +inf (tMin = 0 except for the exit-hit
+// probe of volume hulls, JOBS/SampleBatchJob.cs:465).
 // Returns the distance, the entity-space normal and the rotation that takes it to world space.
 template <bool ALL_LDS>
-__device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time,
+__device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time, float tMin,
                                             float& tOut, V3& nLocal, float4& rot)
 {
     const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)i * 128u);
@@ -226,7 +243,7 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
         const float v = dot(rd, qvec) * invDet;
         if (v < 0 || u + v > 1) return false;
         const float dist = dot(e0, qvec) * invDet;
-        if (dist < 0 || dist > __builtin_inff()) return false;
+        if (dist < tMin || dist > __builtin_inff()) return false;
         const float b0 = 1 - u - v;
         const V3 n0 = v3(a2.y, a2.z, a2.w), n1 = v3(a3.x, a3.y, a3.z), n2 = v3(a3.w, a4.x, a4.y);
         nLocal = v3(n0.x * b0 + n1.x * u + n2.x * v, n0.y * b0 + n1.y * u + n2.y * v, n0.z * b0 + n1.z * u + n2.z * v);
@@ -246,7 +263,7 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
     const V3 dL = rotate(invRot, rd);                // rotate(inverseTransform, ray.Direction)
     if (type == RTOW_ENTITY_SPHERE) {
         float t;
-        if (!sphere_hit(oL, dL, dot(dL, dL), q5.x, t)) return false;
+        if (!sphere_hit_tmin(oL, dL, dot(dL, dL), q5.x, tMin, t)) return false;
         nLocal = v3((oL.x + t * dL.x) / q5.x, (oL.y + t * dL.y) / q5.x, (oL.z + t * dL.z) / q5.x);
         tOut = t;
         return true;
@@ -255,17 +272,17 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
         // HitTests.Hit(Rect) (RT/HitTests.cs:62-78)
         if (dL.z >= 0) return false;
         const float t = -oL.z / dL.z;
-        if (t < 0 || t > __builtin_inff()) return false;
+        if (t < tMin || t > __builtin_inff()) return false;
         const float x = oL.x + t * dL.x, y = oL.y + t * dL.y;
         if (x < q5.x || y < q5.y || x > q5.z || y > q5.w) return false;
         nLocal = v3(0, 0, 1);
         tOut = t;
         return true;
     }
-    // HitTests.Hit(Box) (RT/HitTests.cs:80-113), tMin = 0 so the origin offset is origin + direction * 0
+    // HitTests.Hit(Box) (RT/HitTests.cs:80-113): the origin is first advanced by tMin (origin + direction * tMin)
     const float4 q6 = p[6];
     const V3 ext = v3(q5.x, q5.y, q5.z), invExt = v3(q5.w, q6.x, q6.y);
-    const V3 o = v3(oL.x + dL.x * 0.0f, oL.y + dL.y * 0.0f, oL.z + dL.z * 0.0f);
+    const V3 o = v3(oL.x + dL.x * tMin, oL.y + dL.y * tMin, oL.z + dL.z * tMin);
     const float winding = um_max(um_max(__builtin_fabsf(o.x) * invExt.x, __builtin_fabsf(o.y) * invExt.y), __builtin_fabsf(o.z) * invExt.z) < 1 ? -1.0f : 1.0f;
     V3 sgn = v3(-um_sign(dL.x), -um_sign(dL.y), -um_sign(dL.z));
     const V3 dtp = v3((ext.x * winding * sgn.x - o.x) / dL.x, (ext.y * winding * sgn.y - o.y) / dL.y, (ext.z * winding * sgn.z - o.z) / dL.z);
@@ -275,7 +292,7 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
     sgn = tx ? v3(sgn.x, 0, 0) : ty ? v3(0, sgn.y, 0) : v3(0, 0, tz ? sgn.z : 0);
     if (!(sgn.x != 0 || sgn.y != 0 || sgn.z != 0)) return false;
     float dist = sgn.x != 0 ? dtp.x : sgn.y != 0 ? dtp.y : dtp.z;
-    dist += 0.0f;
+    dist += tMin;
     if (dist > __builtin_inff()) return false;
     nLocal = sgn;
     tOut = dist;
@@ -297,7 +314,10 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 #define STAT_DECL unsigned long long stat[16] = {0}
 #define STAT_ADD(i, v) stat[i] += (unsigned long long)(v)
 #define STAT_LANES(i) stat[i] += 1ull
+// per-segment trace of one pixel: {smp, depth, kind, prim, t bits, curVol, nHits, rng}
+#define DBG_TRACE(kind, primv, tv) do { if (A.stats && pix == A.debugPixel) { const unsigned long long k_ = atomicAdd(&A.stats[20], 1ull); if (k_ < 500) { unsigned long long* d_ = A.stats + 5000 + k_ * 8; d_[0] = smp; d_[1] = (unsigned)depth; d_[2] = (kind); d_[3] = (unsigned)(primv); d_[4] = __float_as_uint(tv); d_[5] = (unsigned)curVol; d_[6] = (unsigned)nHits; d_[7] = rng; } } } while (0)
 #else
+#define DBG_TRACE(kind, primv, tv)
 #define STAT_DECL
 #define STAT_ADD(i, v)
 #define STAT_LANES(i)
@@ -355,8 +375,9 @@ enum : int {
     ST_TEST = 2,     // has leaf candidates awaiting the exact sphere test
     ST_HIT = 3,      // nearest hit known: shade
     ST_SKY = 4,      // missed everything: sky + fold
-    ST_DEAD = 5,
-    ST_COUNT = 5
+    ST_VOL = 5,      // VOLUMES scenes: all hits collected -> sort, containment probe, volume logic (JOBS/SampleBatchJob.cs:194-303)
+    ST_DEAD = 6,
+    ST_COUNT = 6
 };
 
 template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG>
@@ -387,8 +408,12 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     sc.ldsNodeCount = A.ldsNodeCount;
     const SceneLayout L = A.layout;
     const int traceDepth = A.traceDepth;
+    // a one-entity scene has a root whose second child is a placeholder; its (inverted) box cannot be told from a real one by the
+    // symmetric slab test, so it is masked explicitly (wave-uniform, costs one scalar AND per node visit)
+    const bool twoChildren = L.sphereCount > 1u;
     constexpr bool HAS_MOTION = KIND == SCENE_KIND_SPHERES_MOTION;
-    constexpr bool GENERAL = KIND == SCENE_KIND_GENERAL;
+    constexpr bool GENERAL = KIND >= SCENE_KIND_GENERAL;
+    constexpr bool VOLUMES = KIND == SCENE_KIND_VOLUMES;     // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
 
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
@@ -411,6 +436,17 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     V3 sampleNormal = v3(0, 0, 0), sampleAlbedo = v3(0, 0, 0);
     bool firstNonSpecular = false;
     float randomEventsLocal = 0;
+
+    // VOLUMES only: all hits of the current ray (FindHits' hitRecordBuffer, JOBS/SampleBatchJob.cs:450-475), the volume the path
+    // is inside of (currentProbabilisticVolumeMaterial, :180) and RandomEvents left pending by ProbabilisticHit (RT/Material.cs:54)
+    constexpr int kMaxHits = VOLUMES ? 24 : 1;
+    float hitT[kMaxHits], hitTmin0[kMaxHits];
+    unsigned hitCode[kMaxHits];      // primitive | dot(normal, dir) < 0 -> bit 30 | dot > 0 -> bit 31
+    int nHits = 0;
+    int curVol = -1;
+    float pendRE = 0;
+    bool insideHit = false;          // the chosen "hit" is a scattering event inside the volume
+    float hitTmin = 0;               // tMin of the test that produced the chosen hit (exit hits use entry + 0.001)
 
     // per-ray traversal state (resumable across trips)
     V3 inv = v3(0, 0, 0);
@@ -440,11 +476,13 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         inv = v3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
         cur = 0; sp = 0; nc = 0; prim = -1;
         best = __builtin_inff();
+        nHits = 0;
         st = ST_TRAV;
     };
     // traversal finished: classify the result
     auto classify = [&]() {
         rayCount += 1.0f;                                                                  // :203
+        if (VOLUMES) { st = ST_VOL; return; }
         st = prim < 0 ? ST_SKY : ST_HIT;
     };
 
@@ -591,6 +629,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     sampleAlbedo = v3(0, 0, 0);
                     firstNonSpecular = false;
                     randomEventsLocal = 0;
+                    curVol = -1;
+                    pendRE = 0;
                     startRay();
                 }
             }
@@ -623,7 +663,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
                     const float tmax1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmin(vmax(tlz.y, thz.y), best));
                     const bool hit0 = tmin0 <= tmax0;
-                    const bool hit1 = tmin1 <= tmax1;
+                    const bool hit1 = tmin1 <= tmax1 && twoChildren;
                     if (FULL_DIAG) boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
                     const bool leaf0 = hit0 && c0 < 0, leaf1 = hit1 && c1 < 0;
                     cand[nc * kBlockThreads] = (unsigned short)~c0;
@@ -657,10 +697,28 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     STAT_LANES(6);
                     nc--;
                     const int i = cand[nc * kBlockThreads];
-                    if (GENERAL) {
+                    if (VOLUMES) {
+                        // FindHits keeps EVERY hit (:457-460) and injects an exit hit for volume hulls (Box / Sphere, :463-469)
+                        const unsigned mw = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u);
+                        const unsigned type = mw >> kPrimTypeShift;
+                        float tmin = 0.0f;
+                        for (int pass = 0; pass < 2; pass++) {
+                            float t; V3 nl; float4 rq;
+                            if (!general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, tmin, t, nl, rq)) break;
+                            const float dn = dot(normalize(rotate(rq, nl)), rd);
+                            if (nHits < kMaxHits) {
+#pragma unroll
+                                for (int k = 0; k < kMaxHits; k++)
+                                    if (k == nHits) { hitT[k] = t; hitTmin0[k] = tmin; hitCode[k] = (unsigned)i | (dn < 0 ? 0x40000000u : 0u) | (dn > 0 ? 0x80000000u : 0u); }
+                                nHits++;
+                            }
+                            if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME || !(type == RTOW_ENTITY_BOX || type == RTOW_ENTITY_SPHERE)) break;
+                            tmin = t + 0.001f;
+                        }
+                    } else if (GENERAL) {
                         const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
                         float t; V3 nl; float4 rq;
-                        if (general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, t, nl, rq) && t < best) { best = t; prim = i; }
+                        if (general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq) && t < best) { best = t; prim = i; }
                     } else {
                         V3 c; float r, t;
                         sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
@@ -677,16 +735,23 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             STAT_ADD(7, 1);
             if (st == ST_HIT) {
                 STAT_LANES(8);
-                const unsigned mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
-                const unsigned matIdx = mi & 0xffffu;
-                const unsigned cls = (mi >> 16) & 3u;                          // shading class packed by the scene compiler
+                DBG_TRACE(VOLUMES && insideHit ? 1 : 0, prim, best);
+                unsigned mi = 0;
+                if (!(VOLUMES && insideHit)) mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
+                unsigned matIdx = mi & 0xffffu;
+                unsigned cls = (mi >> 16) & 3u;                                // shading class packed by the scene compiler
                 const float t = best;
                 const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
                 V3 N;
-                if (GENERAL) {
+                if (VOLUMES && insideHit) {
+                    // new HitRecord(totalDistance, ray.GetPoint(totalDistance), -ray.Direction, default); material = the volume (:272-273)
+                    N = neg(rd);
+                    matIdx = (unsigned)curVol;
+                    cls = MAT_CLASS_VOLUME;
+                } else if (GENERAL) {
                     // re-run the winning primitive's test for its entity-space normal, then rotate it out (RT/Entity.cs:62-66)
                     float t2; V3 nLocal; float4 rq;
-                    (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, t2, nLocal, rq);
+                    (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq);
                     N = normalize(rotate(rq, nLocal));
                 } else {
                     V3 c; float radius;
@@ -703,9 +768,22 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 bool white = false;
                 bool perfectSpecular = false;
                 V3 sdir;
-                float randomEvents = 0;
+                float randomEvents = VOLUMES ? pendRE : 0.0f;     // rng.RandomEvents may already hold ProbabilisticHit's increments
+                pendRE = 0;
 
-                if (cls == MAT_CLASS_LAMBERT) {
+                if (VOLUMES && cls == MAT_CLASS_VOLUME) {
+                    // ProbabilisticVolume (RT/Material.cs:163-168): isotropic scatter, ray time reset to 0, RandomEvents += 2
+                    const float r0 = rng_next(rng);
+                    const float r1 = rng_next(rng);
+                    const float z = r0 * 2.0f - 1.0f;
+                    const float rr = __builtin_sqrtf(um_max(1.0f - z * z, 0.0f));
+                    const float angle = r1 * kPi * 2.0f;
+                    float sn, cs;
+                    det_sincos(angle, sn, cs);
+                    sdir = v3(cs * rr, sn * rr, z);
+                    rtime = 0;
+                    randomEvents += 2;
+                } else if (cls == MAT_CLASS_LAMBERT) {
                     STAT_ADD(9, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(10);
                     // Standard with glossiness == 0 and metallic == 0 (RT/Material.cs:75-119): roughness = 1, so the rough normal
                     // costs two draws whose result is never used (reflectionChance = saturate(fresnel * 0 * g1) = 0, and the
@@ -713,7 +791,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     (void)rng_next(rng);
                     (void)rng_next(rng);
                     sdir = cosine_hemisphere(rng, N);
-                    randomEvents = 1.0f;
+                    randomEvents += 1.0f;                          // 0 + 0 + 1 * 0 + 1 * 1 on top of whatever was pending
                 } else if (cls == MAT_CLASS_GENERAL) {                                        // RT/Material.cs:75-119
                     STAT_ADD(11, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(12);
                     const float4 m2 = *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags roughness
@@ -808,18 +886,168 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 else startRay();
             }
         }
+        if (VOLUMES && (int)__popcll(__ballot(st == ST_VOL)) >= 1) {
+            ran = true;
+            if (st == ST_VOL) {
+                auto matOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (code & 0xffffu) * 4u); };
+                auto isVolume = [&](unsigned code) { return ((matOf(code) >> 16) & 3u) == MAT_CLASS_VOLUME; };
+                // ---- hitBuffer.Sort(DistanceComparer) (:473-474) ----
+                // The reference sorts a list that starts in its tree's leaf order with a sort that is not stable, and hits at
+                // bit-identical distances (coplanar faces) keep whatever order that leaves: put the hits in leaf order first
+                // (rank, rtow_reforder.h), then run the same small-array sort (NativeSortExtension: compare-exchange for 2 and 3,
+                // insertion above; lists longer than 16 - never seen - are insertion-sorted as well, exact unless they hold a tie).
+                {
+                    auto rankOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.cullOffset) + (code & 0xffffu) * 32u + 12u); };
+                    auto swapHits = [&](int a, int b) {
+                        const float t = hitT[a], tm = hitTmin0[a]; const unsigned c = hitCode[a];
+                        hitT[a] = hitT[b]; hitTmin0[a] = hitTmin0[b]; hitCode[a] = hitCode[b];
+                        hitT[b] = t; hitTmin0[b] = tm; hitCode[b] = c;
+                    };
+                    for (int i = 1; i < nHits; i++) {                                   // leaf order; an entity's exit hit was recorded after its entry
+                        const float t = hitT[i], tm = hitTmin0[i];
+                        const unsigned c = hitCode[i], r = rankOf(c);
+                        int j = i - 1;
+                        while (j >= 0 && rankOf(hitCode[j]) > r) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
+                        hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
+                    }
+                    if (nHits == 2) {
+                        if (hitT[0] > hitT[1]) swapHits(0, 1);
+                    } else if (nHits == 3) {
+                        if (hitT[0] > hitT[1]) swapHits(0, 1);
+                        if (hitT[0] > hitT[2]) swapHits(0, 2);
+                        if (hitT[1] > hitT[2]) swapHits(1, 2);
+                    } else {
+                        for (int i = 1; i < nHits; i++) {
+                            const float t = hitT[i], tm = hitTmin0[i];
+                            const unsigned c = hitCode[i];
+                            int j = i - 1;
+                            while (j >= 0 && t < hitT[j]) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
+                            hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
+                        }
+                    }
+                }
+                // ---- DetermineVolumeContainment (:477-508) ----
+                if (curVol < 0) {
+                    for (int i = 0; i < nHits; i++) {
+                        const unsigned c = hitCode[i];
+                        if (!isVolume(c)) continue;
+                        if (c & 0x40000000u) break;                                   // entry hit, early out
+                        // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
+                        const V3 bd = neg(rd);
+                        const V3 binv = v3(__builtin_amdgcn_rcpf(bd.x), __builtin_amdgcn_rcpf(bd.y), __builtin_amdgcn_rcpf(bd.z));
+                        V3 einv = v3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);                    // math.rcp + "convert NaN to INFINITY" (:409-412)
+                        if (einv.x != einv.x) einv.x = __builtin_inff();
+                        if (einv.y != einv.y) einv.y = __builtin_inff();
+                        if (einv.z != einv.z) einv.z = __builtin_inff();
+                        bool insideVolume = false;
+                        int bsp = 0, bcur = 0;
+                        while (bcur >= 0) {                                              // FindHitCandidates(backwardsRay): no pruning
+                            float4 q0, q1, q2;
+                            int c0, c1;
+                            load_node<ALL_LDS>(sc, L, bcur, q0, q1, q2, c0, c1);
+                            const float t0x = (q0.x - ro.x) * binv.x, t1x = (q1.z - ro.x) * binv.x, u0x = (q0.y - ro.x) * binv.x, u1x = (q1.w - ro.x) * binv.x;
+                            const float t0y = (q0.z - ro.y) * binv.y, t1y = (q2.x - ro.y) * binv.y, u0y = (q0.w - ro.y) * binv.y, u1y = (q2.y - ro.y) * binv.y;
+                            const float t0z = (q1.x - ro.z) * binv.z, t1z = (q2.z - ro.z) * binv.z, u0z = (q1.y - ro.z) * binv.z, u1z = (q2.w - ro.z) * binv.z;
+                            const bool h0 = vmax3(vmin(t0x, t1x), vmin(t0y, t1y), vmax(vmin(t0z, t1z), 0.0f)) <= vmin3(vmax(t0x, t1x), vmax(t0y, t1y), vmax(t0z, t1z));
+                            const bool h1 = vmax3(vmin(u0x, u1x), vmin(u0y, u1y), vmax(vmin(u0z, u1z), 0.0f)) <= vmin3(vmax(u0x, u1x), vmax(u0y, u1y), vmax(u0z, u1z)) && twoChildren;
+                            for (int side = 0; side < 2; side++) {
+                                const int cc = side ? c1 : c0;
+                                if (!(side ? h1 : h0) || cc >= 0) continue;
+                                const unsigned mw = matOf((unsigned)~cc);
+                                if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME) continue;    // AnyBackwardsVolumeEntryHit (:510-524)
+                                {
+                                    // The probe starts ON a surface with tMin = 0, so whether the hull is a candidate at all is decided by the
+                                    // reference's slab test (RT/HitTests.cs:9-21) on the reference tree's box of this entity; repeat it exactly.
+                                    const float4* cb = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.cullOffset) + (unsigned)~cc * 32u);
+                                    const float4 lo = cb[0], hi = cb[1];
+                                    const float a0x = (lo.x - ro.x) * einv.x, a1x = (hi.x - ro.x) * einv.x;
+                                    const float a0y = (lo.y - ro.y) * einv.y, a1y = (hi.y - ro.y) * einv.y;
+                                    const float a0z = (lo.z - ro.z) * einv.z, a1z = (hi.z - ro.z) * einv.z;
+                                    const float tn = um_max(0.0f, um_max(um_max(um_min(a0x, a1x), um_min(a0y, a1y)), um_min(a0z, a1z)));
+                                    const float tf = um_min(um_min(um_max(a0x, a1x), um_max(a0y, a1y)), um_max(a0z, a1z));
+                                    if (!(tn < tf)) continue;
+                                }
+                                float t; V3 nl; float4 rq;
+                                if (general_hit<ALL_LDS>(sc, L, ~cc, mw >> kPrimTypeShift, ro, bd, rtime, 0.0f, t, nl, rq) && dot(normalize(rotate(rq, nl)), bd) > 0) insideVolume = true;
+                            }
+                            const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
+                            if (in0 && in1) { stack[bsp * kBlockThreads] = (unsigned short)c1; bsp++; bcur = c0; }
+                            else if (in0 || in1) bcur = in0 ? c0 : c1;
+                            else if (bsp > 0) { bsp--; bcur = stack[bsp * kBlockThreads]; }
+                            else bcur = -1;
+                        }
+                        if (insideVolume) { curVol = (int)(matOf(c) & 0xffffu); break; }
+                    }
+                }
+                for (int i = 0; i < nHits; i++) DBG_TRACE(10 + i, hitCode[i], hitT[i]);
+                DBG_TRACE(9, 0, 0.0f);
+                // ---- the hit loop of Sample with the volume branch (:205-303) ----
+                int hitIndex = 0;
+                int chosen = -1;
+                insideHit = false;
+                while (hitIndex < nHits) {
+                    const unsigned c = hitCode[hitIndex];
+                    const unsigned mw = matOf(c);
+                    if (curVol >= 0 || ((mw >> 16) & 3u) == MAT_CLASS_VOLUME) {
+                        const bool isEntryHit = curVol < 0;
+                        if (curVol < 0) curVol = (int)(mw & 0xffffu);
+                        int exitHitIndex = hitIndex, lastExitIndex = -1, sameMaterialEntries = 0;
+                        while (exitHitIndex < nHits) {
+                            const unsigned ec = hitCode[exitHitIndex];
+                            if ((int)(matOf(ec) & 0xffffu) == curVol) {
+                                if (ec & 0x40000000u) sameMaterialEntries++;
+                                else { sameMaterialEntries--; lastExitIndex = exitHitIndex; }
+                                if (sameMaterialEntries <= 0) break;
+                            } else
+                                break;
+                            exitHitIndex++;
+                        }
+                        if (sameMaterialEntries > 0 && lastExitIndex != -1) exitHitIndex = lastExitIndex;
+                        if (exitHitIndex < nHits) {
+                            float distanceInVolume = hitT[exitHitIndex];
+                            float entryDistance = 0;
+                            if (isEntryHit) { entryDistance = hitT[hitIndex]; distanceInVolume -= hitT[hitIndex]; }
+                            // Material.ProbabilisticHit (RT/Material.cs:49-65)
+                            const float density = *reinterpret_cast<const float*>(section<ALL_LDS>(sc, L.materialOffset) + (unsigned)curVol * 64u + 36u);
+                            pendRE++;
+                            const float volumeHitDistance = -(1 / um_max(density, 1.1920928955078125e-7f)) * det_log(rng_next(rng));
+                            if (volumeHitDistance < distanceInVolume) {
+                                best = entryDistance + volumeHitDistance;                    // we hit inside the volume
+                                insideHit = true;
+                                break;
+                            }
+                            curVol = -1;                                                     // no hit inside the volume, exit it
+                            const unsigned xc = hitCode[exitHitIndex];
+                            if (isVolume(xc) && (xc & 0x80000000u)) { hitIndex = exitHitIndex + 1; continue; }   // volume exit: next hit
+                            chosen = exitHitIndex;                                           // obstacle
+                            break;
+                        }
+                        nHits = 0;                                                           // no more surfaces (volume has holes)
+                        break;
+                    }
+                    chosen = hitIndex;
+                    break;
+                }
+                if (insideHit) { prim = -1; st = ST_HIT; }
+                else if (chosen >= 0 && chosen < nHits) { best = hitT[chosen]; hitTmin = hitTmin0[chosen]; prim = (int)(hitCode[chosen] & 0xffffu); st = ST_HIT; }
+                else st = ST_SKY;
+            }
+        }
         if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : A.tune[4])) {
             ran = true;
             // ================= sky (:341-374), then fold tail -> head (:384-396) =================
             STAT_ADD(15, 1);
             if (st == ST_SKY) {
+                DBG_TRACE(2, 0xffff, 0.0f);
                 V3 sky = v3(0, 0, 0);
                 if (A.environment.skyType == RTOW_SKY_GRADIENT) {
                     const float s = 0.5f * (rd.y + 1);
                     const V3 b = v3(A.environment.skyBottomColor), tp = v3(A.environment.skyTopColor);
                     sky = v3(b.x + s * (tp.x - b.x), b.y + s * (tp.y - b.y), b.z + s * (tp.z - b.z));
                 }
-                // randomEventsLocalAcc += rng.RandomEvents / pow(2, depth) with RandomEvents == 0 here (:363): adds +0
+                // randomEventsLocalAcc += rng.RandomEvents / pow(2, depth) (:363): RandomEvents is 0 here unless a ProbabilisticHit
+                // that found nothing left its increment pending
+                if (VOLUMES) { randomEventsLocal += pendRE * inv_pow2(depth); pendRE = 0; }
                 if (!firstNonSpecular) { sampleAlbedo = sky; sampleNormal = neg(rd); }
 
                 V3 col = sky; // 0 * 1 + sky
@@ -1084,6 +1312,7 @@ hipError_t launchByKind(const SampleKernelArgs& args, int numBlocks, size_t ldsB
     switch (args.layout.sceneKind) {
         case SCENE_KIND_SPHERES: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES>(args, numBlocks, ldsBytes, stream);
         case SCENE_KIND_SPHERES_MOTION: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES_MOTION>(args, numBlocks, ldsBytes, stream);
+        case SCENE_KIND_VOLUMES: return launchByDiag<ALL_LDS, SCENE_KIND_VOLUMES>(args, numBlocks, ldsBytes, stream);
         default: return launchByDiag<ALL_LDS, SCENE_KIND_GENERAL>(args, numBlocks, ldsBytes, stream);
     }
 }
@@ -1105,7 +1334,7 @@ hipError_t launchBuildChunkOrder(const unsigned* cost, unsigned chunkCount, unsi
 
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream)
 {
-    if (layout.sceneKind != SCENE_KIND_GENERAL) return hipSuccess;
+    if (layout.sceneKind < SCENE_KIND_GENERAL) return hipSuccess;
     const unsigned blocks = (layout.sphereCount + 127u) / 128u;
     hipLaunchKernelGGL(prepare_entities_kernel, dim3(blocks ? blocks : 1), dim3(128), 0, stream, blob, layout);
     return hipGetLastError();

@@ -52,6 +52,7 @@ enum : uint32_t {
     MAT_CLASS_LAMBERT = 0, // Standard, glossiness == 0 and metallic == 0
     MAT_CLASS_GENERAL = 1, // any other Standard
     MAT_CLASS_DIELECTRIC = 2,
+    MAT_CLASS_VOLUME = 3,  // ProbabilisticVolume
 };
 
 struct GpuMaterial {
@@ -87,6 +88,7 @@ enum : uint32_t {
     SCENE_KIND_SPHERES = 0,        // identity-rotation static spheres: GpuSphere only
     SCENE_KIND_SPHERES_MOTION = 1, // identity-rotation spheres, some moving: GpuSphere + GpuMotion
     SCENE_KIND_GENERAL = 2,        // anything else: GpuPrim
+    SCENE_KIND_VOLUMES = 3,        // GENERAL + at least one ProbabilisticVolume material: all hits of a ray are collected and sorted
 };
 // materialIndex[] word: bits 0..15 material, 16..17 shading class, 18..20 RtowEntityType
 constexpr uint32_t kPrimTypeShift = 18;
@@ -102,7 +104,8 @@ struct SceneLayout {
     uint32_t bvhDepth;                      // max number of inner nodes on a root->leaf path == stack bound
     uint32_t sceneKind;                     // SCENE_KIND_*
     uint32_t primOffset;                    // GpuPrim[sphereCount] when sceneKind == SCENE_KIND_GENERAL
-    uint32_t pad[3];
+    uint32_t cullOffset;                    // float[8] {min.xyz, rank, max.xyz, -} per entity when sceneKind == SCENE_KIND_VOLUMES: the reference tree's entity box + leaf-order rank (uint)
+    uint32_t pad[2];
 };
 
 } // namespace rtow

@@ -95,6 +95,11 @@ def dielectric(ior, gloss=1.0, albedo=1.0):
     return abi.Material(abi.MATERIAL_DIELECTRIC, _const_tex(albedo), _const_tex(gloss), _none_tex(), _none_tex(), float(f32(ior)))
 
 
+def volume(color, density):
+    """ProbabilisticVolume (RT/Material.cs:14,40-42,49-65,163-168): isotropic scattering medium of constant density."""
+    return abi.Material(abi.MATERIAL_PROBABILISTIC_VOLUME, _const_tex(color), _none_tex(), _none_tex(), _none_tex(), float(f32(density)))
+
+
 def standard(color, metallic, gloss, emission=None):
     em = _none_tex() if emission is None else _const_tex(emission)
     return abi.Material(abi.MATERIAL_STANDARD, _const_tex(color), _const_tex(gloss), em, _const_tex(metallic), 0.0)
@@ -404,6 +409,51 @@ def mixed_scene():
             s.add_triangle(a, apex, b, blue)
     s.camera = {"position": [0.0, 0.0, 6.5], "target": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 38.0, "aperture": 0.0}
     s.sky_bottom, s.sky_top = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)
+    return s
+
+
+def volume_scene():
+    """`Cornell With Volumes (Book 2)`-like set-up: smoke and fog boxes, a fog sphere with a solid sphere inside it, a glass
+    sphere partly inside the fog, and a camera ray path that starts INSIDE a big thin haze sphere (containment probe)."""
+    s = Scene("volumes")
+    white, red, green = lambertian((0.73, 0.73, 0.73)), lambertian((0.65, 0.05, 0.05)), lambertian((0.12, 0.45, 0.15))
+    light = standard((0.0, 0.0, 0.0), 0.0, 0.0, emission=(7.0, 7.0, 7.0))
+    up90, dn90 = quat_axis_angle((1, 0, 0), -90), quat_axis_angle((1, 0, 0), 90)
+    s.add_rect((0, 0, -2), (4, 4), white)
+    s.add_rect((0, -2, 0), (4, 4), white, rotation=up90)
+    s.add_rect((0, 2, 0), (4, 4), white, rotation=dn90)
+    s.add_rect((-2, 0, 0), (4, 4), red, rotation=quat_axis_angle((0, 1, 0), 90))
+    s.add_rect((2, 0, 0), (4, 4), green, rotation=quat_axis_angle((0, 1, 0), -90))
+    s.add_rect((0, 1.99, 0), (1.6, 1.6), light, rotation=dn90)
+    s.add_box((-0.8, -1.2, -0.5), (1.1, 1.6, 1.1), volume((0.05, 0.05, 0.05), 1.8), rotation=quat_axis_angle((0, 1, 0), 20))     # smoke
+    s.add_box((0.8, -1.5, 0.2), (1.0, 1.0, 1.0), volume((0.95, 0.95, 0.95), 2.5), rotation=quat_axis_angle((0, 1, 0), -17))      # fog
+    s.add_sphere((0.0, 0.6, -0.2), 0.6, volume((0.3, 0.5, 0.9), 3.0))                                                          # fog ball ...
+    s.add_sphere((0.0, 0.6, -0.2), 0.25, metal((0.9, 0.8, 0.3), 0.05))                                                         # ... with a solid core
+    s.add_sphere((0.9, -0.6, 0.9), 0.35, dielectric(1.5))
+    s.add_sphere((0.0, 0.0, 4.0), 3.5, volume((1.0, 1.0, 1.0), 0.04))                                                          # haze around the camera
+    s.camera = {"position": [0.0, 0.0, 6.5], "target": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 38.0, "aperture": 0.0}
+    s.sky_bottom, s.sky_top = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)
+    return s
+
+
+def volume_tie_scene():
+    """Axis-aligned fog boxes standing ON the floor and touching each other and a glass slab: many rays meet two or three
+    surfaces at bit-identical distances, so the result depends on the reference's (unstable) hit-sort tie order."""
+    s = Scene("volume_ties")
+    white = lambertian((0.8, 0.8, 0.8))
+    light = standard((0.0, 0.0, 0.0), 0.0, 0.0, emission=(4.0, 4.0, 4.0))
+    up90, dn90 = quat_axis_angle((1, 0, 0), -90), quat_axis_angle((1, 0, 0), 90)
+    s.add_rect((0, 0, 0), (8, 8), white, rotation=up90)                                  # floor y = 0
+    s.add_rect((0, 0, -2), (8, 4), white)                                                # back wall z = -2 (its lower half is below the floor)
+    s.add_rect((0, 3.0, 0), (3, 3), light, rotation=dn90)
+    fog_a, fog_b = volume((0.9, 0.6, 0.3), 1.5), volume((0.3, 0.6, 0.9), 2.5)
+    s.add_box((-0.5, 0.5, -1.5), (1, 1, 1), fog_a)                                       # bottom on the floor, back on the wall
+    s.add_box((0.5, 0.5, -1.5), (1, 1, 1), fog_b)                                        # shares the x = 0 face with fog_a
+    s.add_box((0.0, 0.25, -0.5), (2, 0.5, 1), fog_a)                                     # same medium, touching both from the front
+    s.add_box((1.5, 0.5, -1.5), (1, 1, 1), dielectric(1.5))                              # glass block sharing the x = 1 face with fog_b
+    s.add_rect((0.0, 1.0, -1.5), (2, 1), standard((0.9, 0.9, 0.9), 1.0, 0.9), rotation=up90)   # a mirror lid exactly on top of both boxes
+    s.camera = {"position": [0.3, 2.2, 4.0], "target": [0.2, 0.4, -1.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": 0.0}
+    s.sky_bottom, s.sky_top = (0.3, 0.3, 0.3), (0.2, 0.3, 0.5)
     return s
 
 

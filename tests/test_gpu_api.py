@@ -137,7 +137,10 @@ def test_error_codes(rt, gpu_context):
     bad.entities[0].materialIndex = 99
     assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE
     bad = scene.desc()
-    bad.materials[0].type = a.MATERIAL_PROBABILISTIC_VOLUME
+    bad.materials[0].type = 7
+    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE
+    bad = scene.desc()
+    bad.materials[0].albedo.type = a.TEXTURE_IMAGE                 # image textures are not built yet
     assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_UNSUPPORTED
     # a failed upload leaves the previous scene usable
     out = rt.sample_batch_host(fresh, p, z)

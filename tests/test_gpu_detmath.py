@@ -1,0 +1,22 @@
+"""GPU: the device's deterministic sin/cos/log/pow (and IEEE / and sqrt) against the oracle's, bit for bit, over dense sweeps -
+including EVERY value Unity's NextFloat() can return for log (ProbabilisticHit) and sincos(2*pi*u)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_device_detmath_matches_oracle_bit_for_bit():
+    src = os.path.join(ROOT, "tests", "native", "detmath_parity.hip")
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "detmath_parity")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-x", "hip", src, "-o", exe],
+                       check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 mismatches" in r.stdout

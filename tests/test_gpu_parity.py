@@ -138,3 +138,21 @@ def test_triangle_mesh_scene(rt, oracle, gpu_context):
     scene.camera = {"position": [2.5, 1.8, 3.0], "target": [0.0, 0.7, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 35.0, "aperture": 0.0}
     gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 72, 6, 8, focus=4.0)
     _compare(gpu, ref)
+
+
+def test_probabilistic_volumes(rt, oracle, gpu_context):
+    """ProbabilisticVolume materials: all-hits collection, exit-hit injection, containment probe (camera inside a haze sphere),
+    the volume branch of Sample and isotropic scatter (JOBS/SampleBatchJob.cs:194-303,463-524, RT/Material.cs:49-65,163-168)."""
+    scene = rt.scenes.volume_scene()
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 100, 100, 8, 10, focus=6.5, diagnostics_stride=16)
+    _compare(gpu, ref)
+    assert gpu["color"][:, 3].sum() > 0
+
+
+def test_volume_hits_at_identical_distances(rt, oracle, gpu_context):
+    """Coplanar hulls / floor / lid: hits at bit-identical distances take the order the reference's unstable hit sort leaves them
+    in, starting from its tree's leaf order (csrc/rtow_reforder.h, tests/test_reference_tie_order.py)."""
+    scene = rt.scenes.volume_tie_scene()
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 96, 8, 12, focus=5.0, diagnostics_stride=16)
+    _compare(gpu, ref)
+    assert gpu["color"][:, 3].sum() > 0

@@ -1,0 +1,120 @@
+"""CPU: the order of hits at bit-identical distances.
+
+The reference leaves such ties in whatever order NativeSortExtension.Sort (com.unity.collections 1.0.0-pre.6, not stable)
+produces from its tree's leaf order.  The oracle restates that sort and the reference tree; the product computes the leaf order
+without building that tree (csrc/rtow_reforder.cpp).  Both are written separately - these tests hold them to each other and the
+sort to its defining properties."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+rt = importlib.import_module("raytracing-in-one-weekend_amd")
+abi = rt.abi
+S = rt.scenes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    src = os.path.join(ROOT, "tests", "native", "reforder_shim.cpp")
+    dep = os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc", "rtow_reforder.cpp")
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libreforder_shim.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(dep)):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-shared", "-fPIC", src, dep, "-o", so], check=True, capture_output=True)
+    lib = C.CDLL(so)
+    lib.shim_leaf_ranks.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    lib.shim_index_sort.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float)]
+    return lib
+
+
+def oracle_sort(keys):
+    lib = ob.load()
+    k = np.ascontiguousarray(keys, dtype=np.float32).copy()
+    ids = np.arange(len(k), dtype=np.int32)
+    lib.oracle_kat_unity_sort(k.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_int)), len(k))
+    return k, ids
+
+
+def test_unity_sort_orders_and_permutes():
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 40)) + [100, 257, 1000]:
+        for ties in (False, True):
+            keys = rng.integers(0, max(2, n // 3), n).astype(np.float32) if ties else rng.random(n, dtype=np.float32)
+            k, ids = oracle_sort(keys)
+            assert np.all(np.diff(k) >= 0)
+            assert sorted(ids.tolist()) == list(range(n))
+            assert np.array_equal(keys[ids], k)
+
+
+def test_unity_sort_small_arrays_tie_behaviour():
+    # two elements and the insertion range (4..16) keep ties in place ...
+    assert oracle_sort([1, 1])[1].tolist() == [0, 1]
+    assert oracle_sort([2, 1, 2, 1, 2])[1].tolist() == [1, 3, 0, 2, 4]
+    keys = np.array([3, 1, 3, 1, 3, 1, 3, 1, 3, 1, 3, 1, 3, 1, 3, 1], dtype=np.float32)
+    assert oracle_sort(keys)[1].tolist() == [1, 3, 5, 7, 9, 11, 13, 15, 0, 2, 4, 6, 8, 10, 12, 14]
+    # ... the three-element compare-exchange network does not: (0,1) (0,2) (1,2) turns [2, 2', 1] into [1, 2', 2]
+    assert oracle_sort([2, 2, 1])[1].tolist() == [2, 1, 0]
+    assert oracle_sort([1, 2, 2])[1].tolist() == [0, 1, 2]
+    assert oracle_sort([2, 1, 2])[1].tolist() == [1, 0, 2]
+
+
+def test_product_index_sort_equals_oracle_sort(shim):
+    rng = np.random.default_rng(11)
+    for n in list(range(0, 40)) + [64, 100, 257, 1000, 5000]:
+        for ties in (False, True):
+            keys = rng.integers(-3, max(2, n // 4), n).astype(np.float32) if ties else (rng.random(n, dtype=np.float32) - np.float32(0.5))
+            _, ids = oracle_sort(keys)
+            idx = np.arange(n, dtype=np.uint32)
+            shim.shim_index_sort(idx.ctypes.data_as(C.POINTER(C.c_uint32)), n, np.ascontiguousarray(keys).ctypes.data_as(C.POINTER(C.c_float)))
+            assert idx.tolist() == ids.tolist(), (n, ties)
+
+
+def test_product_index_sort_adversarial_sequence(shim):
+    # a "median-of-three killer"-style sequence: deep, unbalanced splits (and the heap-sort fallback when the budget runs out)
+    n = 4096
+    keys = np.zeros(n, dtype=np.float32)
+    half = n // 2
+    for i in range(half):
+        keys[i] = i + 1 if i % 2 == 0 else half + i + (1 if i % 2 else 0)
+        keys[half + i] = 2 * (i + 1)
+    _, ids = oracle_sort(keys)
+    idx = np.arange(n, dtype=np.uint32)
+    shim.shim_index_sort(idx.ctypes.data_as(C.POINTER(C.c_uint32)), n, keys.ctypes.data_as(C.POINTER(C.c_float)))
+    assert idx.tolist() == ids.tolist()
+    assert np.all(np.diff(keys[idx]) >= 0)
+
+
+def _boxes(desc_holder):
+    lib = ob.load()
+    d = desc_holder
+    n = d.entityCount
+    boxes = np.zeros((n, 8), dtype=np.float32)
+    out = (C.c_float * 6)()
+    for i in range(n):
+        assert lib.oracle_kat_entity_bounds(C.byref(d.entities[i]), d.triangles, d.triangleCount, out) == 0
+        boxes[i, 0:3] = out[0:3]
+        boxes[i, 4:7] = out[3:6]
+    return boxes
+
+
+@pytest.mark.parametrize("name,max_depth", [("volumes", 0), ("volumes", 2), ("volume_ties", 0), ("volume_ties", 1), ("mixed", 0), ("mixed", 3), ("cover", 0), ("cover", 5), ("moving", 0), ("stress", 6)])
+def test_product_leaf_order_equals_oracle_tree(shim, name, max_depth):
+    scene = {"volumes": S.volume_scene, "volume_ties": S.volume_tie_scene, "mixed": S.mixed_scene, "cover": S.cover_scene, "moving": S.moving_scene,
+             "stress": lambda: S.stress_scene(2000)}[name]()
+    d = scene.desc(max_bvh_depth=max_depth)
+    n = d.entityCount
+    order = (C.c_int * n)()
+    assert ob.load().oracle_kat_hit_tie_order(C.byref(d), order) == n
+    boxes = np.ascontiguousarray(_boxes(d))
+    ranks = np.zeros(n, dtype=np.uint32)
+    shim.shim_leaf_ranks(boxes.ctypes.data_as(C.POINTER(C.c_float)), n, max_depth if max_depth > 0 else 32, ranks.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert sorted(ranks.tolist()) == list(range(n))
+    assert np.argsort(ranks).tolist() == list(order)
