@@ -188,7 +188,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         if (e.type != RTOW_ENTITY_SPHERE || !identity) general = true;
     }
     if (general) prims.resize(n);
-    if (hasVolumes) cullBoxes.assign((size_t)n * 8, 0.0f);
+    if (general) cullBoxes.assign((size_t)n * 8, 0.0f);
     Builder b;
     b.primBox.resize(n);
     for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
@@ -255,7 +255,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
                 bx.hi[a] = std::max(bx.hi[a], (float)std::max(w[a], w[a] + d[a]));
             }
         }
-        if (hasVolumes) {
+        if (general) {
             // The box the reference's own tree gives this entity (BvhBuildingEntity, UNITY/BvhNodeData.cs:23-81), in its fp32 arithmetic.
             // DetermineVolumeContainment's backwards probe (tMin = 0, origin ON a hull surface) is decided by the reference's
             // slab test against exactly this box, so the kernel repeats that test before the exact hull test.
@@ -315,11 +315,9 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         }
     }
 
-    if (hasVolumes) {
-        // tie order of hits at bit-identical distances: the entity's place in the reference tree's leaf order (rtow_reforder.h)
-        const std::vector<uint32_t> ranks = referenceLeafRanks(cullBoxes, n, desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32 /* prefab default */);
-        for (int i = 0; i < n; i++) memcpy(&cullBoxes[(size_t)i * 8 + 3], &ranks[i], 4);
-    }
+    // tie order of hits at bit-identical distances: the entity's place in the reference tree's leaf order (rtow_reforder.h)
+    std::vector<uint32_t> ranks;
+    if (general) ranks = referenceLeafRanks(cullBoxes, n, desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32 /* prefab default */);
 
     // ---- SAH build, then breadth-first renumbering ----
     std::vector<int> idx(n);
@@ -376,6 +374,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.sceneKind = hasVolumes ? SCENE_KIND_VOLUMES : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     L.primOffset = off; if (general) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuPrim));
     L.cullOffset = off; if (hasVolumes) off = align16(off + (uint32_t)n * 32u);
+    L.rankOffset = off; if (general) off = align16(off + (uint32_t)n * 4u);
     L.matIndexOffset = off; off = align16(off + (uint32_t)n * 4u);
     L.materialOffset = off; L.materialCount = (uint32_t)mats.size(); off = align16(off + L.materialCount * (uint32_t)sizeof(GpuMaterial));
     L.totalBytes = off;
@@ -387,6 +386,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     if (hasMotion) memcpy(out->blob.data() + L.motionOffset, motion.data(), motion.size() * sizeof(GpuMotion));
     if (general) memcpy(out->blob.data() + L.primOffset, prims.data(), prims.size() * sizeof(GpuPrim));
     if (hasVolumes) memcpy(out->blob.data() + L.cullOffset, cullBoxes.data(), cullBoxes.size() * 4u);
+    if (general) memcpy(out->blob.data() + L.rankOffset, ranks.data(), ranks.size() * 4u);
     memcpy(out->blob.data() + L.matIndexOffset, matIndex.data(), matIndex.size() * 4u);
     memcpy(out->blob.data() + L.materialOffset, mats.data(), mats.size() * sizeof(GpuMaterial));
     out->layout = L;

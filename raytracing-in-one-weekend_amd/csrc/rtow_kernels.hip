@@ -718,7 +718,12 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     } else if (GENERAL) {
                         const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
                         float t; V3 nl; float4 rq;
-                        if (general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq) && t < best) { best = t; prim = i; }
+                        if (general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq)) {
+                            // two surfaces at the bit-identical distance: the reference's sorted hit list starts with the one that
+                            // comes first in its tree's leaf order (rtow_reforder.h)
+                            const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
+                            if (t < best || (t == best && prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
+                        }
                     } else {
                         V3 c; float r, t;
                         sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
@@ -897,7 +902,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 // (rank, rtow_reforder.h), then run the same small-array sort (NativeSortExtension: compare-exchange for 2 and 3,
                 // insertion above; lists longer than 16 - never seen - are insertion-sorted as well, exact unless they hold a tie).
                 {
-                    auto rankOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.cullOffset) + (code & 0xffffu) * 32u + 12u); };
+                    auto rankOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset) + (code & 0xffffu) * 4u); };
                     auto swapHits = [&](int a, int b) {
                         const float t = hitT[a], tm = hitTmin0[a]; const unsigned c = hitCode[a];
                         hitT[a] = hitT[b]; hitTmin0[a] = hitTmin0[b]; hitCode[a] = hitCode[b];

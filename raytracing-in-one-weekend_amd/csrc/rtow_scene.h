@@ -104,8 +104,9 @@ struct SceneLayout {
     uint32_t bvhDepth;                      // max number of inner nodes on a root->leaf path == stack bound
     uint32_t sceneKind;                     // SCENE_KIND_*
     uint32_t primOffset;                    // GpuPrim[sphereCount] when sceneKind == SCENE_KIND_GENERAL
-    uint32_t cullOffset;                    // float[8] {min.xyz, rank, max.xyz, -} per entity when sceneKind == SCENE_KIND_VOLUMES: the reference tree's entity box + leaf-order rank (uint)
-    uint32_t pad[2];
+    uint32_t cullOffset;                    // float[8] {min.xyz, -, max.xyz, -} per entity when sceneKind == SCENE_KIND_VOLUMES: the reference tree's entity box
+    uint32_t rankOffset;                    // uint32 per entity when sceneKind >= SCENE_KIND_GENERAL: place in the reference tree's leaf order (rtow_reforder.h)
+    uint32_t pad[1];
 };
 
 } // namespace rtow

@@ -457,6 +457,26 @@ def volume_tie_scene():
     return s
 
 
+def coplanar_scene():
+    """No volumes: decals lying exactly IN the plane of a wall / the floor and boxes sharing faces - the nearest hit is a tie
+    between two entities for many pixels, decided by the reference's hit-list order (leaf order of its tree)."""
+    s = Scene("coplanar")
+    up90 = quat_axis_angle((1, 0, 0), -90)
+    s.add_rect((0, 0, 0), (10, 10), lambertian((0.7, 0.7, 0.7)), rotation=up90)          # floor
+    s.add_rect((0, 2, -3), (10, 4), lambertian((0.6, 0.2, 0.2)))                          # wall
+    s.add_rect((-1.5, 2, -3), (2, 2), metal((0.9, 0.9, 0.9), 0.0))                        # mirror decal in the wall's plane
+    s.add_rect((1.5, 2, -3), (2, 2), standard((0.0, 0.0, 0.0), 0.0, 0.0, emission=(3.0, 2.5, 2.0)))   # light panel in the wall's plane
+    s.add_rect((1.5, 2, -3), (1, 1), lambertian((0.1, 0.6, 0.1)))                         # ... and a decal on the decal
+    s.add_rect((0, 0, 1), (3, 3), lambertian((0.2, 0.3, 0.8)), rotation=up90)             # rug in the floor's plane
+    s.add_rect((0.5, 0, 1.5), (1, 1), metal((0.8, 0.7, 0.3), 0.2), rotation=up90)         # tile on the rug
+    s.add_box((-2.5, 0.5, 0.0), (1, 1, 1), dielectric(1.5))                               # two glass blocks sharing a face
+    s.add_box((-1.5, 0.5, 0.0), (1, 1, 1), dielectric(1.3))
+    s.add_sphere((2.5, 0.5, 0.5), 0.5, lambertian((0.8, 0.5, 0.2)))
+    s.add_sphere((2.5, 0.5, 0.5), 0.5, metal((0.9, 0.9, 0.9), 0.1))                       # the same sphere twice
+    s.camera = {"position": [0.5, 2.5, 6.0], "target": [0.0, 1.0, -1.0], "up": [0.0, 1.0, 0.0], "vfov": 45.0, "aperture": 0.0}
+    return s
+
+
 def tiny_scene():
     """Five spheres, one of each material branch + a negative-radius hollow glass shell; for fast unit tests."""
     s = Scene("tiny")

@@ -156,3 +156,11 @@ def test_volume_hits_at_identical_distances(rt, oracle, gpu_context):
     gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 96, 8, 12, focus=5.0, diagnostics_stride=16)
     _compare(gpu, ref)
     assert gpu["color"][:, 3].sum() > 0
+
+
+def test_nearest_hit_ties_between_coplanar_entities(rt, oracle, gpu_context):
+    """Decals in a wall's plane, boxes sharing a face, one sphere twice: the nearest hit is shared by two or three entities and the
+    one that comes first in the reference tree's leaf order wins (JOBS/SampleBatchJob.cs:450-475, csrc/rtow_reforder.h)."""
+    scene = rt.scenes.coplanar_scene()
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 64, 8, 8, focus=6.0, diagnostics_stride=16)
+    _compare(gpu, ref)
