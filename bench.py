@@ -63,21 +63,21 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(rt, scene, width, height, depth, budget_s=15.0):
+def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0):
     """Time the CPU restatement of the reference Burst path (oracle, -O3 -ffast-math build) on this host's cores.
 
     Bounded sample of the SAME workload: the full 1920x1080 frame of the cover scene at a reduced spp, chosen from a
-    short calibration run so that the timed run costs about `budget_s` seconds.  Scheduling mirrors
+    short calibration run so that each of the two timed runs costs about `budget_s` seconds.  Scheduling mirrors
     Schedule(W*H, 1): one task per pixel, dynamic hand-out, all logical cores (UNITY/Raytracer.cs:730).
     """
     from oracle import binding as ob  # checker / baseline only - never on the product path
 
     osc = ob.OracleScene(scene.desc(), kind="fast")
     cores = usable_cores()
-    cal = rt.scenes.make_params(scene, width // 4, height // 4, spp=2, trace_depth=depth)
+    cal = rt.scenes.make_params(scene, width // 2, height // 2, spp=4, trace_depth=depth)
     t = time.perf_counter()
     osc.sample_batch(cal, nthreads=cores)
-    cal_rate = (width // 4) * (height // 4) * 2 / (time.perf_counter() - t)
+    cal_rate = (width // 2) * (height // 2) * 4 / (time.perf_counter() - t)
     spp = int(max(1, min(64, round(budget_s * cal_rate / (width * height)))))
     p = rt.scenes.make_params(scene, width, height, spp=spp, trace_depth=depth)
     best = None

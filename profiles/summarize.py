@@ -35,18 +35,32 @@ def main():
                                            "percentage": float(row["Percentage"])}
     trace = find("trace/**/*kernel_trace.csv")
     if trace:
+        # The first rtowSampleBatch on a (scene, view) launches the same kernel once more with 1 sample per pixel (the cost probe
+        # that orders the pixel chunks); rocprofv3's stats table averages it in.  Split the dispatches here.
+        durs = []
         for row in csv.DictReader(open(trace)):
             if KERNEL in row["Kernel_Name"]:
-                summary["dispatch"] = {k: row[k] for k in ("Kernel_Name", "Workgroup_Size_X", "Grid_Size_X", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
-                break
+                if "dispatch" not in summary:
+                    summary["dispatch"] = {k: row[k] for k in ("Kernel_Name", "Workgroup_Size_X", "Grid_Size_X", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
+                durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        if durs:
+            longest = max(durs)
+            batches = [d for d in durs if d > 0.2 * longest]
+            probes = [d for d in durs if d <= 0.2 * longest]
+            summary["kernel_trace_split"] = {"batch_launches": len(batches), "batch_avg_ns": sum(batches) / len(batches), "batch_min_ns": min(batches), "batch_max_ns": max(batches),
+                                             "probe_launches": len(probes), "probe_avg_ns": (sum(probes) / len(probes)) if probes else None,
+                                             "note": "batch_* = the timed 256-spp launches (compare with bench.py kernel_ms_per_step); probe = the 1-spp cost-probe launch of the same kernel"}
     for f in glob.glob(os.path.join(SRC, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
-        sums, launches = {}, set()
-        for row in csv.DictReader(open(f)):
-            if KERNEL in row["Kernel_Name"]:
+        # counters of the LAST dispatch of the kernel in each pass = the 256-spp batch (the probe launch precedes it)
+        rows = [row for row in csv.DictReader(open(f)) if KERNEL in row["Kernel_Name"]]
+        if not rows:
+            continue
+        last = max(int(row["Dispatch_Id"]) for row in rows)
+        sums = {}
+        for row in rows:
+            if int(row["Dispatch_Id"]) == last:
                 sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                launches.add(row["Dispatch_Id"])
-        for k, v in sums.items():
-            summary["counters_per_launch"][k] = v / max(len(launches), 1)
+        summary["counters_per_launch"].update(sums)
     c = summary["counters_per_launch"]
     d = {}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:

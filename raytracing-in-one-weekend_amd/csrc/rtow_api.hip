@@ -51,6 +51,7 @@ struct RtowContext_t {
     unsigned int* dWorkCounter = nullptr;
     // chunk cost map -> launch order (longest chunks first); valid for one (width, height, slice, scene) configuration
     unsigned int *dChunkCost = nullptr, *dChunkOrder = nullptr;
+    unsigned short* dPixelCost = nullptr;
     uint32_t chunkCapacity = 0;
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
@@ -163,31 +164,32 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     const bool wantOrder = a.chunkCount >= (uint32_t)(4 * ctx->cuCount) && !getenv("RTOW_NO_CHUNK_ORDER");   // tiny frames: not worth it
     if (wantOrder) {
         if (a.chunkCount > ctx->chunkCapacity) {
-            if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); }
+            if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
             ctx->dChunkCost = ctx->dChunkOrder = nullptr;
+            ctx->dPixelCost = nullptr;
             ctx->chunkCapacity = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkCost, 2 * a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkOrder, a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            HIP_TRY(ctx, hipMalloc(&ctx->dPixelCost, (size_t)a.chunkCount * 64 * sizeof(unsigned short)), RTOW_ERROR_MEMORY_ALLOCATION);
             ctx->chunkCapacity = a.chunkCount;
             ctx->orderValid = false;
         }
         if (ctx->orderW != a.width || ctx->orderH != a.height || ctx->orderOff != a.sliceOffset || ctx->orderDiv != a.sliceDivider) ctx->orderValid = false;
-        a.chunkCost = ctx->dChunkCost;
+        a.pixelCost = ctx->dPixelCost;
         if (!ctx->orderValid) {
-            // no cost map yet for this frame configuration: a 1-sample-per-pixel probe of the same kernel (stores nothing)
+            // no cost map yet for this frame configuration: a 1-sample-per-pixel probe of the same kernel (stores nothing else)
             SampleKernelArgs probe = a;
             probe.probeOnly = 1;
             probe.chunkOrder = nullptr;
             probe.cancelFlag = nullptr;
             HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, 2 * a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dPixelCost, 0, (size_t)a.chunkCount * 64 * sizeof(unsigned short), stream), RTOW_ERROR_LAUNCH_FAILURE);   // the last chunk's tail
             HIP_TRY(ctx, launchSampleBatch(probe, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
-            HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 0, stream), RTOW_ERROR_LAUNCH_FAILURE);
+            HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 0, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->orderValid = true;
             ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider;
         }
         a.chunkOrder = ctx->dChunkOrder;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkCost, 0, 2 * a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
     }
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
@@ -195,7 +197,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
     // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
-    if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
 #ifdef RTOW_STATS
     {
         unsigned long long h[16];
@@ -332,7 +334,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->dScene) (void)hipFree(ctx->dScene);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
-    if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); }
+    if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }

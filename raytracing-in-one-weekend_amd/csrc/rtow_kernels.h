@@ -45,9 +45,9 @@ struct SampleKernelArgs {
     // work distribution
     unsigned int* workCounter;            // zeroed before the launch; counts 64-pixel ticket chunks
     const unsigned int* chunkOrder;       // chunk launch order (most expensive first), null = natural order
-    unsigned int* chunkCost;              // [2 * chunkCount]: per-chunk ray count, then per-chunk max pixel ray count, of THIS launch (zeroed before it); null = not recorded
-    uint32_t chunkCount;                  // ceil(totalWork / 64)
-    int32_t probeOnly;                    // 1: cost probe - one sample per pixel, nothing stored but chunkCost
+    unsigned short* pixelCost;            // [64 * chunkCount], ticket order: ray count of every pixel of THIS launch (input of the next launch's order); null = not recorded
+    uint32_t chunkCount;
+    int32_t probeOnly;                    // 1: cost probe - one sample per pixel, nothing stored but pixelCost
     const volatile uint32_t* cancelFlag;  // host-pinned, may be null
     uint32_t totalWork;                   // owned pixels = ownedRows * width
     int32_t width, height;
@@ -79,7 +79,7 @@ struct KernelInfo {
 // launchers (defined in rtow_kernels.hip)
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
-hipError_t launchBuildChunkOrder(const unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream);
+hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream);
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream);  // inverse transforms of general entities, on device
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
                          float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream);

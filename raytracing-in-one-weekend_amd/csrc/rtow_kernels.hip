@@ -503,10 +503,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             if (st == ST_REGEN) {
                 STAT_LANES(2);
                 while (smp >= nsamp) {
-                    if (pix >= 0 && A.chunkCost) {
-                        // cost map for the next launch's order: ray count of the chunk (sum) and of its most expensive pixel (max)
-                        atomicAdd(&A.chunkCost[tick >> 6], (unsigned)rayCount);
-                        atomicMax(&A.chunkCost[A.chunkCount + (tick >> 6)], (unsigned)rayCount);
+                    if (pix >= 0 && A.pixelCost) {
+                        // cost map for the next launch's chunk order: this pixel's ray count, in ticket order (a plain 2-byte store that
+                        // merges in L2 with its chunk's other 63; per-chunk atomics cost a memory-side transaction each)
+                        const unsigned rc = (unsigned)rayCount;
+                        A.pixelCost[tick] = (unsigned short)(rc < 65535u ? rc : 65535u);
                     }
                     if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
                     if (pix >= 0) {
@@ -1105,6 +1106,20 @@ __device__ __forceinline__ float chunk_key(const unsigned* cost, unsigned n, uns
 {
     return byMax ? (float)cost[n + i] * 64.0f + (float)cost[i] * (1.0f / 64.0f) : (float)cost[i];
 }
+// pixelCost[64 * chunk .. +63] -> cost[chunk] = sum, cost[n + chunk] = max; one wave per chunk
+__global__ void __launch_bounds__(256) reduce_chunk_cost_kernel(const unsigned short* __restrict__ pixelCost, unsigned n, unsigned* __restrict__ cost)
+{
+    const unsigned chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (chunk >= n) return;
+    unsigned v = pixelCost[(size_t)chunk * 64u + (threadIdx.x & 63u)];
+    unsigned sum = v, mx = v;
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        const unsigned o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63u) == 0) { cost[chunk] = sum; cost[n + chunk] = mx; }
+}
 __global__ void __launch_bounds__(1024) build_chunk_order_kernel(const unsigned* __restrict__ cost, unsigned n, unsigned* __restrict__ order, int byMax)
 {
     __shared__ unsigned hist[kOrderBuckets];
@@ -1331,8 +1346,9 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     return allLds ? launchByKind<true>(args, numBlocks, ldsBytes, stream) : launchByKind<false>(args, numBlocks, ldsBytes, stream);
 }
 
-hipError_t launchBuildChunkOrder(const unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream)
+hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream)
 {
+    hipLaunchKernelGGL(reduce_chunk_cost_kernel, dim3((chunkCount + 3u) / 4u), dim3(256), 0, stream, pixelCost, chunkCount, cost);
     hipLaunchKernelGGL(build_chunk_order_kernel, dim3(1), dim3(1024), 0, stream, cost, chunkCount, order, byMax);
     return hipGetLastError();
 }
