@@ -56,6 +56,13 @@ struct RtowContext_t {
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
     volatile uint32_t* hCancel = nullptr; // pinned, device-visible
+    // camera-ray candidate lists (primary_candidates_kernel): valid for one (scene upload, view, size, slice, jitter) configuration
+    uint2* dPixCand = nullptr;
+    size_t pixCandCapacity = 0;
+    bool pixCandValid = false;
+    uint64_t sceneSerial = 0, pixCandScene = 0;
+    RtowView pixCandView{};
+    int pixCandW = 0, pixCandH = 0, pixCandOff = 0, pixCandDiv = 0, pixCandJitter = 0;
 
     // grow-only staging for rtowSampleBatch (host buffers) - like CudaBuffer.EnsureCapacity (OptixApi.cs:240-251)
     float *dColor = nullptr, *dNormal = nullptr, *dAlbedo = nullptr, *dScw = nullptr;
@@ -158,6 +165,31 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
     if (blocks < 1) blocks = 1;
+
+    // ---- camera-ray candidate lists: one conservative beam walk per pixel, reused by all its samples (and by later batches of the same view) ----
+    if (!getenv("RTOW_NO_PRIMARY_LISTS")) {
+        const size_t pixels = (size_t)a.width * (size_t)a.height;
+        if (pixels > ctx->pixCandCapacity) {
+            if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
+            ctx->dPixCand = nullptr;
+            ctx->pixCandCapacity = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dPixCand, pixels * sizeof(uint2)), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->pixCandCapacity = pixels;
+            ctx->pixCandValid = false;
+        }
+        const bool same = ctx->pixCandValid && ctx->pixCandScene == ctx->sceneSerial && memcmp(&ctx->pixCandView, &a.view, sizeof(RtowView)) == 0 &&
+                          ctx->pixCandW == a.width && ctx->pixCandH == a.height && ctx->pixCandOff == a.sliceOffset && ctx->pixCandDiv == a.sliceDivider &&
+                          ctx->pixCandJitter == (a.subPixelJitter ? 1 : 0);
+        if (!same) {
+            HIP_TRY(ctx, launchPrimaryCandidates(a, ctx->dPixCand, stream), RTOW_ERROR_LAUNCH_FAILURE);
+            ctx->pixCandValid = true;
+            ctx->pixCandScene = ctx->sceneSerial;
+            ctx->pixCandView = a.view;
+            ctx->pixCandW = a.width; ctx->pixCandH = a.height; ctx->pixCandOff = a.sliceOffset; ctx->pixCandDiv = a.sliceDivider;
+            ctx->pixCandJitter = a.subPixelJitter ? 1 : 0;
+        }
+        a.pixelCandidates = ctx->dPixCand;
+    }
 
     // ---- chunk order: most expensive 64-pixel chunks first, from the ray counts of the previous launch (or of a probe) ----
     a.chunkCount = (a.totalWork + 63u) / 64u;
@@ -335,6 +367,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dScene) (void)hipFree(ctx->dScene);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
+    if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
@@ -383,6 +416,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         ctx->ldsSceneBytes = nodes * (uint32_t)sizeof(GpuNode);
     }
     ctx->haveScene = true;
+    ctx->sceneSerial++;
     ctx->orderValid = false;
     logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
          ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes);

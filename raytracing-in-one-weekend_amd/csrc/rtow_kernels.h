@@ -20,6 +20,7 @@ constexpr int kLdsBytesMax = 160 * 1024;
 #endif
 constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting their exact test (flushed when full)
 constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane]
+constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: first slot empty, second not - "no list, walk the tree"
 constexpr int kQueueBytes = 256;   // per-wave {next, end} pixel-ticket chunk (16 waves x 8 B, padded)
 
 // Everything the sample kernel needs, passed by value (kernarg segment).
@@ -47,6 +48,7 @@ struct SampleKernelArgs {
     const unsigned int* chunkOrder;       // chunk launch order (most expensive first), null = natural order
     unsigned short* pixelCost;            // [64 * chunkCount], ticket order: ray count of every pixel of THIS launch (input of the next launch's order); null = not recorded
     uint32_t chunkCount;
+    const uint2* pixelCandidates;         // [width * height]: camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray
     int32_t probeOnly;                    // 1: cost probe - one sample per pixel, nothing stored but pixelCost
     const volatile uint32_t* cancelFlag;  // host-pinned, may be null
     uint32_t totalWork;                   // owned pixels = ownedRows * width
@@ -79,6 +81,7 @@ struct KernelInfo {
 // launchers (defined in rtow_kernels.hip)
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
+hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream);
 hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream);
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream);  // inverse transforms of general entities, on device
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,

@@ -486,6 +486,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         st = prim < 0 ? ST_SKY : ST_HIT;
     };
 
+    uint2 pcand = make_uint2(kNoPrimaryList, 0u);   // this pixel's camera-ray candidate list (4 x 16 bit), or kNoPrimaryList in .x
     int force = -1;
     STAT_DECL;
 #ifdef RTOW_STATS
@@ -597,6 +598,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     scw0 = w;
                     smp = 0;
                     rayCount = 0; boundsHits = 0; candidates = 0;
+                    // the pixel's camera-ray candidates (primary_candidates_kernel): up to 4 primitive indices, 0xFFFF = none
+                    pcand = A.pixelCandidates ? A.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u);
                 }
                 if (st != ST_DEAD) {
                     // ---- camera ray (:134-135, RT/View.cs:38-48) ----
@@ -633,6 +636,17 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     curVol = -1;
                     pendRE = 0;
                     startRay();
+                    if (pcand.x != kNoPrimaryList) {
+                        // Every camera ray of this pixel can only hit primitives of the pixel's cached list (a conservative beam walk done
+                        // once per pixel and launch): skip the box walk and hand the list to the exact tests.
+                        cand[0 * kBlockThreads] = (unsigned short)(pcand.x & 0xffffu);
+                        cand[1 * kBlockThreads] = (unsigned short)(pcand.x >> 16);
+                        cand[2 * kBlockThreads] = (unsigned short)(pcand.y & 0xffffu);
+                        cand[3 * kBlockThreads] = (unsigned short)(pcand.y >> 16);
+                        nc = ((pcand.x & 0xffffu) != 0xffffu) + ((pcand.x >> 16) != 0xffffu) + ((pcand.y & 0xffffu) != 0xffffu) + ((pcand.y >> 16) != 0xffffu);
+                        cur = -1;
+                        if (nc == 0) classify(); else st = ST_TEST;
+                    }
                 }
             }
         }
@@ -1106,6 +1120,90 @@ __device__ __forceinline__ float chunk_key(const unsigned* cost, unsigned n, uns
 {
     return byMax ? (float)cost[n + i] * 64.0f + (float)cost[i] * (1.0f / 64.0f) : (float)cost[i];
 }
+// ------------------------------------------------------------------------------------------------------------
+// Camera-ray candidate lists.  All camera rays of one pixel (every sample: jitter inside the pixel, origin inside the
+// lens disk) stay inside a thin beam around the pixel's centre ray, and 40 % of all rays are camera rays: one
+// CONSERVATIVE walk of the beam per pixel finds every primitive any of them can hit, and the sample kernel then skips the
+// box walk for depth-0 rays.  One thread per owned pixel, neighbouring pixels walk the same nodes (fully coherent).
+//
+// Bound.  A camera ray is p(s) = o + off + s * u with |off| <= R (lens), u = normalize(G - off), G = LLC + u*H + v*V inside the
+// pixel.  With dc = normalize(G_centre):  |u - dc| <= |normalize(G) - dc| + |normalize(G - off) - normalize(G)| <= chordPix + R / (|G| - R),
+// so the point q(s) = o + s * dc of the centre ray is within  R + s * (chordPix + chordLens)  of p(s).  A hit inside box B happens
+// at s <= far(B) + R (far = distance from o to B's farthest corner), hence the centre ray passes through B grown by
+// delta(B) = R + (far + R) * (chordPix + chordLens) on every side - tested with a slab test, tMin = 0.  chordPix is exact at the
+// pixel's corners (a cone cut by the image plane is convex).  Lists longer than 4 fall back to the normal walk (kNoPrimaryList).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) primary_candidates_kernel(SampleKernelArgs A, uint2* __restrict__ out)
+{
+    const unsigned ticket = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ticket >= A.totalWork) return;
+    const int ownedRow = (int)(ticket / (unsigned)A.width);
+    const int cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
+    const int cy = A.sliceOffset + ownedRow * A.sliceDivider;
+    const int pix = cy * A.width + cx;
+    const SceneLayout& L = A.layout;
+
+    const V3 o = v3(A.view.origin);
+    const V3 llc = v3(A.view.lowerLeftCorner), hv = v3(A.view.horizontal), vv = v3(A.view.vertical);
+    auto towards = [&](float u, float v) { return v3(llc.x + u * hv.x + v * vv.x, llc.y + u * hv.y + v * vv.y, llc.z + u * hv.z + v * vv.z); };
+    const float u0 = A.subPixelJitter ? (float)cx / A.sizeX : ((float)cx + 0.5f) / A.sizeX, u1 = A.subPixelJitter ? ((float)cx + 1.0f) / A.sizeX : u0;
+    const float v0 = A.subPixelJitter ? (float)cy / A.sizeY : ((float)cy + 0.5f) / A.sizeY, v1 = A.subPixelJitter ? ((float)cy + 1.0f) / A.sizeY : v0;
+    const V3 gc = towards(0.5f * (u0 + u1), 0.5f * (v0 + v1));
+    const V3 dc = normalize(gc);
+    float chord = 0, gmin = __builtin_sqrtf(dot(gc, gc));
+    for (int k = 0; k < 4; k++) {
+        const V3 g = towards((k & 1) ? u1 : u0, (k & 2) ? v1 : v0);
+        const V3 d = sub(normalize(g), dc);
+        chord = fmaxf(chord, __builtin_sqrtf(dot(d, d)));
+        gmin = fminf(gmin, __builtin_sqrtf(dot(g, g)));
+    }
+    const V3 right = v3(A.view.right), up = v3(A.view.up);
+    const float R = A.view.lensRadius == 0 ? 0.0f : __builtin_fabsf(A.view.lensRadius) * (__builtin_sqrtf(dot(right, right)) + __builtin_sqrtf(dot(up, up))) * 1.001f;
+    bool ok = gmin > 4.0f * R && chord == chord && gmin == gmin;               // degenerate views: walk normally
+    const float chordLens = R > 0 ? R / (gmin - R) : 0.0f;
+    const float spread = (chord + chordLens) * 1.02f + 2e-6f;                   // + slack for the fp32 evaluation of the directions
+    auto clampInv = [](float d) { const float r = 1.0f / d; return fminf(fmaxf(r, -1e30f), 1e30f); };   // no inf: 0 * inf would be NaN
+    const V3 inv = v3(clampInv(dc.x), clampInv(dc.y), clampInv(dc.z));
+
+    auto beamHitsBox = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
+        const float fx = fmaxf(__builtin_fabsf(lx - o.x), __builtin_fabsf(hx - o.x));
+        const float fy = fmaxf(__builtin_fabsf(ly - o.y), __builtin_fabsf(hy - o.y));
+        const float fz = fmaxf(__builtin_fabsf(lz - o.z), __builtin_fabsf(hz - o.z));
+        const float far = __builtin_sqrtf(fx * fx + fy * fy + fz * fz);
+        const float delta = (R + (far + R) * spread) * 1.01f + 1e-5f * (1.0f + far);
+        const float t0x = (lx - delta - o.x) * inv.x, t1x = (hx + delta - o.x) * inv.x;
+        const float t0y = (ly - delta - o.y) * inv.y, t1y = (hy + delta - o.y) * inv.y;
+        const float t0z = (lz - delta - o.z) * inv.z, t1z = (hz + delta - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+        const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+        return !(tn > tf);                                                      // NaN (cannot happen with finite inv) would count as a hit
+    };
+
+    unsigned list[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+    int count = 0;
+    int stack[RTOW_STACK_CAPACITY + 1];
+    int sp = 0, cur = 0;
+    const GpuNode* nodes = reinterpret_cast<const GpuNode*>(A.sceneBlob + L.nodeOffset);
+    while (ok && cur >= 0) {
+        const GpuNode n = nodes[cur];
+        cur = -1;
+        for (int side = 0; side < 2; side++) {
+            if (side == 1 && L.sphereCount < 2) break;                          // single-entity scene: the second child is a placeholder
+            const int child = side ? n.child1 : n.child0;
+            if (!beamHitsBox(n.lox[side], n.loy[side], n.loz[side], n.hix[side], n.hiy[side], n.hiz[side])) continue;
+            if (child < 0) {
+                if (count == 4) { ok = false; break; }
+                for (int k = 0; k < 4; k++) if (k == count) list[k] = (unsigned)~child & 0xffffu;
+                count++;
+            } else if (cur < 0) cur = child;
+            else if (sp <= RTOW_STACK_CAPACITY) stack[sp++] = child;
+            else ok = false;
+        }
+        if (cur < 0 && sp > 0) cur = stack[--sp];
+    }
+    out[pix] = ok ? make_uint2(list[0] | (list[1] << 16), list[2] | (list[3] << 16)) : make_uint2(kNoPrimaryList, 0u);
+}
+
 // pixelCost[64 * chunk .. +63] -> cost[chunk] = sum, cost[n + chunk] = max; one wave per chunk
 __global__ void __launch_bounds__(256) reduce_chunk_cost_kernel(const unsigned short* __restrict__ pixelCost, unsigned n, unsigned* __restrict__ cost)
 {
@@ -1344,6 +1442,12 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
     return allLds ? launchByKind<true>(args, numBlocks, ldsBytes, stream) : launchByKind<false>(args, numBlocks, ldsBytes, stream);
+}
+
+hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(primary_candidates_kernel, dim3((args.totalWork + 255u) / 256u), dim3(256), 0, stream, args, out);
+    return hipGetLastError();
 }
 
 hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream)

@@ -260,3 +260,42 @@ def test_adaptive_sample_counts_match_oracle(rt, oracle, gpu_context):
         assert np.array_equal(g["diag"][:, 0], r["diag"][:, 0])
         assert np.array_equal(g["diag"][:, 3].view(np.uint32), r["diag"][:, 3].view(np.uint32))   # FULL_DIAGNOSTICS SampleCountWeight
     assert len(np.unique(r2["diag"][:, 0])) > 3
+
+
+def test_camera_ray_candidate_lists_are_conservative(rt, oracle, gpu_context, monkeypatch):
+    """Depth-0 rays take their candidates from a per-pixel list built by one conservative beam walk (primary_candidates_kernel) instead of
+    walking the tree.  The frame must not change by a bit when the lists are switched off, and must equal the oracle, for the cases that
+    stretch the beam: huge pixels (tiny frames), a wide lens, no jitter, interlaced slices, camera inside the geometry, a tree outside LDS."""
+    ctx = gpu_context
+    cases = []
+    cover = rt.scenes.cover_scene()
+    cases.append((cover, dict(width=24, height=14, spp=16, trace_depth=4)))
+    cases.append((cover, dict(width=97, height=31, spp=8, trace_depth=3, jitter=False)))
+    cases.append((cover, dict(width=64, height=36, spp=8, trace_depth=4, slice_offset=1, slice_divider=3)))
+    wide = rt.scenes.moving_scene()
+    wide.camera = dict(wide.camera, aperture=1.5)                       # lens radius 0.75: beams as wide as the spheres
+    cases.append((wide, dict(width=40, height=24, spp=16, trace_depth=3)))
+    wide2 = rt.scenes.cover_scene()
+    wide2.camera = dict(wide2.camera, aperture=0.3, vfov=70.0)
+    cases.append((wide2, dict(width=33, height=19, spp=16, trace_depth=3)))
+    inside = rt.scenes.tiny_scene()
+    inside.camera = {"position": [-1.0, 0.05, -1.0], "target": [1.0, 0.2, -1.0], "up": [0.0, 1.0, 0.0], "vfov": 90.0, "aperture": 0.2}   # inside the glass ball
+    cases.append((inside, dict(width=32, height=32, spp=8, trace_depth=6)))
+    cases.append((rt.scenes.mixed_scene(), dict(width=48, height=32, spp=8, trace_depth=4)))
+    cases.append((rt.scenes.stress_scene(count=3000, max_tentatives=12000), dict(width=60, height=34, spp=4, trace_depth=3)))
+    for scene, kw in cases:
+        desc = scene.desc()
+        ctx.upload_scene(desc)
+        p = rt.scenes.make_params(scene, **kw)
+        monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS", raising=False)
+        with_lists = rt.sample_batch_host(ctx, p)
+        monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
+        without = rt.sample_batch_host(ctx, p)
+        monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS", raising=False)
+        osc = oracle.OracleScene(desc)
+        ref = osc.sample_batch(p)
+        osc.close()
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(with_lists[k].view(np.uint32), without[k].view(np.uint32)), (scene.name, kw, k)
+            assert np.array_equal(with_lists[k].view(np.uint32), ref[k].view(np.uint32)), (scene.name, kw, k)
+        assert np.array_equal(with_lists["diag"][:, 0], ref["diag"][:, 0])
