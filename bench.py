@@ -11,11 +11,12 @@ ping-pong buffers with a fresh seed, exactly like the reference's successive bat
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, no data-path collective inside a batch, ONE RCCL gather per batch.  The total work is fixed
+N > 1: one process per GPU, no data-path collective inside a batch; the batch's results are combined over RCCL afterwards.  The total work is fixed
 (same frame, same spp), so scaling is "strong".  Two partitions (raytracing-in-one-weekend_amd/multigpu.py):
   --partition batches (default)  every rank renders the whole frame with spp/N samples and its own seed from zeroed
-                                 accumulators; rank 0 gathers the partial accumulators and folds them in rank order
-                                 (the reference's batch accumulation, Raytracer.cs:656-661,798-802, run concurrently);
+                                 accumulators; the partials are exchanged (all-to-all), every rank folds one slice of the frame in
+                                 rank order, and the frame is gathered on rank 0 (the reference's batch accumulation,
+                                 Raytracer.cs:656-661,798-802, run concurrently; bit-identical to folding on one rank);
   --partition tiles              the frame is row-interleaved with the reference's slice contract (SliceOffset = rank,
                                  SliceDivider = N, JOBS/SampleBatchJob.cs:69-70) and the colour rows are gathered;
                                  bit-identical to the single-GPU frame but limited by lane-per-pixel granularity
@@ -128,6 +129,11 @@ def main():
     abi = rt.abi
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # RTOW_BENCH_DEBUG_SHARED_GPU=1: development aid for a 1-GPU box - all ranks share cuda:0 and talk over gloo, to exercise the N > 1
+    # host path end to end.  Never a measurement: the line it prints says so in `config.partition`.
+    shared_gpu = os.environ.get("RTOW_BENCH_DEBUG_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -135,7 +141,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
     n = W * H
@@ -150,12 +159,16 @@ def main():
     batches = world > 1 and args.partition == "batches"
 
     def flat():
-        return torch.zeros(mg.ACCUM_FLOATS * n, device=dev)
+        # batches: padded so that the flat accumulator splits into `world` equal slices of whole 11-float units (multigpu.slice_floats)
+        return torch.zeros(mg.padded_floats(n, world) if batches else mg.ACCUM_FLOATS * n, device=dev)
 
     ping_flat, pong_flat = flat(), flat()
     ping, pong = mg.accum_views(ping_flat, n), mg.accum_views(pong_flat, n)
     zero_flat = flat() if batches else None           # never written: the input of every rank's sub-batch
-    gather_bufs = [flat() for _ in range(world)] if (batches and rank == 0) else None
+    # batches: the running accumulation is distributed - this rank's slice of it, the all-to-all receive buffer, and (rank 0) the gathered frame
+    acc_slice = torch.zeros(mg.slice_floats(n, world), device=dev) if batches else None
+    exchange = flat() if batches else None
+    frame_flat = ping_flat if batches else None
     diag = torch.zeros(n, device=dev)
     # parameter block built once (View ctor + auto-focus probe are host work outside the path); only Seed changes per step
     if batches:
@@ -173,10 +186,12 @@ def main():
     stream = torch.cuda.current_stream(dev)
     kernel_ms = []
 
-    def add_fn(dst_views, src_views):
-        d = abi.AccumBuffers(*[t.data_ptr() for t in dst_views])
-        s_ = abi.AccumBuffers(*[t.data_ptr() for t in src_views])
-        rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, n, C.byref(d), C.byref(s_), stream.cuda_stream), "rtowAddAccumDevice")
+    def add_flat(dst, src):
+        # dst += src over a flat slice of 11 * k floats, as the 4-buffer device add over k "pixels" (element for element the same adds)
+        k = dst.numel() // mg.ACCUM_FLOATS
+        d = abi.AccumBuffers(*[dst.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
+        s_ = abi.AccumBuffers(*[src.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
+        rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, k, C.byref(d), C.byref(s_), stream.cuda_stream), "rtowAddAccumDevice")
 
     def launch(p, src, dst):
         bi = abi.AccumBuffers(*[t.data_ptr() for t in src])
@@ -187,14 +202,14 @@ def main():
     def step(i, record=False):
         nonlocal ping, pong, ping_flat, pong_flat
         if batches:
-            # every rank: whole frame, its share of the samples, its own seed, zeroed inputs; one gather; ordered fold on rank 0
+            # every rank: whole frame, its share of the samples, its own seed, zeroed inputs; all-to-all + ordered fold of the slices; gather of the frame
             p = params_for(mg.batch_seed(i + 1, rank, world))
 
             def render_full():
                 launch(p, mg.accum_views(zero_flat, n), pong)
                 return pong_flat
 
-            mg.render_batches(render_full, ping_flat, n, rank, world, add_fn, gather_list=gather_bufs)   # ping = running accumulation (rank 0)
+            mg.render_batches(render_full, acc_slice, n, rank, world, add_flat, exchange=exchange, frame=frame_flat)   # ping = this batch's frame (rank 0)
         else:
             p = params_for(i + 1)
             launch(p, ping, pong)
@@ -258,8 +273,8 @@ def main():
             "config": {
                 "workload": "cover scene (486 spheres, generated per Final Scene (Book 1).asset, seed 700), %dx%d, %d spp per batch, "
                             "%d bounces, white noise, jitter on, reference RNG stream (lane per pixel)" % (W, H, spp, depth),
-                "partition": ("single GPU" if world == 1 else
-                              "batches: every rank renders the whole frame with spp/%d samples and its own seed, one RCCL gather of the partial accumulators, ordered fold on rank 0" % world
+                "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
+                              "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
                               if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch" % world),
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds),
             },

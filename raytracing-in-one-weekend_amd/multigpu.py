@@ -1,8 +1,9 @@
-"""Multi-GPU host logic: one process per GPU, ONE collective per sample batch, two ways to split a batch.
+"""Multi-GPU host logic: one process per GPU, no collective inside a batch, two ways to split a batch.
 
 "tiles"   (`render_partitioned`): the frame is row-interleaved across ranks; bit-identical to the single-GPU frame.
 "batches" (`render_batches`): every rank renders the WHOLE frame with spp / world samples and its own Seed, from zeroed
-          accumulators; rank 0 gathers the partial accumulators and folds them in rank order.  This is the reference's own
+          accumulators; the partial accumulators are folded in rank order - slice by slice on all ranks (one all-to-all) - and
+          the frame is gathered on rank 0.  This is the reference's own
           notion of accumulation - successive batches with fresh seeds summed into the same buffers
           (Assets/Scripts/Unity/Raytracer.cs:656-661,798-802) - run concurrently instead of back to back.
 
@@ -99,23 +100,48 @@ def batch_seed(seed, rank, world):
     return (seed - 1) * world + rank + 1
 
 
-def fold_partials(acc_flat, partials, n, add_fn):
-    """acc += partial_0 + partial_1 + ... in RANK ORDER (deterministic, so the result can be reproduced bit for bit)."""
+def slice_floats(n, world):
+    """Length of one rank's slice of the flat accumulator: 11 floats x ceil(n / world) pixels' worth, so that a slice can be
+    added with the 4-buffer device add (rtowAddAccumDevice) however it straddles the colour | normal | albedo | weight sections."""
+    return ACCUM_FLOATS * ((n + world - 1) // world)
+
+
+def padded_floats(n, world):
+    """Flat accumulator length that splits into `world` equal slices (>= 11 * n; the tail is padding)."""
+    return world * slice_floats(n, world)
+
+
+def fold_partials(acc_flat, partials, add_flat):
+    """acc += partial_0, acc += partial_1, ... in RANK ORDER (deterministic, so the result can be reproduced bit for bit)."""
     for part in partials:
-        add_fn(accum_views(acc_flat, n), accum_views(part, n))
+        add_flat(acc_flat, part)
     return acc_flat
 
 
-def render_batches(render_full, acc_flat, n, rank, world, add_fn, group=None, dst=0, gather_list=None):
-    """One sample batch, batch-parallel.  `render_full()` returns this rank's partial accumulators (from ZERO inputs, its own
-    seed and sample share) as one flat [11 * n] tensor; the partials are gathered on `dst` with ONE collective and folded
-    into `acc_flat` there (ignored on the other ranks)."""
+def render_batches(render_full, acc_slice, n, rank, world, add_flat, group=None, dst=0, exchange=None, frame=None):
+    """One sample batch, batch-parallel, with the fold spread over the ranks.
+
+    `render_full()` returns this rank's partial accumulators (from ZERO inputs, its own seed and sample share) as one flat
+    [padded_floats(n, world)] tensor.  The running accumulation is kept DISTRIBUTED: rank r owns floats [r*m, (r+1)*m) of it
+    (`acc_slice`, m = slice_floats).  Per batch:
+      1. all_to_all: rank r receives slice r of every rank's partial   (each rank sends and receives (world-1)/world of 44 B/pixel,
+         spread over all its xGMI links - instead of rank 0 swallowing world-1 whole partials over its own links);
+      2. acc_slice += partial_0[r], += partial_1[r], ...  in rank order - element for element the same float adds, in the same
+         order, as folding whole partials on one rank, so the frame is bit-identical to that;
+      3. gather of the accumulated slices on `dst`: the frame of this batch (1/world of the frame per peer).
+    Returns the flat frame [padded_floats] on `dst`, None elsewhere.  `exchange` / `frame` are optional preallocated buffers."""
     part = render_full()
+    m = slice_floats(n, world)
     if world == 1:
-        return fold_partials(acc_flat, [part], n, add_fn)
-    if rank == dst and gather_list is None:
-        gather_list = [torch.empty_like(part) for _ in range(world)]   # callers on a hot path pass a preallocated list
-    dist.gather(part, gather_list if rank == dst else None, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return fold_partials(acc_flat, gather_list, n, add_fn)
+        return fold_partials(acc_slice, [part], add_flat)
+    if exchange is None:
+        exchange = torch.empty_like(part)
+    dist.all_to_all_single(exchange, part, group=group)
+    fold_partials(acc_slice, [exchange[j * m:(j + 1) * m] for j in range(world)], add_flat)
+    gather_list = None
+    if rank == dst:
+        if frame is None:
+            frame = torch.empty_like(part)
+        gather_list = list(frame.view(world, m).unbind(0))
+    dist.gather(acc_slice, gather_list, dst=dst, group=group)
+    return frame if rank == dst else None

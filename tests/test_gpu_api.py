@@ -241,6 +241,28 @@ def test_add_accum_device(rt, gpu_context):
     assert rt.lib.load().rtowAddAccumDevice(ctx.handle, 0, C.byref(bd), C.byref(bs), None) == rt.abi.RTOW_ERROR_INVALID_VALUE
 
 
+def test_add_accum_device_on_a_flat_slice(rt, gpu_context):
+    """The distributed fold (multigpu.render_batches) adds SLICES of the flat [colour | normal | albedo | weight] accumulator that
+    straddle the section boundaries: a slice of 11 * k floats goes through the 4-buffer add as k "pixels" at offsets 0, 4k, 7k, 10k."""
+    import importlib
+    mg = importlib.import_module("raytracing-in-one-weekend_amd.multigpu")
+    ctx = gpu_context
+    rng = np.random.default_rng(9)
+    n, world = 1000, 3
+    m, padded = mg.slice_floats(n, world), mg.padded_floats(n, world)
+    assert m == 11 * 334 and padded == 3 * m
+    acc = rng.normal(size=padded).astype(np.float32)
+    part = rng.normal(size=padded).astype(np.float32)
+    dacc, dpart = _dev(rt, ctx, acc), _dev(rt, ctx, part)
+    k = m // mg.ACCUM_FLOATS
+    for r in range(world):
+        bd = rt.abi.AccumBuffers(*[dacc.ptr + 4 * (r * m + o * k) for o in (0, 4, 7, 10)])
+        bs = rt.abi.AccumBuffers(*[dpart.ptr + 4 * (r * m + o * k) for o in (0, 4, 7, 10)])
+        assert rt.lib.load().rtowAddAccumDevice(ctx.handle, k, C.byref(bd), C.byref(bs), None) == 0
+    ctx.synchronize()
+    assert np.array_equal(dacc.download(np.float32, (padded,)), acc + part)
+
+
 def test_adaptive_sample_counts_match_oracle(rt, oracle, gpu_context):
     """SampleCountRange.x != .y with weight extrema (JOBS/SampleBatchJob.cs:118-126), first batch (0/0 -> max) and a second one."""
     ctx = gpu_context
