@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 1
+#define RTOW_API_VERSION 2
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -90,7 +90,7 @@ typedef enum RtowTextureType {     /* RT/Texture.cs:13-21 */
 typedef enum RtowSkyType {         /* RT/Environment.cs:5-10 */
     RTOW_SKY_NONE = 0,
     RTOW_SKY_GRADIENT = 1,
-    RTOW_SKY_CUBEMAP = 2              /* not built yet -> RTOW_ERROR_UNSUPPORTED */
+    RTOW_SKY_CUBEMAP = 2              /* Cubemap.Sample(ray.Direction) on the faces given to rtowUploadSkyCubemap */
 } RtowSkyType;
 
 typedef enum RtowNoiseColor {      /* RT/RandomSource.cs:8-13 */
@@ -177,7 +177,20 @@ typedef struct RtowView {
     float lensRadius;
 } RtowView;
 
-/* RT/Environment.cs:12-17 without the cubemap handle. */
+/* RT/Texture.cs:141-211 `Cubemap`: the six faces of the sky cube as the host's own pixel data.  The reference keeps a pointer to
+ * the face +X of a Unity cubemap and reaches the others by `faceStride`, i.e. it relies on the faces being contiguous in the
+ * order +X, -X, +Y, -Y, +Z, -Z (Unity's CubemapFace order), each face `faceHeight` rows of `faceWidth` pixels, row 0 first.
+ * channelType follows the reference's ChannelType: its ctor only accepts R16G16B16A16_SFloat (SignedHalf, pixelStride 8), its
+ * Sample() also decodes UnsignedByte (value / 255). */
+typedef enum RtowCubemapChannelType { RTOW_CUBEMAP_UNSIGNED_BYTE = 0, RTOW_CUBEMAP_SIGNED_HALF = 1 } RtowCubemapChannelType;
+typedef struct RtowCubemapDesc {
+    int32_t faceWidth, faceHeight;
+    int32_t channelType;            /* RtowCubemapChannelType */
+    int32_t pixelStride;            /* bytes from one pixel to the next (8 for RGBA half, 3 or 4 for bytes); channels 0..2 = r, g, b */
+    const void* faces;              /* 6 * faceWidth * faceHeight * pixelStride bytes, host memory, copied by the call */
+} RtowCubemapDesc;
+
+/* RT/Environment.cs:12-17; the cubemap handle of SkyType.CubeMap is the one uploaded with rtowUploadSkyCubemap. */
 typedef struct RtowEnvironment {
     int32_t skyType;                /* RtowSkyType */
     RtowFloat3 skyBottomColor;
@@ -239,6 +252,12 @@ RTOW_API int rtowDestroyContext(RtowContext context);
  * Copies the description, builds the native BVH, uploads the flat GPU layout. Called only when the world changes. */
 RTOW_API int rtowUploadScene(RtowContext context, const RtowSceneDesc* scene);
 RTOW_API int rtowGetSceneInfo(RtowContext context, RtowSceneInfo* outInfo);
+
+/* replaces: `new Cubemap(skyCubemap)` when the environment is built (UNITY/Raytracer.cs, RT/Texture.cs:150-169): copies the six
+ * faces to the device; sample batches whose environment.skyType is RTOW_SKY_CUBEMAP then evaluate Cubemap.Sample(ray.Direction)
+ * (RT/Texture.cs:171-210, JOBS/SampleBatchJob.cs:356-358).  NULL `cubemap` (or NULL faces) drops the current one: like the
+ * reference's null data pointer, sampling then yields black. */
+RTOW_API int rtowUploadSkyCubemap(RtowContext context, const RtowCubemapDesc* cubemap);
 
 /* replaces: sampleBatchJob.Schedule(totalBufferSize, 1, ...) bracketed by RecordTimeJob 0/1
  * (UNITY/Raytracer.cs:729-738) == SampleBatchJob.Execute for every pixel index (JOBS/SampleBatchJob.cs:59-164).

@@ -71,6 +71,11 @@ def load(kind="strict"):
     lib.oracle_kat_aabb_hit.argtypes = [fp, fp, fp, fp]
     lib.oracle_kat_entity_hit.argtypes = [C.POINTER(abi.Entity), C.POINTER(abi.Triangle), C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, fp]
     lib.oracle_kat_entity_bounds.argtypes = [C.POINTER(abi.Entity), C.POINTER(abi.Triangle), C.c_int, fp]
+    lib.oracle_scene_set_cubemap.argtypes = [C.c_void_p, C.POINTER(abi.CubemapDesc)]
+    lib.oracle_kat_cubemap_sample.argtypes = [C.POINTER(abi.CubemapDesc), fp, fp]
+    lib.oracle_kat_cubemap_sample.restype = None
+    lib.oracle_kat_half_to_float.argtypes = [C.c_uint16]
+    lib.oracle_kat_half_to_float.restype = C.c_float
     lib.oracle_kat_unity_sort.argtypes = [fp, C.POINTER(C.c_int), C.c_int]
     lib.oracle_kat_unity_sort.restype = None
     lib.oracle_kat_hit_tie_order.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_int)]
@@ -103,6 +108,12 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def set_cubemap(self, cubemap_desc):
+        """Environment.SkyCubemap (RT/Environment.cs:16); None drops it."""
+        rc = self.lib.oracle_scene_set_cubemap(self.handle, C.byref(cubemap_desc) if cubemap_desc is not None else None)
+        if rc != 0:
+            raise ValueError("oracle_scene_set_cubemap failed: %d" % rc)
 
     @property
     def node_count(self):

@@ -786,6 +786,79 @@ struct View {
 };
 
 /* ===================================================================================================
+ * Cubemap (RT/Texture.cs:141-211): point-sampled sky cube, faces +X -X +Y -Y +Z -Z contiguous in memory.
+ * =================================================================================================== */
+inline float half_to_float(uint16_t h) /* Unity.Mathematics.half -> float: exact */
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { /* subnormal: man * 2^-24 */
+            const float v = (float)man * 5.9604644775390625e-8f;
+            bits = dm_asuint(v) | sign;
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    return dm_asfloat(bits);
+}
+struct Cubemap {
+    int halfFaceSizeX = 0, halfFaceSizeY = 0, faceSizeMinusOneX = 0, faceSizeMinusOneY = 0;
+    int pixelStrideX = 0, pixelStrideY = 0;      /* pixelStrideVector = (pixelStride, pixelStride * faceSize.x) */
+    int channelType = RTOW_CUBEMAP_SIGNED_HALF;
+    int faceStride = 0;
+    const uint8_t* dataPointer = nullptr;
+
+    void Set(const RtowCubemapDesc& d, const uint8_t* data)                               /* ctor, :150-169 */
+    {
+        halfFaceSizeX = d.faceWidth / 2; halfFaceSizeY = d.faceHeight / 2;
+        faceSizeMinusOneX = d.faceWidth - 1; faceSizeMinusOneY = d.faceHeight - 1;
+        channelType = d.channelType;
+        pixelStrideX = d.pixelStride; pixelStrideY = d.pixelStride * d.faceWidth;
+        faceStride = d.pixelStride * d.faceWidth * d.faceHeight;
+        dataPointer = data;
+    }
+    float3 Sample(float3 vector) const                                                    /* :171-210 */
+    {
+        if (dataPointer == nullptr) return f3(0);
+        /* indexing math adapted from https://scalibq.wordpress.com/2013/06/23/cubemaps/ (reference comment) */
+        const float absVector[4] = {fabsf(vector.x), fabsf(vector.y), fabsf(vector.z), 0.0f};
+        const float maxDistance = um_max(um_max(um_max(absVector[0], absVector[1]), absVector[2]), absVector[3]);   /* cmax(float4) */
+        int laneMask = 0;
+        for (int i = 0; i < 4; i++) if (maxDistance == absVector[i]) laneMask |= 1 << i;                             /* bitmask(maxDistance == absVector) */
+        if (laneMask == 0) return f3(0); /* NaN direction: tzcnt(0) = 32 indexes out of the vector in the reference (undefined); black here */
+        int firstLane = 0;
+        while (!((laneMask >> firstLane) & 1)) firstLane++;                                                           /* tzcnt */
+        if (firstLane > 2) firstLane = 0; /* the zero vector: lane 3 can only be first when all are 0, where lane 0 is first anyway */
+        const float v[3] = {vector.x, vector.y, vector.z};
+        const bool positive = v[firstLane] >= 0;
+        float2 uv;
+        switch (firstLane) {
+            case 0: uv = float2{positive ? -vector.z : vector.z, -vector.y}; break;       /* x */
+            case 1: uv = float2{vector.x, positive ? vector.z : -vector.z}; break;        /* y */
+            default: uv = float2{positive ? vector.x : -vector.x, -vector.y}; break;      /* z */
+        }
+        uv.x = uv.x / absVector[firstLane];
+        uv.y = uv.y / absVector[firstLane];
+        int cx = (int)((uv.x + 1) * (float)halfFaceSizeX), cy = (int)((uv.y + 1) * (float)halfFaceSizeY);
+        cx = cx < faceSizeMinusOneX ? cx : faceSizeMinusOneX;                              /* min((int2) ..., faceSizeMinusOne) */
+        cy = cy < faceSizeMinusOneY ? cy : faceSizeMinusOneY;
+        const uint8_t* pFaceData = dataPointer + (size_t)(firstLane * 2 + (positive ? 0 : 1)) * (size_t)faceStride;
+        pFaceData += cx * pixelStrideX + cy * pixelStrideY;                                /* dot(coords, pixelStrideVector) */
+        switch (channelType) {
+            case RTOW_CUBEMAP_UNSIGNED_BYTE:
+                return f3((float)pFaceData[0], (float)pFaceData[1], (float)pFaceData[2]) / 255.0f;
+            default: {
+                uint16_t t[3];
+                memcpy(t, pFaceData, 6);
+                return f3(half_to_float(t[0]), half_to_float(t[1]), half_to_float(t[2]));
+            }
+        }
+    }
+};
+
+/* ===================================================================================================
  * Scene: entity/material buffers + the reference's BVH builder
  * =================================================================================================== */
 struct BvhBuildingEntity { int entity; AABB Bounds; };
@@ -797,6 +870,8 @@ struct OracleScene {
     std::vector<BvhNode> nodes;        /* node 0 = root */
     int maxDepthSeen = 0;
     bool unsupported = false;
+    Cubemap skyCubemap;                /* Environment.SkyCubemap (RT/Environment.cs:16); set by oracle_scene_set_cubemap */
+    std::vector<uint8_t> skyCubemapData;
 
     /* UNITY/BvhNodeData.cs:23-81 : world-space bounds of an entity (moving: union of start/end boxes) */
     static AABB EntityBounds(const Entity& e)
@@ -1219,6 +1294,9 @@ struct Job {
                         hitSkyColor = um_lerp(f3(p.environment.skyBottomColor), f3(p.environment.skyTopColor),
                                               0.5f * (ray.Direction.y + 1));
                         break;
+                    case RTOW_SKY_CUBEMAP:                                                   /* :356-358 */
+                        hitSkyColor = scene->skyCubemap.Sample(ray.Direction);
+                        break;
                 }
                 s.emissionStack[cursor] = hitSkyColor;
                 s.attenuationStack[cursor] = f3(1);
@@ -1369,6 +1447,27 @@ ORACLE_API void* oracle_scene_create(const RtowSceneDesc* desc)
     return s;
 }
 ORACLE_API void oracle_scene_destroy(void* scene) { delete (OracleScene*)scene; }
+/* Environment.SkyCubemap = new Cubemap(...): copies the six faces (NULL drops the cubemap: Sample() then returns 0 like the
+ * reference's null data pointer) */
+ORACLE_API int oracle_scene_set_cubemap(void* scenePtr, const RtowCubemapDesc* d)
+{
+    OracleScene* sc = (OracleScene*)scenePtr;
+    if (!sc) return 1;
+    if (!d || !d->faces) { sc->skyCubemapData.clear(); sc->skyCubemap = Cubemap(); return 0; }
+    if (d->faceWidth <= 0 || d->faceHeight <= 0 || d->pixelStride <= 0) return 1;
+    const size_t bytes = (size_t)6 * d->faceWidth * d->faceHeight * d->pixelStride;
+    sc->skyCubemapData.assign((const uint8_t*)d->faces, (const uint8_t*)d->faces + bytes);
+    sc->skyCubemap.Set(*d, sc->skyCubemapData.data());
+    return 0;
+}
+ORACLE_API void oracle_kat_cubemap_sample(const RtowCubemapDesc* d, const float* dir, float* out)
+{
+    Cubemap c;
+    c.Set(*d, (const uint8_t*)d->faces);
+    const float3 r = c.Sample(f3(dir[0], dir[1], dir[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+ORACLE_API float oracle_kat_half_to_float(uint16_t h) { return half_to_float(h); }
 ORACLE_API int oracle_scene_node_count(void* scene) { return (int)((OracleScene*)scene)->nodes.size(); }
 ORACLE_API int oracle_scene_depth(void* scene) { return ((OracleScene*)scene)->maxDepthSeen; }
 
@@ -1696,5 +1795,5 @@ ORACLE_API void oracle_abi_sizes(int* out)
     out[3] = (int)sizeof(RtowSceneDesc); out[4] = (int)sizeof(RtowSceneInfo); out[5] = (int)sizeof(RtowView);
     out[6] = (int)sizeof(RtowEnvironment); out[7] = (int)sizeof(RtowSampleParams); out[8] = (int)sizeof(RtowAccumBuffers);
     out[9] = (int)sizeof(RtowContextOptions); out[10] = (int)sizeof(RtowMetrics); out[11] = (int)sizeof(RtowCombineParams);
-    out[12] = (int)sizeof(RtowTriangle);
+    out[12] = (int)sizeof(RtowTriangle); out[13] = (int)sizeof(RtowCubemapDesc);
 }

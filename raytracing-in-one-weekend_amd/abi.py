@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 1
+RTOW_API_VERSION = 2
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -90,6 +90,14 @@ class View(C.Structure):
                 ("forward", Float3), ("up", Float3), ("right", Float3), ("lensRadius", C.c_float)]
 
 
+CUBEMAP_UNSIGNED_BYTE, CUBEMAP_SIGNED_HALF = 0, 1
+
+
+class CubemapDesc(C.Structure):
+    _fields_ = [("faceWidth", C.c_int32), ("faceHeight", C.c_int32), ("channelType", C.c_int32), ("pixelStride", C.c_int32),
+                ("faces", C.c_void_p)]
+
+
 class Environment(C.Structure):
     _fields_ = [("skyType", C.c_int32), ("skyBottomColor", Float3), ("skyTopColor", Float3)]
 
@@ -126,7 +134,7 @@ class CombineParams(C.Structure):
 # every symbol include/rtow.h declares (tests/test_abi.py checks the library exports all of them)
 EXPORTED_SYMBOLS = [
     "rtowGetApiVersion", "rtowErrorString", "rtowCreateContext", "rtowDestroyContext", "rtowUploadScene",
-    "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
+    "rtowUploadSkyCubemap", "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
     "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize",
 ]

@@ -56,6 +56,10 @@ struct RtowContext_t {
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
     volatile uint32_t* hCancel = nullptr; // pinned, device-visible
+    // sky cubemap (rtowUploadSkyCubemap)
+    uint8_t* dCubemap = nullptr;
+    size_t cubemapCapacity = 0;
+    RtowCubemapDesc cubemap{};   // .faces is not kept (host pointer): dCubemap holds the copy, null when none
     // camera-ray candidate lists (primary_candidates_kernel): valid for one (scene upload, view, size, slice, jitter) configuration
     uint2* dPixCand = nullptr;
     size_t pixCandCapacity = 0;
@@ -103,7 +107,7 @@ int validateParams(const RtowSampleParams* p)
     if (p->sliceDivider < 1 || p->sliceOffset < 0 || p->sliceOffset >= p->sliceDivider) return RTOW_ERROR_INVALID_VALUE;
     if (p->traceDepth < 1 || p->traceDepth > 64) return p->traceDepth < 1 ? RTOW_ERROR_INVALID_VALUE : RTOW_ERROR_CAPACITY;
     if (p->noiseColor != RTOW_NOISE_WHITE) return RTOW_ERROR_UNSUPPORTED;
-    if (p->environment.skyType == RTOW_SKY_CUBEMAP) return RTOW_ERROR_UNSUPPORTED;
+    if (p->environment.skyType < RTOW_SKY_NONE || p->environment.skyType > RTOW_SKY_CUBEMAP) return RTOW_ERROR_INVALID_VALUE;
     if (p->diagnosticsStride != 4 && p->diagnosticsStride != 16) return RTOW_ERROR_INVALID_VALUE;
     return RTOW_SUCCESS;
 }
@@ -143,6 +147,12 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.subPixelJitter = p->subPixelJitter;
     a.extremaX = p->sampleCountWeightExtrema.x;
     a.extremaY = p->sampleCountWeightExtrema.y;
+    a.cubemapData = ctx->dCubemap;
+    a.cubemapHalfW = ctx->cubemap.faceWidth / 2; a.cubemapHalfH = ctx->cubemap.faceHeight / 2;                  // RT/Texture.cs:152-154
+    a.cubemapW1 = ctx->cubemap.faceWidth - 1; a.cubemapH1 = ctx->cubemap.faceHeight - 1;
+    a.cubemapPixelStride = ctx->cubemap.pixelStride; a.cubemapRowStride = ctx->cubemap.pixelStride * ctx->cubemap.faceWidth;   // :167
+    a.cubemapFaceStride = ctx->cubemap.pixelStride * ctx->cubemap.faceWidth * ctx->cubemap.faceHeight;         // :168
+    a.cubemapChannelType = ctx->cubemap.channelType;
 
     // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice; RTOW_TUNE overrides for experiments
     static const int kDefaultTune[9] = {RTOW_DEFAULT_TUNE};
@@ -157,8 +167,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.stats = nullptr;
 #ifdef RTOW_STATS
     static unsigned long long* dStats = nullptr;
-    if (!dStats) (void)hipMalloc(&dStats, 16384 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dStats, 0, 16384 * sizeof(unsigned long long), stream);
+    if (!dStats) (void)hipMalloc(&dStats, 32768 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dStats, 0, 32768 * sizeof(unsigned long long), stream);
     a.stats = dStats;
     a.debugPixel = getenv("RTOW_DEBUG_PIXEL") ? atoi(getenv("RTOW_DEBUG_PIXEL")) : -2;
 #endif
@@ -253,6 +263,16 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             std::vector<unsigned long long> r(4096);
             (void)hipMemcpy(r.data(), a.stats + 32, r.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             std::sort(r.begin(), r.end());
+            {
+                std::vector<unsigned long long> rec(4096 * 4);
+                (void)hipMemcpy(rec.data(), a.stats + 9000, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                std::vector<int> idx(4096);
+                for (int i = 0; i < 4096; i++) idx[i] = i;
+                std::sort(idx.begin(), idx.end(), [&](int x, int y) { return rec[x * 4] > rec[y * 4]; });
+                for (int k = 0; k < 4096; k += (k < 16 ? 1 : 512))
+                    fprintf(stderr, "[stats] wave #%d by end time: last pixel ended %.2f ms, started %.2f ms (took %.2f), %llu rays, ticket %llu (chunk %llu)\n", k, rec[idx[k] * 4] / 1e5,
+                            rec[idx[k] * 4 + 1] / 1e5, (rec[idx[k] * 4] - rec[idx[k] * 4 + 1]) / 1e5, rec[idx[k] * 4 + 2], rec[idx[k] * 4 + 3], rec[idx[k] * 4 + 3] / 64);
+            }
             fprintf(stderr, "[stats] residency quantiles ms: min %.2f p10 %.2f p25 %.2f p50 %.2f p75 %.2f p90 %.2f p99 %.2f max %.2f\n", r[0] / 1e5, r[409] / 1e5, r[1024] / 1e5,
                     r[2048] / 1e5, r[3072] / 1e5, r[3686] / 1e5, r[4055] / 1e5, r[4095] / 1e5);
         }
@@ -368,6 +388,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
     if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
+    if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
@@ -420,6 +441,42 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     ctx->orderValid = false;
     logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
          ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowUploadSkyCubemap(RtowContext ctx, const RtowCubemapDesc* cubemap)
+{
+    if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    if (!cubemap || !cubemap->faces) {                       // drop it: Cubemap.Sample returns default when the data pointer is null
+        HIP_TRY(ctx, hipDeviceSynchronize(), RTOW_ERROR_LAUNCH_FAILURE);
+        if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);
+        ctx->dCubemap = nullptr;
+        ctx->cubemapCapacity = 0;
+        ctx->cubemap = RtowCubemapDesc{};
+        return RTOW_SUCCESS;
+    }
+    if (cubemap->faceWidth <= 0 || cubemap->faceHeight <= 0 || cubemap->faceWidth > 32768 || cubemap->faceHeight > 32768) return RTOW_ERROR_INVALID_VALUE;
+    if (cubemap->channelType != RTOW_CUBEMAP_UNSIGNED_BYTE && cubemap->channelType != RTOW_CUBEMAP_SIGNED_HALF) return RTOW_ERROR_INVALID_VALUE;
+    const int minStride = cubemap->channelType == RTOW_CUBEMAP_SIGNED_HALF ? 6 : 3;            // r, g, b are read
+    if (cubemap->pixelStride < minStride || cubemap->pixelStride > 64) return RTOW_ERROR_INVALID_VALUE;
+    if (cubemap->channelType == RTOW_CUBEMAP_SIGNED_HALF && (cubemap->pixelStride & 1)) return RTOW_ERROR_INVALID_VALUE;
+    const size_t bytes = (size_t)6 * (size_t)cubemap->faceWidth * (size_t)cubemap->faceHeight * (size_t)cubemap->pixelStride;
+    HIP_TRY(ctx, hipDeviceSynchronize(), RTOW_ERROR_LAUNCH_FAILURE);                            // no batch may still be reading the old faces
+    if (bytes > ctx->cubemapCapacity) {
+        if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);
+        ctx->dCubemap = nullptr;
+        ctx->cubemapCapacity = 0;
+        ctx->cubemap = RtowCubemapDesc{};
+        HIP_TRY(ctx, hipMalloc(&ctx->dCubemap, bytes), RTOW_ERROR_MEMORY_ALLOCATION);
+        ctx->cubemapCapacity = bytes;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->dCubemap, cubemap->faces, bytes, hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    ctx->cubemap = *cubemap;
+    ctx->cubemap.faces = nullptr;
+    logf(ctx, 3, "sky", "cubemap %dx%d, %s, stride %d (%zu bytes)", cubemap->faceWidth, cubemap->faceHeight,
+         cubemap->channelType == RTOW_CUBEMAP_SIGNED_HALF ? "half" : "byte", cubemap->pixelStride, bytes);
     return RTOW_SUCCESS;
 }
 

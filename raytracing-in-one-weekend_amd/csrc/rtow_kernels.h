@@ -65,6 +65,11 @@ struct SampleKernelArgs {
     int32_t subPixelJitter;
     float extremaX, extremaY;
 
+    // sky cubemap (RT/Texture.cs:141-211), used when environment.skyType == RTOW_SKY_CUBEMAP; cubemapData may be null (-> black)
+    const uint8_t* cubemapData;
+    int32_t cubemapHalfW, cubemapHalfH, cubemapW1, cubemapH1;   // halfFaceSize, faceSizeMinusOne
+    int32_t cubemapPixelStride, cubemapRowStride, cubemapFaceStride, cubemapChannelType;
+
     // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice
     int32_t tune[8];
     int32_t travSlice;

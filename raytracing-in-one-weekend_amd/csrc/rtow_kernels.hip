@@ -127,6 +127,43 @@ __device__ __forceinline__ float smith_g1(V3 w, V3 n, float alpha /* = Roughness
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Cubemap.Sample (RT/Texture.cs:171-210): the face is the first axis whose |component| is the largest (x before y before z), the
+// texel min((int2)((uv + 1) * halfFaceSize), faceSizeMinusOne) of that face, point sampled; RGBA half or byte channels.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_bits_to_float(unsigned h)
+{
+    const unsigned sign = (h & 0x8000u) << 16;
+    const unsigned exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    if (exp == 0) return __uint_as_float(__float_as_uint((float)man * 5.9604644775390625e-8f) | sign);   // zero / subnormal: man * 2^-24, exact
+    if (exp == 31) return __uint_as_float(sign | 0x7f800000u | (man << 13));
+    return __uint_as_float(sign | ((exp + 112u) << 23) | (man << 13));
+}
+__device__ __forceinline__ V3 cubemap_sample(const SampleKernelArgs& A, V3 d)
+{
+    if (!A.cubemapData) return v3(0, 0, 0);
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    const float m = um_max(um_max(um_max(ax, ay), az), 0.0f);                  // cmax(float4(abs(vector), 0))
+    int lane;
+    if (m == ax) lane = 0; else if (m == ay) lane = 1; else if (m == az) lane = 2; else return v3(0, 0, 0);   // NaN direction
+    const float major = lane == 0 ? d.x : lane == 1 ? d.y : d.z;
+    const float amajor = lane == 0 ? ax : lane == 1 ? ay : az;
+    const bool positive = major >= 0;
+    float u, v;
+    if (lane == 0) { u = positive ? -d.z : d.z; v = -d.y; }
+    else if (lane == 1) { u = d.x; v = positive ? d.z : -d.z; }
+    else { u = positive ? d.x : -d.x; v = -d.y; }
+    u = u / amajor;
+    v = v / amajor;
+    int cx = (int)((u + 1) * (float)A.cubemapHalfW), cy = (int)((v + 1) * (float)A.cubemapHalfH);
+    cx = cx < A.cubemapW1 ? cx : A.cubemapW1;
+    cy = cy < A.cubemapH1 ? cy : A.cubemapH1;
+    const uint8_t* px = A.cubemapData + (size_t)(lane * 2 + (positive ? 0 : 1)) * (size_t)A.cubemapFaceStride + cx * A.cubemapPixelStride + cy * A.cubemapRowStride;
+    if (A.cubemapChannelType == RTOW_CUBEMAP_UNSIGNED_BYTE) return v3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    const unsigned short* hp = reinterpret_cast<const unsigned short*>(px);
+    return v3(half_bits_to_float(hp[0]), half_bits_to_float(hp[1]), half_bits_to_float(hp[2]));
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // scene access: LDS image first, HBM/L2 for whatever did not fit
 // ------------------------------------------------------------------------------------------------------------
 struct SceneRefs {
@@ -491,6 +528,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     STAT_DECL;
 #ifdef RTOW_STATS
     const unsigned long long statT0 = wall_clock64();
+    unsigned long long pixT0 = statT0;
 #endif
     for (;;) {
         STAT_ADD(0, 1);
@@ -504,6 +542,13 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             if (st == ST_REGEN) {
                 STAT_LANES(2);
                 while (smp >= nsamp) {
+#ifdef RTOW_STATS
+                    if (pix >= 0 && A.stats) {
+                        // last pixel this wave finished: {end, start, rays, tick} (100 MHz ticks since the wave started); later stores overwrite earlier ones
+                        unsigned long long* rec = A.stats + 9000 + (size_t)(blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)) * 4;
+                        rec[0] = wall_clock64() - statT0; rec[1] = pixT0 - statT0; rec[2] = (unsigned long long)rayCount; rec[3] = tick;
+                    }
+#endif
                     if (pix >= 0 && A.pixelCost) {
                         // cost map for the next launch's chunk order: this pixel's ray count, in ticket order (a plain 2-byte store that
                         // merges in L2 with its chunk's other 63; per-chunk atomics cost a memory-side transaction each)
@@ -566,6 +611,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     }
                     if (ticket == 0xffffffffu) { st = ST_DEAD; break; }
                     tick = ticket;
+#ifdef RTOW_STATS
+                    pixT0 = wall_clock64();
+#endif
                     const int ownedRow = (int)(ticket / (unsigned)A.width);
                     cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
                     cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
@@ -1064,6 +1112,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const float s = 0.5f * (rd.y + 1);
                     const V3 b = v3(A.environment.skyBottomColor), tp = v3(A.environment.skyTopColor);
                     sky = v3(b.x + s * (tp.x - b.x), b.y + s * (tp.y - b.y), b.z + s * (tp.z - b.z));
+                } else if (A.environment.skyType == RTOW_SKY_CUBEMAP) {
+                    sky = cubemap_sample(A, rd);
                 }
                 // randomEventsLocalAcc += rng.RandomEvents / pow(2, depth) (:363): RandomEvents is 0 here unless a ProbabilisticHit
                 // that found nothing left its increment pending

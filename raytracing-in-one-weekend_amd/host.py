@@ -93,6 +93,10 @@ class Context:
         """World rebuild hand-off (the tail of Raytracer.RebuildWorld, UNITY/Raytracer.cs:1167-1183)."""
         check(load().rtowUploadScene(self.handle, C.byref(scene_desc)), "rtowUploadScene")
 
+    def upload_sky_cubemap(self, cubemap_desc):
+        """`new Cubemap(skyCubemap)` (RT/Texture.cs:150-169): the six faces travel once; None drops the cubemap."""
+        check(load().rtowUploadSkyCubemap(self.handle, C.byref(cubemap_desc) if cubemap_desc is not None else None), "rtowUploadSkyCubemap")
+
     def scene_info(self):
         info = abi.SceneInfo()
         check(load().rtowGetSceneInfo(self.handle, C.byref(info)), "rtowGetSceneInfo")

@@ -47,6 +47,7 @@ def load():
     lib.rtowCreateContext.argtypes = [C.POINTER(abi.ContextOptions), C.POINTER(vp)]
     lib.rtowDestroyContext.argtypes = [vp]
     lib.rtowUploadScene.argtypes = [vp, C.POINTER(abi.SceneDesc)]
+    lib.rtowUploadSkyCubemap.argtypes = [vp, C.POINTER(abi.CubemapDesc)]
     lib.rtowGetSceneInfo.argtypes = [vp, C.POINTER(abi.SceneInfo)]
     lib.rtowSampleBatch.argtypes = [vp, C.POINTER(abi.SampleParams), AB, AB, vp, vp]
     lib.rtowSampleBatchDevice.argtypes = [vp, C.POINTER(abi.SampleParams), AB, AB, vp, vp, vp]

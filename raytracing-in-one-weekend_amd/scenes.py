@@ -562,8 +562,51 @@ def make_view(scene, width, height, focus=None):
     return abi.View(v3(origin), v3(llc), v3(horizontal), v3(vertical), v3(forward), v3(up_v), v3(right), float(lens_radius))
 
 
+class SkyCubemap:
+    """Six faces (+X -X +Y -Y +Z -Z, contiguous) of a sky cube in the layout `Cubemap` expects (RT/Texture.cs:141-211)."""
+
+    def __init__(self, faces, channel_type):
+        self.faces = np.ascontiguousarray(faces)            # [6, H, W, C] float16 (C = 4: R16G16B16A16_SFloat) or uint8 (C = 3 / 4)
+        assert self.faces.ndim == 4 and self.faces.shape[0] == 6
+        self.channel_type = channel_type
+
+    def desc(self):
+        _, h, w, c = self.faces.shape
+        return abi.CubemapDesc(w, h, self.channel_type, c * self.faces.itemsize, self.faces.ctypes.data)
+
+
+def synthetic_sky(size=64, half=True, seed=3):
+    """A procedural HDR sky (no HDRI asset travels with the reference): smooth gradient + a hot sun + per-texel noise so that
+    neighbouring texels differ; half floats like the reference's only accepted format, or bytes for its UnsignedByte decode path."""
+    rng = np.random.default_rng(seed)
+    faces = np.zeros((6, size, size, 4), dtype=np.float32)
+    axes = [(0, 1), (0, -1), (1, 1), (1, -1), (2, 1), (2, -1)]
+    t = (np.arange(size, dtype=np.float32) + 0.5) / size * 2 - 1
+    uu, vv = np.meshgrid(t, t)                              # uv of the texel centre: column = u, row = v
+    sun = np.array([0.5, 0.7, -0.5], dtype=np.float32)
+    sun /= np.linalg.norm(sun)
+    for f, (axis, sign) in enumerate(axes):
+        d = np.zeros((size, size, 3), dtype=np.float32)     # inverse of the uv mapping of RT/Texture.cs:184-190
+        if axis == 0:
+            d[..., 0], d[..., 2], d[..., 1] = sign, -sign * uu, -vv
+        elif axis == 1:
+            d[..., 1], d[..., 0], d[..., 2] = sign, uu, sign * vv
+        else:
+            d[..., 2], d[..., 0], d[..., 1] = sign, sign * uu, -vv
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        up = 0.5 * (d[..., 1] + 1)
+        col = (1 - up)[..., None] * np.array([0.9, 0.8, 0.7], np.float32) + up[..., None] * np.array([0.3, 0.5, 1.0], np.float32)
+        col += 40.0 * np.maximum(d @ sun, 0)[..., None] ** 200 * np.array([1.0, 0.9, 0.7], np.float32)
+        col *= 0.9 + 0.2 * rng.random((size, size, 1), dtype=np.float32)
+        faces[f, ..., :3] = col
+        faces[f, ..., 3] = 1
+    if half:
+        return SkyCubemap(faces.astype(np.float16), abi.CUBEMAP_SIGNED_HALF)
+    return SkyCubemap(np.clip(faces[..., :3] * 255 / 2, 0, 255).astype(np.uint8), abi.CUBEMAP_UNSIGNED_BYTE)
+
+
 def make_params(scene, width, height, spp, trace_depth, seed=1, jitter=True, slice_offset=0, slice_divider=1,
-                spp_max=None, extrema=(0.0, 0.0), diagnostics_stride=4, focus=None):
+                spp_max=None, extrema=(0.0, 0.0), diagnostics_stride=4, focus=None, sky_type=None):
     """SampleBatchJob parameter block with the benchmark defaults of SURVEY.md section 8(d)."""
     p = abi.SampleParams()
     p.size = abi.Float2(float(width), float(height))
@@ -571,7 +614,7 @@ def make_params(scene, width, height, spp, trace_depth, seed=1, jitter=True, sli
     p.sliceDivider = slice_divider
     p.seed = seed
     p.view = make_view(scene, width, height, focus)
-    p.environment = abi.Environment(abi.SKY_GRADIENT, abi.Float3(*scene.sky_bottom), abi.Float3(*scene.sky_top))
+    p.environment = abi.Environment(abi.SKY_GRADIENT if sky_type is None else sky_type, abi.Float3(*scene.sky_bottom), abi.Float3(*scene.sky_top))
     p.sampleCountRange[0] = spp
     p.sampleCountRange[1] = spp if spp_max is None else spp_max
     p.traceDepth = trace_depth

@@ -148,6 +148,20 @@ def test_error_codes(rt, gpu_context):
     fresh.close()
 
 
+def test_sky_cubemap_upload_validation(rt, gpu_context):
+    a = rt.abi
+    lib = rt.lib.load()
+    px = (C.c_uint16 * (6 * 4 * 4 * 4))()
+    ok = a.CubemapDesc(4, 4, a.CUBEMAP_SIGNED_HALF, 8, C.addressof(px))
+    assert lib.rtowUploadSkyCubemap(gpu_context.handle, C.byref(ok)) == 0
+    for field, value in (("faceWidth", 0), ("faceHeight", -1), ("channelType", 7), ("pixelStride", 4), ("pixelStride", 7)):
+        bad = a.CubemapDesc(4, 4, a.CUBEMAP_SIGNED_HALF, 8, C.addressof(px))
+        setattr(bad, field, value)
+        assert lib.rtowUploadSkyCubemap(gpu_context.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE, field
+    assert lib.rtowUploadSkyCubemap(None, C.byref(ok)) == a.RTOW_ERROR_INVALID_VALUE
+    assert lib.rtowUploadSkyCubemap(gpu_context.handle, None) == 0           # drop
+
+
 def test_cancellation_token(rt, gpu_context):
     """NativeReference<bool> CancellationToken (JOBS/SampleBatchJob.cs:23,61-62): set mid-batch -> RTOW_ERROR_CANCELLED, promptly."""
     ctx = gpu_context

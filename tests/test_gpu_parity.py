@@ -164,3 +164,31 @@ def test_nearest_hit_ties_between_coplanar_entities(rt, oracle, gpu_context):
     scene = rt.scenes.coplanar_scene()
     gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 64, 8, 8, focus=6.0, diagnostics_stride=16)
     _compare(gpu, ref)
+
+
+def test_sky_cubemap(rt, oracle, gpu_context):
+    """SkyType.CubeMap: Cubemap.Sample(ray.Direction) (RT/Texture.cs:171-210, JOBS/SampleBatchJob.cs:356-358) for both channel decodes,
+    an odd face size, and after dropping the cubemap again (black sky, like the reference's null data pointer)."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    osc = oracle.OracleScene(desc)
+    p = rt.scenes.make_params(scene, 96, 54, spp=8, trace_depth=8, sky_type=rt.abi.SKY_CUBEMAP)
+    try:
+        for sky in (rt.scenes.synthetic_sky(size=64, half=True), rt.scenes.synthetic_sky(size=37, half=False), rt.scenes.synthetic_sky(size=1, half=True)):
+            cd = sky.desc()
+            ctx.upload_sky_cubemap(cd)
+            osc.set_cubemap(cd)
+            gpu = rt.sample_batch_host(ctx, p)
+            ref = osc.sample_batch(p)
+            _compare(gpu, ref)
+            assert gpu["color"][:, :3].max() > 0
+        ctx.upload_sky_cubemap(None)
+        osc.set_cubemap(None)
+        gpu = rt.sample_batch_host(ctx, p)
+        _compare(gpu, osc.sample_batch(p))
+        assert np.all(gpu["color"][:, :3] == 0)
+    finally:
+        ctx.upload_sky_cubemap(None)
+        osc.close()
