@@ -95,8 +95,8 @@ typedef enum RtowSkyType {         /* RT/Environment.cs:5-10 */
 
 typedef enum RtowNoiseColor {      /* RT/RandomSource.cs:8-13 */
     RTOW_NOISE_WHITE = 0,
-    RTOW_NOISE_BLUE = 1,              /* not built (texture-driven) -> RTOW_ERROR_UNSUPPORTED */
-    RTOW_NOISE_SPATIOTEMPORAL_BLUE = 2
+    RTOW_NOISE_BLUE = 1,              /* RT/BlueNoise.cs: texels of the set given to rtowUploadBlueNoise */
+    RTOW_NOISE_SPATIOTEMPORAL_BLUE = 2 /* RT/SpatioTemporalBlueNoise.cs: the five texture sets given to rtowUploadStbNoise */
 } RtowNoiseColor;
 
 /* ---- scene description: flat, index-based PODs ----
@@ -190,6 +190,24 @@ typedef struct RtowCubemapDesc {
     const void* faces;              /* 6 * faceWidth * faceHeight * pixelStride bytes, host memory, copied by the call */
 } RtowCubemapDesc;
 
+/* The host's noise textures (UNITY/BlueNoiseData.cs:19-57, UNITY/SpatioTemporalBlueNoiseData.cs:18-44): square textures of
+ * `rowStride` x `rowStride` texels, `textureCount` of them back to back; a batch reads ONE of them, RtowSampleParams.noiseTextureIndex
+ * (the host's textureIndex after CycleTexture(), UNITY/Raytracer.cs:658-659).  Texel formats are the ones the reference reads:
+ * blue = half4 (8 bytes, .x / .xy used, RT/BlueNoise.cs:26-28); STBN scalar = 1 byte, vector2 / unitVector2 / unitVector3 = RGB24,
+ * cosineUnitVector3 = RGBA32 (RT/SpatioTemporalBlueNoise.cs:61-85).  Host memory, copied by the call; NULL desc drops the set. */
+typedef struct RtowBlueNoiseDesc {
+    uint32_t rowStride, textureCount;
+    const void* texels;
+} RtowBlueNoiseDesc;
+typedef struct RtowStbNoiseDesc {
+    uint32_t rowStride, textureCount;
+    const void* scalar;
+    const void* vector2;
+    const void* cosineUnitVector3;
+    const void* unitVector2;
+    const void* unitVector3;
+} RtowStbNoiseDesc;
+
 /* RT/Environment.cs:12-17; the cubemap handle of SkyType.CubeMap is the one uploaded with rtowUploadSkyCubemap. */
 typedef struct RtowEnvironment {
     int32_t skyType;                /* RtowSkyType */
@@ -212,7 +230,7 @@ typedef struct RtowSampleParams {
     int32_t diagnosticsStride;      /* bytes per pixel of the diagnostics buffer: 4 = {RayCount},
                                        16 = FULL_DIAGNOSTICS {RayCount, BoundsHitCount, CandidateCount,
                                        SampleCountWeight} (UNITY/Raytracer.cs:54-64) */
-    int32_t reserved;
+    int32_t noiseTextureIndex;      /* which texture of the uploaded blue / STBN set this batch reads (ignored for white noise) */
 } RtowSampleParams;
 
 /* The four accumulation buffers (JOBS/SampleBatchJob.cs:41-49): W*H elements each, tightly packed,
@@ -258,6 +276,12 @@ RTOW_API int rtowGetSceneInfo(RtowContext context, RtowSceneInfo* outInfo);
  * (RT/Texture.cs:171-210, JOBS/SampleBatchJob.cs:356-358).  NULL `cubemap` (or NULL faces) drops the current one: like the
  * reference's null data pointer, sampling then yields black. */
 RTOW_API int rtowUploadSkyCubemap(RtowContext context, const RtowCubemapDesc* cubemap);
+
+/* replaces: blueNoise.GetRuntimeData(frameSeed) / stbNoise.GetRuntimeData(frameSeed) (UNITY/Raytracer.cs:702-703): the texture sets the
+ * BlueNoise / SpatioTemporalBlueNoise samplers walk (RT/PerPixelNoise.cs).  A batch with noiseColor Blue / SpatioTemporalBlue and no
+ * uploaded set fails with RTOW_ERROR_INVALID_VALUE. */
+RTOW_API int rtowUploadBlueNoise(RtowContext context, const RtowBlueNoiseDesc* noise);
+RTOW_API int rtowUploadStbNoise(RtowContext context, const RtowStbNoiseDesc* noise);
 
 /* replaces: sampleBatchJob.Schedule(totalBufferSize, 1, ...) bracketed by RecordTimeJob 0/1
  * (UNITY/Raytracer.cs:729-738) == SampleBatchJob.Execute for every pixel index (JOBS/SampleBatchJob.cs:59-164).

@@ -72,6 +72,12 @@ def load(kind="strict"):
     lib.oracle_kat_entity_hit.argtypes = [C.POINTER(abi.Entity), C.POINTER(abi.Triangle), C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, fp]
     lib.oracle_kat_entity_bounds.argtypes = [C.POINTER(abi.Entity), C.POINTER(abi.Triangle), C.c_int, fp]
     lib.oracle_scene_set_cubemap.argtypes = [C.c_void_p, C.POINTER(abi.CubemapDesc)]
+    lib.oracle_scene_set_blue_noise.argtypes = [C.c_void_p, C.POINTER(abi.BlueNoiseDesc)]
+    lib.oracle_scene_set_stb_noise.argtypes = [C.c_void_p, C.POINTER(abi.StbNoiseDesc)]
+    lib.oracle_kat_r2.argtypes = [C.c_uint32, fp]
+    lib.oracle_kat_r2.restype = None
+    lib.oracle_kat_per_pixel_noise.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+    lib.oracle_kat_per_pixel_noise.restype = None
     lib.oracle_kat_cubemap_sample.argtypes = [C.POINTER(abi.CubemapDesc), fp, fp]
     lib.oracle_kat_cubemap_sample.restype = None
     lib.oracle_kat_half_to_float.argtypes = [C.c_uint16]
@@ -114,6 +120,14 @@ class OracleScene:
         rc = self.lib.oracle_scene_set_cubemap(self.handle, C.byref(cubemap_desc) if cubemap_desc is not None else None)
         if rc != 0:
             raise ValueError("oracle_scene_set_cubemap failed: %d" % rc)
+
+    def set_blue_noise(self, desc):
+        if self.lib.oracle_scene_set_blue_noise(self.handle, C.byref(desc) if desc is not None else None) != 0:
+            raise ValueError("oracle_scene_set_blue_noise failed")
+
+    def set_stb_noise(self, desc):
+        if self.lib.oracle_scene_set_stb_noise(self.handle, C.byref(desc) if desc is not None else None) != 0:
+            raise ValueError("oracle_scene_set_stb_noise failed")
 
     @property
     def node_count(self):

@@ -296,20 +296,119 @@ struct Texture {
     }
 };
 
-/* RT/RandomSource.cs:15-150, NoiseColor.White branches; RandomEvents counter :33-37. */
+/* RT/R2.cs:8-16.  The constants are C# `const float` expressions; folded one operation at a time in binary32 here (an assumption
+ * about Roslyn's constant folding).  float * uint converts the uint to float; `% 1` is the IEEE remainder with truncation (fmodf). */
+inline float2 R2Next(uint32_t n)
+{
+    const float g = 1.32471795724474602596f;
+    const float a1 = 1.0f / g;
+    const float a2 = 1.0f / (g * g);
+    return float2{fmodf(0.5f + a1 * (float)n, 1.0f), fmodf(0.5f + a2 * (float)n, 1.0f)};
+}
+inline float half_to_float(uint16_t h) /* Unity.Mathematics.half -> float: exact */
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { /* subnormal: man * 2^-24 */
+            const float v = (float)man * 5.9604644775390625e-8f;
+            bits = dm_asuint(v) | sign;
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    return dm_asfloat(bits);
+}
+/* RT/PerPixelNoise.cs:8-37: a walk over one square noise texture, the same R2 offsets for every pixel, shifted by the pixel's coordinates */
+struct PerPixelNoise {
+    uint32_t cx = 0, cy = 0, rowStride = 1;
+    uint32_t offX = 0, offY = 0, n = 0;
+    void Init(uint32_t seed, uint32_t x, uint32_t y, uint32_t stride) { cx = x; cy = y; rowStride = stride; n = seed; Advance(); }   /* :17-25 */
+    size_t Next()                                                                                                                    /* :27-33: index of the texel */
+    {
+        const uint32_t wx = (cx + offX) % rowStride, wy = (cy + offY) % rowStride;
+        const size_t texel = (size_t)wy * rowStride + wx;
+        Advance();
+        return texel;
+    }
+    void Advance()                                                                                                                   /* :35-38 */
+    {
+        const float2 r = R2Next(n++);
+        offX = (uint32_t)floorf(r.x * (float)rowStride);
+        offY = (uint32_t)floorf(r.y * (float)rowStride);
+    }
+};
+/* the host's noise textures (UNITY/BlueNoiseData.cs, UNITY/SpatioTemporalBlueNoiseData.cs), one texture of each set */
+struct NoiseTextures {
+    uint32_t blueRowStride = 0;
+    const uint16_t* blue = nullptr;                 /* half4 texels */
+    uint32_t stbRowStride = 0;
+    const uint8_t* stbScalar = nullptr;             /* byte */
+    const uint8_t* stbVector2 = nullptr;            /* RGB24 */
+    const uint8_t* stbCosineUnitVector3 = nullptr;  /* RGBA32 */
+    const uint8_t* stbUnitVector2 = nullptr;        /* RGB24 */
+    const uint8_t* stbUnitVector3 = nullptr;        /* RGB24 */
+};
+
+/* RT/RandomSource.cs:15-150 (+ RT/BlueNoise.cs, RT/SpatioTemporalBlueNoise.cs); RandomEvents counter :33-37. */
 struct RandomSource {
+    int noiseColor = RTOW_NOISE_WHITE;
     UmRandom whiteNoise;
+    const NoiseTextures* tex = nullptr;
+    PerPixelNoise blueNoise;                                                       /* BlueNoise.perPixelNoise */
+    PerPixelNoise stbScalar, stbVector2, stbCosine, stbUnit2, stbUnit3;             /* SpatioTemporalBlueNoise.perPixel* */
     float RandomEvents;
-    uint32_t draws; /* oracle-only: number of NextState() calls, for the draw-order KAT */
+    uint32_t draws; /* oracle-only: number of NextState() / texel fetches, for the draw-order KAT */
 
-    float NextFloat() { draws += 1; return whiteNoise.NextFloat(); }             /* :130-139 */
-    float2 NextFloat2() { draws += 2; return whiteNoise.NextFloat2(); }          /* :141-150 */
+    /* BlueNoise.Coordinates / SpatioTemporalBlueNoise.Coordinates setters (JOBS/SampleBatchJob.cs:83-88) */
+    void SetCoordinates(uint32_t seed, uint32_t x, uint32_t y)
+    {
+        if (noiseColor == RTOW_NOISE_BLUE) blueNoise.Init(seed, x, y, tex->blueRowStride);
+        if (noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) {
+            stbScalar.Init(seed, x, y, tex->stbRowStride); stbVector2.Init(seed, x, y, tex->stbRowStride); stbCosine.Init(seed, x, y, tex->stbRowStride);
+            stbUnit2.Init(seed, x, y, tex->stbRowStride); stbUnit3.Init(seed, x, y, tex->stbRowStride);
+        }
+    }
+    float2 BlueTexel() { draws += 1; const uint16_t* t = tex->blue + blueNoise.Next() * 4; return float2{half_to_float(t[0]), half_to_float(t[1])}; }
+    float StbFloat() { draws += 1; return (float)tex->stbScalar[stbScalar.Next()] / 256.0f; }                                         /* STBN :61 */
+    float2 StbFloat2() { draws += 1; const uint8_t* t = tex->stbVector2 + stbVector2.Next() * 3; return float2{(float)t[0] / 256.0f, (float)t[1] / 256.0f}; }   /* :63-67 */
 
+    float NextFloat()                                                             /* :130-139 */
+    {
+        switch (noiseColor) {
+            case RTOW_NOISE_BLUE: return BlueTexel().x;                           /* BlueNoise.cs:26 */
+            case RTOW_NOISE_SPATIOTEMPORAL_BLUE: return StbFloat();
+            default: draws += 1; return whiteNoise.NextFloat();
+        }
+    }
+    float2 NextFloat2()                                                           /* :141-150 */
+    {
+        switch (noiseColor) {
+            case RTOW_NOISE_BLUE: return BlueTexel();                             /* BlueNoise.cs:28: x and y of ONE texel */
+            case RTOW_NOISE_SPATIOTEMPORAL_BLUE: return StbFloat2();
+            default: draws += 2; return whiteNoise.NextFloat2();
+        }
+    }
     float2 InUnitDisk()                                                           /* :40-61 */
     {
-        draws += 2;
-        const float theta = whiteNoise.NextFloat(0.0f, 2.0f * UM_PI);
-        const float radius = sqrtf(whiteNoise.NextFloat());
+        float theta, radius;
+        switch (noiseColor) {
+            case RTOW_NOISE_BLUE:
+                theta = BlueTexel().x * 2 * UM_PI;
+                radius = sqrtf(BlueTexel().x);
+                break;
+            case RTOW_NOISE_SPATIOTEMPORAL_BLUE: {                                /* NextUnitVector2, STBN :75-79 */
+                draws += 1;
+                const uint8_t* t = tex->stbUnitVector2 + stbUnit2.Next() * 3;
+                return float2{(float)t[0] / 256.0f * 2 - 1, (float)t[1] / 256.0f * 2 - 1};
+            }
+            default:
+                draws += 2;
+                theta = whiteNoise.NextFloat(0.0f, 2.0f * UM_PI);
+                radius = sqrtf(whiteNoise.NextFloat());
+                break;
+        }
         float sinTheta, cosTheta;
         dm_sincosf(theta, &sinTheta, &cosTheta);
         return float2{radius * cosTheta, radius * sinTheta};
@@ -317,6 +416,11 @@ struct RandomSource {
     float3 OnCosineWeightedHemisphere(float3 normal);                             /* :63-89 */
     float3 NextFloat3Direction()                                                  /* :113-128 */
     {
+        if (noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) {                       /* NextUnitVector3, STBN :81-85 */
+            draws += 1;
+            const uint8_t* t = tex->stbUnitVector3 + stbUnit3.Next() * 3;
+            return f3((float)t[0] / 256.0f * 2 - 1, (float)t[1] / 256.0f * 2 - 1, (float)t[2] / 256.0f * 2 - 1);
+        }
         const float2 rnd = NextFloat2();
         const float z = rnd.x * 2.0f - 1.0f;
         const float r = sqrtf(um_max(1.0f - z * z, 0.0f));
@@ -346,6 +450,12 @@ inline float3 TangentToWorldSpace(float3 v, float3 normal)
 }
 float3 RandomSource::OnCosineWeightedHemisphere(float3 normal)
 {
+    if (noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) {                           /* NextCosineUnitVector3, STBN :69-73: (r, b, g) */
+        draws += 1;
+        const uint8_t* t = tex->stbCosineUnitVector3 + stbCosine.Next() * 4;
+        const float3 tangentSpaceDirection = f3((float)t[0] / 256.0f * 2 - 1, (float)t[2] / 256.0f * 2 - 1, (float)t[1] / 256.0f * 2 - 1);
+        return TangentToWorldSpace(tangentSpaceDirection, normal);
+    }
     const float2 uv = NextFloat2();
     const float u = uv.x;
     const float radius = sqrtf(u);
@@ -788,21 +898,6 @@ struct View {
 /* ===================================================================================================
  * Cubemap (RT/Texture.cs:141-211): point-sampled sky cube, faces +X -X +Y -Y +Z -Z contiguous in memory.
  * =================================================================================================== */
-inline float half_to_float(uint16_t h) /* Unity.Mathematics.half -> float: exact */
-{
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    const uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
-    uint32_t bits;
-    if (exp == 0) {
-        if (man == 0) bits = sign;
-        else { /* subnormal: man * 2^-24 */
-            const float v = (float)man * 5.9604644775390625e-8f;
-            bits = dm_asuint(v) | sign;
-        }
-    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
-    else bits = sign | ((exp + 112u) << 23) | (man << 13);
-    return dm_asfloat(bits);
-}
 struct Cubemap {
     int halfFaceSizeX = 0, halfFaceSizeY = 0, faceSizeMinusOneX = 0, faceSizeMinusOneY = 0;
     int pixelStrideX = 0, pixelStrideY = 0;      /* pixelStrideVector = (pixelStride, pixelStride * faceSize.x) */
@@ -872,6 +967,26 @@ struct OracleScene {
     bool unsupported = false;
     Cubemap skyCubemap;                /* Environment.SkyCubemap (RT/Environment.cs:16); set by oracle_scene_set_cubemap */
     std::vector<uint8_t> skyCubemapData;
+    /* the host's noise texture sets (UNITY/BlueNoiseData.cs, UNITY/SpatioTemporalBlueNoiseData.cs); set by oracle_scene_set_*_noise */
+    uint32_t blueRowStride = 0, blueTextureCount = 0, stbRowStride = 0, stbTextureCount = 0;
+    std::vector<uint16_t> blueTexels;
+    std::vector<uint8_t> stbScalar, stbVector2, stbCosine, stbUnit2, stbUnit3;
+    bool NoiseFor(int noiseColor, int textureIndex, NoiseTextures* out) const
+    {
+        *out = NoiseTextures();
+        if (noiseColor == RTOW_NOISE_BLUE) {
+            if (textureIndex < 0 || (uint32_t)textureIndex >= blueTextureCount) return false;
+            out->blueRowStride = blueRowStride;
+            out->blue = blueTexels.data() + (size_t)textureIndex * blueRowStride * blueRowStride * 4;
+        } else if (noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) {
+            if (textureIndex < 0 || (uint32_t)textureIndex >= stbTextureCount) return false;
+            const size_t texels = (size_t)stbRowStride * stbRowStride, t = (size_t)textureIndex * texels;
+            out->stbRowStride = stbRowStride;
+            out->stbScalar = stbScalar.data() + t; out->stbVector2 = stbVector2.data() + t * 3; out->stbCosineUnitVector3 = stbCosine.data() + t * 4;
+            out->stbUnitVector2 = stbUnit2.data() + t * 3; out->stbUnitVector3 = stbUnit3.data() + t * 3;
+        }
+        return true;
+    }
 
     /* UNITY/BvhNodeData.cs:23-81 : world-space bounds of an entity (moving: union of start/end boxes) */
     static AABB EntityBounds(const Entity& e)
@@ -1045,6 +1160,7 @@ struct Counters {
 };
 
 struct Job {
+    NoiseTextures noise;               /* BlueNoise / StbNoise fields of the job (the texture of this batch) */
     mutable bool tracePixel = false;   /* ORACLE_TRACE_PIXEL=<index>: per-segment trace on stderr (debugging aid) */
     const OracleScene* scene;
     RtowSampleParams p;
@@ -1349,7 +1465,18 @@ struct Job {
 
         /* :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)) */
         RandomSource rng;
-        rng.whiteNoise.Init((p.seed * 0x8C4CA03Fu) ^ ((uint32_t)index * 0x7383ED49u));
+        rng.noiseColor = p.noiseColor;
+        rng.tex = &noise;
+        rng.whiteNoise.state = 0;                                                              /* `Random whiteNoise = default` (:80) */
+        switch (p.noiseColor) {                                                                /* :81-93 */
+            case RTOW_NOISE_BLUE:
+            case RTOW_NOISE_SPATIOTEMPORAL_BLUE:
+                rng.SetCoordinates(p.seed, (uint32_t)cx, (uint32_t)cy);                        /* seed = frameSeed = Seed (UNITY/Raytracer.cs:696-703) */
+                break;
+            default:
+                rng.whiteNoise.Init((p.seed * 0x8C4CA03Fu) ^ ((uint32_t)index * 0x7383ED49u));
+                break;
+        }
         rng.RandomEvents = 0;
         rng.draws = 0;
 
@@ -1460,6 +1587,44 @@ ORACLE_API int oracle_scene_set_cubemap(void* scenePtr, const RtowCubemapDesc* d
     sc->skyCubemap.Set(*d, sc->skyCubemapData.data());
     return 0;
 }
+/* BlueNoiseData / SpatioTemporalBlueNoiseData: copies the texture sets (NULL drops them) */
+ORACLE_API int oracle_scene_set_blue_noise(void* scenePtr, const RtowBlueNoiseDesc* d)
+{
+    OracleScene* sc = (OracleScene*)scenePtr;
+    if (!sc) return 1;
+    sc->blueTexels.clear(); sc->blueRowStride = sc->blueTextureCount = 0;
+    if (!d || !d->texels) return 0;
+    if (d->rowStride == 0 || d->textureCount == 0) return 1;
+    const size_t n = (size_t)d->rowStride * d->rowStride * d->textureCount * 4;
+    sc->blueTexels.assign((const uint16_t*)d->texels, (const uint16_t*)d->texels + n);
+    sc->blueRowStride = d->rowStride; sc->blueTextureCount = d->textureCount;
+    return 0;
+}
+ORACLE_API int oracle_scene_set_stb_noise(void* scenePtr, const RtowStbNoiseDesc* d)
+{
+    OracleScene* sc = (OracleScene*)scenePtr;
+    if (!sc) return 1;
+    sc->stbScalar.clear(); sc->stbVector2.clear(); sc->stbCosine.clear(); sc->stbUnit2.clear(); sc->stbUnit3.clear();
+    sc->stbRowStride = sc->stbTextureCount = 0;
+    if (!d) return 0;
+    if (!d->scalar || !d->vector2 || !d->cosineUnitVector3 || !d->unitVector2 || !d->unitVector3 || d->rowStride == 0 || d->textureCount == 0) return 1;
+    const size_t n = (size_t)d->rowStride * d->rowStride * d->textureCount;
+    sc->stbScalar.assign((const uint8_t*)d->scalar, (const uint8_t*)d->scalar + n);
+    sc->stbVector2.assign((const uint8_t*)d->vector2, (const uint8_t*)d->vector2 + n * 3);
+    sc->stbCosine.assign((const uint8_t*)d->cosineUnitVector3, (const uint8_t*)d->cosineUnitVector3 + n * 4);
+    sc->stbUnit2.assign((const uint8_t*)d->unitVector2, (const uint8_t*)d->unitVector2 + n * 3);
+    sc->stbUnit3.assign((const uint8_t*)d->unitVector3, (const uint8_t*)d->unitVector3 + n * 3);
+    sc->stbRowStride = d->rowStride; sc->stbTextureCount = d->textureCount;
+    return 0;
+}
+/* R2.Next(n) and the first `count` texel indices a PerPixelNoise(seed, (x, y), rowStride) visits */
+ORACLE_API void oracle_kat_r2(uint32_t n, float* out) { const float2 r = R2Next(n); out[0] = r.x; out[1] = r.y; }
+ORACLE_API void oracle_kat_per_pixel_noise(uint32_t seed, uint32_t x, uint32_t y, uint32_t rowStride, int count, uint32_t* out)
+{
+    PerPixelNoise p;
+    p.Init(seed, x, y, rowStride);
+    for (int i = 0; i < count; i++) out[i] = (uint32_t)p.Next();
+}
 ORACLE_API void oracle_kat_cubemap_sample(const RtowCubemapDesc* d, const float* dir, float* out)
 {
     Cubemap c;
@@ -1502,13 +1667,14 @@ static int sample_impl(void* scenePtr, const RtowSampleParams* params,
                        void* diagnostics, int nthreads, OracleCountersOut* countersOut, const int* pixelIndices, int pixelCount)
 {
     if (!scenePtr || !params) return 1;
-    if (params->noiseColor != RTOW_NOISE_WHITE) return 5;
+    if (params->noiseColor < RTOW_NOISE_WHITE || params->noiseColor > RTOW_NOISE_SPATIOTEMPORAL_BLUE) return 1;
     if (params->sliceDivider < 1 || params->traceDepth < 0) return 1;
     const OracleScene* scene = (const OracleScene*)scenePtr;
     Job job;
     job.scene = scene;
     job.p = *params;
     job.view = MakeView(params->view);
+    if (!scene->NoiseFor(params->noiseColor, params->noiseTextureIndex, &job.noise)) return 1;   /* no such noise texture */
     job.InputColor = inColor; job.InputNormal = inNormal; job.InputAlbedo = inAlbedo; job.InputSampleCountWeight = inScw;
     job.OutputColor = outColor; job.OutputNormal = outNormal; job.OutputAlbedo = outAlbedo; job.OutputSampleCountWeight = outScw;
     job.OutputDiagnostics = (uint8_t*)diagnostics;
@@ -1796,4 +1962,5 @@ ORACLE_API void oracle_abi_sizes(int* out)
     out[6] = (int)sizeof(RtowEnvironment); out[7] = (int)sizeof(RtowSampleParams); out[8] = (int)sizeof(RtowAccumBuffers);
     out[9] = (int)sizeof(RtowContextOptions); out[10] = (int)sizeof(RtowMetrics); out[11] = (int)sizeof(RtowCombineParams);
     out[12] = (int)sizeof(RtowTriangle); out[13] = (int)sizeof(RtowCubemapDesc);
+    out[14] = (int)sizeof(RtowBlueNoiseDesc); out[15] = (int)sizeof(RtowStbNoiseDesc);
 }

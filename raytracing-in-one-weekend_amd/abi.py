@@ -98,6 +98,15 @@ class CubemapDesc(C.Structure):
                 ("faces", C.c_void_p)]
 
 
+class BlueNoiseDesc(C.Structure):
+    _fields_ = [("rowStride", C.c_uint32), ("textureCount", C.c_uint32), ("texels", C.c_void_p)]
+
+
+class StbNoiseDesc(C.Structure):
+    _fields_ = [("rowStride", C.c_uint32), ("textureCount", C.c_uint32), ("scalar", C.c_void_p), ("vector2", C.c_void_p),
+                ("cosineUnitVector3", C.c_void_p), ("unitVector2", C.c_void_p), ("unitVector3", C.c_void_p)]
+
+
 class Environment(C.Structure):
     _fields_ = [("skyType", C.c_int32), ("skyBottomColor", Float3), ("skyTopColor", Float3)]
 
@@ -106,7 +115,7 @@ class SampleParams(C.Structure):
     _fields_ = [("size", Float2), ("sliceOffset", C.c_int32), ("sliceDivider", C.c_int32), ("seed", C.c_uint32),
                 ("view", View), ("environment", Environment), ("sampleCountRange", C.c_uint32 * 2),
                 ("traceDepth", C.c_int32), ("subPixelJitter", C.c_int32), ("noiseColor", C.c_int32),
-                ("sampleCountWeightExtrema", Float2), ("diagnosticsStride", C.c_int32), ("reserved", C.c_int32)]
+                ("sampleCountWeightExtrema", Float2), ("diagnosticsStride", C.c_int32), ("noiseTextureIndex", C.c_int32)]
 
 
 class AccumBuffers(C.Structure):
@@ -134,7 +143,7 @@ class CombineParams(C.Structure):
 # every symbol include/rtow.h declares (tests/test_abi.py checks the library exports all of them)
 EXPORTED_SYMBOLS = [
     "rtowGetApiVersion", "rtowErrorString", "rtowCreateContext", "rtowDestroyContext", "rtowUploadScene",
-    "rtowUploadSkyCubemap", "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
+    "rtowUploadSkyCubemap", "rtowUploadBlueNoise", "rtowUploadStbNoise", "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
     "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize",
 ]

@@ -56,6 +56,11 @@ struct RtowContext_t {
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
     volatile uint32_t* hCancel = nullptr; // pinned, device-visible
+    // noise texture sets (rtowUploadBlueNoise / rtowUploadStbNoise): device copies, `textureCount` textures back to back
+    uint8_t* dBlueNoise = nullptr;
+    uint32_t blueRowStride = 0, blueTextureCount = 0;
+    uint8_t* dStbNoise = nullptr;        // scalar | vector2 | cosineUnitVector3 | unitVector2 | unitVector3 sets, in this order
+    uint32_t stbRowStride = 0, stbTextureCount = 0;
     // sky cubemap (rtowUploadSkyCubemap)
     uint8_t* dCubemap = nullptr;
     size_t cubemapCapacity = 0;
@@ -106,7 +111,7 @@ int validateParams(const RtowSampleParams* p)
     if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return RTOW_ERROR_INVALID_VALUE;
     if (p->sliceDivider < 1 || p->sliceOffset < 0 || p->sliceOffset >= p->sliceDivider) return RTOW_ERROR_INVALID_VALUE;
     if (p->traceDepth < 1 || p->traceDepth > 64) return p->traceDepth < 1 ? RTOW_ERROR_INVALID_VALUE : RTOW_ERROR_CAPACITY;
-    if (p->noiseColor != RTOW_NOISE_WHITE) return RTOW_ERROR_UNSUPPORTED;
+    if (p->noiseColor < RTOW_NOISE_WHITE || p->noiseColor > RTOW_NOISE_SPATIOTEMPORAL_BLUE) return RTOW_ERROR_INVALID_VALUE;
     if (p->environment.skyType < RTOW_SKY_NONE || p->environment.skyType > RTOW_SKY_CUBEMAP) return RTOW_ERROR_INVALID_VALUE;
     if (p->diagnosticsStride != 4 && p->diagnosticsStride != 16) return RTOW_ERROR_INVALID_VALUE;
     return RTOW_SUCCESS;
@@ -147,6 +152,21 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.subPixelJitter = p->subPixelJitter;
     a.extremaX = p->sampleCountWeightExtrema.x;
     a.extremaY = p->sampleCountWeightExtrema.y;
+    a.noiseColor = p->noiseColor;
+    if (p->noiseColor == RTOW_NOISE_BLUE) {
+        if (!ctx->dBlueNoise || p->noiseTextureIndex < 0 || (uint32_t)p->noiseTextureIndex >= ctx->blueTextureCount) return RTOW_ERROR_INVALID_VALUE;
+        a.blueRowStride = ctx->blueRowStride;
+        a.blueNoise = ctx->dBlueNoise + (size_t)p->noiseTextureIndex * ctx->blueRowStride * ctx->blueRowStride * 8u;
+    } else if (p->noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) {
+        if (!ctx->dStbNoise || p->noiseTextureIndex < 0 || (uint32_t)p->noiseTextureIndex >= ctx->stbTextureCount) return RTOW_ERROR_INVALID_VALUE;
+        const size_t texels = (size_t)ctx->stbRowStride * ctx->stbRowStride, all = texels * ctx->stbTextureCount, t = (size_t)p->noiseTextureIndex * texels;
+        a.stbRowStride = ctx->stbRowStride;
+        a.stbScalar = ctx->dStbNoise + t;                                    // 1 byte per texel
+        a.stbVector2 = ctx->dStbNoise + all + t * 3;                         // RGB24
+        a.stbCosineUnitVector3 = ctx->dStbNoise + all * 4 + t * 4;           // RGBA32
+        a.stbUnitVector2 = ctx->dStbNoise + all * 8 + t * 3;                 // RGB24
+        a.stbUnitVector3 = ctx->dStbNoise + all * 11 + t * 3;                // RGB24
+    }
     a.cubemapData = ctx->dCubemap;
     a.cubemapHalfW = ctx->cubemap.faceWidth / 2; a.cubemapHalfH = ctx->cubemap.faceHeight / 2;                  // RT/Texture.cs:152-154
     a.cubemapW1 = ctx->cubemap.faceWidth - 1; a.cubemapH1 = ctx->cubemap.faceHeight - 1;
@@ -389,6 +409,8 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
     if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
     if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);
+    if (ctx->dBlueNoise) (void)hipFree(ctx->dBlueNoise);
+    if (ctx->dStbNoise) (void)hipFree(ctx->dStbNoise);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
@@ -477,6 +499,49 @@ RTOW_API int rtowUploadSkyCubemap(RtowContext ctx, const RtowCubemapDesc* cubema
     ctx->cubemap.faces = nullptr;
     logf(ctx, 3, "sky", "cubemap %dx%d, %s, stride %d (%zu bytes)", cubemap->faceWidth, cubemap->faceHeight,
          cubemap->channelType == RTOW_CUBEMAP_SIGNED_HALF ? "half" : "byte", cubemap->pixelStride, bytes);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowUploadBlueNoise(RtowContext ctx, const RtowBlueNoiseDesc* noise)
+{
+    if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipDeviceSynchronize(), RTOW_ERROR_LAUNCH_FAILURE);
+    if (ctx->dBlueNoise) (void)hipFree(ctx->dBlueNoise);
+    ctx->dBlueNoise = nullptr;
+    ctx->blueRowStride = ctx->blueTextureCount = 0;
+    if (!noise || !noise->texels) return RTOW_SUCCESS;
+    if (noise->rowStride == 0 || noise->rowStride > 16384 || noise->textureCount == 0 || noise->textureCount > 4096) return RTOW_ERROR_INVALID_VALUE;
+    const size_t bytes = (size_t)noise->rowStride * noise->rowStride * noise->textureCount * 8u;      // half4 texels
+    HIP_TRY(ctx, hipMalloc(&ctx->dBlueNoise, bytes), RTOW_ERROR_MEMORY_ALLOCATION);
+    HIP_TRY(ctx, hipMemcpy(ctx->dBlueNoise, noise->texels, bytes, hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    ctx->blueRowStride = noise->rowStride;
+    ctx->blueTextureCount = noise->textureCount;
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowUploadStbNoise(RtowContext ctx, const RtowStbNoiseDesc* noise)
+{
+    if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    HIP_TRY(ctx, hipDeviceSynchronize(), RTOW_ERROR_LAUNCH_FAILURE);
+    if (ctx->dStbNoise) (void)hipFree(ctx->dStbNoise);
+    ctx->dStbNoise = nullptr;
+    ctx->stbRowStride = ctx->stbTextureCount = 0;
+    if (!noise) return RTOW_SUCCESS;
+    if (!noise->scalar || !noise->vector2 || !noise->cosineUnitVector3 || !noise->unitVector2 || !noise->unitVector3) return RTOW_ERROR_INVALID_VALUE;
+    if (noise->rowStride == 0 || noise->rowStride > 16384 || noise->textureCount == 0 || noise->textureCount > 4096) return RTOW_ERROR_INVALID_VALUE;
+    const size_t all = (size_t)noise->rowStride * noise->rowStride * noise->textureCount;
+    HIP_TRY(ctx, hipMalloc(&ctx->dStbNoise, all * 14u), RTOW_ERROR_MEMORY_ALLOCATION);                // 1 + 3 + 4 + 3 + 3 bytes per texel
+    HIP_TRY(ctx, hipMemcpy(ctx->dStbNoise, noise->scalar, all, hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpy(ctx->dStbNoise + all, noise->vector2, all * 3, hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpy(ctx->dStbNoise + all * 4, noise->cosineUnitVector3, all * 4, hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpy(ctx->dStbNoise + all * 8, noise->unitVector2, all * 3, hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpy(ctx->dStbNoise + all * 11, noise->unitVector3, all * 3, hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    ctx->stbRowStride = noise->rowStride;
+    ctx->stbTextureCount = noise->textureCount;
     return RTOW_SUCCESS;
 }
 

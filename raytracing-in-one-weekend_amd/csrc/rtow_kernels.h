@@ -65,6 +65,16 @@ struct SampleKernelArgs {
     int32_t subPixelJitter;
     float extremaX, extremaY;
 
+    // noise source (RT/RandomSource.cs): the texture of this batch for Blue / SpatioTemporalBlue (null for white)
+    int32_t noiseColor;                   // RtowNoiseColor
+    uint32_t blueRowStride, stbRowStride;
+    const void* blueNoise;                // half4[blueRowStride^2]
+    const uint8_t* stbScalar;             // byte
+    const uint8_t* stbVector2;            // RGB24
+    const uint8_t* stbCosineUnitVector3;  // RGBA32
+    const uint8_t* stbUnitVector2;        // RGB24
+    const uint8_t* stbUnitVector3;        // RGB24
+
     // sky cubemap (RT/Texture.cs:141-211), used when environment.skyType == RTOW_SKY_CUBEMAP; cubemapData may be null (-> black)
     const uint8_t* cubemapData;
     int32_t cubemapHalfW, cubemapHalfH, cubemapW1, cubemapH1;   // halfFaceSize, faceSizeMinusOne

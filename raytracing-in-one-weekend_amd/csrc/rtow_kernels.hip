@@ -78,18 +78,18 @@ __device__ __forceinline__ float rng_next(unsigned& state)
     return __uint_as_float(0x3f800000u | (t >> 9)) - 1.0f;
 }
 
-// RandomSource.OnCosineWeightedHemisphere (RT/RandomSource.cs:63-89) + Tools.TangentToWorldSpace (UTIL/Tools.cs:19-37)
-__device__ __forceinline__ V3 cosine_hemisphere(unsigned& rng, V3 n)
+// Unity.Mathematics.half -> float (exact)
+__device__ __forceinline__ float half_bits_to_float(unsigned h)
 {
-    const float u = rng_next(rng);
-    const float v = rng_next(rng);
-    const float radius = __builtin_sqrtf(u);
-    const float theta = v * 2 * kPi;
-    float sinT, cosT;
-    det_sincos(theta, sinT, cosT);
-    const float tx = radius * cosT, tz = radius * sinT;
-    const float ty = __builtin_sqrtf(1 - u);
-
+    const unsigned sign = (h & 0x8000u) << 16;
+    const unsigned exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    if (exp == 0) return __uint_as_float(__float_as_uint((float)man * 5.9604644775390625e-8f) | sign);   // zero / subnormal: man * 2^-24, exact
+    if (exp == 31) return __uint_as_float(sign | 0x7f800000u | (man << 13));
+    return __uint_as_float(sign | ((exp + 112u) << 23) | (man << 13));
+}
+// Tools.TangentToWorldSpace (UTIL/Tools.cs:19-37): corrected Frisvad / Pixar basis, float3x3(tangent, normal, bitangent) * v, normalized
+__device__ __forceinline__ V3 tangent_to_world(float tx, float ty, float tz, V3 n)
+{
     const float s = n.z >= 0 ? 1.0f : -1.0f;
     const float a = -1 / (s + n.z);
     const float b = n.x * n.y * a;
@@ -100,6 +100,137 @@ __device__ __forceinline__ V3 cosine_hemisphere(unsigned& rng, V3 n)
                     tangent.z * tx + n.z * ty + bitangent.z * tz);
     return normalize(r);
 }
+// RandomSource.OnCosineWeightedHemisphere (RT/RandomSource.cs:63-89) from its two uniform numbers
+__device__ __forceinline__ V3 cosine_hemisphere_uv(float u, float v, V3 n)
+{
+    const float radius = __builtin_sqrtf(u);
+    const float theta = v * 2 * kPi;
+    float sinT, cosT;
+    det_sincos(theta, sinT, cosT);
+    const float tx = radius * cosT, tz = radius * sinT;
+    const float ty = __builtin_sqrtf(1 - u);
+    return tangent_to_world(tx, ty, tz, n);
+}
+// RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128) from its two uniform numbers
+__device__ __forceinline__ V3 direction_uv(float r0, float r1)
+{
+    const float z = r0 * 2.0f - 1.0f;
+    const float rr = __builtin_sqrtf(um_max(1.0f - z * z, 0.0f));
+    const float angle = r1 * kPi * 2.0f;
+    float sn, cs;
+    det_sincos(angle, sn, cs);
+    return v3(cs * rr, sn * rr, z);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// RandomSource (RT/RandomSource.cs:15-150), one specialisation per NoiseColor.
+//   White              Unity.Mathematics.Random, seeded per pixel (JOBS/SampleBatchJob.cs:91)
+//   Blue               RT/BlueNoise.cs: one half4 texture walked by PerPixelNoise (RT/PerPixelNoise.cs) - the R2 sequence (RT/R2.cs) gives
+//                      the same offsets to every pixel, the pixel's coordinates shift them; NextFloat2 is .xy of ONE texel
+//   SpatioTemporalBlue RT/SpatioTemporalBlueNoise.cs: five byte textures (scalar, vector2, cosine-weighted unit vector3, unit vector2,
+//                      unit vector3), each with its own PerPixelNoise walk
+// PerPixelNoise keeps (offset, n) with offset = floor(R2(n - 1) * rowStride): a function of n, so n alone is the state.
+// ------------------------------------------------------------------------------------------------------------
+struct NoiseSite { const SampleKernelArgs* A; unsigned cx, cy; };   // where the texture-driven sources read: the batch's textures, the pixel
+
+// index of the texel PerPixelNoise.Next() reads for counter value n (n = seed + 1 + number of earlier Next() calls), RT/PerPixelNoise.cs:27-38
+__device__ __forceinline__ unsigned noise_texel(unsigned n, unsigned rowStride, unsigned cx, unsigned cy)
+{
+    constexpr float g = 1.32471795724474602596f;        // RT/R2.cs:11-13, folded one binary32 operation at a time
+    constexpr float a1 = 1.0f / g;
+    constexpr float a2 = 1.0f / (g * g);
+    const float fn = (float)(n - 1u);
+    const float x = 0.5f + a1 * fn, y = 0.5f + a2 * fn;
+    const float rx = x - __builtin_floorf(x), ry = y - __builtin_floorf(y);          // % 1 of a non-negative float: exact
+    const unsigned ox = (unsigned)__builtin_floorf(rx * (float)rowStride), oy = (unsigned)__builtin_floorf(ry * (float)rowStride);
+    return ((cy + oy) % rowStride) * rowStride + ((cx + ox) % rowStride);
+}
+
+template <int NOISE>
+struct Rng;
+
+template <>
+struct Rng<RTOW_NOISE_WHITE> {
+    unsigned s;
+    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned pix)
+    {
+        s = (at.A->seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u);   // :91; the Random ctor then discards one NextState()
+        (void)rng_next(s);
+    }
+    __device__ __forceinline__ float next(const NoiseSite&) { return rng_next(s); }
+    __device__ __forceinline__ void next2(const NoiseSite&, float& a, float& b) { a = rng_next(s); b = rng_next(s); }
+    __device__ __forceinline__ void in_unit_disk(const NoiseSite&, float& x, float& y)       // RT/RandomSource.cs:40-61
+    {
+        const float theta = rng_next(s) * (2.0f * kPi - 0.0f) + 0.0f;                        // NextFloat(0, 2 * PI)
+        const float radius = __builtin_sqrtf(rng_next(s));
+        float sinT, cosT;
+        det_sincos(theta, sinT, cosT);
+        x = radius * cosT; y = radius * sinT;
+    }
+    __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite&, V3 n) { const float u = rng_next(s), v = rng_next(s); return cosine_hemisphere_uv(u, v, n); }
+    __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite&) { (void)rng_next(s); (void)rng_next(s); }
+    __device__ __forceinline__ V3 direction(const NoiseSite&) { const float r0 = rng_next(s), r1 = rng_next(s); return direction_uv(r0, r1); }
+    __device__ __forceinline__ unsigned trace_value() const { return s; }
+};
+
+template <>
+struct Rng<RTOW_NOISE_BLUE> {
+    unsigned s;                                                   // PerPixelNoise.n
+    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = at.A->seed + 1u; }   // n = seed; Advance() (:17-25)
+    __device__ __forceinline__ void texel(const NoiseSite& at, float& x, float& y)
+    {
+        const uint2 t = reinterpret_cast<const uint2*>(at.A->blueNoise)[noise_texel(s, at.A->blueRowStride, at.cx, at.cy)];   // half4
+        s++;
+        x = half_bits_to_float(t.x & 0xffffu); y = half_bits_to_float(t.x >> 16);
+    }
+    __device__ __forceinline__ float next(const NoiseSite& at) { float x, y; texel(at, x, y); return x; }              // BlueNoise.cs:26
+    __device__ __forceinline__ void next2(const NoiseSite& at, float& a, float& b) { texel(at, a, b); }                  // BlueNoise.cs:28
+    __device__ __forceinline__ void in_unit_disk(const NoiseSite& at, float& x, float& y)
+    {
+        const float theta = next(at) * 2 * kPi;
+        const float radius = __builtin_sqrtf(next(at));
+        float sinT, cosT;
+        det_sincos(theta, sinT, cosT);
+        x = radius * cosT; y = radius * sinT;
+    }
+    __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite& at, V3 n) { float u, v; texel(at, u, v); return cosine_hemisphere_uv(u, v, n); }
+    __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite&) { s++; }
+    __device__ __forceinline__ V3 direction(const NoiseSite& at) { float r0, r1; texel(at, r0, r1); return direction_uv(r0, r1); }
+    __device__ __forceinline__ unsigned trace_value() const { return s; }
+};
+
+template <>
+struct Rng<RTOW_NOISE_SPATIOTEMPORAL_BLUE> {
+    unsigned s, v2, cs, u2, u3;                                   // n of perPixelScalar / Vector2 / CosineUnitVector3 / UnitVector2 / UnitVector3
+    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = v2 = cs = u2 = u3 = at.A->seed + 1u; }
+    __device__ __forceinline__ float next(const NoiseSite& at)                                                           // STBN :61
+    {
+        const unsigned i = noise_texel(s++, at.A->stbRowStride, at.cx, at.cy);
+        return (float)at.A->stbScalar[i] / 256.0f;
+    }
+    __device__ __forceinline__ void next2(const NoiseSite& at, float& a, float& b)                                       // :63-67
+    {
+        const uint8_t* t = at.A->stbVector2 + (size_t)noise_texel(v2++, at.A->stbRowStride, at.cx, at.cy) * 3u;
+        a = (float)t[0] / 256.0f; b = (float)t[1] / 256.0f;
+    }
+    __device__ __forceinline__ void in_unit_disk(const NoiseSite& at, float& x, float& y)                                // NextUnitVector2, :75-79
+    {
+        const uint8_t* t = at.A->stbUnitVector2 + (size_t)noise_texel(u2++, at.A->stbRowStride, at.cx, at.cy) * 3u;
+        x = (float)t[0] / 256.0f * 2 - 1; y = (float)t[1] / 256.0f * 2 - 1;
+    }
+    __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite& at, V3 n)                                           // NextCosineUnitVector3, :69-73: (r, b, g)
+    {
+        const uint8_t* t = at.A->stbCosineUnitVector3 + (size_t)noise_texel(cs++, at.A->stbRowStride, at.cx, at.cy) * 4u;
+        return tangent_to_world((float)t[0] / 256.0f * 2 - 1, (float)t[2] / 256.0f * 2 - 1, (float)t[1] / 256.0f * 2 - 1, n);
+    }
+    __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite&) { cs++; }
+    __device__ __forceinline__ V3 direction(const NoiseSite& at)                                                         // NextUnitVector3, :81-85
+    {
+        const uint8_t* t = at.A->stbUnitVector3 + (size_t)noise_texel(u3++, at.A->stbRowStride, at.cx, at.cy) * 3u;
+        return v3((float)t[0] / 256.0f * 2 - 1, (float)t[1] / 256.0f * 2 - 1, (float)t[2] / 256.0f * 2 - 1);
+    }
+    __device__ __forceinline__ unsigned trace_value() const { return s; }
+};
 
 // Microfacet.TrowbridgeReitz.RoughnessToAlpha / Lambda, SmithMaskingShadowing (RT/Microfacet.cs:9-12,53-80)
 __device__ __forceinline__ float roughness_to_alpha(float roughness)
@@ -130,14 +261,6 @@ __device__ __forceinline__ float smith_g1(V3 w, V3 n, float alpha /* = Roughness
 // Cubemap.Sample (RT/Texture.cs:171-210): the face is the first axis whose |component| is the largest (x before y before z), the
 // texel min((int2)((uv + 1) * halfFaceSize), faceSizeMinusOne) of that face, point sampled; RGBA half or byte channels.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float half_bits_to_float(unsigned h)
-{
-    const unsigned sign = (h & 0x8000u) << 16;
-    const unsigned exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
-    if (exp == 0) return __uint_as_float(__float_as_uint((float)man * 5.9604644775390625e-8f) | sign);   // zero / subnormal: man * 2^-24, exact
-    if (exp == 31) return __uint_as_float(sign | 0x7f800000u | (man << 13));
-    return __uint_as_float(sign | ((exp + 112u) << 23) | (man << 13));
-}
 __device__ __forceinline__ V3 cubemap_sample(const SampleKernelArgs& A, V3 d)
 {
     if (!A.cubemapData) return v3(0, 0, 0);
@@ -352,7 +475,7 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 #define STAT_ADD(i, v) stat[i] += (unsigned long long)(v)
 #define STAT_LANES(i) stat[i] += 1ull
 // per-segment trace of one pixel: {smp, depth, kind, prim, t bits, curVol, nHits, rng}
-#define DBG_TRACE(kind, primv, tv) do { if (A.stats && pix == A.debugPixel) { const unsigned long long k_ = atomicAdd(&A.stats[20], 1ull); if (k_ < 500) { unsigned long long* d_ = A.stats + 5000 + k_ * 8; d_[0] = smp; d_[1] = (unsigned)depth; d_[2] = (kind); d_[3] = (unsigned)(primv); d_[4] = __float_as_uint(tv); d_[5] = (unsigned)curVol; d_[6] = (unsigned)nHits; d_[7] = rng; } } } while (0)
+#define DBG_TRACE(kind, primv, tv) do { if (A.stats && pix == A.debugPixel) { const unsigned long long k_ = atomicAdd(&A.stats[20], 1ull); if (k_ < 500) { unsigned long long* d_ = A.stats + 5000 + k_ * 8; d_[0] = smp; d_[1] = (unsigned)depth; d_[2] = (kind); d_[3] = (unsigned)(primv); d_[4] = __float_as_uint(tv); d_[5] = (unsigned)curVol; d_[6] = (unsigned)nHits; d_[7] = rng.trace_value(); } } } while (0)
 #else
 #define DBG_TRACE(kind, primv, tv)
 #define STAT_DECL
@@ -417,7 +540,7 @@ enum : int {
     ST_COUNT = 6
 };
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG>
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE>
 __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -456,7 +579,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     int st = ST_REGEN;
     int pix = -1;
     unsigned tick = 0;          // ticket (owned-pixel number) of the current pixel
-    unsigned rng = 0;
+    Rng<NOISE> rng{};
     unsigned smp = 0, nsamp = 0;
     int cx = 0, cy = 0;
     V3 colorAcc = v3(0, 0, 0), normalAcc = v3(0, 0, 0), albedoAcc = v3(0, 0, 0);
@@ -630,8 +753,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     sampleCount = (int)last.w;
 
                     // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
-                    rng = (A.seed * 0x8C4CA03Fu) ^ ((unsigned)pix * 0x7383ED49u);
-                    (void)rng_next(rng);
+                    rng.begin_pixel(NoiseSite{&A, (unsigned)cx, (unsigned)cy}, (unsigned)pix);
 
                     // :118-126
                     const float w = scwAcc / (float)sampleCount;
@@ -655,25 +777,23 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const V3 viewLLC = v3(A.view.lowerLeftCorner), viewH = v3(A.view.horizontal), viewV = v3(A.view.vertical);
                     const float lensRadius = A.view.lensRadius;
                     float jx = 0.5f, jy = 0.5f;
-                    if (A.subPixelJitter) { jx = rng_next(rng); jy = rng_next(rng); }
+                    const NoiseSite at{&A, (unsigned)cx, (unsigned)cy};
+                    if (A.subPixelJitter) rng.next2(at, jx, jy);
                     const float u = ((float)cx + jx) / A.sizeX;
                     const float v = ((float)cy + jy) / A.sizeY;
                     float rdx = 0, rdy = 0;
                     if (lensRadius != 0) {
-                        // RandomSource.InUnitDisk (RT/RandomSource.cs:40-61): theta = NextFloat(0, 2*PI), radius = sqrt(NextFloat())
-                        const float theta = rng_next(rng) * (2.0f * kPi - 0.0f) + 0.0f;
-                        const float radius = __builtin_sqrtf(rng_next(rng));
-                        float sinT, cosT;
-                        det_sincos(theta, sinT, cosT);
-                        rdx = lensRadius * (radius * cosT);
-                        rdy = lensRadius * (radius * sinT);
+                        float dx, dy;
+                        rng.in_unit_disk(at, dx, dy);                                         // RandomSource.InUnitDisk (RT/RandomSource.cs:40-61)
+                        rdx = lensRadius * dx;
+                        rdy = lensRadius * dy;
                     }
                     const V3 offset = v3(viewRight.x * rdx + viewUp.x * rdy, viewRight.y * rdx + viewUp.y * rdy, viewRight.z * rdx + viewUp.z * rdy);
                     ro = add(v3(A.view.origin), offset);
                     rd = normalize(v3(viewLLC.x - offset.x + u * viewH.x + v * viewV.x,
                                       viewLLC.y - offset.y + u * viewH.y + v * viewV.y,
                                       viewLLC.z - offset.z + u * viewH.z + v * viewV.z));
-                    rtime = rng_next(rng);
+                    rtime = rng.next(at);
 
                     depth = 0;
                     hist.clear();
@@ -836,29 +956,22 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 bool white = false;
                 bool perfectSpecular = false;
                 V3 sdir;
+                const NoiseSite at{&A, (unsigned)cx, (unsigned)cy};
                 float randomEvents = VOLUMES ? pendRE : 0.0f;     // rng.RandomEvents may already hold ProbabilisticHit's increments
                 pendRE = 0;
 
                 if (VOLUMES && cls == MAT_CLASS_VOLUME) {
                     // ProbabilisticVolume (RT/Material.cs:163-168): isotropic scatter, ray time reset to 0, RandomEvents += 2
-                    const float r0 = rng_next(rng);
-                    const float r1 = rng_next(rng);
-                    const float z = r0 * 2.0f - 1.0f;
-                    const float rr = __builtin_sqrtf(um_max(1.0f - z * z, 0.0f));
-                    const float angle = r1 * kPi * 2.0f;
-                    float sn, cs;
-                    det_sincos(angle, sn, cs);
-                    sdir = v3(cs * rr, sn * rr, z);
+                    sdir = rng.direction(at);                          // NextFloat3Direction
                     rtime = 0;
                     randomEvents += 2;
                 } else if (cls == MAT_CLASS_LAMBERT) {
                     STAT_ADD(9, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(10);
                     // Standard with glossiness == 0 and metallic == 0 (RT/Material.cs:75-119): roughness = 1, so the rough normal
-                    // costs two draws whose result is never used (reflectionChance = saturate(fresnel * 0 * g1) = 0, and the
+                    // costs one cosine-hemisphere draw (two white-noise numbers) whose result is never used (reflectionChance = saturate(fresnel * 0 * g1) = 0, and the
                     // rough-metal branch needs metallic > 0); RandomEvents = 0 + 0 + 1 * 0 + 1 * 1.
-                    (void)rng_next(rng);
-                    (void)rng_next(rng);
-                    sdir = cosine_hemisphere(rng, N);
+                    rng.skip_cosine_hemisphere(at);
+                    sdir = rng.cosine_hemisphere(at, N);
                     randomEvents += 1.0f;                          // 0 + 0 + 1 * 0 + 1 * 1 on top of whatever was pending
                 } else if (cls == MAT_CLASS_GENERAL) {                                        // RT/Material.cs:75-119
                     STAT_ADD(11, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(12);
@@ -870,7 +983,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     perfectSpecular = (__float_as_uint(m2.z) & MAT_FLAG_PERFECT_SPECULAR) != 0;
                     V3 roughN = N;
                     if (roughness > 0) {
-                        const V3 h = cosine_hemisphere(rng, N);
+                        const V3 h = rng.cosine_hemisphere(at, N);
                         roughN = normalize(v3(N.x + roughness * (h.x - N.x), N.y + roughness * (h.y - N.y), N.z + roughness * (h.z - N.z)));
                     }
                     const float incidentCosine = -dot(rd, roughN);
@@ -878,14 +991,14 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const float g1 = smith_g1(rd, N, m3.x);
                     const float reflectionChance = um_saturate(fresnel * glossiness * g1);
 
-                    if (reflectionChance > 0 && rng_next(rng) < reflectionChance) {
+                    if (reflectionChance > 0 && rng.next(at) < reflectionChance) {
                         sdir = reflect(rd, roughN);
                         reflectance = v3(1, 1, 1);
                         white = true;
-                    } else if (metallic > 0 && rng_next(rng) < metallic) {
+                    } else if (metallic > 0 && rng.next(at) < metallic) {
                         sdir = reflect(rd, roughN);
                     } else {
-                        sdir = cosine_hemisphere(rng, N);
+                        sdir = rng.cosine_hemisphere(at, N);
                     }
                     if (reflectionChance > 0 && reflectionChance < 1) randomEvents++;
                     if (metallic > 0 && metallic < 1) randomEvents++;
@@ -898,15 +1011,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     perfectSpecular = true;
                     const float ior = m2.y;
                     const float roughness = m2.w;                                 // 1 - glossiness
-                    // RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128)
-                    const float r0 = rng_next(rng);
-                    const float r1 = rng_next(rng);
-                    const float z = r0 * 2.0f - 1.0f;
-                    const float rr = __builtin_sqrtf(um_max(1.0f - z * z, 0.0f));
-                    const float angle = r1 * kPi * 2.0f;
-                    float sn, cs;
-                    det_sincos(angle, sn, cs);
-                    const V3 rdir = v3(cs * rr, sn * rr, z);
+                    const V3 rdir = rng.direction(at);                             // RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128)
                     const V3 roughN = normalize(v3(N.x + roughness * rdir.x, N.y + roughness * rdir.y, N.z + roughness * rdir.z));
 
                     float niOverNt, cosine;
@@ -925,7 +1030,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                                                 niOverNt * (rd.y - outwardN.y * dt) - outwardN.y * sq,
                                                 niOverNt * (rd.z - outwardN.z * dt) - outwardN.z * sq);
                         const float schlickV = m3.z + (1 - m3.z) * det_pow5(1 - cosine);
-                        if (rng_next(rng) > schlickV) { sdir = refracted; refractOk = true; }
+                        if (rng.next(at) > schlickV) { sdir = refracted; refractOk = true; }
                     }
                     if (!refractOk) {
                         sdir = reflect(rd, roughN);
@@ -1078,7 +1183,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             // Material.ProbabilisticHit (RT/Material.cs:49-65)
                             const float density = *reinterpret_cast<const float*>(section<ALL_LDS>(sc, L.materialOffset) + (unsigned)curVol * 64u + 36u);
                             pendRE++;
-                            const float volumeHitDistance = -(1 / um_max(density, 1.1920928955078125e-7f)) * det_log(rng_next(rng));
+                            const float volumeHitDistance = -(1 / um_max(density, 1.1920928955078125e-7f)) * det_log(rng.next(NoiseSite{&A, (unsigned)cx, (unsigned)cy}));
                             if (volumeHitDistance < distanceInVolume) {
                                 best = entryDistance + volumeHitDistance;                    // we hit inside the volume
                                 insideHit = true;
@@ -1449,10 +1554,10 @@ __global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG>
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE>
 hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG>;
+    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(numBlocks), dim3(kBlockThreads), ldsBytes, stream, args);
@@ -1462,9 +1567,12 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t lds
 template <bool ALL_LDS, int KIND, bool FULL_DIAG>
 hipError_t launchByDepth(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
-    return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG>(args, numBlocks, ldsBytes, stream);
+    // the texture-driven noise sources are not the hot configuration: one (generic-history) variant each keeps the build small
+    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_BLUE>(args, numBlocks, ldsBytes, stream);
+    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_SPATIOTEMPORAL_BLUE>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE>(args, numBlocks, ldsBytes, stream);
+    return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE>(args, numBlocks, ldsBytes, stream);
 }
 
 template <bool ALL_LDS, int KIND>

@@ -97,6 +97,14 @@ class Context:
         """`new Cubemap(skyCubemap)` (RT/Texture.cs:150-169): the six faces travel once; None drops the cubemap."""
         check(load().rtowUploadSkyCubemap(self.handle, C.byref(cubemap_desc) if cubemap_desc is not None else None), "rtowUploadSkyCubemap")
 
+    def upload_blue_noise(self, desc):
+        """BlueNoiseData's textures (UNITY/BlueNoiseData.cs): half4 texels, `textureCount` square textures; None drops the set."""
+        check(load().rtowUploadBlueNoise(self.handle, C.byref(desc) if desc is not None else None), "rtowUploadBlueNoise")
+
+    def upload_stb_noise(self, desc):
+        """SpatioTemporalBlueNoiseData's five texture sets (UNITY/SpatioTemporalBlueNoiseData.cs); None drops them."""
+        check(load().rtowUploadStbNoise(self.handle, C.byref(desc) if desc is not None else None), "rtowUploadStbNoise")
+
     def scene_info(self):
         info = abi.SceneInfo()
         check(load().rtowGetSceneInfo(self.handle, C.byref(info)), "rtowGetSceneInfo")

@@ -48,6 +48,8 @@ def load():
     lib.rtowDestroyContext.argtypes = [vp]
     lib.rtowUploadScene.argtypes = [vp, C.POINTER(abi.SceneDesc)]
     lib.rtowUploadSkyCubemap.argtypes = [vp, C.POINTER(abi.CubemapDesc)]
+    lib.rtowUploadBlueNoise.argtypes = [vp, C.POINTER(abi.BlueNoiseDesc)]
+    lib.rtowUploadStbNoise.argtypes = [vp, C.POINTER(abi.StbNoiseDesc)]
     lib.rtowGetSceneInfo.argtypes = [vp, C.POINTER(abi.SceneInfo)]
     lib.rtowSampleBatch.argtypes = [vp, C.POINTER(abi.SampleParams), AB, AB, vp, vp]
     lib.rtowSampleBatchDevice.argtypes = [vp, C.POINTER(abi.SampleParams), AB, AB, vp, vp, vp]

@@ -562,6 +562,34 @@ def make_view(scene, width, height, focus=None):
     return abi.View(v3(origin), v3(llc), v3(horizontal), v3(vertical), v3(forward), v3(up_v), v3(right), float(lens_radius))
 
 
+class NoiseTextures:
+    """Stand-ins for the host's noise textures (the reference's blue-noise assets are not in the mount; any texel values exercise the
+    samplers): a set of `count` square half4 textures for BlueNoise, and the five byte-texture sets of SpatioTemporalBlueNoise."""
+
+    def __init__(self, row_stride=16, count=2, seed=11):
+        rng = np.random.default_rng(seed)
+        n = count * row_stride * row_stride
+        self.row_stride, self.count = row_stride, count
+        self.blue = rng.random((n, 4), dtype=np.float32).astype(np.float16)                # half4, values in [0, 1)
+        self.scalar = rng.integers(0, 256, n, dtype=np.uint8)
+        self.vector2 = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        self.unit_vector2 = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        self.unit_vector3 = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        # cosine-weighted unit vectors, stored the way the reference decodes them: (r, b, g) / 256 * 2 - 1 = (x, y, z), y up
+        u, v = rng.random(n), rng.random(n)
+        r, th = np.sqrt(u), 2 * np.pi * v
+        x, y, z = r * np.cos(th), np.sqrt(1 - u), r * np.sin(th)
+        enc = lambda a: np.clip(np.floor((a + 1) / 2 * 256), 0, 255).astype(np.uint8)
+        self.cosine_unit_vector3 = np.stack([enc(x), enc(z), enc(y), np.full(n, 255, np.uint8)], axis=1)
+
+    def blue_desc(self):
+        return abi.BlueNoiseDesc(self.row_stride, self.count, self.blue.ctypes.data)
+
+    def stb_desc(self):
+        return abi.StbNoiseDesc(self.row_stride, self.count, self.scalar.ctypes.data, self.vector2.ctypes.data, self.cosine_unit_vector3.ctypes.data,
+                                self.unit_vector2.ctypes.data, self.unit_vector3.ctypes.data)
+
+
 class SkyCubemap:
     """Six faces (+X -X +Y -Y +Z -Z, contiguous) of a sky cube in the layout `Cubemap` expects (RT/Texture.cs:141-211)."""
 
@@ -606,7 +634,7 @@ def synthetic_sky(size=64, half=True, seed=3):
 
 
 def make_params(scene, width, height, spp, trace_depth, seed=1, jitter=True, slice_offset=0, slice_divider=1,
-                spp_max=None, extrema=(0.0, 0.0), diagnostics_stride=4, focus=None, sky_type=None):
+                spp_max=None, extrema=(0.0, 0.0), diagnostics_stride=4, focus=None, sky_type=None, noise_color=None, noise_texture_index=0):
     """SampleBatchJob parameter block with the benchmark defaults of SURVEY.md section 8(d)."""
     p = abi.SampleParams()
     p.size = abi.Float2(float(width), float(height))
@@ -619,8 +647,8 @@ def make_params(scene, width, height, spp, trace_depth, seed=1, jitter=True, sli
     p.sampleCountRange[1] = spp if spp_max is None else spp_max
     p.traceDepth = trace_depth
     p.subPixelJitter = 1 if jitter else 0
-    p.noiseColor = abi.NOISE_WHITE
+    p.noiseColor = abi.NOISE_WHITE if noise_color is None else noise_color
     p.sampleCountWeightExtrema = abi.Float2(float(extrema[0]), float(extrema[1]))
     p.diagnosticsStride = diagnostics_stride
-    p.reserved = 0
+    p.noiseTextureIndex = noise_texture_index
     return p

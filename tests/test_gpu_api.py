@@ -119,7 +119,8 @@ def test_error_codes(rt, gpu_context):
 
     fresh.upload_scene(scene.desc())
     for field, value, code in (("traceDepth", 0, a.RTOW_ERROR_INVALID_VALUE), ("traceDepth", 65, a.RTOW_ERROR_CAPACITY),
-                               ("sliceDivider", 0, a.RTOW_ERROR_INVALID_VALUE), ("noiseColor", a.NOISE_BLUE, a.RTOW_ERROR_UNSUPPORTED),
+                               ("sliceDivider", 0, a.RTOW_ERROR_INVALID_VALUE), ("noiseColor", a.NOISE_BLUE, a.RTOW_ERROR_INVALID_VALUE),   # no blue-noise set uploaded
+                               ("noiseColor", 3, a.RTOW_ERROR_INVALID_VALUE),
                                ("diagnosticsStride", 8, a.RTOW_ERROR_INVALID_VALUE)):
         q = rt.scenes.make_params(scene, 8, 8, spp=1, trace_depth=4)
         setattr(q, field, value)

@@ -192,3 +192,37 @@ def test_sky_cubemap(rt, oracle, gpu_context):
     finally:
         ctx.upload_sky_cubemap(None)
         osc.close()
+
+
+@pytest.mark.parametrize("noise_color", ["blue", "stbn"])
+def test_texture_driven_noise_sources(rt, oracle, gpu_context, noise_color):
+    """NoiseColor.Blue / SpatioTemporalBlue (RT/RandomSource.cs, RT/BlueNoise.cs, RT/SpatioTemporalBlueNoise.cs, RT/PerPixelNoise.cs, RT/R2.cs):
+    every branch of the source - jitter, lens disk, time, cosine hemisphere (and the lambert path's unused one), sphere direction, scalar
+    draws incl. ProbabilisticHit - on sphere, moving + defocus, general and volume scenes, both diagnostics layouts, several textures."""
+    ctx = gpu_context
+    color = rt.abi.NOISE_BLUE if noise_color == "blue" else rt.abi.NOISE_SPATIOTEMPORAL_BLUE
+    noise = rt.scenes.NoiseTextures(row_stride=16, count=3)
+    ctx.upload_blue_noise(noise.blue_desc())
+    ctx.upload_stb_noise(noise.stb_desc())
+    cases = [(rt.scenes.cover_scene(), dict(w=64, h=36, spp=8, depth=8, noise_texture_index=0)),
+             (rt.scenes.moving_scene(), dict(w=48, h=27, spp=8, depth=6, noise_texture_index=2, seed=77)),
+             (rt.scenes.mixed_scene(), dict(w=48, h=32, spp=6, depth=5, noise_texture_index=1, diagnostics_stride=16)),
+             (rt.scenes.volume_scene(), dict(w=40, h=40, spp=6, depth=12, noise_texture_index=1, focus=6.5)),
+             (rt.scenes.tiny_scene(), dict(w=32, h=18, spp=5, depth=20, noise_texture_index=0, jitter=False))]
+    try:
+        for scene, kw in cases:
+            desc = scene.desc()
+            kw = dict(kw)
+            p = rt.scenes.make_params(scene, kw.pop("w"), kw.pop("h"), spp=kw.pop("spp"), trace_depth=kw.pop("depth"), noise_color=color, **kw)
+            ctx.upload_scene(desc)
+            gpu = rt.sample_batch_host(ctx, p)
+            osc = oracle.OracleScene(desc)
+            osc.set_blue_noise(noise.blue_desc())
+            osc.set_stb_noise(noise.stb_desc())
+            ref = osc.sample_batch(p)
+            osc.close()
+            _compare(gpu, ref)
+            assert gpu["color"][:, 3].sum() > 0
+    finally:
+        ctx.upload_blue_noise(None)
+        ctx.upload_stb_noise(None)
