@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 2
+#define RTOW_API_VERSION 3
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -83,7 +83,7 @@ typedef enum RtowTextureType {     /* RT/Texture.cs:13-21 */
     RTOW_TEXTURE_CONSTANT = 1,
     RTOW_TEXTURE_CHECKER_PATTERN = 2, /* dead in the reference (commented out, RT/Texture.cs:61-78) */
     RTOW_TEXTURE_PERLIN_NOISE = 3,    /* dead in the reference                                      */
-    RTOW_TEXTURE_IMAGE = 4,           /* not built yet -> RTOW_ERROR_UNSUPPORTED                    */
+    RTOW_TEXTURE_IMAGE = 4,           /* RT/Texture.cs:80-89,126-135: byte image, point sampled at the hit's texture coordinates */
     RTOW_TEXTURE_CONSTANT_SCALAR = 5
 } RtowTextureType;
 
@@ -104,13 +104,23 @@ typedef enum RtowNoiseColor {      /* RT/RandomSource.cs:8-13 */
  * (RT/BvhNode.cs:8-9, RT/Entity.cs:35-37); that graph cannot cross to a device, so the
  * boundary takes the same information as flat arrays with indices. */
 
-/* Constant subset of RT/Texture.cs:23-49 (Type, MainColor, Parameter, ScalarValueChannel). */
+/* RT/Texture.cs:23-49 (Type, MainColor, Parameter, ScalarValueChannel; ImageSize / ImagePointer / PixelStride through imageIndex). */
 typedef struct RtowTexture {
     int32_t type;               /* RtowTextureType */
     RtowFloat3 mainColor;       /* Texture.MainColor */
     float parameter;            /* Texture.Parameter (ConstantValue for ConstantScalar) */
     int32_t scalarValueChannel; /* Texture.ScalarValueChannel (0..2) */
+    int32_t imageIndex;         /* RTOW_TEXTURE_IMAGE: index into RtowSceneDesc.images; < 0 = null ImagePointer (samples as 0, :82-83) */
 } RtowTexture;
+
+/* The pixel data an Image texture points at (Texture.ImagePointer / ImageSize / PixelStride, RT/Texture.cs:28-30): rows of `width`
+ * pixels, `pixelStride` bytes each, channels 0..2 = r, g, b (one byte each).  Point sampled at (int2)(uv * ImageSize) (:85-88);
+ * the reference reads out of bounds for uv outside [0, 1) - here the texel coordinate is clamped into the image. */
+typedef struct RtowImage {
+    int32_t width, height;
+    int32_t pixelStride;
+    const uint8_t* pixels;      /* host memory, copied by rtowUploadScene */
+} RtowImage;
 
 /* RT/Material.cs:16-47.  `parameter` is IndexOfRefraction (Dielectric) or Density (Volume);
  * the reference ctor leaves it 0 for Standard (Material.cs:36-45). */
@@ -154,6 +164,8 @@ typedef struct RtowSceneDesc {
     int32_t maxBvhDepth;            /* UNITY/Raytracer.cs:88 (prefab default 32); 0 = builder default */
     const RtowTriangle* triangles;  /* payloads of RTOW_ENTITY_TRIANGLE entities (RtowEntity.contentIndex); may be NULL */
     int32_t triangleCount;
+    const RtowImage* images;        /* pixel data of RTOW_TEXTURE_IMAGE textures (RtowTexture.imageIndex); may be NULL */
+    int32_t imageCount;
 } RtowSceneDesc;
 
 typedef struct RtowSceneInfo {

@@ -277,20 +277,41 @@ struct Texture {
     float3 MainColor;
     float Parameter;
     int ScalarValueChannel;
-    float3 SampleColor() const
+    int ImageSizeX = 0, ImageSizeY = 0;           /* ImageSize */
+    const uint8_t* ImagePointer = nullptr;
+    int PixelStride = 3;
+    /* (int2)(textureCoordinates * ImageSize), then the pixel (:85-87).  The reference indexes out of the image for coordinates
+     * outside [0, 1) (undefined); clamped here, as the product does. */
+    const uint8_t* Pixel(float2 uv) const
+    {
+        int x = (int)(uv.x * (float)ImageSizeX), y = (int)(uv.y * (float)ImageSizeY);
+        x = x < 0 ? 0 : x > ImageSizeX - 1 ? ImageSizeX - 1 : x;
+        y = y < 0 ? 0 : y > ImageSizeY - 1 ? ImageSizeY - 1 : y;
+        return ImagePointer + ((size_t)y * ImageSizeX + x) * PixelStride;
+    }
+    float3 SampleColor(float2 uv) const                                             /* RT/Texture.cs:51-93 */
     {
         switch (Type) {
             case RTOW_TEXTURE_CONSTANT: return MainColor;
             case RTOW_TEXTURE_CONSTANT_SCALAR: return f3(Parameter);
+            case RTOW_TEXTURE_IMAGE: {
+                if (ImagePointer == nullptr) return f3(0);
+                const uint8_t* p = Pixel(uv);
+                return f3((float)p[0], (float)p[1], (float)p[2]) / 255.0f * MainColor;
+            }
         }
         return f3(0);
     }
-    float SampleScalar() const
+    float SampleScalar(float2 uv) const                                             /* :96-138 */
     {
+        const float main = ScalarValueChannel == 0 ? MainColor.x : ScalarValueChannel == 1 ? MainColor.y : MainColor.z;
         switch (Type) {
-            case RTOW_TEXTURE_CONSTANT:
-                return ScalarValueChannel == 0 ? MainColor.x : ScalarValueChannel == 1 ? MainColor.y : MainColor.z;
+            case RTOW_TEXTURE_CONSTANT: return main;
             case RTOW_TEXTURE_CONSTANT_SCALAR: return Parameter;
+            case RTOW_TEXTURE_IMAGE: {
+                if (ImagePointer == nullptr) return 0.0f;
+                return (float)Pixel(uv)[ScalarValueChannel] / 255.0f * main;
+            }
         }
         return 0.0f;
     }
@@ -540,7 +561,7 @@ struct Material {
         return r0 + (1 - r0) * dm_powf(1 - cosine, 5);
     }
     /* :176-179 */
-    float3 Emit() const { return Emission.SampleColor(); }
+    float3 Emit(float2 texCoords) const { return Emission.SampleColor(texCoords); }
 
     /* :49-65 */
     bool ProbabilisticHit(float* hitDistance, RandomSource& rng) const
@@ -558,11 +579,11 @@ struct Material {
     /* :68-173 */
     void Scatter(const Ray& ray, const HitRecord& rec, RandomSource& rng, float3* reflectance, Ray* scattered) const
     {
-        *reflectance = Albedo.SampleColor();
+        *reflectance = Albedo.SampleColor(rec.TexCoords);
         switch (Type) {
             case RTOW_MATERIAL_STANDARD: {
-                const float metallic = Metallic.SampleScalar();
-                const float glossiness = Glossiness.SampleScalar();
+                const float metallic = Metallic.SampleScalar(rec.TexCoords);
+                const float glossiness = Glossiness.SampleScalar(rec.TexCoords);
 
                 const float roughness = dm_powf(1 - glossiness, 2);
                 const float3 roughNormal = roughness > 0
@@ -599,7 +620,7 @@ struct Material {
                 break;
             }
             case RTOW_MATERIAL_DIELECTRIC: {
-                const float roughness = 1 - Glossiness.SampleScalar();
+                const float roughness = 1 - Glossiness.SampleScalar(rec.TexCoords);
                 const float3 roughNormal = um_normalize(rec.Normal + roughness * rng.NextFloat3Direction());
 
                 float niOverNt, cosine;
@@ -965,6 +986,8 @@ struct OracleScene {
     std::vector<BvhNode> nodes;        /* node 0 = root */
     int maxDepthSeen = 0;
     bool unsupported = false;
+    struct ImageCopy { int width, height, pixelStride; std::vector<uint8_t> pixels; };
+    std::vector<ImageCopy> images;     /* pixel data of Image textures (the host's Texture2D data) */
     Cubemap skyCubemap;                /* Environment.SkyCubemap (RT/Environment.cs:16); set by oracle_scene_set_cubemap */
     std::vector<uint8_t> skyCubemapData;
     /* the host's noise texture sets (UNITY/BlueNoiseData.cs, UNITY/SpatioTemporalBlueNoiseData.cs); set by oracle_scene_set_*_noise */
@@ -1116,13 +1139,26 @@ struct OracleScene {
 
     void Build(const RtowSceneDesc* d)
     {
+        images.clear();
+        for (int i = 0; i < d->imageCount && d->images; i++) {
+            const RtowImage& im = d->images[i];
+            ImageCopy c{im.width, im.height, im.pixelStride, {}};
+            if (im.width <= 0 || im.height <= 0 || im.pixelStride < 3 || !im.pixels) unsupported = true;
+            else c.pixels.assign(im.pixels, im.pixels + (size_t)im.width * im.height * im.pixelStride);
+            images.push_back(std::move(c));
+        }
         materials.resize(d->materialCount);
         for (int i = 0; i < d->materialCount; i++) {
             const RtowMaterial& m = d->materials[i];
             auto tex = [this](const RtowTexture& t) {
-                if (t.type != RTOW_TEXTURE_NONE && t.type != RTOW_TEXTURE_CONSTANT && t.type != RTOW_TEXTURE_CONSTANT_SCALAR)
+                if (t.type != RTOW_TEXTURE_NONE && t.type != RTOW_TEXTURE_CONSTANT && t.type != RTOW_TEXTURE_CONSTANT_SCALAR && t.type != RTOW_TEXTURE_IMAGE)
                     unsupported = true;
-                return Texture{t.type, f3(t.mainColor), t.parameter, t.scalarValueChannel};
+                Texture r{t.type, f3(t.mainColor), t.parameter, t.scalarValueChannel};
+                if (t.type == RTOW_TEXTURE_IMAGE && t.imageIndex >= 0) {
+                    if (t.imageIndex >= (int)images.size()) unsupported = true;
+                    else { const ImageCopy& im = images[t.imageIndex]; r.ImageSizeX = im.width; r.ImageSizeY = im.height; r.PixelStride = im.pixelStride; r.ImagePointer = im.pixels.data(); }
+                }
+                return r;
             };
             /* RT/Material.cs:28-46: `parameter` only stored for Dielectric / ProbabilisticVolume */
             float parameter = 0;
@@ -1376,7 +1412,7 @@ struct Job {
                 Ray scatteredRay;
                 material->Scatter(ray, rec, rng, &albedo, &scatteredRay);                    /* :308 */
 
-                const float3 emission = material->Emit();                                    /* :310 */
+                const float3 emission = material->Emit(rec.TexCoords);                                    /* :310 */
                 s.emissionStack[cursor] = emission;                                          /* :311 */
 
                 if (depth == 0) *sampleNormal = rec.Normal;                                  /* :313-314 */
@@ -1906,7 +1942,7 @@ ORACLE_API void oracle_kat_scatter(const RtowMaterial* m, const float* ro, const
     float3 reflectance;
     Ray scattered;
     mat.Scatter(Ray(f3(ro[0], ro[1], ro[2]), f3(rd[0], rd[1], rd[2]), time), rec, rng, &reflectance, &scattered);
-    const float3 em = mat.Emit();
+    const float3 em = mat.Emit(rec.TexCoords);
     *rngState = rng.whiteNoise.state;
     out[0] = reflectance.x; out[1] = reflectance.y; out[2] = reflectance.z;
     out[3] = scattered.Origin.x; out[4] = scattered.Origin.y; out[5] = scattered.Origin.z;
@@ -1962,5 +1998,5 @@ ORACLE_API void oracle_abi_sizes(int* out)
     out[6] = (int)sizeof(RtowEnvironment); out[7] = (int)sizeof(RtowSampleParams); out[8] = (int)sizeof(RtowAccumBuffers);
     out[9] = (int)sizeof(RtowContextOptions); out[10] = (int)sizeof(RtowMetrics); out[11] = (int)sizeof(RtowCombineParams);
     out[12] = (int)sizeof(RtowTriangle); out[13] = (int)sizeof(RtowCubemapDesc);
-    out[14] = (int)sizeof(RtowBlueNoiseDesc); out[15] = (int)sizeof(RtowStbNoiseDesc);
+    out[14] = (int)sizeof(RtowBlueNoiseDesc); out[15] = (int)sizeof(RtowStbNoiseDesc); out[16] = (int)sizeof(RtowImage);
 }

@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 2
+RTOW_API_VERSION = 3
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -54,7 +54,11 @@ class Float4(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("type", C.c_int32), ("mainColor", Float3), ("parameter", C.c_float),
-                ("scalarValueChannel", C.c_int32)]
+                ("scalarValueChannel", C.c_int32), ("imageIndex", C.c_int32)]
+
+
+class Image(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixelStride", C.c_int32), ("pixels", C.c_void_p)]
 
 
 class Material(C.Structure):
@@ -76,7 +80,8 @@ class Triangle(C.Structure):
 class SceneDesc(C.Structure):
     _fields_ = [("entities", C.POINTER(Entity)), ("entityCount", C.c_int32),
                 ("materials", C.POINTER(Material)), ("materialCount", C.c_int32),
-                ("maxBvhDepth", C.c_int32), ("triangles", C.POINTER(Triangle)), ("triangleCount", C.c_int32)]
+                ("maxBvhDepth", C.c_int32), ("triangles", C.POINTER(Triangle)), ("triangleCount", C.c_int32),
+                ("images", C.POINTER(Image)), ("imageCount", C.c_int32)]
 
 
 class SceneInfo(C.Structure):

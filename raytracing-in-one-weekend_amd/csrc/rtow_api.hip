@@ -56,6 +56,9 @@ struct RtowContext_t {
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
     volatile uint32_t* hCancel = nullptr; // pinned, device-visible
+    // Image-texture blob of the current scene (CompiledScene.texBlob), HBM only
+    uint8_t* dTexBlob = nullptr;
+    size_t texBlobCapacity = 0;
     // noise texture sets (rtowUploadBlueNoise / rtowUploadStbNoise): device copies, `textureCount` textures back to back
     uint8_t* dBlueNoise = nullptr;
     uint32_t blueRowStride = 0, blueTextureCount = 0;
@@ -152,6 +155,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.subPixelJitter = p->subPixelJitter;
     a.extremaX = p->sampleCountWeightExtrema.x;
     a.extremaY = p->sampleCountWeightExtrema.y;
+    a.texBlob = ctx->dTexBlob;
+    a.texLayout = ctx->scene.texLayout;
     a.noiseColor = p->noiseColor;
     if (p->noiseColor == RTOW_NOISE_BLUE) {
         if (!ctx->dBlueNoise || p->noiseTextureIndex < 0 || (uint32_t)p->noiseTextureIndex >= ctx->blueTextureCount) return RTOW_ERROR_INVALID_VALUE;
@@ -411,6 +416,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);
     if (ctx->dBlueNoise) (void)hipFree(ctx->dBlueNoise);
     if (ctx->dStbNoise) (void)hipFree(ctx->dStbNoise);
+    if (ctx->dTexBlob) (void)hipFree(ctx->dTexBlob);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
@@ -443,6 +449,18 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         ctx->dSceneCapacity = compiled.blob.size();
     }
     HIP_TRY(ctx, hipMemcpy(ctx->dScene, compiled.blob.data(), compiled.blob.size(), hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    if (!compiled.texBlob.empty()) {
+        if (compiled.texBlob.size() > ctx->texBlobCapacity) {
+            if (ctx->dTexBlob) (void)hipFree(ctx->dTexBlob);
+            ctx->dTexBlob = nullptr;
+            ctx->texBlobCapacity = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dTexBlob, compiled.texBlob.size()), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->texBlobCapacity = compiled.texBlob.size();
+        }
+        HIP_TRY(ctx, hipMemcpy(ctx->dTexBlob, compiled.texBlob.data(), compiled.texBlob.size(), hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+        compiled.texBlob.clear();
+        compiled.texBlob.shrink_to_fit();                                     // the host copy is not needed again
+    }
     HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchPrepareEntities(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);

@@ -109,7 +109,17 @@ float texScalar(const RtowTexture& t)
 }
 bool texSupported(const RtowTexture& t)
 {
-    return t.type == RTOW_TEXTURE_NONE || t.type == RTOW_TEXTURE_CONSTANT || t.type == RTOW_TEXTURE_CONSTANT_SCALAR;
+    return t.type == RTOW_TEXTURE_NONE || t.type == RTOW_TEXTURE_CONSTANT || t.type == RTOW_TEXTURE_CONSTANT_SCALAR || t.type == RTOW_TEXTURE_IMAGE;
+}
+GpuTexture packTexture(const RtowTexture& t)
+{
+    GpuTexture g{};
+    g.type = t.type;
+    g.image = t.type == RTOW_TEXTURE_IMAGE ? t.imageIndex : -1;
+    g.channel = t.scalarValueChannel;
+    g.parameter = t.parameter;
+    g.mainColor[0] = t.mainColor.x; g.mainColor[1] = t.mainColor.y; g.mainColor[2] = t.mainColor.z;
+    return g;
 }
 bool almostOne(float v) { return std::fabs(1.0f - v) < 1e-6f; } // UTIL/MathExtensions.cs:24-27 with rhs = 1
 
@@ -144,7 +154,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     // ---- materials (RT/Material.cs:28-46, constant textures folded) ----
     std::vector<GpuMaterial> mats(desc->materialCount);
     std::vector<uint32_t> matClass(desc->materialCount);
-    bool hasVolumes = false;
+    bool hasVolumes = false, hasImageTextures = false;
     for (int i = 0; i < desc->materialCount; i++) {
         const RtowMaterial& m = desc->materials[i];
         if (m.type != RTOW_MATERIAL_STANDARD && m.type != RTOW_MATERIAL_DIELECTRIC && m.type != RTOW_MATERIAL_PROBABILISTIC_VOLUME) {
@@ -153,9 +163,23 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         }
         hasVolumes |= m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME;
         if (!texSupported(m.albedo) || !texSupported(m.glossiness) || !texSupported(m.emission) || !texSupported(m.metallic)) {
-            *err = "texture type not built yet (only None / Constant / ConstantScalar)";
+            *err = "texture type not built (CheckerPattern / PerlinNoise are dead code in the reference)";
             return RTOW_ERROR_UNSUPPORTED;
         }
+        bool textured = false;
+        for (const RtowTexture* t : {&m.albedo, &m.glossiness, &m.emission, &m.metallic}) {
+            if (t->type != RTOW_TEXTURE_IMAGE) continue;
+            textured = true;
+            if (t->imageIndex >= desc->imageCount || (t->imageIndex >= 0 && !desc->images)) {
+                *err = "imageIndex out of range";
+                return RTOW_ERROR_INVALID_VALUE;
+            }
+            if (t->scalarValueChannel < 0 || t->scalarValueChannel > 2) {
+                *err = "scalarValueChannel out of range";
+                return RTOW_ERROR_INVALID_VALUE;
+            }
+        }
+        hasImageTextures |= textured;
         GpuMaterial g{};
         for (int c = 0; c < 3; c++) { g.albedo[c] = texColor(m.albedo, c); g.emission[c] = texColor(m.emission, c); }
         g.type = m.type;
@@ -170,9 +194,10 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
                     almostOne(m.metallic.mainColor.z) && m.glossiness.type == RTOW_TEXTURE_CONSTANT && almostOne(m.glossiness.mainColor.x) &&
                     almostOne(m.glossiness.mainColor.y) && almostOne(m.glossiness.mainColor.z); // :190-192
         if (spec) g.flags |= MAT_FLAG_PERFECT_SPECULAR;
+        if (textured) g.flags |= MAT_FLAG_TEXTURED;
         mats[i] = g;
         matClass[i] = m.type == RTOW_MATERIAL_PROBABILISTIC_VOLUME ? MAT_CLASS_VOLUME : m.type == RTOW_MATERIAL_DIELECTRIC ? MAT_CLASS_DIELECTRIC
-                      : (g.glossiness == 0.0f && g.metallic == 0.0f) ? MAT_CLASS_LAMBERT : MAT_CLASS_GENERAL;
+                      : (g.glossiness == 0.0f && g.metallic == 0.0f && !textured) ? MAT_CLASS_LAMBERT : MAT_CLASS_GENERAL;
     }
 
     // ---- entities -> primitives ----
@@ -181,7 +206,11 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     std::vector<GpuPrim> prims;
     std::vector<float> cullBoxes;
     std::vector<uint32_t> matIndex(n);
-    bool hasMotion = false, general = hasVolumes;   // volume scenes always take the general-entity path
+    if (hasVolumes && hasImageTextures) {
+        *err = "Image textures together with ProbabilisticVolume materials are not built yet";
+        return RTOW_ERROR_UNSUPPORTED;
+    }
+    bool hasMotion = false, general = hasVolumes || hasImageTextures;   // volume / textured scenes always take the general-entity path
     for (int i = 0; i < n; i++) {
         const RtowEntity& e = desc->entities[i];
         const bool identity = e.rotation.x == 0.0f && e.rotation.y == 0.0f && e.rotation.z == 0.0f && e.rotation.w == 1.0f;
@@ -371,7 +400,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.sphereOffset = off; L.sphereCount = (uint32_t)n; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuSphere));
     L.hasMotion = hasMotion ? 1u : 0u;
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
-    L.sceneKind = hasVolumes ? SCENE_KIND_VOLUMES : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
+    L.sceneKind = hasVolumes ? SCENE_KIND_VOLUMES : hasImageTextures ? SCENE_KIND_TEXTURED : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     L.primOffset = off; if (general) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuPrim));
     L.cullOffset = off; if (hasVolumes) off = align16(off + (uint32_t)n * 32u);
     L.rankOffset = off; if (general) off = align16(off + (uint32_t)n * 4u);
@@ -390,6 +419,47 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     memcpy(out->blob.data() + L.matIndexOffset, matIndex.data(), matIndex.size() * 4u);
     memcpy(out->blob.data() + L.materialOffset, mats.data(), mats.size() * sizeof(GpuMaterial));
     out->layout = L;
+    // ---- Image textures: a second blob, HBM only ----
+    out->texBlob.clear();
+    out->texLayout = TexLayout{};
+    if (hasImageTextures) {
+        TexLayout T{};
+        std::vector<GpuTexMaterial> tm(desc->materialCount);
+        for (int i = 0; i < desc->materialCount; i++) {
+            const RtowMaterial& m = desc->materials[i];
+            tm[i] = GpuTexMaterial{packTexture(m.albedo), packTexture(m.glossiness), packTexture(m.emission), packTexture(m.metallic)};
+        }
+        std::vector<GpuImage> images(desc->imageCount > 0 ? desc->imageCount : 0);
+        uint64_t pixelBytes = 0;
+        for (size_t i = 0; i < images.size(); i++) {
+            const RtowImage& im = desc->images[i];
+            if (im.width <= 0 || im.height <= 0 || im.width > 32768 || im.height > 32768 || im.pixelStride < 3 || im.pixelStride > 16 || !im.pixels) {
+                *err = "bad image (size, pixelStride < 3 or null pixels)";
+                return RTOW_ERROR_INVALID_VALUE;
+            }
+            images[i] = GpuImage{(uint32_t)pixelBytes, im.width, im.height, im.pixelStride};
+            pixelBytes += ((uint64_t)im.width * im.height * im.pixelStride + 15u) & ~15ull;
+            if (pixelBytes > 0xf0000000ull) {
+                *err = "more than 3.75 GiB of image pixels";
+                return RTOW_ERROR_CAPACITY;
+            }
+        }
+        T.materialOffset = 0;
+        T.imageOffset = align16((uint32_t)(tm.size() * sizeof(GpuTexMaterial)));
+        T.pixelOffset = align16(T.imageOffset + (uint32_t)(images.size() * sizeof(GpuImage)));
+        const uint64_t total = (uint64_t)T.pixelOffset + pixelBytes;
+        if (total > 0xffffffffull) {
+            *err = "texture blob exceeds 4 GiB";
+            return RTOW_ERROR_CAPACITY;
+        }
+        T.totalBytes = (uint32_t)total;
+        out->texBlob.assign(T.totalBytes, 0);
+        memcpy(out->texBlob.data() + T.materialOffset, tm.data(), tm.size() * sizeof(GpuTexMaterial));
+        if (!images.empty()) memcpy(out->texBlob.data() + T.imageOffset, images.data(), images.size() * sizeof(GpuImage));
+        for (size_t i = 0; i < images.size(); i++)
+            memcpy(out->texBlob.data() + T.pixelOffset + images[i].offset, desc->images[i].pixels, (size_t)images[i].width * images[i].height * images[i].pixelStride);
+        out->texLayout = T;
+    }
     out->entityCount = n;
     out->materialCount = desc->materialCount;
     return RTOW_SUCCESS;

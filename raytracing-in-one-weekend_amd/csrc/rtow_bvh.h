@@ -20,6 +20,8 @@ struct CompiledScene {
     SceneLayout layout;
     int entityCount = 0;
     int materialCount = 0;
+    std::vector<uint8_t> texBlob; // Image-texture blob (HBM only), see TexLayout; empty when the scene has no Image texture
+    TexLayout texLayout{};
 };
 
 // Returns an RtowResult; *err describes failures.

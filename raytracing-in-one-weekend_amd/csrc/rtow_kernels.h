@@ -65,6 +65,10 @@ struct SampleKernelArgs {
     int32_t subPixelJitter;
     float extremaX, extremaY;
 
+    // Image textures (SCENE_KIND_TEXTURED): GpuTexMaterial / GpuImage tables and pixels, in HBM
+    const uint8_t* texBlob;
+    TexLayout texLayout;
+
     // noise source (RT/RandomSource.cs): the texture of this batch for Blue / SpatioTemporalBlue (null for white)
     int32_t noiseColor;                   // RtowNoiseColor
     uint32_t blueRowStride, stbRowStride;

@@ -287,6 +287,37 @@ __device__ __forceinline__ V3 cubemap_sample(const SampleKernelArgs& A, V3 d)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Texture.SampleColor / SampleScalar (RT/Texture.cs:51-138) for the per-hit evaluation of textured materials.  Image: the texel
+// (int2)(uv * ImageSize) - clamped into the image, where the reference would read out of bounds - as bytes / 255 * MainColor.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const uint8_t* texture_pixel(const SampleKernelArgs& A, const GpuTexture& t, float2 uv)
+{
+    const GpuImage im = reinterpret_cast<const GpuImage*>(A.texBlob + A.texLayout.imageOffset)[t.image];
+    int x = (int)(uv.x * (float)im.width), y = (int)(uv.y * (float)im.height);
+    x = x < 0 ? 0 : x > im.width - 1 ? im.width - 1 : x;
+    y = y < 0 ? 0 : y > im.height - 1 ? im.height - 1 : y;
+    return A.texBlob + A.texLayout.pixelOffset + im.offset + ((size_t)y * (size_t)im.width + (size_t)x) * (size_t)im.pixelStride;
+}
+__device__ __forceinline__ V3 texture_color(const SampleKernelArgs& A, const GpuTexture& t, float2 uv)
+{
+    if (t.type == RTOW_TEXTURE_CONSTANT) return v3(t.mainColor[0], t.mainColor[1], t.mainColor[2]);
+    if (t.type == RTOW_TEXTURE_CONSTANT_SCALAR) return v3(t.parameter, t.parameter, t.parameter);
+    if (t.type == RTOW_TEXTURE_IMAGE && t.image >= 0) {
+        const uint8_t* px = texture_pixel(A, t, uv);
+        return v3((float)px[0] / 255.0f * t.mainColor[0], (float)px[1] / 255.0f * t.mainColor[1], (float)px[2] / 255.0f * t.mainColor[2]);
+    }
+    return v3(0, 0, 0);
+}
+__device__ __forceinline__ float texture_scalar(const SampleKernelArgs& A, const GpuTexture& t, float2 uv)
+{
+    const float main = t.channel == 0 ? t.mainColor[0] : t.channel == 1 ? t.mainColor[1] : t.mainColor[2];
+    if (t.type == RTOW_TEXTURE_CONSTANT) return main;
+    if (t.type == RTOW_TEXTURE_CONSTANT_SCALAR) return t.parameter;
+    if (t.type == RTOW_TEXTURE_IMAGE && t.image >= 0) return (float)texture_pixel(A, t, uv)[t.channel] / 255.0f * main;
+    return 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // scene access: LDS image first, HBM/L2 for whatever did not fit
 // ------------------------------------------------------------------------------------------------------------
 struct SceneRefs {
@@ -384,9 +415,10 @@ __device__ __forceinline__ float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.
 // Returns the distance, the entity-space normal and the rotation that takes it to world space.
 template <bool ALL_LDS>
 __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time, float tMin,
-                                            float& tOut, V3& nLocal, float4& rot)
+                                            float& tOut, V3& nLocal, float4& rot, float2* texCoord = nullptr)
 {
     const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)i * 128u);
+    if (texCoord) *texCoord = make_float2(0, 0);       // only triangles have texture coordinates (RT/Entity.cs:108, RT/HitTests.cs:123)
     if (type == RTOW_ENTITY_TRIANGLE) {
         // HitTests.Hit(Triangle) (RT/HitTests.cs:115-150); triangles are tested in world space (RT/Entity.cs:91-93)
         const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
@@ -407,6 +439,10 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
         const float b0 = 1 - u - v;
         const V3 n0 = v3(a2.y, a2.z, a2.w), n1 = v3(a3.x, a3.y, a3.z), n2 = v3(a3.w, a4.x, a4.y);
         nLocal = v3(n0.x * b0 + n1.x * u + n2.x * v, n0.y * b0 + n1.y * u + n2.y * v, n0.z * b0 + n1.z * u + n2.z * v);
+        if (texCoord) {                                  // mul(tri.TextureCoordinates, barycentricCoords) (:148): float2x3 columns t0 t1 t2
+            const float4 a5 = p[5];
+            *texCoord = make_float2(a4.z * b0 + a5.x * u + a5.z * v, a4.w * b0 + a5.y * u + a5.w * v);
+        }
         tOut = dist;
         return true;
     }
@@ -574,6 +610,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     constexpr bool HAS_MOTION = KIND == SCENE_KIND_SPHERES_MOTION;
     constexpr bool GENERAL = KIND >= SCENE_KIND_GENERAL;
     constexpr bool VOLUMES = KIND == SCENE_KIND_VOLUMES;     // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
+    constexpr bool TEXTURED = KIND == SCENE_KIND_TEXTURED;   // Image textures present: albedo / emission / metallic / glossiness are per hit
 
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
@@ -599,6 +636,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 
     // VOLUMES only: all hits of the current ray (FindHits' hitRecordBuffer, JOBS/SampleBatchJob.cs:450-475), the volume the path
     // is inside of (currentProbabilisticVolumeMaterial, :180) and RandomEvents left pending by ProbabilisticHit (RT/Material.cs:54)
+    // TEXTURED only: what the fold needs of every hit of the current path (the 16-bit history code only names a material)
+    float texHist[TEXTURED ? HW * 2 * 6 : 1];
     constexpr int kMaxHits = VOLUMES ? 24 : 1;
     float hitT[kMaxHits], hitTmin0[kMaxHits];
     unsigned hitCode[kMaxHits];      // primitive | dot(normal, dir) < 0 -> bit 30 | dot > 0 -> bit 31
@@ -931,6 +970,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 const float t = best;
                 const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
                 V3 N;
+                float2 hitUv = make_float2(0, 0);                               // rec.TexCoords
                 if (VOLUMES && insideHit) {
                     // new HitRecord(totalDistance, ray.GetPoint(totalDistance), -ray.Direction, default); material = the volume (:272-273)
                     N = neg(rd);
@@ -939,7 +979,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 } else if (GENERAL) {
                     // re-run the winning primitive's test for its entity-space normal, then rotate it out (RT/Entity.cs:62-66)
                     float t2; V3 nLocal; float4 rq;
-                    (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq);
+                    (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq, TEXTURED ? &hitUv : nullptr);
                     N = normalize(rotate(rq, nLocal));
                 } else {
                     V3 c; float radius;
@@ -952,7 +992,38 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 const float4 m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
                 const float4 m1 = *reinterpret_cast<const float4*>(mp + 16);  // emission.yz type metallic
                 V3 reflectance = v3(m0.x, m0.y, m0.z);
-                const V3 emission = v3(m0.w, m1.x, m1.y);
+                V3 emission = v3(m0.w, m1.x, m1.y);
+                float metallicHit = m1.w;
+                float4 m2hit = make_float4(0, 0, 0, 0), m3hit = make_float4(0, 0, 0, 0);
+                if (TEXTURED) {
+                    m2hit = *reinterpret_cast<const float4*>(mp + 32);
+                    m3hit = *reinterpret_cast<const float4*>(mp + 48);
+                    if (__float_as_uint(m2hit.z) & MAT_FLAG_TEXTURED) {
+                        // Material.Scatter / Emit evaluate the four textures at rec.TexCoords (RT/Material.cs:71,77-78,123,176-179), and
+                        // everything derived from metallic / glossiness (prepare_materials_kernel's program) follows per hit
+                        const GpuTexMaterial tm = reinterpret_cast<const GpuTexMaterial*>(A.texBlob + A.texLayout.materialOffset)[matIdx];
+                        reflectance = texture_color(A, tm.albedo, hitUv);
+                        emission = texture_color(A, tm.emission, hitUv);
+                        const float glossiness = texture_scalar(A, tm.glossiness, hitUv);
+                        float roughness, ior, invIor = 0.0f, alpha = 0.0f;
+                        if (__float_as_int(m1.z) == RTOW_MATERIAL_STANDARD) {
+                            metallicHit = texture_scalar(A, tm.metallic, hitUv);
+                            roughness = det_sq(1 - glossiness);
+                            ior = 1.5f + metallicHit * (1.1f - 1.5f);
+                            alpha = roughness_to_alpha(roughness);
+                        } else {
+                            roughness = 1 - glossiness;
+                            ior = m2hit.y;
+                            invIor = 1 / ior;
+                        }
+                        float r0 = (1 - ior) / (1 + ior);
+                        r0 *= r0;
+                        m2hit = make_float4(glossiness, m2hit.y, m2hit.z, roughness);
+                        m3hit = make_float4(alpha, ior, r0, invIor);
+                    }
+                    texHist[depth * 6 + 0] = reflectance.x; texHist[depth * 6 + 1] = reflectance.y; texHist[depth * 6 + 2] = reflectance.z;
+                    texHist[depth * 6 + 3] = emission.x; texHist[depth * 6 + 4] = emission.y; texHist[depth * 6 + 5] = emission.z;
+                }
                 bool white = false;
                 bool perfectSpecular = false;
                 V3 sdir;
@@ -975,9 +1046,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     randomEvents += 1.0f;                          // 0 + 0 + 1 * 0 + 1 * 1 on top of whatever was pending
                 } else if (cls == MAT_CLASS_GENERAL) {                                        // RT/Material.cs:75-119
                     STAT_ADD(11, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(12);
-                    const float4 m2 = *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags roughness
-                    const float4 m3 = *reinterpret_cast<const float4*>(mp + 48);  // alpha ior r0 1/ior
-                    const float metallic = m1.w;
+                    const float4 m2 = TEXTURED ? m2hit : *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags roughness
+                    const float4 m3 = TEXTURED ? m3hit : *reinterpret_cast<const float4*>(mp + 48);  // alpha ior r0 1/ior
+                    const float metallic = TEXTURED ? metallicHit : m1.w;
                     const float glossiness = m2.x;
                     const float roughness = m2.w;                                 // pow(1 - glossiness, 2)
                     perfectSpecular = (__float_as_uint(m2.z) & MAT_FLAG_PERFECT_SPECULAR) != 0;
@@ -1005,8 +1076,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     randomEvents += roughness * (reflectionChance + (1 - reflectionChance) * metallic);
                     randomEvents += (1 - reflectionChance) * (1 - metallic);
                 } else {                                                                      // Dielectric, RT/Material.cs:121-161
-                    const float4 m2 = *reinterpret_cast<const float4*>(mp + 32);
-                    const float4 m3 = *reinterpret_cast<const float4*>(mp + 48);
+                    const float4 m2 = TEXTURED ? m2hit : *reinterpret_cast<const float4*>(mp + 32);
+                    const float4 m3 = TEXTURED ? m3hit : *reinterpret_cast<const float4*>(mp + 48);
                     STAT_ADD(13, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(14);
                     perfectSpecular = true;
                     const float ior = m2.y;
@@ -1232,6 +1303,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const float4 m0 = *reinterpret_cast<const float4*>(mp);
                     const float2 m1 = *reinterpret_cast<const float2*>(mp + 16);
                     const bool white = (code & 0x8000u) != 0;
+                    if (TEXTURED) {
+                        const V3 att = white ? v3(1, 1, 1) : v3(texHist[i * 6 + 0], texHist[i * 6 + 1], texHist[i * 6 + 2]);
+                        col = v3(col.x * att.x + texHist[i * 6 + 3], col.y * att.y + texHist[i * 6 + 4], col.z * att.z + texHist[i * 6 + 5]);
+                        continue;
+                    }
                     const V3 att = white ? v3(1, 1, 1) : v3(m0.x, m0.y, m0.z);
                     col = v3(col.x * att.x + m0.w, col.y * att.y + m1.x, col.z * att.z + m1.y);
                 }
@@ -1589,6 +1665,7 @@ hipError_t launchByKind(const SampleKernelArgs& args, int numBlocks, size_t ldsB
         case SCENE_KIND_SPHERES: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES>(args, numBlocks, ldsBytes, stream);
         case SCENE_KIND_SPHERES_MOTION: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES_MOTION>(args, numBlocks, ldsBytes, stream);
         case SCENE_KIND_VOLUMES: return launchByDiag<ALL_LDS, SCENE_KIND_VOLUMES>(args, numBlocks, ldsBytes, stream);
+        case SCENE_KIND_TEXTURED: return launchByDiag<ALL_LDS, SCENE_KIND_TEXTURED>(args, numBlocks, ldsBytes, stream);
         default: return launchByDiag<ALL_LDS, SCENE_KIND_GENERAL>(args, numBlocks, ldsBytes, stream);
     }
 }

@@ -72,6 +72,29 @@ struct GpuMaterial {
 };
 static_assert(sizeof(GpuMaterial) == 64, "GpuMaterial must be 64 bytes");
 
+// Image textures (RT/Texture.cs:80-89,126-135) live in a second blob that stays in HBM (images do not fit LDS):
+//   GpuTexMaterial[materialCount]  |  GpuImage[imageCount]  |  pixel bytes
+struct GpuTexture {
+    int32_t type;        // RtowTextureType
+    int32_t image;       // index into the GpuImage table, < 0: null ImagePointer
+    int32_t channel;     // ScalarValueChannel
+    float parameter;     // ConstantValue
+    float mainColor[3];
+    float pad;
+};
+struct GpuTexMaterial {
+    GpuTexture albedo, glossiness, emission, metallic;
+};
+struct GpuImage {
+    uint32_t offset;     // of the first pixel, from the start of the pixel section
+    int32_t width, height, pixelStride;
+};
+static_assert(sizeof(GpuTexture) == 32 && sizeof(GpuTexMaterial) == 128 && sizeof(GpuImage) == 16, "texture blob records");
+struct TexLayout {
+    uint32_t materialOffset, imageOffset, pixelOffset, totalBytes;   // totalBytes == 0: the scene has no Image texture
+};
+constexpr uint32_t MAT_FLAG_TEXTURED = 2u;      // GpuMaterial.flags: at least one of the four textures is an Image - evaluate per hit
+
 // General primitive record (128 B) for scenes that are not identity-rotation spheres: Rect / Box / Triangle entities,
 // rotated entities (RT/Entity.cs:27-127).  One fixed-stride array so a leaf code indexes it directly.
 //   transformed entity (sphere / rect / box):
@@ -89,6 +112,7 @@ enum : uint32_t {
     SCENE_KIND_SPHERES_MOTION = 1, // identity-rotation spheres, some moving: GpuSphere + GpuMotion
     SCENE_KIND_GENERAL = 2,        // anything else: GpuPrim
     SCENE_KIND_VOLUMES = 3,        // GENERAL + at least one ProbabilisticVolume material: all hits of a ray are collected and sorted
+    SCENE_KIND_TEXTURED = 4,       // GENERAL + at least one Image texture: materials are evaluated per hit at the hit's texture coordinates
 };
 // materialIndex[] word: bits 0..15 material, 16..17 shading class, 18..20 RtowEntityType
 constexpr uint32_t kPrimTypeShift = 18;

@@ -75,11 +75,21 @@ class UnityRandom:
 def _const_tex(v):
     if np.isscalar(v):
         v = (v, v, v)
-    return abi.Texture(abi.TEXTURE_CONSTANT, abi.Float3(*[float(f32(c)) for c in v]), 0.0, 0)
+    return abi.Texture(abi.TEXTURE_CONSTANT, abi.Float3(*[float(f32(c)) for c in v]), 0.0, 0, -1)
 
 
 def _none_tex():
-    return abi.Texture(abi.TEXTURE_NONE, abi.Float3(0, 0, 0), 0.0, 0)
+    return abi.Texture(abi.TEXTURE_NONE, abi.Float3(0, 0, 0), 0.0, 0, -1)
+
+
+def image_tex(image_index, main_color=(1.0, 1.0, 1.0), channel=0):
+    """TextureType.Image (RT/Texture.cs:80-89,126-135): texel / 255 * MainColor; `image_index` into Scene.images (-1: null pointer)."""
+    return abi.Texture(abi.TEXTURE_IMAGE, abi.Float3(*[float(f32(c)) for c in main_color]), 0.0, channel, image_index)
+
+
+def scalar_tex(value):
+    """TextureType.ConstantScalar (RT/Texture.cs:58-59,103-104)."""
+    return abi.Texture(abi.TEXTURE_CONSTANT_SCALAR, abi.Float3(0, 0, 0), float(f32(value)), 0, -1)
 
 
 def lambertian(color):
@@ -123,6 +133,7 @@ class Scene:
         self.tri_index = []      # index into self.triangles, -1 for non-triangles
         self.triangles = []      # abi.Triangle payloads
         self.materials = []      # abi.Material
+        self.images = []         # uint8 arrays [H, W, C] referenced by Image textures (RtowTexture.imageIndex)
         self.camera = {}
         self.sky_bottom = (1.0, 1.0, 1.0)
         self.sky_top = (0.5, 0.7, 1.0)
@@ -197,8 +208,13 @@ class Scene:
             e.contentIndex = max(self.tri_index[i], 0)
         mats = (abi.Material * len(self.materials))(*self.materials)
         tris = (abi.Triangle * max(len(self.triangles), 1))(*self.triangles)
-        d = abi.SceneDesc(ents, n, mats, len(self.materials), max_bvh_depth, tris if self.triangles else None, len(self.triangles))
-        self._keepalive = (ents, mats, tris)
+        imgs = (abi.Image * max(len(self.images), 1))()
+        pix = [np.ascontiguousarray(im, dtype=np.uint8) for im in self.images]
+        for k, im in enumerate(pix):
+            imgs[k] = abi.Image(im.shape[1], im.shape[0], im.shape[2], im.ctypes.data)
+        d = abi.SceneDesc(ents, n, mats, len(self.materials), max_bvh_depth, tris if self.triangles else None, len(self.triangles),
+                          imgs if self.images else None, len(self.images))
+        self._keepalive = (ents, mats, tris, imgs, pix)
         return d
 
     # -- reproducible serialisation for tests/golden ------------------------------------------------
@@ -226,7 +242,7 @@ class Scene:
         s = Scene(d["name"])
 
         def tex(t):
-            return abi.Texture(t[0], abi.Float3(t[1], t[2], t[3]), t[4], t[5])
+            return abi.Texture(t[0], abi.Float3(t[1], t[2], t[3]), t[4], t[5], -1)
 
         s.materials = [abi.Material(m[0], tex(m[1]), tex(m[2]), tex(m[3]), tex(m[4]), m[5]) for m in d["materials"]]
         s.positions = [np.asarray(p, dtype=np.float32) for p in d["positions"]]
@@ -474,6 +490,48 @@ def coplanar_scene():
     s.add_sphere((2.5, 0.5, 0.5), 0.5, lambertian((0.8, 0.5, 0.2)))
     s.add_sphere((2.5, 0.5, 0.5), 0.5, metal((0.9, 0.9, 0.9), 0.1))                       # the same sphere twice
     s.camera = {"position": [0.5, 2.5, 6.0], "target": [0.0, 1.0, -1.0], "up": [0.0, 1.0, 0.0], "vfov": 45.0, "aperture": 0.0}
+    return s
+
+
+def _quad(s, p00, p10, p11, p01, material, uv0=(0.0, 0.0), uv1=(1.0, 1.0)):
+    """Two triangles p00-p10-p11 / p00-p11-p01 with the texture coordinates of a [uv0, uv1] rectangle."""
+    (u0, v0), (u1, v1) = uv0, uv1
+    s.add_triangle(p00, p10, p11, material, uvs=((u0, v0), (u1, v0), (u1, v1)))
+    s.add_triangle(p00, p11, p01, material, uvs=((u0, v0), (u1, v1), (u0, v1)))
+
+
+def textured_scene():
+    """Triangle meshes with Image textures on every texture slot (albedo, emission, glossiness, metallic; Standard and Dielectric),
+    a constant-scalar texture, a null image pointer, and image-textured spheres / rects (whose texture coordinates are always 0).
+    The reference's texture assets are not in the mount: the images are procedural."""
+    s = Scene("textured")
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:32, 0:48]
+    checker = np.where(((xx // 6) + (yy // 4)) % 2 == 0, 230, 40).astype(np.uint8)
+    albedo = np.stack([checker, (xx * 5) % 256, (yy * 7) % 256], axis=-1).astype(np.uint8)                 # 32 x 48, RGB24
+    emissive = np.zeros((16, 16, 4), dtype=np.uint8)                                                         # RGBA32: a few hot texels
+    emissive[4:7, 9:12, :3] = (255, 200, 120)
+    emissive[12, 2, :3] = (90, 90, 255)
+    params = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)                                                 # gloss in .g, metal in .b
+    s.images = [albedo, emissive, params]
+    wall = abi.Material(abi.MATERIAL_STANDARD, image_tex(0), _const_tex(0.0), _none_tex(), _const_tex(0.0), 0.0)
+    lamp = abi.Material(abi.MATERIAL_STANDARD, image_tex(0, (0.2, 0.2, 0.2)), _const_tex(0.0), image_tex(1, (6.0, 6.0, 6.0)), _const_tex(0.0), 0.0)
+    shiny = abi.Material(abi.MATERIAL_STANDARD, image_tex(0, (0.9, 0.8, 0.7)), image_tex(2, (1.0, 1.0, 1.0), channel=1), _none_tex(), image_tex(2, (1.0, 1.0, 0.9), channel=2), 0.0)
+    frosted = abi.Material(abi.MATERIAL_DIELECTRIC, _const_tex((1.0, 1.0, 1.0)), image_tex(2, (1.0, 1.0, 1.0), channel=0), _none_tex(), _none_tex(), 1.5)
+    missing = abi.Material(abi.MATERIAL_STANDARD, image_tex(-1), scalar_tex(0.3), _none_tex(), scalar_tex(0.5), 0.0)     # null ImagePointer -> albedo 0
+    ball = abi.Material(abi.MATERIAL_STANDARD, image_tex(0, (1.0, 0.5, 0.5)), _const_tex(0.2), _none_tex(), _const_tex(0.1), 0.0)
+    plain = lambertian((0.6, 0.6, 0.6))
+    _quad(s, (-3, 0, -3), (3, 0, -3), (3, 0, 3), (-3, 0, 3), wall, uv1=(3.0 / 3.0, 1.0))                      # floor
+    _quad(s, (-3, 0, -3), (-3, 4, -3), (3, 4, -3), (3, 0, -3), shiny, uv0=(0.0, 0.0), uv1=(0.999, 0.999))    # back wall
+    _quad(s, (-3, 0, 3), (-3, 4, 3), (-3, 4, -3), (-3, 0, -3), lamp)                                          # left wall with hot texels
+    _quad(s, (0.2, 0.3, 0.5), (1.8, 0.3, 0.5), (1.8, 1.9, 0.2), (0.2, 1.9, 0.2), frosted, uv0=(0.1, 0.2), uv1=(0.9, 0.8))   # glass pane
+    _quad(s, (-2.2, 0.01, 0.5), (-1.0, 0.01, 0.5), (-1.0, 0.01, 1.7), (-2.2, 0.01, 1.7), missing)
+    _quad(s, (-1.5, 3.99, -1.5), (1.5, 3.99, -1.5), (1.5, 3.99, 1.5), (-1.5, 3.99, 1.5), standard((0, 0, 0), 0.0, 0.0, emission=(5.0, 5.0, 5.0)))
+    s.add_sphere((-1.2, 0.6, -0.8), 0.6, ball)                                                                # texture coordinates (0, 0): one texel
+    s.add_rect((2.99, 1.5, 0.0), (2.0, 2.0), wall, rotation=quat_axis_angle((0, 1, 0), -90))
+    s.add_sphere((0.9, 0.45, 1.6), 0.45, plain)
+    s.camera = {"position": [0.3, 1.8, 6.5], "target": [0.0, 1.3, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 48.0, "aperture": 0.0}
+    s.sky_bottom, s.sky_top = (0.05, 0.05, 0.08), (0.1, 0.15, 0.3)
     return s
 
 

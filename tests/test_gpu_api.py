@@ -141,8 +141,12 @@ def test_error_codes(rt, gpu_context):
     bad.materials[0].type = 7
     assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE
     bad = scene.desc()
-    bad.materials[0].albedo.type = a.TEXTURE_IMAGE                 # image textures are not built yet
+    bad.materials[0].albedo.type = a.TEXTURE_CHECKER_PATTERN       # dead code in the reference (RT/Texture.cs:61-78)
     assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_UNSUPPORTED
+    bad = scene.desc()
+    bad.materials[0].albedo.type = a.TEXTURE_IMAGE
+    bad.materials[0].albedo.imageIndex = 3                          # no such image
+    assert lib.rtowUploadScene(fresh.handle, C.byref(bad)) == a.RTOW_ERROR_INVALID_VALUE
     # a failed upload leaves the previous scene usable
     out = rt.sample_batch_host(fresh, p, z)
     assert out["color"][:, 3].sum() > 0

@@ -226,3 +226,15 @@ def test_texture_driven_noise_sources(rt, oracle, gpu_context, noise_color):
     finally:
         ctx.upload_blue_noise(None)
         ctx.upload_stb_noise(None)
+
+
+def test_image_textures(rt, oracle, gpu_context):
+    """TextureType.Image on albedo / emission / glossiness / metallic, Standard and Dielectric, triangle texture coordinates, the (0, 0)
+    coordinates of every other entity type, a null image pointer (RT/Texture.cs:80-89,126-135, RT/Material.cs:71-78,123,176-179) - per-hit
+    material evaluation and the per-hit colours the fold needs."""
+    scene = rt.scenes.textured_scene()
+    for w, h, spp, depth, stride in ((96, 64, 8, 8, 4), (64, 40, 6, 12, 16), (40, 28, 4, 20, 4)):
+        gpu, ref = _run_both(rt, oracle, gpu_context, scene, w, h, spp, depth, diagnostics_stride=stride)
+        _compare(gpu, ref)
+        assert gpu["color"][:, 3].sum() > 0
+    assert gpu_context.scene_info().bvhNodeCount == scene.entity_count - 1
