@@ -206,10 +206,6 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     std::vector<GpuPrim> prims;
     std::vector<float> cullBoxes;
     std::vector<uint32_t> matIndex(n);
-    if (hasVolumes && hasImageTextures) {
-        *err = "Image textures together with ProbabilisticVolume materials are not built yet";
-        return RTOW_ERROR_UNSUPPORTED;
-    }
     bool hasMotion = false, general = hasVolumes || hasImageTextures;   // volume / textured scenes always take the general-entity path
     for (int i = 0; i < n; i++) {
         const RtowEntity& e = desc->entities[i];
@@ -400,7 +396,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.sphereOffset = off; L.sphereCount = (uint32_t)n; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuSphere));
     L.hasMotion = hasMotion ? 1u : 0u;
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
-    L.sceneKind = hasVolumes ? SCENE_KIND_VOLUMES : hasImageTextures ? SCENE_KIND_TEXTURED : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
+    L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? SCENE_KIND_TEXTURED : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     L.primOffset = off; if (general) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuPrim));
     L.cullOffset = off; if (hasVolumes) off = align16(off + (uint32_t)n * 32u);
     L.rankOffset = off; if (general) off = align16(off + (uint32_t)n * 4u);

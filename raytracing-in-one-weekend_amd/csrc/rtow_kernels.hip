@@ -609,8 +609,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     const bool twoChildren = L.sphereCount > 1u;
     constexpr bool HAS_MOTION = KIND == SCENE_KIND_SPHERES_MOTION;
     constexpr bool GENERAL = KIND >= SCENE_KIND_GENERAL;
-    constexpr bool VOLUMES = KIND == SCENE_KIND_VOLUMES;     // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
-    constexpr bool TEXTURED = KIND == SCENE_KIND_TEXTURED;   // Image textures present: albedo / emission / metallic / glossiness are per hit
+    constexpr bool VOLUMES = KIND == SCENE_KIND_VOLUMES || KIND == SCENE_KIND_VOLUMES_TEXTURED;   // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
+    constexpr bool TEXTURED = KIND == SCENE_KIND_TEXTURED || KIND == SCENE_KIND_VOLUMES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
 
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
@@ -1666,6 +1666,7 @@ hipError_t launchByKind(const SampleKernelArgs& args, int numBlocks, size_t ldsB
         case SCENE_KIND_SPHERES_MOTION: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES_MOTION>(args, numBlocks, ldsBytes, stream);
         case SCENE_KIND_VOLUMES: return launchByDiag<ALL_LDS, SCENE_KIND_VOLUMES>(args, numBlocks, ldsBytes, stream);
         case SCENE_KIND_TEXTURED: return launchByDiag<ALL_LDS, SCENE_KIND_TEXTURED>(args, numBlocks, ldsBytes, stream);
+        case SCENE_KIND_VOLUMES_TEXTURED: return launchByDiag<ALL_LDS, SCENE_KIND_VOLUMES_TEXTURED>(args, numBlocks, ldsBytes, stream);
         default: return launchByDiag<ALL_LDS, SCENE_KIND_GENERAL>(args, numBlocks, ldsBytes, stream);
     }
 }

@@ -113,6 +113,7 @@ enum : uint32_t {
     SCENE_KIND_GENERAL = 2,        // anything else: GpuPrim
     SCENE_KIND_VOLUMES = 3,        // GENERAL + at least one ProbabilisticVolume material: all hits of a ray are collected and sorted
     SCENE_KIND_TEXTURED = 4,       // GENERAL + at least one Image texture: materials are evaluated per hit at the hit's texture coordinates
+    SCENE_KIND_VOLUMES_TEXTURED = 5, // both
 };
 // materialIndex[] word: bits 0..15 material, 16..17 shading class, 18..20 RtowEntityType
 constexpr uint32_t kPrimTypeShift = 18;

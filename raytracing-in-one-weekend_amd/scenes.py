@@ -535,6 +535,22 @@ def textured_scene():
     return s
 
 
+def textured_volume_scene():
+    """`volume_scene` with Image textures: a textured floor mesh, an image-textured (uv = 0) wall, and fog whose albedo is an image."""
+    s = volume_scene()
+    s.name = "textured_volumes"
+    rng = np.random.default_rng(5)
+    s.images = [rng.integers(30, 256, (16, 16, 3), dtype=np.uint8), np.full((2, 2, 3), (200, 220, 255), dtype=np.uint8)]
+    tiles = abi.Material(abi.MATERIAL_STANDARD, image_tex(0), _const_tex(0.3), _none_tex(), _const_tex(0.0), 0.0)
+    _quad(s, (-2, -1.99, -2), (2, -1.99, -2), (2, -1.99, 2), (-2, -1.99, 2), tiles, uv1=(2.0, 2.0))      # a tiled mesh just above the floor rect
+    s.materials[s.material_index[0]].albedo = image_tex(0, (0.73, 0.73, 0.73))                              # back wall rect: texel (0, 0) only
+    for i, m in enumerate(s.materials):
+        if m.type == abi.MATERIAL_PROBABILISTIC_VOLUME:
+            m.albedo = image_tex(1, (m.albedo.mainColor.x, m.albedo.mainColor.y, m.albedo.mainColor.z))       # fog colour from an image
+            break
+    return s
+
+
 def tiny_scene():
     """Five spheres, one of each material branch + a negative-radius hollow glass shell; for fast unit tests."""
     s = Scene("tiny")

@@ -238,3 +238,10 @@ def test_image_textures(rt, oracle, gpu_context):
         _compare(gpu, ref)
         assert gpu["color"][:, 3].sum() > 0
     assert gpu_context.scene_info().bvhNodeCount == scene.entity_count - 1
+
+
+def test_image_textures_with_probabilistic_volumes(rt, oracle, gpu_context):
+    scene = rt.scenes.textured_volume_scene()
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 64, 64, 6, 10, focus=6.5, diagnostics_stride=16)
+    _compare(gpu, ref)
+    assert gpu["color"][:, 3].sum() > 0
