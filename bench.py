@@ -75,11 +75,12 @@ def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0):
 
     osc = ob.OracleScene(scene.desc(), kind="fast")
     cores = usable_cores()
-    cal = rt.scenes.make_params(scene, width // 2, height // 2, spp=4, trace_depth=depth)
+    # calibration on the workload itself (full frame, 8 spp, ~1 s): small frames under-report the rate (thread start-up, cold caches)
+    cal = rt.scenes.make_params(scene, width, height, spp=8, trace_depth=depth)
     t = time.perf_counter()
     osc.sample_batch(cal, nthreads=cores)
-    cal_rate = (width // 2) * (height // 2) * 4 / (time.perf_counter() - t)
-    spp = int(max(1, min(64, round(budget_s * cal_rate / (width * height)))))
+    cal_rate = width * height * 8 / (time.perf_counter() - t)
+    spp = int(max(8, min(128, round(budget_s * cal_rate / (width * height)))))
     p = rt.scenes.make_params(scene, width, height, spp=spp, trace_depth=depth)
     best = None
     rays = 0
