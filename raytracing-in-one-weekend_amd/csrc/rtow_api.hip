@@ -38,6 +38,8 @@ struct RtowContext_t {
 
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
+    hipEvent_t evBatchDone = nullptr;   // end of everything the last sample batch enqueued (kernel + chunk-order refresh)
+    bool haveBatchDone = false;
     bool haveTiming = false;
 
     // scene
@@ -201,6 +203,10 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
     if (blocks < 1) blocks = 1;
 
+    // Batches of one context share its ticket counter, cost map, chunk order and candidate lists, and each one consumes what the
+    // previous one produced: whatever stream this batch was given, it starts after everything the previous batch enqueued.
+    if (ctx->haveBatchDone) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->evBatchDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+
     // ---- camera-ray candidate lists: one conservative beam walk per pixel, reused by all its samples (and by later batches of the same view) ----
     if (!getenv("RTOW_NO_PRIMARY_LISTS")) {
         const size_t pixels = (size_t)a.width * (size_t)a.height;
@@ -265,6 +271,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
     // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
     if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipEventRecord(ctx->evBatchDone, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    ctx->haveBatchDone = true;
 #ifdef RTOW_STATS
     {
         unsigned long long h[16];
@@ -392,6 +400,7 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     if (options) { ctx->logCb = options->logCallback; ctx->logData = options->logCallbackData; ctx->logLevel = options->logCallbackLevel; }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->evStart) == hipSuccess && hipEventCreate(&ctx->evStop) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->evBatchDone, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dWorkCounter, sizeof(unsigned int)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dPartials, sizeof(MetricsPartial) * kMetricsBlocks) == hipSuccess;
     void* pinned = nullptr;
@@ -423,6 +432,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dDiag) (void)hipFree(ctx->dDiag);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
+    if (ctx->evBatchDone) (void)hipEventDestroy(ctx->evBatchDone);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RTOW_SUCCESS;
@@ -440,7 +450,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         logf(ctx, 2, "scene", "%s", err.c_str());
         return rc;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipDeviceSynchronize(), RTOW_ERROR_LAUNCH_FAILURE);   // no batch (on whatever stream it was given) may still be reading the old scene
     if (compiled.blob.size() > ctx->dSceneCapacity) {
         if (ctx->dScene) (void)hipFree(ctx->dScene);
         ctx->dScene = nullptr;
