@@ -77,6 +77,11 @@ def main():
     out["moving_96x54_4spp_d8"] = {k: sha(rm[k]) for k in ("color", "normal", "albedo", "scw")}
     osm.close()
 
+    # one small render per further feature (volumes, ties, textures, HDRI sky, texture-driven noise, adaptive sampling)
+    sys.path.insert(0, HERE)
+    from feature_cases import feature_cases, render_digests  # noqa: E402
+    out["features"] = {name: render_digests(rt, ob, name, case) for name, case in feature_cases(rt).items()}
+
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", os.listdir(HERE))
