@@ -694,10 +694,15 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 #endif
     for (;;) {
         STAT_ADD(0, 1);
-        // Stages run in pipeline order; each one only if enough lanes wait in it (thresholds in A.tune), so a lane can
-        // still advance a whole path segment per trip when the wave is dense, while sparse stages batch up.
+        // Stages run in pipeline order; each one only if enough lanes wait in it, so a lane can still advance a whole path segment per
+        // trip when the wave is dense, while sparse stages batch up.  A.tune[] holds the thresholds in 64ths of the wave's LIVE lanes
+        // (lanes that still have pixels): 1 = "any lane", 48 = three quarters of them.  Depth-0 rays skip the box walk (camera-ray lists),
+        // so without a threshold the walk would run every trip for the ~60 % of lanes on a bounce segment; holding it back until
+        // most live lanes want it lets the camera segments (REGEN -> TEST -> HIT) of the others catch up first.
+        const int live = (int)__popcll(__ballot(st != ST_DEAD));
+        auto need = [&](int k) { const int t = (live * A.tune[k] + 63) >> 6; return t < 1 ? 1 : t; };
         bool ran = false;
-        if ((int)__popcll(__ballot(st == ST_REGEN)) >= (force == ST_REGEN ? 1 : A.tune[0])) {
+        if ((int)__popcll(__ballot(st == ST_REGEN)) >= (force == ST_REGEN ? 1 : need(0))) {
             ran = true;
             // ================= next sample of this pixel, or next pixel =================
             STAT_ADD(1, 1);
@@ -857,7 +862,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 }
             }
         }
-        if ((int)__popcll(__ballot(st == ST_TRAV)) >= (force == ST_TRAV ? 1 : A.tune[1])) {
+        if ((int)__popcll(__ballot(st == ST_TRAV)) >= (force == ST_TRAV ? 1 : need(1))) {
             ran = true;
             // ================= box walk: FindHitCandidates (JOBS/SampleBatchJob.cs:403-448), resumable =================
             if (st == ST_TRAV) {
@@ -908,7 +913,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 }
             }
         }
-        if ((int)__popcll(__ballot(st == ST_TEST)) >= (force == ST_TEST ? 1 : A.tune[2])) {
+        if ((int)__popcll(__ballot(st == ST_TEST)) >= (force == ST_TEST ? 1 : need(2))) {
             ran = true;
             // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
             if (st == ST_TEST) {
@@ -956,7 +961,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 else classify();
             }
         }
-        if ((int)__popcll(__ballot(st == ST_HIT)) >= (force == ST_HIT ? 1 : A.tune[3])) {
+        if ((int)__popcll(__ballot(st == ST_HIT)) >= (force == ST_HIT ? 1 : need(3))) {
             ran = true;
             // ================= surface hit: Entity.Hit record + Material.Scatter =================
             STAT_ADD(7, 1);
@@ -1277,7 +1282,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 else st = ST_SKY;
             }
         }
-        if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : A.tune[4])) {
+        if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : need(4))) {
             ran = true;
             // ================= sky (:341-374), then fold tail -> head (:384-396) =================
             STAT_ADD(15, 1);
