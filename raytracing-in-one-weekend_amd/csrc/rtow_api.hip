@@ -24,7 +24,7 @@
 // minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: any
 // threshold above 1 loses (waiting lanes cost more than the skipped stage saves); slicing the walk at 16 wins ~5 %.
 #ifndef RTOW_DEFAULT_TUNE
-#define RTOW_DEFAULT_TUNE 8, 48, 1, 1, 1, 1, 1, 1, 16   /* REGEN from 1/8, TRAV from 3/4 of the live lanes; TEST, HIT, SKY at once; 16 node visits per walk slice */
+#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 1, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4 of the live lanes; TEST, HIT, SKY at once; 16 node visits per walk slice */
 #endif
 
 using namespace rtow;
@@ -224,6 +224,14 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         if (!same) {
             HIP_TRY(ctx, launchPrimaryCandidates(a, ctx->dPixCand, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->pixCandValid = true;
+#ifdef RTOW_STATS
+            if (const char* dump = getenv("RTOW_DUMP_PRIMARY_LISTS")) {      // development aid: the lists as raw uint2[width * height]
+                std::vector<uint2> host(pixels);
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(host.data(), ctx->dPixCand, pixels * sizeof(uint2), hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(dump, "wb")) { fwrite(host.data(), sizeof(uint2), pixels, f); fclose(f); }
+            }
+#endif
             ctx->pixCandScene = ctx->sceneSerial;
             ctx->pixCandView = a.view;
             ctx->pixCandW = a.width; ctx->pixCandH = a.height; ctx->pixCandOff = a.sliceOffset; ctx->pixCandDiv = a.sliceDivider;

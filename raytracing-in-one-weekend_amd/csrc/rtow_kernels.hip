@@ -849,14 +849,34 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     pendRE = 0;
                     startRay();
                     if (pcand.x != kNoPrimaryList) {
-                        // Every camera ray of this pixel can only hit primitives of the pixel's cached list (a conservative beam walk done
-                        // once per pixel and launch): skip the box walk and hand the list to the exact tests.
-                        cand[0 * kBlockThreads] = (unsigned short)(pcand.x & 0xffffu);
-                        cand[1 * kBlockThreads] = (unsigned short)(pcand.x >> 16);
-                        cand[2 * kBlockThreads] = (unsigned short)(pcand.y & 0xffffu);
-                        cand[3 * kBlockThreads] = (unsigned short)(pcand.y >> 16);
-                        nc = ((pcand.x & 0xffffu) != 0xffffu) + ((pcand.x >> 16) != 0xffffu) + ((pcand.y & 0xffffu) != 0xffffu) + ((pcand.y >> 16) != 0xffffu);
+                        // Every camera ray of this pixel can only hit primitives under the (at most four) leaf-parent nodes of the pixel's
+                        // list: instead of walking the tree, visit just those nodes - with the walk's own slab test of this very ray against
+                        // their leaf boxes (same expressions, so the same candidates the walk would find: a ray that misses a leaf's box must
+                        // not reach that leaf's exact test, whose rounding can report a hit for a far, small sphere it passes closely).
+                        const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
+                        const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
                         cur = -1;
+                        for (int k = 0; k < 4; k++) {
+                            const unsigned node = (k < 2 ? pcand.x >> (16 * k) : pcand.y >> (16 * (k - 2))) & 0xffffu;
+                            if (node == 0xffffu) break;
+                            float4 q0, q1, q2;
+                            int c0, c1;
+                            load_node<ALL_LDS>(sc, L, (int)node, q0, q1, q2, c0, c1);
+                            const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
+                            const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
+                            const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
+                            const float tmin0 = vmax3(vmin(tlx.x, thx.x), vmin(tly.x, thy.x), vmax(vmin(tlz.x, thz.x), 0.0f));
+                            const float tmax0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmin(vmax(tlz.x, thz.x), best));
+                            const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
+                            const float tmax1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmin(vmax(tlz.y, thz.y), best));
+                            const bool leaf0 = tmin0 <= tmax0 && c0 < 0;
+                            const bool leaf1 = tmin1 <= tmax1 && twoChildren && c1 < 0;
+                            if (FULL_DIAG) boundsHits += (leaf0 ? 1.0f : 0.0f) + (leaf1 ? 1.0f : 0.0f);
+                            cand[nc * kBlockThreads] = (unsigned short)~c0;
+                            nc += leaf0 ? 1 : 0;
+                            cand[nc * kBlockThreads] = (unsigned short)~c1;
+                            nc += leaf1 ? 1 : 0;
+                        }
                         if (nc == 0) classify(); else st = ST_TEST;
                     }
                 }
@@ -1357,7 +1377,7 @@ __device__ __forceinline__ float chunk_key(const unsigned* cost, unsigned n, uns
     return byMax ? (float)cost[n + i] * 64.0f + (float)cost[i] * (1.0f / 64.0f) : (float)cost[i];
 }
 // ------------------------------------------------------------------------------------------------------------
-// Camera-ray candidate lists.  All camera rays of one pixel (every sample: jitter inside the pixel, origin inside the
+// Camera-ray node lists.  All camera rays of one pixel (every sample: jitter inside the pixel, origin inside the
 // lens disk) stay inside a thin beam around the pixel's centre ray, and 40 % of all rays are camera rays: one
 // CONSERVATIVE walk of the beam per pixel finds every primitive any of them can hit, and the sample kernel then skips the
 // box walk for depth-0 rays.  One thread per owned pixel, neighbouring pixels walk the same nodes (fully coherent).
@@ -1421,19 +1441,23 @@ __global__ void __launch_bounds__(256) primary_candidates_kernel(SampleKernelArg
     int sp = 0, cur = 0;
     const GpuNode* nodes = reinterpret_cast<const GpuNode*>(A.sceneBlob + L.nodeOffset);
     while (ok && cur >= 0) {
-        const GpuNode n = nodes[cur];
+        const int node = cur;
+        const GpuNode n = nodes[node];
         cur = -1;
+        bool leafChildInBeam = false;
         for (int side = 0; side < 2; side++) {
             if (side == 1 && L.sphereCount < 2) break;                          // single-entity scene: the second child is a placeholder
             const int child = side ? n.child1 : n.child0;
             if (!beamHitsBox(n.lox[side], n.loy[side], n.loz[side], n.hix[side], n.hiy[side], n.hiz[side])) continue;
-            if (child < 0) {
-                if (count == 4) { ok = false; break; }
-                for (int k = 0; k < 4; k++) if (k == count) list[k] = (unsigned)~child & 0xffffu;
-                count++;
-            } else if (cur < 0) cur = child;
+            if (child < 0) leafChildInBeam = true;
+            else if (cur < 0) cur = child;
             else if (sp <= RTOW_STACK_CAPACITY) stack[sp++] = child;
             else ok = false;
+        }
+        if (leafChildInBeam) {                                                  // the NODE goes on the list: its leaf boxes are re-tested per ray
+            if (count == 4) ok = false;
+            for (int k = 0; k < 4; k++) if (k == count) list[k] = (unsigned)node;
+            count++;
         }
         if (cur < 0 && sp > 0) cur = stack[--sp];
     }

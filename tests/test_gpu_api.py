@@ -304,8 +304,8 @@ def test_adaptive_sample_counts_match_oracle(rt, oracle, gpu_context):
 
 
 def test_camera_ray_candidate_lists_are_conservative(rt, oracle, gpu_context, monkeypatch):
-    """Depth-0 rays take their candidates from a per-pixel list built by one conservative beam walk (primary_candidates_kernel) instead of
-    walking the tree.  The frame must not change by a bit when the lists are switched off, and must equal the oracle, for the cases that
+    """Depth-0 rays take their candidates from a per-pixel list of leaf-parent nodes built by one conservative beam walk
+    (primary_candidates_kernel) instead of walking the tree.  The frame must not change by a bit when the lists are switched off, and must equal the oracle, for the cases that
     stretch the beam: huge pixels (tiny frames), a wide lens, no jitter, interlaced slices, camera inside the geometry, a tree outside LDS."""
     ctx = gpu_context
     cases = []

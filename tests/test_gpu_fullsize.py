@@ -79,3 +79,34 @@ def test_config4_stress_10k_spheres(rt, oracle, gpu_context):
 def test_config5_moving_defocus_1080p(rt, oracle, gpu_context):
     """BASELINE.json configs[4]: moving spheres + aperture 0.05 at 1920x1080, 64 spp."""
     _check_sparse(rt, oracle, gpu_context, rt.scenes.moving_scene(), 1920, 1080, 64, 8, count=500, seed=7, stride=16)
+
+
+@pytest.mark.parametrize("name", ["cover", "moving", "stress", "mixed"])
+def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, monkeypatch, name):
+    """Results-neutral machinery at full size: camera-ray candidate lists on / off, longest-chunk-first ordering on / off (first launch =
+    probe order, second = measured order) and different stage thresholds must all give the same 1080p frame, bit for bit."""
+    ctx = gpu_context
+    scene = {"cover": rt.scenes.cover_scene, "moving": rt.scenes.moving_scene, "stress": lambda: rt.scenes.stress_scene(count=6000, max_tentatives=30000),
+             "mixed": rt.scenes.mixed_scene}[name]()
+    ctx.upload_scene(scene.desc())
+    w, h, spp = 1920, 1080, 6
+    p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=8)
+    for var in ("RTOW_NO_PRIMARY_LISTS", "RTOW_NO_CHUNK_ORDER", "RTOW_TUNE"):
+        monkeypatch.delenv(var, raising=False)
+    base = _device_render(rt, ctx, p, w * h, 4)
+    again = _device_render(rt, ctx, p, w * h, 4)              # chunk order now comes from the first launch's cost map
+    variants = {"second launch": again}
+    monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
+    variants["no camera-ray lists"] = _device_render(rt, ctx, p, w * h, 4)
+    monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
+    monkeypatch.setenv("RTOW_NO_CHUNK_ORDER", "1")
+    variants["row-order tickets"] = _device_render(rt, ctx, p, w * h, 4)
+    monkeypatch.delenv("RTOW_NO_CHUNK_ORDER")
+    monkeypatch.setenv("RTOW_TUNE", "1,1,1,1,1,1,1,16")
+    variants["every stage at once"] = _device_render(rt, ctx, p, w * h, 4)
+    monkeypatch.setenv("RTOW_TUNE", "32,64,16,16,16,1,1,5")
+    variants["heavy thresholds, 5-visit walk slices"] = _device_render(rt, ctx, p, w * h, 4)
+    monkeypatch.delenv("RTOW_TUNE")
+    for what, r in variants.items():
+        for k in ("color", "normal", "albedo", "scw", "diag"):
+            assert np.array_equal(base[k].view(np.uint32), r[k].view(np.uint32)), (name, what, k)
