@@ -110,3 +110,21 @@ def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, monkeypatch,
     for what, r in variants.items():
         for k in ("color", "normal", "albedo", "scw", "diag"):
             assert np.array_equal(base[k].view(np.uint32), r[k].view(np.uint32)), (name, what, k)
+
+
+@pytest.mark.parametrize("name,spp", [("cover", 6), ("stress", 4), ("moving", 4)])
+def test_whole_1080p_frame_equals_the_oracle(rt, oracle, gpu_context, name, spp):
+    """Every one of the 2 073 600 pixels of a full-size frame (at a sample count the CPU checker finishes in seconds), not a sparse sample:
+    rare events - a far, small sphere's exact test that only its box test keeps a ray away from, a tie, a stack corner - show up here."""
+    scene = {"cover": rt.scenes.cover_scene, "moving": rt.scenes.moving_scene, "stress": lambda: rt.scenes.stress_scene(count=6000, max_tentatives=30000)}[name]()
+    desc = scene.desc()
+    gpu_context.upload_scene(desc)
+    w, h = 1920, 1080
+    p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=8)
+    gpu = _device_render(rt, gpu_context, p, w * h, 4)
+    osc = oracle.OracleScene(desc)
+    ref = osc.sample_batch(p)
+    osc.close()
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (name, k, int(np.any(gpu[k].view(np.uint32).reshape(w * h, -1) != ref[k].view(np.uint32).reshape(w * h, -1), axis=1).sum()))
+    assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0])
