@@ -371,11 +371,20 @@ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, f
     const float c = dot(oc, oc) - radius * radius;
     const float disc = b * b - a * c;
     if (disc > 0) {
+        // t = (-b -+ sq) / a with a = dot(d, d) >= 0: a numerator that is not positive gives a quotient that is not positive (or NaN) and
+        // fails `t > 0` whatever a is, so its IEEE division is skipped - bit-identical, and the common "sphere behind the origin" case
+        // (every ray leaving the ground sphere) costs no division at all.
         const float sq = __builtin_sqrtf(disc);
-        float t = (-b - sq) / a;
-        if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
-        t = (-b + sq) / a;
-        if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
+        const float n0 = -b - sq;
+        if (n0 > 0) {
+            const float t = n0 / a;
+            if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
+        }
+        const float n1 = -b + sq;
+        if (n1 > 0) {
+            const float t = n1 / a;
+            if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
+        }
     }
     return false;
 }
@@ -387,11 +396,17 @@ __device__ __forceinline__ bool sphere_hit_tmin(V3 oc, V3 d, float a, float radi
     const float c = dot(oc, oc) - radius * radius;
     const float disc = b * b - a * c;
     if (disc > 0) {
-        const float sq = __builtin_sqrtf(disc);
-        float t = (-b - sq) / a;
-        if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
-        t = (-b + sq) / a;
-        if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
+        const float sq = __builtin_sqrtf(disc);                    // tMin >= 0 here: the numerator shortcut of sphere_hit applies unchanged
+        const float n0 = -b - sq;
+        if (n0 > 0) {
+            const float t = n0 / a;
+            if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
+        }
+        const float n1 = -b + sq;
+        if (n1 > 0) {
+            const float t = n1 / a;
+            if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
+        }
     }
     return false;
 }
