@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--rng", choices=["reference", "per-sample"], default="reference",
+                    help="reference: the reference's per-pixel generator (same seed, same image: the headline); per-sample: RTOW_RNG_PER_SAMPLE, a different stream")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--partition", choices=("batches", "tiles"), default="batches", help="how N > 1 GPUs split a batch")
@@ -180,6 +182,7 @@ def main():
     def params_for(seed):
         p = abi.SampleParams.from_buffer_copy(base)
         p.seed = seed
+        p.rngPolicy = abi.RNG_PER_SAMPLE if args.rng == "per-sample" else abi.RNG_REFERENCE
         return p
 
     import ctypes as C
@@ -273,7 +276,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "cover scene (486 spheres, generated per Final Scene (Book 1).asset, seed 700), %dx%d, %d spp per batch, "
-                            "%d bounces, white noise, jitter on, reference RNG stream (lane per pixel)" % (W, H, spp, depth),
+                            "%d bounces, white noise, jitter on, %s" % (W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_PER_SAMPLE (NOT the reference stream; lane per 16-sample group)"),
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
                               "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
                               if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch" % world),

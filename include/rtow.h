@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 3
+#define RTOW_API_VERSION 4
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -194,6 +194,17 @@ typedef struct RtowView {
  * order +X, -X, +Y, -Y, +Z, -Z (Unity's CubemapFace order), each face `faceHeight` rows of `faceWidth` pixels, row 0 first.
  * channelType follows the reference's ChannelType: its ctor only accepts R16G16B16A16_SFloat (SignedHalf, pixelStride 8), its
  * Sample() also decodes UnsignedByte (value / 255). */
+/* How white-noise generators are assigned (the texture-driven colours are per pixel by construction).
+ *   RTOW_RNG_REFERENCE   the reference: one Unity.Mathematics.Random per pixel per batch, seeded from (Seed, pixel index), running
+ *                        through all the pixel's samples (JOBS/SampleBatchJob.cs:91,132-157).  Same seed, same image as the reference.
+ *   RTOW_RNG_PER_SAMPLE  NOT the reference's stream (a different, statistically equivalent image): sample s of pixel i gets its own
+ *                        generator, seeded ((Seed * 0x8C4CA03F) ^ (i * 0x7383ED49)) ^ ((s + 1) * 0x9E3779B9) (0x9E3779B9 if that is 0)
+ *                        and advanced once like the Random ctor does; samples are taken in groups of 16, every group summed from zero
+ *                        in sample order, and the groups added to the accumulators in group order (colour, normal, albedo, successes,
+ *                        sample-count weight; the fallback AOVs are sample 0's).  A pixel's samples become independent units of work:
+ *                        no long tail at the end of a batch, and a frame can be split over GPUs by rows without starving lanes. */
+typedef enum RtowRngPolicy { RTOW_RNG_REFERENCE = 0, RTOW_RNG_PER_SAMPLE = 1 } RtowRngPolicy;
+
 typedef enum RtowCubemapChannelType { RTOW_CUBEMAP_UNSIGNED_BYTE = 0, RTOW_CUBEMAP_SIGNED_HALF = 1 } RtowCubemapChannelType;
 typedef struct RtowCubemapDesc {
     int32_t faceWidth, faceHeight;
@@ -243,6 +254,7 @@ typedef struct RtowSampleParams {
                                        16 = FULL_DIAGNOSTICS {RayCount, BoundsHitCount, CandidateCount,
                                        SampleCountWeight} (UNITY/Raytracer.cs:54-64) */
     int32_t noiseTextureIndex;      /* which texture of the uploaded blue / STBN set this batch reads (ignored for white noise) */
+    int32_t rngPolicy;              /* RtowRngPolicy; 0 = the reference's stream */
 } RtowSampleParams;
 
 /* The four accumulation buffers (JOBS/SampleBatchJob.cs:41-49): W*H elements each, tightly packed,

@@ -1537,8 +1537,28 @@ struct Job {
         }
         diagnostics.SampleCountWeight = sampleCountWeight;                                   /* :128-130 */
 
+        /* RTOW_RNG_PER_SAMPLE (include/rtow.h; NOT the reference): every sample has its own generator; groups of 16 samples are summed
+         * from zero in sample order and the groups added to the accumulators in group order */
+        const bool perSample = p.rngPolicy == RTOW_RNG_PER_SAMPLE;
+        float3 gColor = f3(0), gNormal = f3(0), gAlbedo = f3(0);
+        float gWeight = 0;
+        int gCount = 0;
+        auto closeGroup = [&]() {
+            if (gCount > 0) { colorAcc += gColor; normalAcc += gNormal; albedoAcc += gAlbedo; sampleCount += gCount; }
+            sampleCountWeightAcc += gWeight;
+            gColor = gNormal = gAlbedo = f3(0);
+            gWeight = 0;
+            gCount = 0;
+        };
+
         for (uint32_t smp = 0; smp < samplesToAccumulate; smp++) {                            /* :132-157 */
             if (tracePixel) fprintf(stderr, "[otrace] sample %u\n", smp);
+            if (perSample) {
+                uint32_t state = ((p.seed * 0x8C4CA03Fu) ^ ((uint32_t)index * 0x7383ED49u)) ^ ((smp + 1u) * 0x9E3779B9u);
+                if (state == 0) state = 0x9E3779B9u;
+                rng.whiteNoise.Init(state);
+                rng.RandomEvents = 0;
+            }
             float2 jitter;
             if (p.subPixelJitter) jitter = rng.NextFloat2();
             else jitter = float2{0.5f, 0.5f};
@@ -1546,7 +1566,15 @@ struct Job {
             const Ray eyeRay = view.GetRay(normalizedCoordinates, rng);
 
             float3 sampleColor, sampleNormal, sampleAlbedo;
-            if (Sample(eyeRay, rng, s, &sampleColor, &sampleNormal, &sampleAlbedo, diagnostics, &sampleCountWeightAcc)) {
+            if (perSample) {
+                if (Sample(eyeRay, rng, s, &sampleColor, &sampleNormal, &sampleAlbedo, diagnostics, &gWeight)) {
+                    gColor += sampleColor;
+                    gNormal += sampleNormal;
+                    gAlbedo += sampleAlbedo;
+                    gCount++;
+                }
+                if (smp % 16 == 15 || smp + 1 == samplesToAccumulate) closeGroup();
+            } else if (Sample(eyeRay, rng, s, &sampleColor, &sampleNormal, &sampleAlbedo, diagnostics, &sampleCountWeightAcc)) {
                 colorAcc += sampleColor;
                 normalAcc += sampleNormal;
                 albedoAcc += sampleAlbedo;
@@ -1704,6 +1732,7 @@ static int sample_impl(void* scenePtr, const RtowSampleParams* params,
 {
     if (!scenePtr || !params) return 1;
     if (params->noiseColor < RTOW_NOISE_WHITE || params->noiseColor > RTOW_NOISE_SPATIOTEMPORAL_BLUE) return 1;
+    if (params->rngPolicy != RTOW_RNG_REFERENCE && !(params->rngPolicy == RTOW_RNG_PER_SAMPLE && params->noiseColor == RTOW_NOISE_WHITE)) return 1;
     if (params->sliceDivider < 1 || params->traceDepth < 0) return 1;
     const OracleScene* scene = (const OracleScene*)scenePtr;
     Job job;

@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 3
+RTOW_API_VERSION = 4
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -96,6 +96,7 @@ class View(C.Structure):
 
 
 CUBEMAP_UNSIGNED_BYTE, CUBEMAP_SIGNED_HALF = 0, 1
+RNG_REFERENCE, RNG_PER_SAMPLE = 0, 1
 
 
 class CubemapDesc(C.Structure):
@@ -120,7 +121,8 @@ class SampleParams(C.Structure):
     _fields_ = [("size", Float2), ("sliceOffset", C.c_int32), ("sliceDivider", C.c_int32), ("seed", C.c_uint32),
                 ("view", View), ("environment", Environment), ("sampleCountRange", C.c_uint32 * 2),
                 ("traceDepth", C.c_int32), ("subPixelJitter", C.c_int32), ("noiseColor", C.c_int32),
-                ("sampleCountWeightExtrema", Float2), ("diagnosticsStride", C.c_int32), ("noiseTextureIndex", C.c_int32)]
+                ("sampleCountWeightExtrema", Float2), ("diagnosticsStride", C.c_int32), ("noiseTextureIndex", C.c_int32),
+                ("rngPolicy", C.c_int32)]
 
 
 class AccumBuffers(C.Structure):

@@ -58,6 +58,10 @@ struct RtowContext_t {
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
     volatile uint32_t* hCancel = nullptr; // pinned, device-visible
+    // RTOW_RNG_PER_SAMPLE: one 64-byte record per (owned pixel, sample group) unit
+    float* dUnitRecords = nullptr;
+    size_t unitRecordCapacity = 0;
+    uint32_t orderGroups = 1;     // groups per pixel the chunk cost map was recorded with
     // Image-texture blob of the current scene (CompiledScene.texBlob), HBM only
     uint8_t* dTexBlob = nullptr;
     size_t texBlobCapacity = 0;
@@ -117,6 +121,8 @@ int validateParams(const RtowSampleParams* p)
     if (p->sliceDivider < 1 || p->sliceOffset < 0 || p->sliceOffset >= p->sliceDivider) return RTOW_ERROR_INVALID_VALUE;
     if (p->traceDepth < 1 || p->traceDepth > 64) return p->traceDepth < 1 ? RTOW_ERROR_INVALID_VALUE : RTOW_ERROR_CAPACITY;
     if (p->noiseColor < RTOW_NOISE_WHITE || p->noiseColor > RTOW_NOISE_SPATIOTEMPORAL_BLUE) return RTOW_ERROR_INVALID_VALUE;
+    if (p->rngPolicy != RTOW_RNG_REFERENCE && p->rngPolicy != RTOW_RNG_PER_SAMPLE) return RTOW_ERROR_INVALID_VALUE;
+    if (p->rngPolicy == RTOW_RNG_PER_SAMPLE && p->noiseColor != RTOW_NOISE_WHITE) return RTOW_ERROR_INVALID_VALUE;   // the texture walks are per pixel by construction
     if (p->environment.skyType < RTOW_SKY_NONE || p->environment.skyType > RTOW_SKY_CUBEMAP) return RTOW_ERROR_INVALID_VALUE;
     if (p->diagnosticsStride != 4 && p->diagnosticsStride != 16) return RTOW_ERROR_INVALID_VALUE;
     return RTOW_SUCCESS;
@@ -199,6 +205,25 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.stats = dStats;
     a.debugPixel = getenv("RTOW_DEBUG_PIXEL") ? atoi(getenv("RTOW_DEBUG_PIXEL")) : -2;
 #endif
+    const uint32_t ownedPixels = a.totalWork;
+    a.groupsPerPixel = 1;
+    if (p->rngPolicy == RTOW_RNG_PER_SAMPLE) {
+        // work units are (owned pixel, group of kSampleGroup samples); each leaves a record that fold_unit_records_kernel adds up
+        uint32_t groups = (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
+        groups = (groups + kSampleGroup - 1) / kSampleGroup;
+        if (groups < 1) groups = 1;
+        if ((uint64_t)ownedPixels * groups > 0x7fffffffull) return RTOW_ERROR_CAPACITY;
+        a.groupsPerPixel = groups;
+        a.totalWork = ownedPixels * groups;
+        if ((size_t)a.totalWork > ctx->unitRecordCapacity) {
+            if (ctx->dUnitRecords) (void)hipFree(ctx->dUnitRecords);
+            ctx->dUnitRecords = nullptr;
+            ctx->unitRecordCapacity = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dUnitRecords, (size_t)a.totalWork * 64u), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->unitRecordCapacity = a.totalWork;
+        }
+        a.unitRecords = ctx->dUnitRecords;
+    }
     int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
     if (blocks < 1) blocks = 1;
@@ -222,7 +247,9 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
                           ctx->pixCandW == a.width && ctx->pixCandH == a.height && ctx->pixCandOff == a.sliceOffset && ctx->pixCandDiv == a.sliceDivider &&
                           ctx->pixCandJitter == (a.subPixelJitter ? 1 : 0);
         if (!same) {
-            HIP_TRY(ctx, launchPrimaryCandidates(a, ctx->dPixCand, stream), RTOW_ERROR_LAUNCH_FAILURE);
+            SampleKernelArgs perPixel = a;                       // the lists are per pixel whatever the work units are
+            perPixel.totalWork = ownedPixels;
+            HIP_TRY(ctx, launchPrimaryCandidates(perPixel, ctx->dPixCand, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->pixCandValid = true;
 #ifdef RTOW_STATS
             if (const char* dump = getenv("RTOW_DUMP_PRIMARY_LISTS")) {      // development aid: the lists as raw uint2[width * height]
@@ -255,8 +282,16 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             ctx->chunkCapacity = a.chunkCount;
             ctx->orderValid = false;
         }
-        if (ctx->orderW != a.width || ctx->orderH != a.height || ctx->orderOff != a.sliceOffset || ctx->orderDiv != a.sliceDivider) ctx->orderValid = false;
+        if (ctx->orderW != a.width || ctx->orderH != a.height || ctx->orderOff != a.sliceOffset || ctx->orderDiv != a.sliceDivider || ctx->orderGroups != a.groupsPerPixel) ctx->orderValid = false;
         a.pixelCost = ctx->dPixelCost;
+        bool haveOrder = true;
+        if (!ctx->orderValid && a.unitRecords) {
+            // per-sample units are small and alike: the first batch simply runs in natural order and records the map for the next
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dPixelCost, 0, (size_t)a.chunkCount * 64 * sizeof(unsigned short), stream), RTOW_ERROR_LAUNCH_FAILURE);
+            haveOrder = false;
+            ctx->orderValid = true;
+            ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider; ctx->orderGroups = a.groupsPerPixel;
+        }
         if (!ctx->orderValid) {
             // no cost map yet for this frame configuration: a 1-sample-per-pixel probe of the same kernel (stores nothing else)
             SampleKernelArgs probe = a;
@@ -268,14 +303,15 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             HIP_TRY(ctx, launchSampleBatch(probe, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
             HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 0, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->orderValid = true;
-            ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider;
+            ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider; ctx->orderGroups = a.groupsPerPixel;
         }
-        a.chunkOrder = ctx->dChunkOrder;
+        a.chunkOrder = haveOrder ? ctx->dChunkOrder : nullptr;
     }
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStart, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    if (a.unitRecords) HIP_TRY(ctx, launchFoldUnitRecords(a, stream), RTOW_ERROR_LAUNCH_FAILURE);   // inside the timed region: part of the batch
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
     // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
     if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
@@ -434,6 +470,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dBlueNoise) (void)hipFree(ctx->dBlueNoise);
     if (ctx->dStbNoise) (void)hipFree(ctx->dStbNoise);
     if (ctx->dTexBlob) (void)hipFree(ctx->dTexBlob);
+    if (ctx->dUnitRecords) (void)hipFree(ctx->dUnitRecords);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }

@@ -21,6 +21,7 @@ constexpr int kLdsBytesMax = 160 * 1024;
 constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting their exact test (flushed when full)
 constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane]
 constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: first slot empty, second not - "no list, walk the tree"
+constexpr unsigned kSampleGroup = 16;   // RTOW_RNG_PER_SAMPLE: samples per work unit (part of that policy's definition: partial sums are per group)
 constexpr int kQueueBytes = 256;   // per-wave {next, end} pixel-ticket chunk (16 waves x 8 B, padded)
 
 // Everything the sample kernel needs, passed by value (kernarg segment).
@@ -65,6 +66,10 @@ struct SampleKernelArgs {
     int32_t subPixelJitter;
     float extremaX, extremaY;
 
+    // RTOW_RNG_PER_SAMPLE: work units are (owned pixel, group of kSampleGroup samples); totalWork counts units
+    float* unitRecords;                   // [totalWork] x 16 floats, null = reference policy (units are pixels)
+    uint32_t groupsPerPixel;              // ceil(sampleCountMax / kSampleGroup), 1 under the reference policy
+
     // Image textures (SCENE_KIND_TEXTURED): GpuTexMaterial / GpuImage tables and pixels, in HBM
     const uint8_t* texBlob;
     TexLayout texLayout;
@@ -101,6 +106,7 @@ struct KernelInfo {
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
 hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream);
+hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream);
 hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream);
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream);  // inverse transforms of general entities, on device
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,

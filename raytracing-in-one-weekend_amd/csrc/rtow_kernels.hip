@@ -157,6 +157,13 @@ struct Rng<RTOW_NOISE_WHITE> {
         s = (at.A->seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u);   // :91; the Random ctor then discards one NextState()
         (void)rng_next(s);
     }
+    // RTOW_RNG_PER_SAMPLE: sample `smp` of the pixel gets its own generator (include/rtow.h)
+    __device__ __forceinline__ void begin_sample(const NoiseSite& at, unsigned pix, unsigned smp)
+    {
+        s = ((at.A->seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u)) ^ ((smp + 1u) * 0x9E3779B9u);
+        if (s == 0u) s = 0x9E3779B9u;                            // Random needs a non-zero state
+        (void)rng_next(s);
+    }
     __device__ __forceinline__ float next(const NoiseSite&) { return rng_next(s); }
     __device__ __forceinline__ void next2(const NoiseSite&, float& a, float& b) { a = rng_next(s); b = rng_next(s); }
     __device__ __forceinline__ void in_unit_disk(const NoiseSite&, float& x, float& y)       // RT/RandomSource.cs:40-61
@@ -177,6 +184,7 @@ template <>
 struct Rng<RTOW_NOISE_BLUE> {
     unsigned s;                                                   // PerPixelNoise.n
     __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = at.A->seed + 1u; }   // n = seed; Advance() (:17-25)
+    __device__ __forceinline__ void begin_sample(const NoiseSite&, unsigned, unsigned) {}
     __device__ __forceinline__ void texel(const NoiseSite& at, float& x, float& y)
     {
         const uint2 t = reinterpret_cast<const uint2*>(at.A->blueNoise)[noise_texel(s, at.A->blueRowStride, at.cx, at.cy)];   // half4
@@ -203,6 +211,7 @@ template <>
 struct Rng<RTOW_NOISE_SPATIOTEMPORAL_BLUE> {
     unsigned s, v2, cs, u2, u3;                                   // n of perPixelScalar / Vector2 / CosineUnitVector3 / UnitVector2 / UnitVector3
     __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = v2 = cs = u2 = u3 = at.A->seed + 1u; }
+    __device__ __forceinline__ void begin_sample(const NoiseSite&, unsigned, unsigned) {}
     __device__ __forceinline__ float next(const NoiseSite& at)                                                           // STBN :61
     {
         const unsigned i = noise_texel(s++, at.A->stbRowStride, at.cx, at.cy);
@@ -591,7 +600,7 @@ enum : int {
     ST_COUNT = 6
 };
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE>
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
 __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -632,6 +641,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     int pix = -1;
     unsigned tick = 0;          // ticket (owned-pixel number) of the current pixel
     Rng<NOISE> rng{};
+    V3 fbNormal = v3(0, 0, 0), fbAlbedo = v3(0, 0, 0);   // PER_SAMPLE: AOVs of the batch's sample 0 (the fallback when nothing succeeds)
+    unsigned unitGroup = 0;                                // PER_SAMPLE: which 16-sample group of its pixel this lane works on
     unsigned smp = 0, nsamp = 0;
     int cx = 0, cy = 0;
     V3 colorAcc = v3(0, 0, 0), normalAcc = v3(0, 0, 0), albedoAcc = v3(0, 0, 0);
@@ -675,6 +686,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             normalAcc = add(normalAcc, sampleNormal);
             albedoAcc = add(albedoAcc, sampleAlbedo);
             sampleCount++;
+        } else if (PER_SAMPLE) {
+            if (smp == 0) { fbNormal = sampleNormal; fbAlbedo = sampleAlbedo; }
         } else if (smp == 0 && !A.probeOnly) {
             // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
             // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
@@ -738,6 +751,16 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         A.pixelCost[tick] = (unsigned short)(rc < 65535u ? rc : 65535u);
                     }
                     if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
+                    if (PER_SAMPLE && pix >= 0) {
+                        // ---- unit done: its partial sums go to the record the fold kernel adds up in group order ----
+                        const bool fallback = unitGroup == 0 && sampleCount == 0;       // then sample 0 failed: the record carries its AOVs instead of sums
+                        float4* rec = reinterpret_cast<float4*>(A.unitRecords) + (size_t)tick * 4u;
+                        rec[0] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
+                        rec[1] = fallback ? make_float4(fbNormal.x, fbNormal.y, fbNormal.z, rayCount) : make_float4(normalAcc.x, normalAcc.y, normalAcc.z, rayCount);
+                        rec[2] = fallback ? make_float4(fbAlbedo.x, fbAlbedo.y, fbAlbedo.z, scwAcc) : make_float4(albedoAcc.x, albedoAcc.y, albedoAcc.z, scwAcc);
+                        rec[3] = make_float4(boundsHits, candidates, 0, 0);
+                        pix = -1;
+                    }
                     if (pix >= 0) {
                         // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
                         reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
@@ -793,6 +816,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     }
                     if (ticket == 0xffffffffu) { st = ST_DEAD; break; }
                     tick = ticket;
+                    if (PER_SAMPLE) { unitGroup = ticket % A.groupsPerPixel; ticket = ticket / A.groupsPerPixel; }   // unit = (owned pixel, sample group)
 #ifdef RTOW_STATS
                     pixT0 = wall_clock64();
 #endif
@@ -802,7 +826,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     pix = cy * A.width + cx;
 
                     float4 last = make_float4(0, 0, 0, 0);
-                    if (!A.probeOnly) {
+                    if (PER_SAMPLE) {
+                        // a unit only needs what decides the pixel's sample count (:118-126); the fold kernel reads the accumulators
+                        last.w = A.inColor[4 * (size_t)pix + 3];
+                        scwAcc = A.inScw[pix];
+                    } else if (!A.probeOnly) {
                         last = reinterpret_cast<const float4*>(A.inColor)[pix];                           // :72-78
                         normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
                         albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
@@ -810,12 +838,14 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     }
                     colorAcc = v3(last.x, last.y, last.z);
                     sampleCount = (int)last.w;
+                    const float scwIn = scwAcc;
+                    const int countIn = sampleCount;
 
                     // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
                     rng.begin_pixel(NoiseSite{&A, (unsigned)cx, (unsigned)cy}, (unsigned)pix);
 
                     // :118-126
-                    const float w = scwAcc / (float)sampleCount;
+                    const float w = scwIn / (float)countIn;
                     if (w == 0) {
                         nsamp = A.sampleCountMin;
                     } else {
@@ -826,6 +856,15 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     if (A.probeOnly) nsamp = 1;
                     scw0 = w;
                     smp = 0;
+                    if (PER_SAMPLE) {
+                        // this unit: samples [16 g, 16 g + 16) of the pixel's nsamp, accumulated from zero
+                        smp = unitGroup * kSampleGroup;
+                        nsamp = nsamp < smp + kSampleGroup ? nsamp : smp + kSampleGroup;
+                        if (nsamp < smp) nsamp = smp;
+                        colorAcc = v3(0, 0, 0); normalAcc = v3(0, 0, 0); albedoAcc = v3(0, 0, 0);
+                        sampleCount = 0;
+                        scwAcc = 0;
+                    }
                     rayCount = 0; boundsHits = 0; candidates = 0;
                     // the pixel's camera-ray candidates (primary_candidates_kernel): up to 4 primitive indices, 0xFFFF = none
                     pcand = A.pixelCandidates ? A.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u);
@@ -837,6 +876,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const float lensRadius = A.view.lensRadius;
                     float jx = 0.5f, jy = 0.5f;
                     const NoiseSite at{&A, (unsigned)cx, (unsigned)cy};
+                    if (PER_SAMPLE) rng.begin_sample(at, (unsigned)pix, smp);
                     if (A.subPixelJitter) rng.next2(at, jx, jy);
                     const float u = ((float)cx + jx) / A.sizeX;
                     const float v = ((float)cy + jy) / A.sizeY;
@@ -1392,6 +1432,59 @@ __device__ __forceinline__ float chunk_key(const unsigned* cost, unsigned n, uns
     return byMax ? (float)cost[n + i] * 64.0f + (float)cost[i] * (1.0f / 64.0f) : (float)cost[i];
 }
 // ------------------------------------------------------------------------------------------------------------
+// RTOW_RNG_PER_SAMPLE: the sample kernel's units (pixel, group of 16 samples) leave one 64-byte record each; this kernel adds a
+// pixel's records to its accumulators IN GROUP ORDER (so the result does not depend on which lane ran which unit) and writes the
+// outputs and diagnostics of SampleBatchJob.Execute (JOBS/SampleBatchJob.cs:159-163).
+//   record = {colour.xyz, successes | normal.xyz, rays | albedo.xyz, sampleCountWeight | boundsHits, candidates, -, -};
+//   a group-0 record with no success carries the AOVs of the batch's sample 0 (the fallback, :152-156) instead of sums.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fold_unit_records_kernel(SampleKernelArgs A)
+{
+    const unsigned ticket = blockIdx.x * blockDim.x + threadIdx.x;       // owned pixel
+    const unsigned pixels = A.totalWork / A.groupsPerPixel;
+    if (ticket >= pixels) return;
+    const int ownedRow = (int)(ticket / (unsigned)A.width);
+    const int cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
+    const int cy = A.sliceOffset + ownedRow * A.sliceDivider;
+    const size_t pix = (size_t)cy * (size_t)A.width + (size_t)cx;
+    const float4 last = reinterpret_cast<const float4*>(A.inColor)[pix];
+    V3 color = v3(last.x, last.y, last.z);
+    V3 normal = v3(A.inNormal[3 * pix], A.inNormal[3 * pix + 1], A.inNormal[3 * pix + 2]);
+    V3 albedo = v3(A.inAlbedo[3 * pix], A.inAlbedo[3 * pix + 1], A.inAlbedo[3 * pix + 2]);
+    float scw = A.inScw[pix];
+    int count = (int)last.w;
+    const float weight = scw / (float)count;                              // Diagnostics.SampleCountWeight (:128-130)
+    float rays = 0, bounds = 0, cands = 0;
+    V3 fbNormal = v3(0, 0, 0), fbAlbedo = v3(0, 0, 0);
+    const float4* rec = reinterpret_cast<const float4*>(A.unitRecords) + (size_t)ticket * A.groupsPerPixel * 4u;
+    for (unsigned g = 0; g < A.groupsPerPixel; g++, rec += 4) {
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        if (r0.w > 0) {
+            color = add(color, v3(r0.x, r0.y, r0.z));
+            normal = add(normal, v3(r1.x, r1.y, r1.z));
+            albedo = add(albedo, v3(r2.x, r2.y, r2.z));
+            count += (int)r0.w;
+        } else if (g == 0) {
+            fbNormal = v3(r1.x, r1.y, r1.z);
+            fbAlbedo = v3(r2.x, r2.y, r2.z);
+        }
+        scw += r2.w;
+        rays += r1.w;
+        bounds += r3.x;
+        cands += r3.y;
+    }
+    reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(color.x, color.y, color.z, (float)count);
+    const V3 on = count == 0 ? fbNormal : normal, oa = count == 0 ? fbAlbedo : albedo;
+    A.outNormal[3 * pix] = on.x; A.outNormal[3 * pix + 1] = on.y; A.outNormal[3 * pix + 2] = on.z;
+    A.outAlbedo[3 * pix] = oa.x; A.outAlbedo[3 * pix + 1] = oa.y; A.outAlbedo[3 * pix + 2] = oa.z;
+    A.outScw[pix] = scw;
+    if (A.diagnostics) {
+        if (A.diagnosticsStride >= 16) *reinterpret_cast<float4*>(A.diagnostics + pix * 16u) = make_float4(rays, bounds, cands, weight);
+        else *reinterpret_cast<float*>(A.diagnostics + pix * 4u) = rays;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Camera-ray node lists.  All camera rays of one pixel (every sample: jitter inside the pixel, origin inside the
 // lens disk) stay inside a thin beam around the pixel's centre ray, and 40 % of all rays are camera rays: one
 // CONSERVATIVE walk of the beam per pixel finds every primitive any of them can hit, and the sample kernel then skips the
@@ -1674,10 +1767,10 @@ __global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE>
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
 hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE>;
+    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE, PER_SAMPLE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(numBlocks), dim3(kBlockThreads), ldsBytes, stream, args);
@@ -1688,11 +1781,16 @@ template <bool ALL_LDS, int KIND, bool FULL_DIAG>
 hipError_t launchByDepth(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
     // the texture-driven noise sources are not the hot configuration: one (generic-history) variant each keeps the build small
-    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_BLUE>(args, numBlocks, ldsBytes, stream);
-    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_SPATIOTEMPORAL_BLUE>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE>(args, numBlocks, ldsBytes, stream);
-    return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE>(args, numBlocks, ldsBytes, stream);
+    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_BLUE, false>(args, numBlocks, ldsBytes, stream);
+    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false>(args, numBlocks, ldsBytes, stream);
+    if (args.unitRecords) {      // RTOW_RNG_PER_SAMPLE
+        if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
+        if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
+        return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
+    }
+    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
+    return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
 }
 
 template <bool ALL_LDS, int KIND>
@@ -1722,6 +1820,13 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
     return allLds ? launchByKind<true>(args, numBlocks, ldsBytes, stream) : launchByKind<false>(args, numBlocks, ldsBytes, stream);
+}
+
+hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream)
+{
+    const unsigned pixels = args.totalWork / args.groupsPerPixel;
+    hipLaunchKernelGGL(fold_unit_records_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, args);
+    return hipGetLastError();
 }
 
 hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream)

@@ -708,7 +708,7 @@ def synthetic_sky(size=64, half=True, seed=3):
 
 
 def make_params(scene, width, height, spp, trace_depth, seed=1, jitter=True, slice_offset=0, slice_divider=1,
-                spp_max=None, extrema=(0.0, 0.0), diagnostics_stride=4, focus=None, sky_type=None, noise_color=None, noise_texture_index=0):
+                spp_max=None, extrema=(0.0, 0.0), diagnostics_stride=4, focus=None, sky_type=None, noise_color=None, noise_texture_index=0, rng_policy=0):
     """SampleBatchJob parameter block with the benchmark defaults of SURVEY.md section 8(d)."""
     p = abi.SampleParams()
     p.size = abi.Float2(float(width), float(height))
@@ -725,4 +725,5 @@ def make_params(scene, width, height, spp, trace_depth, seed=1, jitter=True, sli
     p.sampleCountWeightExtrema = abi.Float2(float(extrema[0]), float(extrema[1]))
     p.diagnosticsStride = diagnostics_stride
     p.noiseTextureIndex = noise_texture_index
+    p.rngPolicy = rng_policy
     return p
