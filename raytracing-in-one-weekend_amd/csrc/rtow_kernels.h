@@ -103,6 +103,13 @@ struct KernelInfo {
 };
 
 // launchers (defined in rtow_kernels.hip)
+// per scene kind, each defined in its own translation unit (rtow_sample_*.hip)
+hipError_t launchSampleSpheres(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleSpheresMotion(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleGeneral(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleVolumes(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleTextured(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleVolumesTextured(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
 hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream);

@@ -1,1424 +1,11 @@
-// rtow_kernels.hip - hand-written gfx950 (CDNA4) kernels of the sample-batch path.
-//
-// sample_batch_kernel replaces SampleBatchJob.Execute + Sample + FindHitCandidates + FindHits + Entity.Hit +
-// Sphere.Hit + Material.Scatter + View.GetRay + RandomSource (JOBS/SampleBatchJob.cs:59-475, RT/*.cs).
-//
-// Shape of the kernel (see DESIGN.md "Kernel"):
-//  * persistent: one 1024-lane workgroup per CU; the whole scene image (BVH nodes, spheres, materials) is staged
-//    once into LDS with coalesced 16-byte loads, next to a [level][lane] 16-bit traversal stack;
-//  * one lane = one PIXEL (the reference seeds its xorshift32 once per pixel and runs it through all of that
-//    pixel's samples, JOBS/SampleBatchJob.cs:91,132-157, so samples of a pixel are inherently sequential);
-//  * per-lane state machine with path regeneration: every trip of the main loop advances every live lane by
-//    exactly one path segment (traverse + shade); a lane whose path ended starts its next sample - or pulls its
-//    next pixel from a global ticket counter (wave-aggregated atomic) - in the same trip, so lanes never idle on
-//    a finished path;
-//  * closest-hit traversal, near child first, with t-pruning: equivalent to the reference's collect-all /
-//    sort / take [0] (JOBS/SampleBatchJob.cs:403-475, 205-209) because only element 0 is consumed when no
-//    ProbabilisticVolume exists;
-//  * the per-depth emission/attenuation stacks (JOBS/SampleBatchJob.cs:103-104,311,330) are kept as 16-bit
-//    material codes packed in VGPRs and re-expanded when the path is folded tail -> head (:384-396), which keeps the
-//    colour bit-identical to the reference's fold order without 2 x TraceDepth float3 of per-lane storage.
-//
-// Numerics: compiled with -ffp-contract=off; every expression below is written in the evaluation order of the C#
-// source (left to right, no fusion), with IEEE division and square root, and the deterministic transcendental
-// functions of rtow_detmath.hip.h.  No MFMA: there is no dense contraction anywhere on this path.
-#include "rtow_kernels.h"
-
-#include "rtow_detmath.hip.h"
+// rtow_kernels.hip - the small kernels around the sample-batch megakernel (rtow_sample_kernel.hip.h): per-sample record fold, camera-ray
+// node lists, chunk ordering, scene preparation and the post passes (CombineJob, FinalizeTexturesJob, ReduceMetricsJob), and the host
+// launchers of all of them.
+#include "rtow_sample_kernel.hip.h"
 
 namespace rtow {
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------------------
-// small float3 helpers; each spells out the reference's evaluation order
-// ------------------------------------------------------------------------------------------------------------
-struct V3 { float x, y, z; };
-
-__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 v3(const RtowFloat3& a) { return v3(a.x, a.y, a.z); }
-__device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ V3 scale(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-// math.normalize(v) = rsqrt(dot(v, v)) * v with rsqrt(x) = 1 / sqrt(x)
-__device__ __forceinline__ V3 normalize(V3 v) { const float r = 1.0f / __builtin_sqrtf(dot(v, v)); return scale(r, v); }
-// math.reflect(i, n) = i - 2f * n * dot(i, n)
-__device__ __forceinline__ V3 reflect(V3 i, V3 n)
-{
-    const float d = dot(i, n);
-    return v3(i.x - (2.0f * n.x) * d, i.y - (2.0f * n.y) * d, i.z - (2.0f * n.z) * d);
-}
-// math.min / math.max return the FIRST operand when the second is NaN
-__device__ __forceinline__ float um_min(float x, float y) { return (y != y || x < y) ? x : y; }
-__device__ __forceinline__ float um_max(float x, float y) { return (y != y || x > y) ? x : y; }
-__device__ __forceinline__ float um_saturate(float x) { return um_max(0.0f, um_min(1.0f, x)); }
-
-constexpr float kPi = 3.14159265f; // math.PI
-
-// x / pow(2, depth) == x * 2^-depth exactly (scaling by a power of two), including the subnormal end of the range;
-// pow(2, depth) overflows to +inf from depth 128 on, where the quotient is 0.
-__device__ __forceinline__ float inv_pow2(int depth)
-{
-    if (depth <= 126) return __uint_as_float((unsigned)(127 - depth) << 23);
-    if (depth == 127) return __uint_as_float(0x00400000u);
-    return 0.0f;
-}
-
-// Unity.Mathematics.Random: NextState returns the pre-update state; NextFloat = asfloat(0x3f800000 | (s >> 9)) - 1
-__device__ __forceinline__ float rng_next(unsigned& state)
-{
-    const unsigned t = state;
-    unsigned s = t;
-    s ^= s << 13;
-    s ^= s >> 17;
-    s ^= s << 5;
-    state = s;
-    return __uint_as_float(0x3f800000u | (t >> 9)) - 1.0f;
-}
-
-// Unity.Mathematics.half -> float (exact)
-__device__ __forceinline__ float half_bits_to_float(unsigned h)
-{
-    const unsigned sign = (h & 0x8000u) << 16;
-    const unsigned exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
-    if (exp == 0) return __uint_as_float(__float_as_uint((float)man * 5.9604644775390625e-8f) | sign);   // zero / subnormal: man * 2^-24, exact
-    if (exp == 31) return __uint_as_float(sign | 0x7f800000u | (man << 13));
-    return __uint_as_float(sign | ((exp + 112u) << 23) | (man << 13));
-}
-// Tools.TangentToWorldSpace (UTIL/Tools.cs:19-37): corrected Frisvad / Pixar basis, float3x3(tangent, normal, bitangent) * v, normalized
-__device__ __forceinline__ V3 tangent_to_world(float tx, float ty, float tz, V3 n)
-{
-    const float s = n.z >= 0 ? 1.0f : -1.0f;
-    const float a = -1 / (s + n.z);
-    const float b = n.x * n.y * a;
-    const V3 tangent = v3(1 + s * n.x * n.x * a, s * b, -s * n.x);
-    const V3 bitangent = v3(b, s + n.y * n.y * a, -n.y);
-    const V3 r = v3(tangent.x * tx + n.x * ty + bitangent.x * tz,
-                    tangent.y * tx + n.y * ty + bitangent.y * tz,
-                    tangent.z * tx + n.z * ty + bitangent.z * tz);
-    return normalize(r);
-}
-// RandomSource.OnCosineWeightedHemisphere (RT/RandomSource.cs:63-89) from its two uniform numbers
-__device__ __forceinline__ V3 cosine_hemisphere_uv(float u, float v, V3 n)
-{
-    const float radius = __builtin_sqrtf(u);
-    const float theta = v * 2 * kPi;
-    float sinT, cosT;
-    det_sincos(theta, sinT, cosT);
-    const float tx = radius * cosT, tz = radius * sinT;
-    const float ty = __builtin_sqrtf(1 - u);
-    return tangent_to_world(tx, ty, tz, n);
-}
-// RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128) from its two uniform numbers
-__device__ __forceinline__ V3 direction_uv(float r0, float r1)
-{
-    const float z = r0 * 2.0f - 1.0f;
-    const float rr = __builtin_sqrtf(um_max(1.0f - z * z, 0.0f));
-    const float angle = r1 * kPi * 2.0f;
-    float sn, cs;
-    det_sincos(angle, sn, cs);
-    return v3(cs * rr, sn * rr, z);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// RandomSource (RT/RandomSource.cs:15-150), one specialisation per NoiseColor.
-//   White              Unity.Mathematics.Random, seeded per pixel (JOBS/SampleBatchJob.cs:91)
-//   Blue               RT/BlueNoise.cs: one half4 texture walked by PerPixelNoise (RT/PerPixelNoise.cs) - the R2 sequence (RT/R2.cs) gives
-//                      the same offsets to every pixel, the pixel's coordinates shift them; NextFloat2 is .xy of ONE texel
-//   SpatioTemporalBlue RT/SpatioTemporalBlueNoise.cs: five byte textures (scalar, vector2, cosine-weighted unit vector3, unit vector2,
-//                      unit vector3), each with its own PerPixelNoise walk
-// PerPixelNoise keeps (offset, n) with offset = floor(R2(n - 1) * rowStride): a function of n, so n alone is the state.
-// ------------------------------------------------------------------------------------------------------------
-struct NoiseSite { const SampleKernelArgs* A; unsigned cx, cy; };   // where the texture-driven sources read: the batch's textures, the pixel
-
-// index of the texel PerPixelNoise.Next() reads for counter value n (n = seed + 1 + number of earlier Next() calls), RT/PerPixelNoise.cs:27-38
-__device__ __forceinline__ unsigned noise_texel(unsigned n, unsigned rowStride, unsigned cx, unsigned cy)
-{
-    constexpr float g = 1.32471795724474602596f;        // RT/R2.cs:11-13, folded one binary32 operation at a time
-    constexpr float a1 = 1.0f / g;
-    constexpr float a2 = 1.0f / (g * g);
-    const float fn = (float)(n - 1u);
-    const float x = 0.5f + a1 * fn, y = 0.5f + a2 * fn;
-    const float rx = x - __builtin_floorf(x), ry = y - __builtin_floorf(y);          // % 1 of a non-negative float: exact
-    const unsigned ox = (unsigned)__builtin_floorf(rx * (float)rowStride), oy = (unsigned)__builtin_floorf(ry * (float)rowStride);
-    return ((cy + oy) % rowStride) * rowStride + ((cx + ox) % rowStride);
-}
-
-template <int NOISE>
-struct Rng;
-
-template <>
-struct Rng<RTOW_NOISE_WHITE> {
-    unsigned s;
-    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned pix)
-    {
-        s = (at.A->seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u);   // :91; the Random ctor then discards one NextState()
-        (void)rng_next(s);
-    }
-    // RTOW_RNG_PER_SAMPLE: sample `smp` of the pixel gets its own generator (include/rtow.h)
-    __device__ __forceinline__ void begin_sample(const NoiseSite& at, unsigned pix, unsigned smp)
-    {
-        s = ((at.A->seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u)) ^ ((smp + 1u) * 0x9E3779B9u);
-        if (s == 0u) s = 0x9E3779B9u;                            // Random needs a non-zero state
-        (void)rng_next(s);
-    }
-    __device__ __forceinline__ float next(const NoiseSite&) { return rng_next(s); }
-    __device__ __forceinline__ void next2(const NoiseSite&, float& a, float& b) { a = rng_next(s); b = rng_next(s); }
-    __device__ __forceinline__ void in_unit_disk(const NoiseSite&, float& x, float& y)       // RT/RandomSource.cs:40-61
-    {
-        const float theta = rng_next(s) * (2.0f * kPi - 0.0f) + 0.0f;                        // NextFloat(0, 2 * PI)
-        const float radius = __builtin_sqrtf(rng_next(s));
-        float sinT, cosT;
-        det_sincos(theta, sinT, cosT);
-        x = radius * cosT; y = radius * sinT;
-    }
-    __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite&, V3 n) { const float u = rng_next(s), v = rng_next(s); return cosine_hemisphere_uv(u, v, n); }
-    __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite&) { (void)rng_next(s); (void)rng_next(s); }
-    __device__ __forceinline__ V3 direction(const NoiseSite&) { const float r0 = rng_next(s), r1 = rng_next(s); return direction_uv(r0, r1); }
-    __device__ __forceinline__ unsigned trace_value() const { return s; }
-};
-
-template <>
-struct Rng<RTOW_NOISE_BLUE> {
-    unsigned s;                                                   // PerPixelNoise.n
-    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = at.A->seed + 1u; }   // n = seed; Advance() (:17-25)
-    __device__ __forceinline__ void begin_sample(const NoiseSite&, unsigned, unsigned) {}
-    __device__ __forceinline__ void texel(const NoiseSite& at, float& x, float& y)
-    {
-        const uint2 t = reinterpret_cast<const uint2*>(at.A->blueNoise)[noise_texel(s, at.A->blueRowStride, at.cx, at.cy)];   // half4
-        s++;
-        x = half_bits_to_float(t.x & 0xffffu); y = half_bits_to_float(t.x >> 16);
-    }
-    __device__ __forceinline__ float next(const NoiseSite& at) { float x, y; texel(at, x, y); return x; }              // BlueNoise.cs:26
-    __device__ __forceinline__ void next2(const NoiseSite& at, float& a, float& b) { texel(at, a, b); }                  // BlueNoise.cs:28
-    __device__ __forceinline__ void in_unit_disk(const NoiseSite& at, float& x, float& y)
-    {
-        const float theta = next(at) * 2 * kPi;
-        const float radius = __builtin_sqrtf(next(at));
-        float sinT, cosT;
-        det_sincos(theta, sinT, cosT);
-        x = radius * cosT; y = radius * sinT;
-    }
-    __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite& at, V3 n) { float u, v; texel(at, u, v); return cosine_hemisphere_uv(u, v, n); }
-    __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite&) { s++; }
-    __device__ __forceinline__ V3 direction(const NoiseSite& at) { float r0, r1; texel(at, r0, r1); return direction_uv(r0, r1); }
-    __device__ __forceinline__ unsigned trace_value() const { return s; }
-};
-
-template <>
-struct Rng<RTOW_NOISE_SPATIOTEMPORAL_BLUE> {
-    unsigned s, v2, cs, u2, u3;                                   // n of perPixelScalar / Vector2 / CosineUnitVector3 / UnitVector2 / UnitVector3
-    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = v2 = cs = u2 = u3 = at.A->seed + 1u; }
-    __device__ __forceinline__ void begin_sample(const NoiseSite&, unsigned, unsigned) {}
-    __device__ __forceinline__ float next(const NoiseSite& at)                                                           // STBN :61
-    {
-        const unsigned i = noise_texel(s++, at.A->stbRowStride, at.cx, at.cy);
-        return (float)at.A->stbScalar[i] / 256.0f;
-    }
-    __device__ __forceinline__ void next2(const NoiseSite& at, float& a, float& b)                                       // :63-67
-    {
-        const uint8_t* t = at.A->stbVector2 + (size_t)noise_texel(v2++, at.A->stbRowStride, at.cx, at.cy) * 3u;
-        a = (float)t[0] / 256.0f; b = (float)t[1] / 256.0f;
-    }
-    __device__ __forceinline__ void in_unit_disk(const NoiseSite& at, float& x, float& y)                                // NextUnitVector2, :75-79
-    {
-        const uint8_t* t = at.A->stbUnitVector2 + (size_t)noise_texel(u2++, at.A->stbRowStride, at.cx, at.cy) * 3u;
-        x = (float)t[0] / 256.0f * 2 - 1; y = (float)t[1] / 256.0f * 2 - 1;
-    }
-    __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite& at, V3 n)                                           // NextCosineUnitVector3, :69-73: (r, b, g)
-    {
-        const uint8_t* t = at.A->stbCosineUnitVector3 + (size_t)noise_texel(cs++, at.A->stbRowStride, at.cx, at.cy) * 4u;
-        return tangent_to_world((float)t[0] / 256.0f * 2 - 1, (float)t[2] / 256.0f * 2 - 1, (float)t[1] / 256.0f * 2 - 1, n);
-    }
-    __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite&) { cs++; }
-    __device__ __forceinline__ V3 direction(const NoiseSite& at)                                                         // NextUnitVector3, :81-85
-    {
-        const uint8_t* t = at.A->stbUnitVector3 + (size_t)noise_texel(u3++, at.A->stbRowStride, at.cx, at.cy) * 3u;
-        return v3((float)t[0] / 256.0f * 2 - 1, (float)t[1] / 256.0f * 2 - 1, (float)t[2] / 256.0f * 2 - 1);
-    }
-    __device__ __forceinline__ unsigned trace_value() const { return s; }
-};
-
-// Microfacet.TrowbridgeReitz.RoughnessToAlpha / Lambda, SmithMaskingShadowing (RT/Microfacet.cs:9-12,53-80)
-__device__ __forceinline__ float roughness_to_alpha(float roughness)
-{
-    roughness = um_max(roughness, 1e-3f);
-    const float x = det_log(roughness);
-    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
-}
-__device__ __forceinline__ float smith_g1(V3 w, V3 n, float alpha /* = RoughnessToAlpha(roughness), per material */)
-{
-    const float cosTheta = dot(n, w);
-    const float sqCos = cosTheta * cosTheta;
-    const float sqSin = um_max(0.0f, 1 - sqCos);
-    const float sinTheta = __builtin_sqrtf(sqSin);
-    const float tanTheta = sinTheta / cosTheta;
-    const float absTan = __builtin_fabsf(tanTheta);
-    float lambda;
-    if (__builtin_isinf(absTan)) {
-        lambda = 0;
-    } else {
-        const float a2t2 = (alpha * absTan) * (alpha * absTan);
-        lambda = (-1 + __builtin_sqrtf(1 + a2t2)) / 2;
-    }
-    return 1 / (1 + lambda);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Cubemap.Sample (RT/Texture.cs:171-210): the face is the first axis whose |component| is the largest (x before y before z), the
-// texel min((int2)((uv + 1) * halfFaceSize), faceSizeMinusOne) of that face, point sampled; RGBA half or byte channels.
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ V3 cubemap_sample(const SampleKernelArgs& A, V3 d)
-{
-    if (!A.cubemapData) return v3(0, 0, 0);
-    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
-    const float m = um_max(um_max(um_max(ax, ay), az), 0.0f);                  // cmax(float4(abs(vector), 0))
-    int lane;
-    if (m == ax) lane = 0; else if (m == ay) lane = 1; else if (m == az) lane = 2; else return v3(0, 0, 0);   // NaN direction
-    const float major = lane == 0 ? d.x : lane == 1 ? d.y : d.z;
-    const float amajor = lane == 0 ? ax : lane == 1 ? ay : az;
-    const bool positive = major >= 0;
-    float u, v;
-    if (lane == 0) { u = positive ? -d.z : d.z; v = -d.y; }
-    else if (lane == 1) { u = d.x; v = positive ? d.z : -d.z; }
-    else { u = positive ? d.x : -d.x; v = -d.y; }
-    u = u / amajor;
-    v = v / amajor;
-    int cx = (int)((u + 1) * (float)A.cubemapHalfW), cy = (int)((v + 1) * (float)A.cubemapHalfH);
-    cx = cx < A.cubemapW1 ? cx : A.cubemapW1;
-    cy = cy < A.cubemapH1 ? cy : A.cubemapH1;
-    const uint8_t* px = A.cubemapData + (size_t)(lane * 2 + (positive ? 0 : 1)) * (size_t)A.cubemapFaceStride + cx * A.cubemapPixelStride + cy * A.cubemapRowStride;
-    if (A.cubemapChannelType == RTOW_CUBEMAP_UNSIGNED_BYTE) return v3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
-    const unsigned short* hp = reinterpret_cast<const unsigned short*>(px);
-    return v3(half_bits_to_float(hp[0]), half_bits_to_float(hp[1]), half_bits_to_float(hp[2]));
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Texture.SampleColor / SampleScalar (RT/Texture.cs:51-138) for the per-hit evaluation of textured materials.  Image: the texel
-// (int2)(uv * ImageSize) - clamped into the image, where the reference would read out of bounds - as bytes / 255 * MainColor.
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ const uint8_t* texture_pixel(const SampleKernelArgs& A, const GpuTexture& t, float2 uv)
-{
-    const GpuImage im = reinterpret_cast<const GpuImage*>(A.texBlob + A.texLayout.imageOffset)[t.image];
-    int x = (int)(uv.x * (float)im.width), y = (int)(uv.y * (float)im.height);
-    x = x < 0 ? 0 : x > im.width - 1 ? im.width - 1 : x;
-    y = y < 0 ? 0 : y > im.height - 1 ? im.height - 1 : y;
-    return A.texBlob + A.texLayout.pixelOffset + im.offset + ((size_t)y * (size_t)im.width + (size_t)x) * (size_t)im.pixelStride;
-}
-__device__ __forceinline__ V3 texture_color(const SampleKernelArgs& A, const GpuTexture& t, float2 uv)
-{
-    if (t.type == RTOW_TEXTURE_CONSTANT) return v3(t.mainColor[0], t.mainColor[1], t.mainColor[2]);
-    if (t.type == RTOW_TEXTURE_CONSTANT_SCALAR) return v3(t.parameter, t.parameter, t.parameter);
-    if (t.type == RTOW_TEXTURE_IMAGE && t.image >= 0) {
-        const uint8_t* px = texture_pixel(A, t, uv);
-        return v3((float)px[0] / 255.0f * t.mainColor[0], (float)px[1] / 255.0f * t.mainColor[1], (float)px[2] / 255.0f * t.mainColor[2]);
-    }
-    return v3(0, 0, 0);
-}
-__device__ __forceinline__ float texture_scalar(const SampleKernelArgs& A, const GpuTexture& t, float2 uv)
-{
-    const float main = t.channel == 0 ? t.mainColor[0] : t.channel == 1 ? t.mainColor[1] : t.mainColor[2];
-    if (t.type == RTOW_TEXTURE_CONSTANT) return main;
-    if (t.type == RTOW_TEXTURE_CONSTANT_SCALAR) return t.parameter;
-    if (t.type == RTOW_TEXTURE_IMAGE && t.image >= 0) return (float)texture_pixel(A, t, uv)[t.channel] / 255.0f * main;
-    return 0.0f;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// scene access: LDS image first, HBM/L2 for whatever did not fit
-// ------------------------------------------------------------------------------------------------------------
-struct SceneRefs {
-    const uint8_t* lds;     // LDS copy of the blob prefix
-    const uint8_t* glob;    // full blob in HBM
-    uint32_t ldsNodeCount;
-};
-
-template <bool ALL_LDS>
-__device__ __forceinline__ void load_node(const SceneRefs& sc, const SceneLayout& L, int idx, float4& q0, float4& q1, float4& q2, int& c0, int& c1)
-{
-    const uint32_t off = L.nodeOffset + (uint32_t)idx * 64u;
-    const uint8_t* base = (ALL_LDS || (uint32_t)idx < sc.ldsNodeCount) ? sc.lds : sc.glob;
-    const float4* p = reinterpret_cast<const float4*>(base + off);
-    q0 = p[0];
-    q1 = p[1];
-    q2 = p[2];
-    const int2 c = *reinterpret_cast<const int2*>(base + off + 48);
-    c0 = c.x;
-    c1 = c.y;
-}
-
-template <bool ALL_LDS>
-__device__ __forceinline__ const uint8_t* section(const SceneRefs& sc, uint32_t offset)
-{
-    return (ALL_LDS ? sc.lds : sc.glob) + offset;
-}
-
-// centre of primitive `i` at ray time `time` (Entity.TransformAtTime, RT/Entity.cs:124-127) and its signed radius
-template <bool ALL_LDS, bool HAS_MOTION>
-__device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout& L, int i, float time, V3& c, float& radius)
-{
-    const float4 s = *reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.sphereOffset) + (uint32_t)i * 16u);
-    c = v3(s.x, s.y, s.z);
-    radius = s.w;
-    if (HAS_MOTION) {
-        const uint8_t* mp = section<ALL_LDS>(sc, L.motionOffset) + (uint32_t)i * 32u;
-        const float4 m0 = *reinterpret_cast<const float4*>(mp);      // dx dy dz t0
-        const float2 m1 = *reinterpret_cast<const float2*>(mp + 16); // t1 moving
-        if (__float_as_int(m1.y) != 0) {
-            const float f = um_max(0.0f, um_min(1.0f, (time - m0.w) / (m1.x - m0.w))); // clamp(unlerp(t0, t1, t), 0, 1)
-            c = v3(c.x + m0.x * f, c.y + m0.y * f, c.z + m0.z * f);
-        }
-    }
-}
-
-// HitTests.Hit(Sphere) (RT/HitTests.cs:23-60) in entity space (oc = origin - centre), tMin = 0, tMax = +inf
-__device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, float& tOut)
-{
-    const float b = dot(oc, d);
-    const float c = dot(oc, oc) - radius * radius;
-    const float disc = b * b - a * c;
-    if (disc > 0) {
-        // t = (-b -+ sq) / a with a = dot(d, d) >= 0: a numerator that is not positive gives a quotient that is not positive (or NaN) and
-        // fails `t > 0` whatever a is, so its IEEE division is skipped - bit-identical, and the common "sphere behind the origin" case
-        // (every ray leaving the ground sphere) costs no division at all.
-        const float sq = __builtin_sqrtf(disc);
-        const float n0 = -b - sq;
-        if (n0 > 0) {
-            const float t = n0 / a;
-            if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
-        }
-        const float n1 = -b + sq;
-        if (n1 > 0) {
-            const float t = n1 / a;
-            if (t < __builtin_inff() && t > 0) { tOut = t; return true; }
-        }
-    }
-    return false;
-}
-
-// the same test with an arbitrary tMin (strict: t > tMin), RT/HitTests.cs:40,49
-__device__ __forceinline__ bool sphere_hit_tmin(V3 oc, V3 d, float a, float radius, float tMin, float& tOut)
-{
-    const float b = dot(oc, d);
-    const float c = dot(oc, oc) - radius * radius;
-    const float disc = b * b - a * c;
-    if (disc > 0) {
-        const float sq = __builtin_sqrtf(disc);                    // tMin >= 0 here: the numerator shortcut of sphere_hit applies unchanged
-        const float n0 = -b - sq;
-        if (n0 > 0) {
-            const float t = n0 / a;
-            if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
-        }
-        const float n1 = -b + sq;
-        if (n1 > 0) {
-            const float t = n1 / a;
-            if (t < __builtin_inff() && t > tMin) { tOut = t; return true; }
-        }
-    }
-    return false;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// general entities (SCENE_KIND_GENERAL): Rect / Box / Triangle and rotated or moving transforms, RT/Entity.cs:58-127
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-// math.mul(quaternion q, float3 v): t = 2 * cross(q.xyz, v); v + q.w * t + cross(q.xyz, t)
-__device__ __forceinline__ V3 rotate(float4 q, V3 v)
-{
-    const V3 qv = v3(q.x, q.y, q.z);
-    const V3 t = scale(2.0f, cross(qv, v));
-    const V3 c = cross(qv, t);
-    return v3(v.x + q.w * t.x + c.x, v.y + q.w * t.y + c.y, v.z + q.w * t.z + c.z);
-}
-__device__ __forceinline__ float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); }
-
-// Entity.HitInternal + HitContent for primitive `i` (RT/Entity.cs:74-122) with tMax = +inf (tMin = 0 except for the exit-hit
-// probe of volume hulls, JOBS/SampleBatchJob.cs:465).
-// Returns the distance, the entity-space normal and the rotation that takes it to world space.
-template <bool ALL_LDS>
-__device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time, float tMin,
-                                            float& tOut, V3& nLocal, float4& rot, float2* texCoord = nullptr)
-{
-    const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)i * 128u);
-    if (texCoord) *texCoord = make_float2(0, 0);       // only triangles have texture coordinates (RT/Entity.cs:108, RT/HitTests.cs:123)
-    if (type == RTOW_ENTITY_TRIANGLE) {
-        // HitTests.Hit(Triangle) (RT/HitTests.cs:115-150); triangles are tested in world space (RT/Entity.cs:91-93)
-        const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
-        rot = p[6];
-        const V3 e0 = v3(a0.x, a0.y, a0.z), e1 = v3(a0.w, a1.x, a1.y), v0 = v3(a1.z, a1.w, a2.x);
-        const V3 pvec = cross(rd, e0);
-        const float det = dot(e1, pvec);
-        if (det == 0) return false;
-        const float invDet = 1 / det;
-        const V3 tvec = sub(ro, v0);
-        const float u = dot(tvec, pvec) * invDet;
-        if (u < 0 || u > 1) return false;
-        const V3 qvec = cross(tvec, e1);
-        const float v = dot(rd, qvec) * invDet;
-        if (v < 0 || u + v > 1) return false;
-        const float dist = dot(e0, qvec) * invDet;
-        if (dist < tMin || dist > __builtin_inff()) return false;
-        const float b0 = 1 - u - v;
-        const V3 n0 = v3(a2.y, a2.z, a2.w), n1 = v3(a3.x, a3.y, a3.z), n2 = v3(a3.w, a4.x, a4.y);
-        nLocal = v3(n0.x * b0 + n1.x * u + n2.x * v, n0.y * b0 + n1.y * u + n2.y * v, n0.z * b0 + n1.z * u + n2.z * v);
-        if (texCoord) {                                  // mul(tri.TextureCoordinates, barycentricCoords) (:148): float2x3 columns t0 t1 t2
-            const float4 a5 = p[5];
-            *texCoord = make_float2(a4.z * b0 + a5.x * u + a5.z * v, a4.w * b0 + a5.y * u + a5.w * v);
-        }
-        tOut = dist;
-        return true;
-    }
-    rot = p[0];
-    const float4 invRot = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
-    V3 invT = v3(q4.y, q4.z, q4.w);
-    if (__float_as_int(q2.w) != 0) {
-        // TransformAtTime (RT/Entity.cs:124-127) and its inverse (:87-88): invTranslation = mul(invRot, -pos(t))
-        const float f = um_max(0.0f, um_min(1.0f, (time - q3.w) / (q4.x - q3.w)));
-        const V3 pt = v3(q2.x + q3.x * f, q2.y + q3.y * f, q2.z + q3.z * f);
-        invT = rotate(invRot, neg(pt));
-    }
-    const V3 oL = add(rotate(invRot, ro), invT);     // transform(inverseTransform, ray.Origin)
-    const V3 dL = rotate(invRot, rd);                // rotate(inverseTransform, ray.Direction)
-    if (type == RTOW_ENTITY_SPHERE) {
-        float t;
-        if (!sphere_hit_tmin(oL, dL, dot(dL, dL), q5.x, tMin, t)) return false;
-        nLocal = v3((oL.x + t * dL.x) / q5.x, (oL.y + t * dL.y) / q5.x, (oL.z + t * dL.z) / q5.x);
-        tOut = t;
-        return true;
-    }
-    if (type == RTOW_ENTITY_RECT) {
-        // HitTests.Hit(Rect) (RT/HitTests.cs:62-78)
-        if (dL.z >= 0) return false;
-        const float t = -oL.z / dL.z;
-        if (t < tMin || t > __builtin_inff()) return false;
-        const float x = oL.x + t * dL.x, y = oL.y + t * dL.y;
-        if (x < q5.x || y < q5.y || x > q5.z || y > q5.w) return false;
-        nLocal = v3(0, 0, 1);
-        tOut = t;
-        return true;
-    }
-    // HitTests.Hit(Box) (RT/HitTests.cs:80-113): the origin is first advanced by tMin (origin + direction * tMin)
-    const float4 q6 = p[6];
-    const V3 ext = v3(q5.x, q5.y, q5.z), invExt = v3(q5.w, q6.x, q6.y);
-    const V3 o = v3(oL.x + dL.x * tMin, oL.y + dL.y * tMin, oL.z + dL.z * tMin);
-    const float winding = um_max(um_max(__builtin_fabsf(o.x) * invExt.x, __builtin_fabsf(o.y) * invExt.y), __builtin_fabsf(o.z) * invExt.z) < 1 ? -1.0f : 1.0f;
-    V3 sgn = v3(-um_sign(dL.x), -um_sign(dL.y), -um_sign(dL.z));
-    const V3 dtp = v3((ext.x * winding * sgn.x - o.x) / dL.x, (ext.y * winding * sgn.y - o.y) / dL.y, (ext.z * winding * sgn.z - o.z) / dL.z);
-    const bool tx = dtp.x >= 0 && __builtin_fabsf(o.y + dL.y * dtp.x) < ext.y && __builtin_fabsf(o.z + dL.z * dtp.x) < ext.z;
-    const bool ty = dtp.y >= 0 && __builtin_fabsf(o.z + dL.z * dtp.y) < ext.z && __builtin_fabsf(o.x + dL.x * dtp.y) < ext.x;
-    const bool tz = dtp.z >= 0 && __builtin_fabsf(o.x + dL.x * dtp.z) < ext.x && __builtin_fabsf(o.y + dL.y * dtp.z) < ext.y;
-    sgn = tx ? v3(sgn.x, 0, 0) : ty ? v3(0, sgn.y, 0) : v3(0, 0, tz ? sgn.z : 0);
-    if (!(sgn.x != 0 || sgn.y != 0 || sgn.z != 0)) return false;
-    float dist = sgn.x != 0 ? dtp.x : sgn.y != 0 ? dtp.y : dtp.z;
-    dist += tMin;
-    if (dist > __builtin_inff()) return false;
-    nLocal = sgn;
-    tOut = dist;
-    return true;
-}
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// Raw VALU min/max (IEEE mode: a NaN operand yields the other operand).  __builtin_fminf/fmaxf would first canonicalise
-// both inputs (v_max_f32 x, x), which doubles the instruction count of the slab test for nothing.
-__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-
-// Development-only wave-level statistics (make stats -> librtow_hip_stats.so): how often each stage runs and with how
-// many lanes.  Compiled out of the product build.
-#ifdef RTOW_STATS
-#define STAT_DECL unsigned long long stat[16] = {0}
-#define STAT_ADD(i, v) stat[i] += (unsigned long long)(v)
-#define STAT_LANES(i) stat[i] += 1ull
-// per-segment trace of one pixel: {smp, depth, kind, prim, t bits, curVol, nHits, rng}
-#define DBG_TRACE(kind, primv, tv) do { if (A.stats && pix == A.debugPixel) { const unsigned long long k_ = atomicAdd(&A.stats[20], 1ull); if (k_ < 500) { unsigned long long* d_ = A.stats + 5000 + k_ * 8; d_[0] = smp; d_[1] = (unsigned)depth; d_[2] = (kind); d_[3] = (unsigned)(primv); d_[4] = __float_as_uint(tv); d_[5] = (unsigned)curVol; d_[6] = (unsigned)nHits; d_[7] = rng.trace_value(); } } } while (0)
-#else
-#define DBG_TRACE(kind, primv, tv)
-#define STAT_DECL
-#define STAT_ADD(i, v)
-#define STAT_LANES(i)
-#endif
-
-// ------------------------------------------------------------------------------------------------------------
-// path history: one 16-bit code per surface hit (bit 15 = "reflectance was overridden to 1", bits 0..14 = material).
-// The reference keeps float3 emission / attenuation stacks (JOBS/SampleBatchJob.cs:103-104,311,330) and folds them
-// tail -> head (:384-396); the codes are re-expanded at the fold, which reproduces the fold order bit for bit.
-// Depth <= 8 and <= 16 keep the codes in named 64-bit registers (an indexed array would be demoted to scratch).
-// ------------------------------------------------------------------------------------------------------------
-template <int HW> struct Hist {
-    unsigned w[HW];
-    __device__ __forceinline__ void clear() { for (int i = 0; i < HW; i++) w[i] = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code) { w[depth >> 1] |= code << ((unsigned)(depth & 1) * 16u); }
-    __device__ __forceinline__ unsigned get(int depth) const { return (w[depth >> 1] >> ((unsigned)(depth & 1) * 16u)) & 0xffffu; }
-};
-template <> struct Hist<4> {
-    unsigned long long a, b;
-    __device__ __forceinline__ void clear() { a = 0; b = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code)
-    {
-        const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
-        if (depth < 4) a |= v; else b |= v;
-    }
-    __device__ __forceinline__ unsigned get(int depth) const { return (unsigned)((depth < 4 ? a : b) >> ((unsigned)(depth & 3) * 16u)) & 0xffffu; }
-};
-template <> struct Hist<8> {
-    unsigned long long a, b, c, d;
-    __device__ __forceinline__ void clear() { a = 0; b = 0; c = 0; d = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code)
-    {
-        const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
-        const int q = depth >> 2;
-        if (q == 0) a |= v; else if (q == 1) b |= v; else if (q == 2) c |= v; else d |= v;
-    }
-    __device__ __forceinline__ unsigned get(int depth) const
-    {
-        const int q = depth >> 2;
-        const unsigned long long v = q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
-        return (unsigned)(v >> ((unsigned)(depth & 3) * 16u)) & 0xffffu;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------------------
-// the megakernel
-// ------------------------------------------------------------------------------------------------------------
-// Lane states.  Every trip of the main loop the wavefront takes a population vote (__ballot + popcount per state) and
-// runs ONLY the stage with the most lanes waiting; the other lanes keep their state and wait.  Rare, expensive stages
-// (glass, rough metal) therefore execute with many lanes batched up instead of being dragged through every trip by
-// one straggler, and the box walk never waits for the slowest ray: this is what replaces per-bounce compaction.
-enum : int {
-    ST_REGEN = 0,    // needs its next sample (or next pixel)
-    ST_TRAV = 1,     // walking BVH boxes (resumable; at most A.travSlice node visits per trip)
-    ST_TEST = 2,     // has leaf candidates awaiting the exact sphere test
-    ST_HIT = 3,      // nearest hit known: shade
-    ST_SKY = 4,      // missed everything: sky + fold
-    ST_VOL = 5,      // VOLUMES scenes: all hits collected -> sort, containment probe, volume logic (JOBS/SampleBatchJob.cs:194-303)
-    ST_DEAD = 6,
-    ST_COUNT = 6
-};
-
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
-__global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = (int)threadIdx.x;
-
-    // ---- stage the scene image into LDS: coalesced 16 B per lane ----
-    // [level][lane] uint16 arrays; within a wave lane l sits at 2*(l&31) + (l>>5), so the 32 lanes the LDS services together
-    // touch 32 different dwords (= banks) whatever level each of them is at
-    unsigned short* const stack = reinterpret_cast<unsigned short*>(smem) + (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
-    unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;                // [slot][lane] leaf candidates
-    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytes) + (tid >> 6) * 2;  // {next, end} ticket chunk of this wave
-    uint8_t* const ldsScene = smem + kStackBytes + kQueueBytes;
-    if ((tid & 63) == 0) { waveQueue[0] = 0; waveQueue[1] = 0; }
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(A.sceneBlob);
-        uint4* dst = reinterpret_cast<uint4*>(ldsScene);
-        const uint32_t n16 = A.ldsSceneBytes >> 4;
-        for (uint32_t i = (uint32_t)tid; i < n16; i += kBlockThreads) dst[i] = src[i];
-    }
-    __syncthreads();
-
-    SceneRefs sc;
-    sc.lds = ldsScene;
-    sc.glob = A.sceneBlob;
-    sc.ldsNodeCount = A.ldsNodeCount;
-    const SceneLayout L = A.layout;
-    const int traceDepth = A.traceDepth;
-    // a one-entity scene has a root whose second child is a placeholder; its (inverted) box cannot be told from a real one by the
-    // symmetric slab test, so it is masked explicitly (wave-uniform, costs one scalar AND per node visit)
-    const bool twoChildren = L.sphereCount > 1u;
-    constexpr bool HAS_MOTION = KIND == SCENE_KIND_SPHERES_MOTION;
-    constexpr bool GENERAL = KIND >= SCENE_KIND_GENERAL;
-    constexpr bool VOLUMES = KIND == SCENE_KIND_VOLUMES || KIND == SCENE_KIND_VOLUMES_TEXTURED;   // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
-    constexpr bool TEXTURED = KIND == SCENE_KIND_TEXTURED || KIND == SCENE_KIND_VOLUMES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
-
-    // ---- per-lane persistent state ----
-    int st = ST_REGEN;
-    int pix = -1;
-    unsigned tick = 0;          // ticket (owned-pixel number) of the current pixel
-    Rng<NOISE> rng{};
-    V3 fbNormal = v3(0, 0, 0), fbAlbedo = v3(0, 0, 0);   // PER_SAMPLE: AOVs of the batch's sample 0 (the fallback when nothing succeeds)
-    unsigned unitGroup = 0;                                // PER_SAMPLE: which 16-sample group of its pixel this lane works on
-    unsigned smp = 0, nsamp = 0;
-    int cx = 0, cy = 0;
-    V3 colorAcc = v3(0, 0, 0), normalAcc = v3(0, 0, 0), albedoAcc = v3(0, 0, 0);
-    float scwAcc = 0, scw0 = 0;
-    int sampleCount = 0;
-    float rayCount = 0, boundsHits = 0, candidates = 0;
-
-    // per-path state
-    V3 ro = v3(0, 0, 0), rd = v3(0, 0, 1);
-    float rtime = 0;
-    int depth = 0;
-    Hist<HW> hist;
-    hist.clear();
-    V3 sampleNormal = v3(0, 0, 0), sampleAlbedo = v3(0, 0, 0);
-    bool firstNonSpecular = false;
-    float randomEventsLocal = 0;
-
-    // VOLUMES only: all hits of the current ray (FindHits' hitRecordBuffer, JOBS/SampleBatchJob.cs:450-475), the volume the path
-    // is inside of (currentProbabilisticVolumeMaterial, :180) and RandomEvents left pending by ProbabilisticHit (RT/Material.cs:54)
-    // TEXTURED only: what the fold needs of every hit of the current path (the 16-bit history code only names a material)
-    float texHist[TEXTURED ? HW * 2 * 6 : 1];
-    constexpr int kMaxHits = VOLUMES ? 24 : 1;
-    float hitT[kMaxHits], hitTmin0[kMaxHits];
-    unsigned hitCode[kMaxHits];      // primitive | dot(normal, dir) < 0 -> bit 30 | dot > 0 -> bit 31
-    int nHits = 0;
-    int curVol = -1;
-    float pendRE = 0;
-    bool insideHit = false;          // the chosen "hit" is a scattering event inside the volume
-    float hitTmin = 0;               // tMin of the test that produced the chosen hit (exit hits use entry + 0.001)
-
-    // per-ray traversal state (resumable across trips)
-    V3 inv = v3(0, 0, 0);
-    int cur = 0, sp = 0, nc = 0, prim = -1;
-    float best = 0;
-
-    // end of a sample (JOBS/SampleBatchJob.cs:137-156)
-    auto endSample = [&](bool ok, V3 sampleColor) {
-        if (ok) {                                                                         // :145-149, :398
-            scwAcc += randomEventsLocal;
-            colorAcc = add(colorAcc, sampleColor);
-            normalAcc = add(normalAcc, sampleNormal);
-            albedoAcc = add(albedoAcc, sampleAlbedo);
-            sampleCount++;
-        } else if (PER_SAMPLE) {
-            if (smp == 0) { fbNormal = sampleNormal; fbAlbedo = sampleAlbedo; }
-        } else if (smp == 0 && !A.probeOnly) {
-            // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
-            // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
-            A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
-            A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
-        }
-        smp++;
-        st = ST_REGEN;
-    };
-    // a new ray segment starts: reset the traversal state
-    auto startRay = [&]() {
-        // reciprocal direction for the box walk only: v_rcp_f32 (<= 1 ulp) is enough there, the boxes are padded by 1e-5
-        inv = v3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
-        cur = 0; sp = 0; nc = 0; prim = -1;
-        best = __builtin_inff();
-        nHits = 0;
-        st = ST_TRAV;
-    };
-    // traversal finished: classify the result
-    auto classify = [&]() {
-        rayCount += 1.0f;                                                                  // :203
-        if (VOLUMES) { st = ST_VOL; return; }
-        st = prim < 0 ? ST_SKY : ST_HIT;
-    };
-
-    uint2 pcand = make_uint2(kNoPrimaryList, 0u);   // this pixel's camera-ray candidate list (4 x 16 bit), or kNoPrimaryList in .x
-    int force = -1;
-    STAT_DECL;
-#ifdef RTOW_STATS
-    const unsigned long long statT0 = wall_clock64();
-    unsigned long long pixT0 = statT0;
-#endif
-    for (;;) {
-        STAT_ADD(0, 1);
-        // Stages run in pipeline order; each one only if enough lanes wait in it, so a lane can still advance a whole path segment per
-        // trip when the wave is dense, while sparse stages batch up.  A.tune[] holds the thresholds in 64ths of the wave's LIVE lanes
-        // (lanes that still have pixels): 1 = "any lane", 48 = three quarters of them.  Depth-0 rays skip the box walk (camera-ray lists),
-        // so without a threshold the walk would run every trip for the ~60 % of lanes on a bounce segment; holding it back until
-        // most live lanes want it lets the camera segments (REGEN -> TEST -> HIT) of the others catch up first.
-        const int live = (int)__popcll(__ballot(st != ST_DEAD));
-        auto need = [&](int k) { const int t = (live * A.tune[k] + 63) >> 6; return t < 1 ? 1 : t; };
-        bool ran = false;
-        if ((int)__popcll(__ballot(st == ST_REGEN)) >= (force == ST_REGEN ? 1 : need(0))) {
-            ran = true;
-            // ================= next sample of this pixel, or next pixel =================
-            STAT_ADD(1, 1);
-            if (st == ST_REGEN) {
-                STAT_LANES(2);
-                while (smp >= nsamp) {
-#ifdef RTOW_STATS
-                    if (pix >= 0 && A.stats) {
-                        // last pixel this wave finished: {end, start, rays, tick} (100 MHz ticks since the wave started); later stores overwrite earlier ones
-                        unsigned long long* rec = A.stats + 9000 + (size_t)(blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)) * 4;
-                        rec[0] = wall_clock64() - statT0; rec[1] = pixT0 - statT0; rec[2] = (unsigned long long)rayCount; rec[3] = tick;
-                    }
-#endif
-                    if (pix >= 0 && A.pixelCost) {
-                        // cost map for the next launch's chunk order: this pixel's ray count, in ticket order (a plain 2-byte store that
-                        // merges in L2 with its chunk's other 63; per-chunk atomics cost a memory-side transaction each)
-                        const unsigned rc = (unsigned)rayCount;
-                        A.pixelCost[tick] = (unsigned short)(rc < 65535u ? rc : 65535u);
-                    }
-                    if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
-                    if (PER_SAMPLE && pix >= 0) {
-                        // ---- unit done: its partial sums go to the record the fold kernel adds up in group order ----
-                        const bool fallback = unitGroup == 0 && sampleCount == 0;       // then sample 0 failed: the record carries its AOVs instead of sums
-                        float4* rec = reinterpret_cast<float4*>(A.unitRecords) + (size_t)tick * 4u;
-                        rec[0] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
-                        rec[1] = fallback ? make_float4(fbNormal.x, fbNormal.y, fbNormal.z, rayCount) : make_float4(normalAcc.x, normalAcc.y, normalAcc.z, rayCount);
-                        rec[2] = fallback ? make_float4(fbAlbedo.x, fbAlbedo.y, fbAlbedo.z, scwAcc) : make_float4(albedoAcc.x, albedoAcc.y, albedoAcc.z, scwAcc);
-                        rec[3] = make_float4(boundsHits, candidates, 0, 0);
-                        pix = -1;
-                    }
-                    if (pix >= 0) {
-                        // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
-                        reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
-                        if (sampleCount != 0) {
-                            A.outNormal[3 * (size_t)pix + 0] = normalAcc.x; A.outNormal[3 * (size_t)pix + 1] = normalAcc.y; A.outNormal[3 * (size_t)pix + 2] = normalAcc.z;
-                            A.outAlbedo[3 * (size_t)pix + 0] = albedoAcc.x; A.outAlbedo[3 * (size_t)pix + 1] = albedoAcc.y; A.outAlbedo[3 * (size_t)pix + 2] = albedoAcc.z;
-                        } else if (nsamp == 0) {
-                            // no sample ran: the fallbacks keep their default (0) value (:115)
-                            A.outNormal[3 * (size_t)pix + 0] = 0; A.outNormal[3 * (size_t)pix + 1] = 0; A.outNormal[3 * (size_t)pix + 2] = 0;
-                            A.outAlbedo[3 * (size_t)pix + 0] = 0; A.outAlbedo[3 * (size_t)pix + 1] = 0; A.outAlbedo[3 * (size_t)pix + 2] = 0;
-                        } // else: sample 0 failed and its AOVs were stored as the fallback by endSample
-                        A.outScw[pix] = scwAcc;
-                        if (A.diagnostics) {
-                            if (FULL_DIAG)
-                                *reinterpret_cast<float4*>(A.diagnostics + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
-                            else
-                                *reinterpret_cast<float*>(A.diagnostics + (size_t)pix * 4u) = rayCount;
-                        }
-                        pix = -1;
-                    }
-                    // ---- pull the next owned pixel ----
-                    // Tickets are handed to WAVES in chunks of 64 consecutive pixels (one global atomic per chunk) and to lanes
-                    // from the wave's chunk by ballot rank, so every 64-byte line of the accumulator arrays is read and written
-                    // by a single CU within about one pixel-time and coalesces in that XCD's L2 instead of being fetched and
-                    // written back once per pixel from eight different L2s.
-                    unsigned ticket = 0xffffffffu;
-                    for (bool got = false; !got;) {
-                        const unsigned long long need = __ballot(1);                  // lanes asking right now (all still in this loop)
-                        const int lane = tid & 63;
-                        const int leader = __builtin_ctzll(need);
-                        const int rank = __popcll(need & ((1ull << lane) - 1ull));
-                        const unsigned next = waveQueue[0], end = waveQueue[1];      // wave-private: same value in every lane
-                        if (next == 0xffffffffu) break;                               // queue exhausted (or cancelled)
-                        if (next == end) {
-                            if (lane == leader) {
-                                bool cancelled = false;
-                                if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
-                                const unsigned slot = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
-                                if (slot >= A.chunkCount) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
-                                else {
-                                    // most expensive chunks first (cost map of the previous launch, or of a 1-spp probe), so that the
-                                    // chunks handed out last - the ones that decide when a wave can retire - are the cheap ones
-                                    const unsigned base = (A.chunkOrder ? A.chunkOrder[slot] : slot) * 64u;
-                                    waveQueue[0] = base;
-                                    waveQueue[1] = (A.totalWork - base < 64u) ? A.totalWork : base + 64u;
-                                }
-                            }
-                            continue;
-                        }
-                        const unsigned take = (unsigned)__popcll(need) < end - next ? (unsigned)__popcll(need) : end - next;
-                        if ((unsigned)rank < take) { ticket = next + (unsigned)rank; got = true; }
-                        if (lane == leader) waveQueue[0] = next + take;
-                    }
-                    if (ticket == 0xffffffffu) { st = ST_DEAD; break; }
-                    tick = ticket;
-                    if (PER_SAMPLE) { unitGroup = ticket % A.groupsPerPixel; ticket = ticket / A.groupsPerPixel; }   // unit = (owned pixel, sample group)
-#ifdef RTOW_STATS
-                    pixT0 = wall_clock64();
-#endif
-                    const int ownedRow = (int)(ticket / (unsigned)A.width);
-                    cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
-                    cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
-                    pix = cy * A.width + cx;
-
-                    float4 last = make_float4(0, 0, 0, 0);
-                    if (PER_SAMPLE) {
-                        // a unit only needs what decides the pixel's sample count (:118-126); the fold kernel reads the accumulators
-                        last.w = A.inColor[4 * (size_t)pix + 3];
-                        scwAcc = A.inScw[pix];
-                    } else if (!A.probeOnly) {
-                        last = reinterpret_cast<const float4*>(A.inColor)[pix];                           // :72-78
-                        normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
-                        albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
-                        scwAcc = A.inScw[pix];
-                    }
-                    colorAcc = v3(last.x, last.y, last.z);
-                    sampleCount = (int)last.w;
-                    const float scwIn = scwAcc;
-                    const int countIn = sampleCount;
-
-                    // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
-                    rng.begin_pixel(NoiseSite{&A, (unsigned)cx, (unsigned)cy}, (unsigned)pix);
-
-                    // :118-126
-                    const float w = scwIn / (float)countIn;
-                    if (w == 0) {
-                        nsamp = A.sampleCountMin;
-                    } else {
-                        const float nw = um_saturate((w - A.extremaX) / (A.extremaY - A.extremaX));
-                        const float lo = (float)A.sampleCountMin, hi = (float)A.sampleCountMax;
-                        nsamp = (unsigned)__builtin_rintf(lo + nw * (hi - lo));
-                    }
-                    if (A.probeOnly) nsamp = 1;
-                    scw0 = w;
-                    smp = 0;
-                    if (PER_SAMPLE) {
-                        // this unit: samples [16 g, 16 g + 16) of the pixel's nsamp, accumulated from zero
-                        smp = unitGroup * kSampleGroup;
-                        nsamp = nsamp < smp + kSampleGroup ? nsamp : smp + kSampleGroup;
-                        if (nsamp < smp) nsamp = smp;
-                        colorAcc = v3(0, 0, 0); normalAcc = v3(0, 0, 0); albedoAcc = v3(0, 0, 0);
-                        sampleCount = 0;
-                        scwAcc = 0;
-                    }
-                    rayCount = 0; boundsHits = 0; candidates = 0;
-                    // the pixel's camera-ray candidates (primary_candidates_kernel): up to 4 primitive indices, 0xFFFF = none
-                    pcand = A.pixelCandidates ? A.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u);
-                }
-                if (st != ST_DEAD) {
-                    // ---- camera ray (:134-135, RT/View.cs:38-48) ----
-                    const V3 viewRight = v3(A.view.right), viewUp = v3(A.view.up);
-                    const V3 viewLLC = v3(A.view.lowerLeftCorner), viewH = v3(A.view.horizontal), viewV = v3(A.view.vertical);
-                    const float lensRadius = A.view.lensRadius;
-                    float jx = 0.5f, jy = 0.5f;
-                    const NoiseSite at{&A, (unsigned)cx, (unsigned)cy};
-                    if (PER_SAMPLE) rng.begin_sample(at, (unsigned)pix, smp);
-                    if (A.subPixelJitter) rng.next2(at, jx, jy);
-                    const float u = ((float)cx + jx) / A.sizeX;
-                    const float v = ((float)cy + jy) / A.sizeY;
-                    float rdx = 0, rdy = 0;
-                    if (lensRadius != 0) {
-                        float dx, dy;
-                        rng.in_unit_disk(at, dx, dy);                                         // RandomSource.InUnitDisk (RT/RandomSource.cs:40-61)
-                        rdx = lensRadius * dx;
-                        rdy = lensRadius * dy;
-                    }
-                    const V3 offset = v3(viewRight.x * rdx + viewUp.x * rdy, viewRight.y * rdx + viewUp.y * rdy, viewRight.z * rdx + viewUp.z * rdy);
-                    ro = add(v3(A.view.origin), offset);
-                    rd = normalize(v3(viewLLC.x - offset.x + u * viewH.x + v * viewV.x,
-                                      viewLLC.y - offset.y + u * viewH.y + v * viewV.y,
-                                      viewLLC.z - offset.z + u * viewH.z + v * viewV.z));
-                    rtime = rng.next(at);
-
-                    depth = 0;
-                    hist.clear();
-                    sampleNormal = v3(0, 0, 0);
-                    sampleAlbedo = v3(0, 0, 0);
-                    firstNonSpecular = false;
-                    randomEventsLocal = 0;
-                    curVol = -1;
-                    pendRE = 0;
-                    startRay();
-                    if (pcand.x != kNoPrimaryList) {
-                        // Every camera ray of this pixel can only hit primitives under the (at most four) leaf-parent nodes of the pixel's
-                        // list: instead of walking the tree, visit just those nodes - with the walk's own slab test of this very ray against
-                        // their leaf boxes (same expressions, so the same candidates the walk would find: a ray that misses a leaf's box must
-                        // not reach that leaf's exact test, whose rounding can report a hit for a far, small sphere it passes closely).
-                        const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
-                        const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
-                        cur = -1;
-                        for (int k = 0; k < 4; k++) {
-                            const unsigned node = (k < 2 ? pcand.x >> (16 * k) : pcand.y >> (16 * (k - 2))) & 0xffffu;
-                            if (node == 0xffffu) break;
-                            float4 q0, q1, q2;
-                            int c0, c1;
-                            load_node<ALL_LDS>(sc, L, (int)node, q0, q1, q2, c0, c1);
-                            const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
-                            const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
-                            const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
-                            const float tmin0 = vmax3(vmin(tlx.x, thx.x), vmin(tly.x, thy.x), vmax(vmin(tlz.x, thz.x), 0.0f));
-                            const float tmax0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmin(vmax(tlz.x, thz.x), best));
-                            const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
-                            const float tmax1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmin(vmax(tlz.y, thz.y), best));
-                            const bool leaf0 = tmin0 <= tmax0 && c0 < 0;
-                            const bool leaf1 = tmin1 <= tmax1 && twoChildren && c1 < 0;
-                            if (FULL_DIAG) boundsHits += (leaf0 ? 1.0f : 0.0f) + (leaf1 ? 1.0f : 0.0f);
-                            cand[nc * kBlockThreads] = (unsigned short)~c0;
-                            nc += leaf0 ? 1 : 0;
-                            cand[nc * kBlockThreads] = (unsigned short)~c1;
-                            nc += leaf1 ? 1 : 0;
-                        }
-                        if (nc == 0) classify(); else st = ST_TEST;
-                    }
-                }
-            }
-        }
-        if ((int)__popcll(__ballot(st == ST_TRAV)) >= (force == ST_TRAV ? 1 : need(1))) {
-            ran = true;
-            // ================= box walk: FindHitCandidates (JOBS/SampleBatchJob.cs:403-448), resumable =================
-            if (st == ST_TRAV) {
-                const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
-                const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
-                int budget = A.travSlice;
-                // Branch-free node visit: every LDS access of the iteration is issued up front (node, plus the stack slot a
-                // pop would need), candidate / stack slots are written unconditionally and only the counters are predicated,
-                // so the wave's EXEC mask changes only at the loop test.
-                while (budget > 0 && cur >= 0 && nc <= kCandCapacity - 2) {
-                    budget--;
-                    STAT_ADD(3, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0);
-                    STAT_LANES(4);
-                    float4 q0, q1, q2;
-                    int c0, c1;
-                    load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
-                    const int spm1 = sp > 0 ? sp - 1 : 0;
-                    const int popped = stack[spm1 * kBlockThreads];
-                    // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
-                    const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
-                    const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
-                    const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
-                    const float tmin0 = vmax3(vmin(tlx.x, thx.x), vmin(tly.x, thy.x), vmax(vmin(tlz.x, thz.x), 0.0f));
-                    const float tmax0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmin(vmax(tlz.x, thz.x), best));
-                    const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
-                    const float tmax1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmin(vmax(tlz.y, thz.y), best));
-                    const bool hit0 = tmin0 <= tmax0;
-                    const bool hit1 = tmin1 <= tmax1 && twoChildren;
-                    if (FULL_DIAG) boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
-                    const bool leaf0 = hit0 && c0 < 0, leaf1 = hit1 && c1 < 0;
-                    cand[nc * kBlockThreads] = (unsigned short)~c0;
-                    nc += leaf0 ? 1 : 0;
-                    cand[nc * kBlockThreads] = (unsigned short)~c1;
-                    nc += leaf1 ? 1 : 0;
-                    const bool in0 = hit0 && c0 >= 0;
-                    const bool in1 = hit1 && c1 >= 0;
-                    const bool both = in0 && in1;
-                    const bool swap = tmin1 < tmin0;                         // near child first
-                    stack[sp * kBlockThreads] = (unsigned short)(swap ? c0 : c1);
-                    const int next = both ? (swap ? c1 : c0) : (in0 ? c0 : c1);
-                    const bool any = in0 || in1;
-                    cur = any ? next : (sp > 0 ? popped : -1);
-                    sp = any ? sp + (both ? 1 : 0) : spm1;
-                }
-                if (cur < 0 || nc > kCandCapacity - 2) {
-                    if (nc > 0) st = ST_TEST;      // exact tests pending (walk finished, or the list is full)
-                    else classify();               // walk finished with nothing left to test
-                }
-            }
-        }
-        if ((int)__popcll(__ballot(st == ST_TEST)) >= (force == ST_TEST ? 1 : need(2))) {
-            ran = true;
-            // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
-            if (st == ST_TEST) {
-                const float a = dot(rd, rd);
-                if (FULL_DIAG) candidates += (float)nc;
-                while (nc > 0) {
-                    STAT_ADD(5, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0);
-                    STAT_LANES(6);
-                    nc--;
-                    const int i = cand[nc * kBlockThreads];
-                    if (VOLUMES) {
-                        // FindHits keeps EVERY hit (:457-460) and injects an exit hit for volume hulls (Box / Sphere, :463-469)
-                        const unsigned mw = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u);
-                        const unsigned type = mw >> kPrimTypeShift;
-                        float tmin = 0.0f;
-                        for (int pass = 0; pass < 2; pass++) {
-                            float t; V3 nl; float4 rq;
-                            if (!general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, tmin, t, nl, rq)) break;
-                            const float dn = dot(normalize(rotate(rq, nl)), rd);
-                            if (nHits < kMaxHits) {
-#pragma unroll
-                                for (int k = 0; k < kMaxHits; k++)
-                                    if (k == nHits) { hitT[k] = t; hitTmin0[k] = tmin; hitCode[k] = (unsigned)i | (dn < 0 ? 0x40000000u : 0u) | (dn > 0 ? 0x80000000u : 0u); }
-                                nHits++;
-                            }
-                            if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME || !(type == RTOW_ENTITY_BOX || type == RTOW_ENTITY_SPHERE)) break;
-                            tmin = t + 0.001f;
-                        }
-                    } else if (GENERAL) {
-                        const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
-                        float t; V3 nl; float4 rq;
-                        if (general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq)) {
-                            // two surfaces at the bit-identical distance: the reference's sorted hit list starts with the one that
-                            // comes first in its tree's leaf order (rtow_reforder.h)
-                            const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
-                            if (t < best || (t == best && prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
-                        }
-                    } else {
-                        V3 c; float r, t;
-                        sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
-                        if (sphere_hit(sub(ro, c), rd, a, r, t) && t < best) { best = t; prim = i; }
-                    }
-                }
-                if (cur >= 0) st = ST_TRAV;        // the list was full: resume the walk, now pruned by `best`
-                else classify();
-            }
-        }
-        if ((int)__popcll(__ballot(st == ST_HIT)) >= (force == ST_HIT ? 1 : need(3))) {
-            ran = true;
-            // ================= surface hit: Entity.Hit record + Material.Scatter =================
-            STAT_ADD(7, 1);
-            if (st == ST_HIT) {
-                STAT_LANES(8);
-                DBG_TRACE(VOLUMES && insideHit ? 1 : 0, prim, best);
-                unsigned mi = 0;
-                if (!(VOLUMES && insideHit)) mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
-                unsigned matIdx = mi & 0xffffu;
-                unsigned cls = (mi >> 16) & 3u;                                // shading class packed by the scene compiler
-                const float t = best;
-                const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
-                V3 N;
-                float2 hitUv = make_float2(0, 0);                               // rec.TexCoords
-                if (VOLUMES && insideHit) {
-                    // new HitRecord(totalDistance, ray.GetPoint(totalDistance), -ray.Direction, default); material = the volume (:272-273)
-                    N = neg(rd);
-                    matIdx = (unsigned)curVol;
-                    cls = MAT_CLASS_VOLUME;
-                } else if (GENERAL) {
-                    // re-run the winning primitive's test for its entity-space normal, then rotate it out (RT/Entity.cs:62-66)
-                    float t2; V3 nLocal; float4 rq;
-                    (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq, TEXTURED ? &hitUv : nullptr);
-                    N = normalize(rotate(rq, nLocal));
-                } else {
-                    V3 c; float radius;
-                    sphere_at<ALL_LDS, HAS_MOTION>(sc, L, prim, rtime, c, radius);
-                    const V3 oc = sub(ro, c);
-                    const V3 nLocal = v3((oc.x + t * rd.x) / radius, (oc.y + t * rd.y) / radius, (oc.z + t * rd.z) / radius); // r.GetPoint(t) / radius
-                    N = normalize(nLocal);                                                    // RT/Entity.cs:65
-                }
-                const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + matIdx * 64u;
-                const float4 m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
-                const float4 m1 = *reinterpret_cast<const float4*>(mp + 16);  // emission.yz type metallic
-                V3 reflectance = v3(m0.x, m0.y, m0.z);
-                V3 emission = v3(m0.w, m1.x, m1.y);
-                float metallicHit = m1.w;
-                float4 m2hit = make_float4(0, 0, 0, 0), m3hit = make_float4(0, 0, 0, 0);
-                if (TEXTURED) {
-                    m2hit = *reinterpret_cast<const float4*>(mp + 32);
-                    m3hit = *reinterpret_cast<const float4*>(mp + 48);
-                    if (__float_as_uint(m2hit.z) & MAT_FLAG_TEXTURED) {
-                        // Material.Scatter / Emit evaluate the four textures at rec.TexCoords (RT/Material.cs:71,77-78,123,176-179), and
-                        // everything derived from metallic / glossiness (prepare_materials_kernel's program) follows per hit
-                        const GpuTexMaterial tm = reinterpret_cast<const GpuTexMaterial*>(A.texBlob + A.texLayout.materialOffset)[matIdx];
-                        reflectance = texture_color(A, tm.albedo, hitUv);
-                        emission = texture_color(A, tm.emission, hitUv);
-                        const float glossiness = texture_scalar(A, tm.glossiness, hitUv);
-                        float roughness, ior, invIor = 0.0f, alpha = 0.0f;
-                        if (__float_as_int(m1.z) == RTOW_MATERIAL_STANDARD) {
-                            metallicHit = texture_scalar(A, tm.metallic, hitUv);
-                            roughness = det_sq(1 - glossiness);
-                            ior = 1.5f + metallicHit * (1.1f - 1.5f);
-                            alpha = roughness_to_alpha(roughness);
-                        } else {
-                            roughness = 1 - glossiness;
-                            ior = m2hit.y;
-                            invIor = 1 / ior;
-                        }
-                        float r0 = (1 - ior) / (1 + ior);
-                        r0 *= r0;
-                        m2hit = make_float4(glossiness, m2hit.y, m2hit.z, roughness);
-                        m3hit = make_float4(alpha, ior, r0, invIor);
-                    }
-                    texHist[depth * 6 + 0] = reflectance.x; texHist[depth * 6 + 1] = reflectance.y; texHist[depth * 6 + 2] = reflectance.z;
-                    texHist[depth * 6 + 3] = emission.x; texHist[depth * 6 + 4] = emission.y; texHist[depth * 6 + 5] = emission.z;
-                }
-                bool white = false;
-                bool perfectSpecular = false;
-                V3 sdir;
-                const NoiseSite at{&A, (unsigned)cx, (unsigned)cy};
-                float randomEvents = VOLUMES ? pendRE : 0.0f;     // rng.RandomEvents may already hold ProbabilisticHit's increments
-                pendRE = 0;
-
-                if (VOLUMES && cls == MAT_CLASS_VOLUME) {
-                    // ProbabilisticVolume (RT/Material.cs:163-168): isotropic scatter, ray time reset to 0, RandomEvents += 2
-                    sdir = rng.direction(at);                          // NextFloat3Direction
-                    rtime = 0;
-                    randomEvents += 2;
-                } else if (cls == MAT_CLASS_LAMBERT) {
-                    STAT_ADD(9, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(10);
-                    // Standard with glossiness == 0 and metallic == 0 (RT/Material.cs:75-119): roughness = 1, so the rough normal
-                    // costs one cosine-hemisphere draw (two white-noise numbers) whose result is never used (reflectionChance = saturate(fresnel * 0 * g1) = 0, and the
-                    // rough-metal branch needs metallic > 0); RandomEvents = 0 + 0 + 1 * 0 + 1 * 1.
-                    rng.skip_cosine_hemisphere(at);
-                    sdir = rng.cosine_hemisphere(at, N);
-                    randomEvents += 1.0f;                          // 0 + 0 + 1 * 0 + 1 * 1 on top of whatever was pending
-                } else if (cls == MAT_CLASS_GENERAL) {                                        // RT/Material.cs:75-119
-                    STAT_ADD(11, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(12);
-                    const float4 m2 = TEXTURED ? m2hit : *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags roughness
-                    const float4 m3 = TEXTURED ? m3hit : *reinterpret_cast<const float4*>(mp + 48);  // alpha ior r0 1/ior
-                    const float metallic = TEXTURED ? metallicHit : m1.w;
-                    const float glossiness = m2.x;
-                    const float roughness = m2.w;                                 // pow(1 - glossiness, 2)
-                    perfectSpecular = (__float_as_uint(m2.z) & MAT_FLAG_PERFECT_SPECULAR) != 0;
-                    V3 roughN = N;
-                    if (roughness > 0) {
-                        const V3 h = rng.cosine_hemisphere(at, N);
-                        roughN = normalize(v3(N.x + roughness * (h.x - N.x), N.y + roughness * (h.y - N.y), N.z + roughness * (h.z - N.z)));
-                    }
-                    const float incidentCosine = -dot(rd, roughN);
-                    const float fresnel = m3.z + (1 - m3.z) * det_pow5(1 - incidentCosine);   // Schlick, r0 from lerp(1.5, 1.1, metallic)
-                    const float g1 = smith_g1(rd, N, m3.x);
-                    const float reflectionChance = um_saturate(fresnel * glossiness * g1);
-
-                    if (reflectionChance > 0 && rng.next(at) < reflectionChance) {
-                        sdir = reflect(rd, roughN);
-                        reflectance = v3(1, 1, 1);
-                        white = true;
-                    } else if (metallic > 0 && rng.next(at) < metallic) {
-                        sdir = reflect(rd, roughN);
-                    } else {
-                        sdir = rng.cosine_hemisphere(at, N);
-                    }
-                    if (reflectionChance > 0 && reflectionChance < 1) randomEvents++;
-                    if (metallic > 0 && metallic < 1) randomEvents++;
-                    randomEvents += roughness * (reflectionChance + (1 - reflectionChance) * metallic);
-                    randomEvents += (1 - reflectionChance) * (1 - metallic);
-                } else {                                                                      // Dielectric, RT/Material.cs:121-161
-                    const float4 m2 = TEXTURED ? m2hit : *reinterpret_cast<const float4*>(mp + 32);
-                    const float4 m3 = TEXTURED ? m3hit : *reinterpret_cast<const float4*>(mp + 48);
-                    STAT_ADD(13, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(14);
-                    perfectSpecular = true;
-                    const float ior = m2.y;
-                    const float roughness = m2.w;                                 // 1 - glossiness
-                    const V3 rdir = rng.direction(at);                             // RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128)
-                    const V3 roughN = normalize(v3(N.x + roughness * rdir.x, N.y + roughness * rdir.y, N.z + roughness * rdir.z));
-
-                    float niOverNt, cosine;
-                    V3 outwardN;
-                    const float dDotN = dot(rd, roughN);
-                    if (dDotN > 0) { outwardN = neg(roughN); niOverNt = ior; cosine = ior * dDotN; }
-                    else { outwardN = roughN; niOverNt = m3.w; cosine = -dDotN; }
-
-                    // Refract (:198-210)
-                    const float dt = dot(rd, outwardN);
-                    const float disc = 1 - niOverNt * niOverNt * (1 - dt * dt);
-                    bool refractOk = false;
-                    if (disc > 0) {
-                        const float sq = __builtin_sqrtf(disc);
-                        const V3 refracted = v3(niOverNt * (rd.x - outwardN.x * dt) - outwardN.x * sq,
-                                                niOverNt * (rd.y - outwardN.y * dt) - outwardN.y * sq,
-                                                niOverNt * (rd.z - outwardN.z * dt) - outwardN.z * sq);
-                        const float schlickV = m3.z + (1 - m3.z) * det_pow5(1 - cosine);
-                        if (rng.next(at) > schlickV) { sdir = refracted; refractOk = true; }
-                    }
-                    if (!refractOk) {
-                        sdir = reflect(rd, roughN);
-                        reflectance = v3(1, 1, 1);
-                        white = true;
-                    }
-                    randomEvents++;
-                    randomEvents += roughness;
-                }
-
-                hist.set(depth, (white ? 0x8000u : 0u) | matIdx);                             // :311,330 (re-expanded at the fold)
-                if (depth == 0) sampleNormal = N;                                             // :313-314
-                if (!firstNonSpecular && !perfectSpecular) {                                  // :316-328
-                    sampleAlbedo = add(emission, reflectance);
-                    sampleNormal = N;
-                    firstNonSpecular = true;
-                }
-                randomEventsLocal += randomEvents * inv_pow2(depth);                          // RandomEvents / pow(2, depth), :332
-
-                // ray = scattered.OffsetTowards(dot(dir, N) >= 0 ? N : -N)  (:335-336, RT/Ray.cs:18)
-                const V3 offN = dot(sdir, N) >= 0 ? N : neg(N);
-                ro = v3(P.x + 0.001f * offN.x, P.y + 0.001f * offN.y, P.z + 0.001f * offN.z);
-                rd = sdir;
-                depth++;
-                if (depth == traceDepth) endSample(false, v3(0, 0, 0));                       // :379-381
-                else startRay();
-            }
-        }
-        if (VOLUMES && (int)__popcll(__ballot(st == ST_VOL)) >= 1) {
-            ran = true;
-            if (st == ST_VOL) {
-                auto matOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (code & 0xffffu) * 4u); };
-                auto isVolume = [&](unsigned code) { return ((matOf(code) >> 16) & 3u) == MAT_CLASS_VOLUME; };
-                // ---- hitBuffer.Sort(DistanceComparer) (:473-474) ----
-                // The reference sorts a list that starts in its tree's leaf order with a sort that is not stable, and hits at
-                // bit-identical distances (coplanar faces) keep whatever order that leaves: put the hits in leaf order first
-                // (rank, rtow_reforder.h), then run the same small-array sort (NativeSortExtension: compare-exchange for 2 and 3,
-                // insertion above; lists longer than 16 - never seen - are insertion-sorted as well, exact unless they hold a tie).
-                {
-                    auto rankOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset) + (code & 0xffffu) * 4u); };
-                    auto swapHits = [&](int a, int b) {
-                        const float t = hitT[a], tm = hitTmin0[a]; const unsigned c = hitCode[a];
-                        hitT[a] = hitT[b]; hitTmin0[a] = hitTmin0[b]; hitCode[a] = hitCode[b];
-                        hitT[b] = t; hitTmin0[b] = tm; hitCode[b] = c;
-                    };
-                    for (int i = 1; i < nHits; i++) {                                   // leaf order; an entity's exit hit was recorded after its entry
-                        const float t = hitT[i], tm = hitTmin0[i];
-                        const unsigned c = hitCode[i], r = rankOf(c);
-                        int j = i - 1;
-                        while (j >= 0 && rankOf(hitCode[j]) > r) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
-                        hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
-                    }
-                    if (nHits == 2) {
-                        if (hitT[0] > hitT[1]) swapHits(0, 1);
-                    } else if (nHits == 3) {
-                        if (hitT[0] > hitT[1]) swapHits(0, 1);
-                        if (hitT[0] > hitT[2]) swapHits(0, 2);
-                        if (hitT[1] > hitT[2]) swapHits(1, 2);
-                    } else {
-                        for (int i = 1; i < nHits; i++) {
-                            const float t = hitT[i], tm = hitTmin0[i];
-                            const unsigned c = hitCode[i];
-                            int j = i - 1;
-                            while (j >= 0 && t < hitT[j]) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
-                            hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
-                        }
-                    }
-                }
-                // ---- DetermineVolumeContainment (:477-508) ----
-                if (curVol < 0) {
-                    for (int i = 0; i < nHits; i++) {
-                        const unsigned c = hitCode[i];
-                        if (!isVolume(c)) continue;
-                        if (c & 0x40000000u) break;                                   // entry hit, early out
-                        // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
-                        const V3 bd = neg(rd);
-                        const V3 binv = v3(__builtin_amdgcn_rcpf(bd.x), __builtin_amdgcn_rcpf(bd.y), __builtin_amdgcn_rcpf(bd.z));
-                        V3 einv = v3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);                    // math.rcp + "convert NaN to INFINITY" (:409-412)
-                        if (einv.x != einv.x) einv.x = __builtin_inff();
-                        if (einv.y != einv.y) einv.y = __builtin_inff();
-                        if (einv.z != einv.z) einv.z = __builtin_inff();
-                        bool insideVolume = false;
-                        int bsp = 0, bcur = 0;
-                        while (bcur >= 0) {                                              // FindHitCandidates(backwardsRay): no pruning
-                            float4 q0, q1, q2;
-                            int c0, c1;
-                            load_node<ALL_LDS>(sc, L, bcur, q0, q1, q2, c0, c1);
-                            const float t0x = (q0.x - ro.x) * binv.x, t1x = (q1.z - ro.x) * binv.x, u0x = (q0.y - ro.x) * binv.x, u1x = (q1.w - ro.x) * binv.x;
-                            const float t0y = (q0.z - ro.y) * binv.y, t1y = (q2.x - ro.y) * binv.y, u0y = (q0.w - ro.y) * binv.y, u1y = (q2.y - ro.y) * binv.y;
-                            const float t0z = (q1.x - ro.z) * binv.z, t1z = (q2.z - ro.z) * binv.z, u0z = (q1.y - ro.z) * binv.z, u1z = (q2.w - ro.z) * binv.z;
-                            const bool h0 = vmax3(vmin(t0x, t1x), vmin(t0y, t1y), vmax(vmin(t0z, t1z), 0.0f)) <= vmin3(vmax(t0x, t1x), vmax(t0y, t1y), vmax(t0z, t1z));
-                            const bool h1 = vmax3(vmin(u0x, u1x), vmin(u0y, u1y), vmax(vmin(u0z, u1z), 0.0f)) <= vmin3(vmax(u0x, u1x), vmax(u0y, u1y), vmax(u0z, u1z)) && twoChildren;
-                            for (int side = 0; side < 2; side++) {
-                                const int cc = side ? c1 : c0;
-                                if (!(side ? h1 : h0) || cc >= 0) continue;
-                                const unsigned mw = matOf((unsigned)~cc);
-                                if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME) continue;    // AnyBackwardsVolumeEntryHit (:510-524)
-                                {
-                                    // The probe starts ON a surface with tMin = 0, so whether the hull is a candidate at all is decided by the
-                                    // reference's slab test (RT/HitTests.cs:9-21) on the reference tree's box of this entity; repeat it exactly.
-                                    const float4* cb = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.cullOffset) + (unsigned)~cc * 32u);
-                                    const float4 lo = cb[0], hi = cb[1];
-                                    const float a0x = (lo.x - ro.x) * einv.x, a1x = (hi.x - ro.x) * einv.x;
-                                    const float a0y = (lo.y - ro.y) * einv.y, a1y = (hi.y - ro.y) * einv.y;
-                                    const float a0z = (lo.z - ro.z) * einv.z, a1z = (hi.z - ro.z) * einv.z;
-                                    const float tn = um_max(0.0f, um_max(um_max(um_min(a0x, a1x), um_min(a0y, a1y)), um_min(a0z, a1z)));
-                                    const float tf = um_min(um_min(um_max(a0x, a1x), um_max(a0y, a1y)), um_max(a0z, a1z));
-                                    if (!(tn < tf)) continue;
-                                }
-                                float t; V3 nl; float4 rq;
-                                if (general_hit<ALL_LDS>(sc, L, ~cc, mw >> kPrimTypeShift, ro, bd, rtime, 0.0f, t, nl, rq) && dot(normalize(rotate(rq, nl)), bd) > 0) insideVolume = true;
-                            }
-                            const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
-                            if (in0 && in1) { stack[bsp * kBlockThreads] = (unsigned short)c1; bsp++; bcur = c0; }
-                            else if (in0 || in1) bcur = in0 ? c0 : c1;
-                            else if (bsp > 0) { bsp--; bcur = stack[bsp * kBlockThreads]; }
-                            else bcur = -1;
-                        }
-                        if (insideVolume) { curVol = (int)(matOf(c) & 0xffffu); break; }
-                    }
-                }
-                for (int i = 0; i < nHits; i++) DBG_TRACE(10 + i, hitCode[i], hitT[i]);
-                DBG_TRACE(9, 0, 0.0f);
-                // ---- the hit loop of Sample with the volume branch (:205-303) ----
-                int hitIndex = 0;
-                int chosen = -1;
-                insideHit = false;
-                while (hitIndex < nHits) {
-                    const unsigned c = hitCode[hitIndex];
-                    const unsigned mw = matOf(c);
-                    if (curVol >= 0 || ((mw >> 16) & 3u) == MAT_CLASS_VOLUME) {
-                        const bool isEntryHit = curVol < 0;
-                        if (curVol < 0) curVol = (int)(mw & 0xffffu);
-                        int exitHitIndex = hitIndex, lastExitIndex = -1, sameMaterialEntries = 0;
-                        while (exitHitIndex < nHits) {
-                            const unsigned ec = hitCode[exitHitIndex];
-                            if ((int)(matOf(ec) & 0xffffu) == curVol) {
-                                if (ec & 0x40000000u) sameMaterialEntries++;
-                                else { sameMaterialEntries--; lastExitIndex = exitHitIndex; }
-                                if (sameMaterialEntries <= 0) break;
-                            } else
-                                break;
-                            exitHitIndex++;
-                        }
-                        if (sameMaterialEntries > 0 && lastExitIndex != -1) exitHitIndex = lastExitIndex;
-                        if (exitHitIndex < nHits) {
-                            float distanceInVolume = hitT[exitHitIndex];
-                            float entryDistance = 0;
-                            if (isEntryHit) { entryDistance = hitT[hitIndex]; distanceInVolume -= hitT[hitIndex]; }
-                            // Material.ProbabilisticHit (RT/Material.cs:49-65)
-                            const float density = *reinterpret_cast<const float*>(section<ALL_LDS>(sc, L.materialOffset) + (unsigned)curVol * 64u + 36u);
-                            pendRE++;
-                            const float volumeHitDistance = -(1 / um_max(density, 1.1920928955078125e-7f)) * det_log(rng.next(NoiseSite{&A, (unsigned)cx, (unsigned)cy}));
-                            if (volumeHitDistance < distanceInVolume) {
-                                best = entryDistance + volumeHitDistance;                    // we hit inside the volume
-                                insideHit = true;
-                                break;
-                            }
-                            curVol = -1;                                                     // no hit inside the volume, exit it
-                            const unsigned xc = hitCode[exitHitIndex];
-                            if (isVolume(xc) && (xc & 0x80000000u)) { hitIndex = exitHitIndex + 1; continue; }   // volume exit: next hit
-                            chosen = exitHitIndex;                                           // obstacle
-                            break;
-                        }
-                        nHits = 0;                                                           // no more surfaces (volume has holes)
-                        break;
-                    }
-                    chosen = hitIndex;
-                    break;
-                }
-                if (insideHit) { prim = -1; st = ST_HIT; }
-                else if (chosen >= 0 && chosen < nHits) { best = hitT[chosen]; hitTmin = hitTmin0[chosen]; prim = (int)(hitCode[chosen] & 0xffffu); st = ST_HIT; }
-                else st = ST_SKY;
-            }
-        }
-        if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : need(4))) {
-            ran = true;
-            // ================= sky (:341-374), then fold tail -> head (:384-396) =================
-            STAT_ADD(15, 1);
-            if (st == ST_SKY) {
-                DBG_TRACE(2, 0xffff, 0.0f);
-                V3 sky = v3(0, 0, 0);
-                if (A.environment.skyType == RTOW_SKY_GRADIENT) {
-                    const float s = 0.5f * (rd.y + 1);
-                    const V3 b = v3(A.environment.skyBottomColor), tp = v3(A.environment.skyTopColor);
-                    sky = v3(b.x + s * (tp.x - b.x), b.y + s * (tp.y - b.y), b.z + s * (tp.z - b.z));
-                } else if (A.environment.skyType == RTOW_SKY_CUBEMAP) {
-                    sky = cubemap_sample(A, rd);
-                }
-                // randomEventsLocalAcc += rng.RandomEvents / pow(2, depth) (:363): RandomEvents is 0 here unless a ProbabilisticHit
-                // that found nothing left its increment pending
-                if (VOLUMES) { randomEventsLocal += pendRE * inv_pow2(depth); pendRE = 0; }
-                if (!firstNonSpecular) { sampleAlbedo = sky; sampleNormal = neg(rd); }
-
-                V3 col = sky; // 0 * 1 + sky
-                for (int i = depth - 1; i >= 0; i--) {
-                    const unsigned code = hist.get(i);
-                    const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + (code & 0x7fffu) * 64u;
-                    const float4 m0 = *reinterpret_cast<const float4*>(mp);
-                    const float2 m1 = *reinterpret_cast<const float2*>(mp + 16);
-                    const bool white = (code & 0x8000u) != 0;
-                    if (TEXTURED) {
-                        const V3 att = white ? v3(1, 1, 1) : v3(texHist[i * 6 + 0], texHist[i * 6 + 1], texHist[i * 6 + 2]);
-                        col = v3(col.x * att.x + texHist[i * 6 + 3], col.y * att.y + texHist[i * 6 + 4], col.z * att.z + texHist[i * 6 + 5]);
-                        continue;
-                    }
-                    const V3 att = white ? v3(1, 1, 1) : v3(m0.x, m0.y, m0.z);
-                    col = v3(col.x * att.x + m0.w, col.y * att.y + m1.x, col.z * att.z + m1.y);
-                }
-                endSample(true, col);
-            }
-        }
-        // nothing met its threshold: force the most populated stage next trip (or stop when every lane is dead)
-        if (ran) {
-            force = -1;
-        } else {
-            int top = 0;
-            force = -1;
-            for (int k = ST_REGEN; k < ST_COUNT; k++) {
-                const int n = (int)__popcll(__ballot(st == k));
-                if (n > top) { top = n; force = k; }
-            }
-            if (top == 0) break;
-        }
-    }
-#ifdef RTOW_STATS
-    // every lane counted the same wave-level events for 'per-run' slots; lane-population slots were added by all active lanes.
-    if (A.stats) for (int i = 0; i < 16; i++) atomicAdd(&A.stats[i], stat[i]);
-    if (A.stats && (threadIdx.x & 63) == 0) {
-        const unsigned long long dt = wall_clock64() - statT0;   // 100 MHz ticks this wave was resident
-        atomicAdd(&A.stats[16], dt);
-        atomicMax(&A.stats[17], dt);
-        atomicAdd(&A.stats[18], 1ull);
-        A.stats[32 + blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)] = dt;   // per-wave residency
-    }
-#endif
-}
 
 // Launch order of the 64-pixel ticket chunks: most expensive first (longest-processing-time-first), from the per-chunk ray
 // counts of the previous launch.  Counting sort on a 1024-bucket quantisation of the cost; the order inside a bucket is
@@ -1767,59 +354,20 @@ __global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
-hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
-{
-    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE, PER_SAMPLE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(numBlocks), dim3(kBlockThreads), ldsBytes, stream, args);
-    return hipGetLastError();
-}
-
-template <bool ALL_LDS, int KIND, bool FULL_DIAG>
-hipError_t launchByDepth(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
-{
-    // the texture-driven noise sources are not the hot configuration: one (generic-history) variant each keeps the build small
-    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_BLUE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.unitRecords) {      // RTOW_RNG_PER_SAMPLE
-        if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
-        if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
-        return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
-    }
-    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-    return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-}
-
-template <bool ALL_LDS, int KIND>
-hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
-{
-    if (args.diagnostics && args.diagnosticsStride >= 16) return launchByDepth<ALL_LDS, KIND, true>(args, numBlocks, ldsBytes, stream);
-    return launchByDepth<ALL_LDS, KIND, false>(args, numBlocks, ldsBytes, stream);
-}
-
-template <bool ALL_LDS>
-hipError_t launchByKind(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
-{
-    switch (args.layout.sceneKind) {
-        case SCENE_KIND_SPHERES: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES>(args, numBlocks, ldsBytes, stream);
-        case SCENE_KIND_SPHERES_MOTION: return launchByDiag<ALL_LDS, SCENE_KIND_SPHERES_MOTION>(args, numBlocks, ldsBytes, stream);
-        case SCENE_KIND_VOLUMES: return launchByDiag<ALL_LDS, SCENE_KIND_VOLUMES>(args, numBlocks, ldsBytes, stream);
-        case SCENE_KIND_TEXTURED: return launchByDiag<ALL_LDS, SCENE_KIND_TEXTURED>(args, numBlocks, ldsBytes, stream);
-        case SCENE_KIND_VOLUMES_TEXTURED: return launchByDiag<ALL_LDS, SCENE_KIND_VOLUMES_TEXTURED>(args, numBlocks, ldsBytes, stream);
-        default: return launchByDiag<ALL_LDS, SCENE_KIND_GENERAL>(args, numBlocks, ldsBytes, stream);
-    }
-}
-
 } // namespace
 
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
     const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
-    return allLds ? launchByKind<true>(args, numBlocks, ldsBytes, stream) : launchByKind<false>(args, numBlocks, ldsBytes, stream);
+    switch (args.layout.sceneKind) {
+        case SCENE_KIND_SPHERES: return launchSampleSpheres(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_SPHERES_MOTION: return launchSampleSpheresMotion(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_VOLUMES: return launchSampleVolumes(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_TEXTURED: return launchSampleTextured(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_VOLUMES_TEXTURED: return launchSampleVolumesTextured(args, numBlocks, ldsBytes, stream, allLds);
+        default: return launchSampleGeneral(args, numBlocks, ldsBytes, stream, allLds);
+    }
 }
 
 hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream)

@@ -1,0 +1,6 @@
+// every instantiation of sample_batch_kernel for SCENE_KIND_TEXTURED scenes (see rtow_sample_kernel.hip.h)
+#include "rtow_sample_kernel.hip.h"
+
+namespace rtow {
+RTOW_DEFINE_KIND_LAUNCHER(launchSampleTextured, SCENE_KIND_TEXTURED)
+}
