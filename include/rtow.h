@@ -161,7 +161,9 @@ typedef struct RtowSceneDesc {
     int32_t entityCount;
     const RtowMaterial* materials;
     int32_t materialCount;
-    int32_t maxBvhDepth;            /* UNITY/Raytracer.cs:88 (prefab default 32); 0 = builder default */
+    int32_t maxBvhDepth;            /* the host's MaxBvhDepth (UNITY/Raytracer.cs:88, prefab default 32; 0 = that default).  The library builds
+                                       its own tree to its own depth; this value only reproduces the order in which the host's tree
+                                       would enumerate hits at identical distances (leaves are forced at that depth) */
     const RtowTriangle* triangles;  /* payloads of RTOW_ENTITY_TRIANGLE entities (RtowEntity.contentIndex); may be NULL */
     int32_t triangleCount;
     const RtowImage* images;        /* pixel data of RTOW_TEXTURE_IMAGE textures (RtowTexture.imageIndex); may be NULL */

@@ -490,7 +490,9 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     CompiledScene compiled;
     std::string err;
-    const int rc = compileScene(scene, scene->maxBvhDepth, &compiled, &err);
+    // the library's own tree is always built to the LDS stack's depth; scene->maxBvhDepth (the host's tree) only decides the order of
+    // hits at identical distances (rtow_reforder.h)
+    const int rc = compileScene(scene, RTOW_STACK_CAPACITY, &compiled, &err);
     if (rc != RTOW_SUCCESS) {
         logf(ctx, 2, "scene", "%s", err.c_str());
         return rc;

@@ -1,0 +1,111 @@
+"""GPU: seeded random scenes - random mixes of every entity type, transform, material class, texture kind, camera (also inside geometry),
+lens, noise colour, RNG policy, slice and trace depth - rendered small and compared with the oracle bit for bit.  Catches the
+combinations nobody thought of writing a scene for."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_scene(rt, seed):
+    S, abi = rt.scenes, rt.abi
+    rng = np.random.default_rng(seed)
+    s = S.Scene("fuzz%d" % seed)
+    use_volumes = rng.random() < 0.35
+    use_textures = rng.random() < 0.35
+    if use_textures:
+        s.images = [rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(3, 5))), dtype=np.uint8) for _ in range(2)]
+
+    def tex_or(const):
+        if use_textures and rng.random() < 0.4:
+            return S.image_tex(int(rng.integers(-1, 2)), tuple(rng.random(3) * 1.2), channel=int(rng.integers(0, 3)))
+        return const
+
+    def material():
+        k = rng.random()
+        if use_volumes and k < 0.25:
+            return S.volume(tuple(rng.random(3)), float(rng.uniform(0.2, 3.0)))
+        if k < 0.45:
+            m = S.lambertian(tuple(rng.random(3)))
+        elif k < 0.7:
+            m = S.standard(tuple(rng.uniform(0.3, 1.0, 3)), float(rng.choice([0.0, 0.4, 1.0])), float(rng.choice([0.0, 0.6, 1.0])),
+                           emission=tuple(rng.random(3) * 3) if rng.random() < 0.3 else None)
+        elif k < 0.85:
+            m = S.metal(tuple(rng.uniform(0.5, 1.0, 3)), float(rng.uniform(0.0, 0.5)))
+        else:
+            m = S.dielectric(float(rng.uniform(1.1, 2.0)))
+            m.glossiness = tex_or(S._const_tex(float(rng.choice([1.0, 0.7]))))
+            return m
+        m.albedo = tex_or(m.albedo)
+        if m.type == abi.MATERIAL_STANDARD and rng.random() < 0.5:
+            m.glossiness = tex_or(m.glossiness)
+            m.metallic = tex_or(m.metallic)
+        return m
+
+    def quat():
+        if rng.random() < 0.4:
+            return (0.0, 0.0, 0.0, 1.0)
+        axis = rng.normal(size=3)
+        return S.quat_axis_angle(tuple(axis / np.linalg.norm(axis)), float(rng.uniform(-180, 180)))
+
+    n = int(rng.integers(1, 14))
+    for _ in range(n):
+        pos = tuple(rng.uniform(-2.5, 2.5, 3))
+        moving = rng.random() < 0.25
+        kw = dict(moving=moving, dest_offset=tuple(rng.uniform(-0.6, 0.6, 3)) if moving else (0, 0, 0), time_range=(0.0, 1.0) if moving else (0, 0))
+        t = rng.random()
+        if t < 0.4:
+            s.add_sphere(pos, float(rng.uniform(0.2, 1.1)) * (-1 if rng.random() < 0.1 else 1), material(), **kw)
+        elif t < 0.6:
+            s.add_rect(pos, tuple(rng.uniform(0.5, 3.0, 2)), material(), rotation=quat(), **kw)
+        elif t < 0.8:
+            s.add_box(pos, tuple(rng.uniform(0.3, 1.8, 3)), material(), rotation=quat(), **kw)
+        else:
+            v = [np.array(pos) + rng.uniform(-1.5, 1.5, 3) for _ in range(3)]
+            s.add_triangle(v[0], v[1], v[2], material(), uvs=tuple(tuple(rng.uniform(-0.2, 1.3, 2)) for _ in range(3)))
+    if rng.random() < 0.6:
+        s.add_sphere((0, -101.5, 0), 100.0, S.lambertian((0.5, 0.5, 0.5)))
+    cam = rng.uniform(-4, 4, 3)
+    if rng.random() < 0.2 and n > 0:
+        cam = np.asarray(s.positions[0], dtype=np.float64) + rng.uniform(-0.05, 0.05, 3)      # inside / on the first entity
+    s.camera = {"position": [float(c) for c in cam], "target": [float(c) for c in rng.uniform(-1, 1, 3)], "up": [0.0, 1.0, 0.0],
+                "vfov": float(rng.uniform(20, 100)), "aperture": float(rng.choice([0.0, 0.0, 0.1, 0.8]))}
+    s.sky_bottom, s.sky_top = tuple(rng.random(3)), tuple(rng.random(3))
+    return s, rng
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RTOW_FUZZ_SEEDS", "24")))))   # RTOW_FUZZ_SEEDS=1000 for a soak run
+def test_random_scene(rt, oracle, gpu_context, seed):
+    abi = rt.abi
+    scene, rng = _random_scene(rt, 1000 + seed)
+    desc = scene.desc(max_bvh_depth=int(rng.choice([32, 32, 3])))
+    ctx = gpu_context
+    ctx.upload_scene(desc)
+    noise_color = int(rng.choice([abi.NOISE_WHITE, abi.NOISE_WHITE, abi.NOISE_BLUE, abi.NOISE_SPATIOTEMPORAL_BLUE]))
+    policy = int(rng.choice([abi.RNG_REFERENCE, abi.RNG_PER_SAMPLE])) if noise_color == abi.NOISE_WHITE else abi.RNG_REFERENCE
+    div = int(rng.choice([1, 1, 2, 3]))
+    p = rt.scenes.make_params(scene, int(rng.integers(8, 48)), int(rng.integers(8, 36)), spp=int(rng.integers(1, 20)), trace_depth=int(rng.choice([1, 2, 5, 8, 12, 17, 40])),
+                              seed=int(rng.integers(1, 1 << 30)), jitter=bool(rng.random() < 0.8), slice_offset=int(rng.integers(0, div)), slice_divider=div,
+                              diagnostics_stride=int(rng.choice([4, 16])), focus=float(rng.uniform(1.0, 8.0)), noise_color=noise_color,
+                              noise_texture_index=int(rng.integers(0, 2)), rng_policy=policy,
+                              sky_type=int(rng.choice([abi.SKY_GRADIENT, abi.SKY_GRADIENT, abi.SKY_CUBEMAP, abi.SKY_NONE])))
+    noise = rt.scenes.NoiseTextures(row_stride=8, count=2, seed=seed)
+    sky = rt.scenes.synthetic_sky(size=8, half=bool(rng.random() < 0.5), seed=seed)
+    osc = oracle.OracleScene(desc)
+    try:
+        ctx.upload_blue_noise(noise.blue_desc()); ctx.upload_stb_noise(noise.stb_desc()); ctx.upload_sky_cubemap(sky.desc())
+        osc.set_blue_noise(noise.blue_desc()); osc.set_stb_noise(noise.stb_desc()); osc.set_cubemap(sky.desc())
+        n = int(p.size.x) * int(p.size.y)
+        ins = {"color": rng.random((n, 4)).astype(np.float32), "normal": rng.normal(size=(n, 3)).astype(np.float32),
+               "albedo": rng.random((n, 3)).astype(np.float32), "scw": rng.random(n).astype(np.float32)}
+        ins["color"][:, 3] = rng.integers(0, 5, n)
+        gpu = rt.sample_batch_host(ctx, p, ins)
+        ref = osc.sample_batch(p, ins)
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (seed, k)
+        assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0]), seed
+    finally:
+        ctx.upload_blue_noise(None); ctx.upload_stb_noise(None); ctx.upload_sky_cubemap(None)
+        osc.close()
