@@ -51,6 +51,8 @@ def _random_scene(rt, seed):
         return S.quat_axis_angle(tuple(axis / np.linalg.norm(axis)), float(rng.uniform(-180, 180)))
 
     n = int(rng.integers(1, 14))
+    if os.environ.get("RTOW_FUZZ_HEAVY") and rng.random() < 0.5:
+        n = int(rng.integers(14, 120))                                    # soak runs: deeper trees, candidate-list flushes, longer hit lists
     for _ in range(n):
         pos = tuple(rng.uniform(-2.5, 2.5, 3))
         moving = rng.random() < 0.25
@@ -86,7 +88,8 @@ def test_random_scene(rt, oracle, gpu_context, seed):
     noise_color = int(rng.choice([abi.NOISE_WHITE, abi.NOISE_WHITE, abi.NOISE_BLUE, abi.NOISE_SPATIOTEMPORAL_BLUE]))
     policy = int(rng.choice([abi.RNG_REFERENCE, abi.RNG_PER_SAMPLE])) if noise_color == abi.NOISE_WHITE else abi.RNG_REFERENCE
     div = int(rng.choice([1, 1, 2, 3]))
-    p = rt.scenes.make_params(scene, int(rng.integers(8, 48)), int(rng.integers(8, 36)), spp=int(rng.integers(1, 20)), trace_depth=int(rng.choice([1, 2, 5, 8, 12, 17, 40])),
+    big = 3 if os.environ.get("RTOW_FUZZ_HEAVY") else 1
+    p = rt.scenes.make_params(scene, int(rng.integers(8, 48 * big)), int(rng.integers(8, 36 * big)), spp=int(rng.integers(1, 20)), trace_depth=int(rng.choice([1, 2, 5, 8, 12, 17, 40])),
                               seed=int(rng.integers(1, 1 << 30)), jitter=bool(rng.random() < 0.8), slice_offset=int(rng.integers(0, div)), slice_divider=div,
                               diagnostics_stride=int(rng.choice([4, 16])), focus=float(rng.uniform(1.0, 8.0)), noise_color=noise_color,
                               noise_texture_index=int(rng.integers(0, 2)), rng_policy=policy,
