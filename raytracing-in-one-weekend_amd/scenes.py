@@ -551,6 +551,41 @@ def textured_volume_scene():
     return s
 
 
+def mesh_scene(subdivisions=3):
+    """A triangle-mesh scene like the reference's live ones (UNITY/MeshData.cs feeds `Triangle` entities): three icospheres
+    (20 * 4^subdivisions triangles each, smooth normals) of different materials on a two-triangle floor."""
+    s = Scene("mesh")
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    verts = [np.array(v, dtype=np.float64) / np.linalg.norm(v) for v in verts]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+             (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(subdivisions):
+        cache, out = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            out += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = out
+    for centre, radius, mat in (((-2.2, 1.0, 0.0), 1.0, lambertian((0.7, 0.3, 0.3))), ((0.0, 1.0, 0.0), 1.0, dielectric(1.5)), ((2.2, 1.0, 0.0), 1.0, metal((0.8, 0.8, 0.9), 0.05))):
+        s.materials.append(mat)
+        mi = len(s.materials) - 1
+        c = np.array(centre)
+        for a, b, cc in faces:
+            s.add_triangle(c + radius * verts[a], c + radius * verts[b], c + radius * verts[cc], mi, normals=(verts[a], verts[b], verts[cc]))
+    _quad(s, (-30, 0, -30), (30, 0, -30), (30, 0, 30), (-30, 0, 30), lambertian((0.5, 0.5, 0.5)))
+    s.camera = {"position": [0.0, 2.2, 7.5], "target": [0.0, 0.9, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 35.0, "aperture": 0.0}
+    return s
+
+
 def tiny_scene():
     """Five spheres, one of each material branch + a negative-radius hollow glass shell; for fast unit tests."""
     s = Scene("tiny")

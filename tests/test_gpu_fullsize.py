@@ -131,11 +131,11 @@ def test_whole_1080p_frame_equals_the_oracle(rt, oracle, gpu_context, name, spp)
 
 
 @pytest.mark.parametrize("name,w,h,spp,depth", [("mixed", 1920, 1080, 3, 8), ("volumes", 1280, 720, 3, 10), ("textured", 1920, 1080, 3, 8),
-                                                ("coplanar", 1280, 720, 3, 8), ("volume_ties", 960, 540, 3, 10)])
+                                                ("coplanar", 1280, 720, 3, 8), ("volume_ties", 960, 540, 3, 10), ("mesh", 1280, 720, 2, 8)])
 def test_whole_frames_of_the_other_kernel_variants_equal_the_oracle(rt, oracle, gpu_context, name, w, h, spp, depth):
     """The general-entity, volume and textured variants over every pixel of a large frame."""
     S = rt.scenes
-    scene = {"mixed": S.mixed_scene, "volumes": S.volume_scene, "textured": S.textured_scene, "coplanar": S.coplanar_scene, "volume_ties": S.volume_tie_scene}[name]()
+    scene = {"mixed": S.mixed_scene, "volumes": S.volume_scene, "textured": S.textured_scene, "coplanar": S.coplanar_scene, "volume_ties": S.volume_tie_scene, "mesh": S.mesh_scene}[name]()
     desc = scene.desc()
     gpu_context.upload_scene(desc)
     p = S.make_params(scene, w, h, spp=spp, trace_depth=depth, focus=6.0)
