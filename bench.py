@@ -46,10 +46,11 @@ def measured_hbm_traffic():
     for f in reversed(files):
         try:
             d = json.load(open(f))
-            return float(d["derived"]["hbm_traffic_bytes"]), os.path.basename(f)
+            secondary = {k: round(float(d["derived"][k]), 4) for k in ("valu_issue_utilisation", "valu_lane_utilisation", "lds_busy_fraction") if k in d["derived"]}
+            return float(d["derived"]["hbm_traffic_bytes"]), os.path.basename(f), secondary
         except (KeyError, ValueError, OSError):
             continue
-    return None, None
+    return None, None, {}
 
 
 def usable_cores():
@@ -260,7 +261,7 @@ def main():
         rank_spp = mg.batch_split(spp, rank, world) if batches else spp
         alg_bytes = owned_pixels * 92 + int(info.sceneBytesDevice)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_hbm_traffic() if world == 1 else (None, None)
+        traffic, traffic_src, secondary = measured_hbm_traffic() if world == 1 else (None, None, {})
         out = {
             "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce",
             "value": round(total_samples / elapsed / 1e6, 2),
@@ -297,6 +298,7 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel": "sample_batch_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "secondary": secondary,   # what actually limits the kernel: from the same committed PMC summary as `traffic`
                 "note": "graph-traversal path: algorithmic HBM traffic is 92 B/pixel per launch, so the HBM fraction is tiny by construction; "
                         "the kernel is VALU/LDS-latency bound (see DESIGN.md, profiles/)",
             },
