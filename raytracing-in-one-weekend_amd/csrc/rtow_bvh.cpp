@@ -213,7 +213,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         if (e.type != RTOW_ENTITY_SPHERE || !identity) general = true;
     }
     if (general) prims.resize(n);
-    if (general) cullBoxes.assign((size_t)n * 8, 0.0f);
+    cullBoxes.assign((size_t)n * 8, 0.0f);
     Builder b;
     b.primBox.resize(n);
     for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
@@ -280,10 +280,12 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
                 bx.hi[a] = std::max(bx.hi[a], (float)std::max(w[a], w[a] + d[a]));
             }
         }
-        if (general) {
+        {
             // The box the reference's own tree gives this entity (BvhBuildingEntity, UNITY/BvhNodeData.cs:23-81), in its fp32 arithmetic.
-            // DetermineVolumeContainment's backwards probe (tMin = 0, origin ON a hull surface) is decided by the reference's
-            // slab test against exactly this box, so the kernel repeats that test before the exact hull test.
+            // In the reference a primitive is only ever tested when the ray passes ITS box (single-entity leaves), and that guard is part
+            // of the result: the exact test of a far, small sphere reports hits for rays that graze its box from outside.  The GPU tree
+            // therefore carries exactly this box on its leaf children (inner boxes stay padded unions); DetermineVolumeContainment's
+            // backwards probe uses the same boxes.
             const float q[4] = {e.rotation.x, e.rotation.y, e.rotation.z, e.rotation.w};
             const float p0[3] = {e.position.x, e.position.y, e.position.z};
             float pMin[3], pMax[3];
@@ -354,7 +356,9 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         GpuNode g{};
         Box empty;
         empty.reset(); // lo = +FLT_MAX, hi = -FLT_MAX: never hit
-        setBoxes(g, b.primBox[0], empty);
+        Box only;
+        for (int a = 0; a < 3; a++) { only.lo[a] = cullBoxes[a]; only.hi[a] = cullBoxes[4 + a]; }   // the reference's own entity box, like every leaf child
+        setBoxes(g, only, empty);
         g.child0 = ~0; g.child1 = ~0;
         gnodes.push_back(g);
         depthSeen = 1;
@@ -378,7 +382,13 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         for (size_t i = 0; i < bfs.size(); i++) {
             const TmpNode& t = b.nodes[bfs[i]];
             GpuNode g{};
-            setBoxes(g, t.box[0], t.box[1]);
+            Box cb[2] = {t.box[0], t.box[1]};
+            for (int c = 0; c < 2; c++)
+                if (t.child[c] < 0) {                                         // leaf child: the reference's own entity box, unpadded
+                    const float* e = &cullBoxes[(size_t)(~t.child[c]) * 8];
+                    for (int a = 0; a < 3; a++) { cb[c].lo[a] = e[a]; cb[c].hi[a] = e[4 + a]; }
+                }
+            setBoxes(g, cb[0], cb[1]);
             g.child0 = t.child[0] >= 0 ? newIndex[t.child[0]] : t.child[0];
             g.child1 = t.child[1] >= 0 ? newIndex[t.child[1]] : t.child[1];
             gnodes[i] = g;

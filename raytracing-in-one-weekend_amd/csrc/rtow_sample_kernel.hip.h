@@ -702,8 +702,12 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     };
     // a new ray segment starts: reset the traversal state
     auto startRay = [&]() {
-        // reciprocal direction for the box walk only: v_rcp_f32 (<= 1 ulp) is enough there, the boxes are padded by 1e-5
-        inv = v3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+        // rayInvDirection = rcp(ray.Direction), NaN -> +INF (JOBS/SampleBatchJob.cs:408-412).  The IEEE quotient, not v_rcp_f32: the leaf
+        // children of the tree carry the reference's own entity boxes and must pass or fail the reference's own slab test (RT/HitTests.cs:9-21)
+        inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        if (inv.x != inv.x) inv.x = __builtin_inff();
+        if (inv.y != inv.y) inv.y = __builtin_inff();
+        if (inv.z != inv.z) inv.z = __builtin_inff();
         cur = 0; sp = 0; nc = 0; prim = -1;
         best = __builtin_inff();
         nHits = 0;
@@ -924,11 +928,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
                             const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
                             const float tmin0 = vmax3(vmin(tlx.x, thx.x), vmin(tly.x, thy.x), vmax(vmin(tlz.x, thz.x), 0.0f));
-                            const float tmax0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmin(vmax(tlz.x, thz.x), best));
+                            const float tfar0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmax(tlz.x, thz.x));
                             const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
-                            const float tmax1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmin(vmax(tlz.y, thz.y), best));
-                            const bool leaf0 = tmin0 <= tmax0 && c0 < 0;
-                            const bool leaf1 = tmin1 <= tmax1 && twoChildren && c1 < 0;
+                            const float tfar1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmax(tlz.y, thz.y));
+                            const bool leaf0 = c0 < 0 && tmin0 < tfar0;                        // AxisAlignedBoundingBox.Hit on the entity's own box
+                            const bool leaf1 = c1 < 0 && tmin1 < tfar1 && twoChildren;
                             if (FULL_DIAG) boundsHits += (leaf0 ? 1.0f : 0.0f) + (leaf1 ? 1.0f : 0.0f);
                             cand[nc * kBlockThreads] = (unsigned short)~c0;
                             nc += leaf0 ? 1 : 0;
@@ -964,13 +968,16 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
                     const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
                     const float tmin0 = vmax3(vmin(tlx.x, thx.x), vmin(tly.x, thy.x), vmax(vmin(tlz.x, thz.x), 0.0f));
-                    const float tmax0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmin(vmax(tlz.x, thz.x), best));
+                    const float tfar0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmax(tlz.x, thz.x));
                     const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
-                    const float tmax1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmin(vmax(tlz.y, thz.y), best));
-                    const bool hit0 = tmin0 <= tmax0;
-                    const bool hit1 = tmin1 <= tmax1 && twoChildren;
-                    if (FULL_DIAG) boundsHits += (hit0 ? 1.0f : 0.0f) + (hit1 ? 1.0f : 0.0f);
-                    const bool leaf0 = hit0 && c0 < 0, leaf1 = hit1 && c1 < 0;
+                    const float tfar1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmax(tlz.y, thz.y));
+                    // inner child (padded box): conservative, pruned by the nearest hit so far.  Leaf child (the reference's own entity box):
+                    // AxisAlignedBoundingBox.Hit itself, tMin < tMax (RT/HitTests.cs:15-20) - pruning by `best` on top (<=, so that a tie at
+                    // exactly `best` is still tested) cannot change which hit is nearest.
+                    const bool hit0 = tmin0 <= vmin(tfar0, best);
+                    const bool hit1 = tmin1 <= vmin(tfar1, best) && twoChildren;
+                    const bool leaf0 = c0 < 0 && hit0 && tmin0 < tfar0, leaf1 = c1 < 0 && hit1 && tmin1 < tfar1;
+                    if (FULL_DIAG) boundsHits += ((c0 < 0 ? leaf0 : hit0) ? 1.0f : 0.0f) + ((c1 < 0 ? leaf1 : hit1) ? 1.0f : 0.0f);
                     cand[nc * kBlockThreads] = (unsigned short)~c0;
                     nc += leaf0 ? 1 : 0;
                     cand[nc * kBlockThreads] = (unsigned short)~c1;
@@ -1261,11 +1268,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         if (c & 0x40000000u) break;                                   // entry hit, early out
                         // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
                         const V3 bd = neg(rd);
-                        const V3 binv = v3(__builtin_amdgcn_rcpf(bd.x), __builtin_amdgcn_rcpf(bd.y), __builtin_amdgcn_rcpf(bd.z));
                         V3 einv = v3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);                    // math.rcp + "convert NaN to INFINITY" (:409-412)
                         if (einv.x != einv.x) einv.x = __builtin_inff();
                         if (einv.y != einv.y) einv.y = __builtin_inff();
                         if (einv.z != einv.z) einv.z = __builtin_inff();
+                        const V3 binv = einv;                                                    // leaf boxes are exact: the walk needs the exact reciprocal too
                         bool insideVolume = false;
                         int bsp = 0, bcur = 0;
                         while (bcur >= 0) {                                              // FindHitCandidates(backwardsRay): no pruning
