@@ -1,25 +1,26 @@
 // rtow_sample_kernel.hip.h - the sample-batch megakernel (hand-written gfx950 / CDNA4) and the device helpers shared with the small
-// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_kind*.hip): the kernel has ~190
+// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_*.hip): the kernel has ~190
 // template instantiations and compiling them side by side keeps the build under a minute.
 //
 // sample_batch_kernel replaces SampleBatchJob.Execute + Sample + FindHitCandidates + FindHits + Entity.Hit +
 // Sphere.Hit + Material.Scatter + View.GetRay + RandomSource (JOBS/SampleBatchJob.cs:59-475, RT/*.cs).
 //
-// Shape of the kernel (see DESIGN.md "Kernel"):
-//  * persistent: one 1024-lane workgroup per CU; the whole scene image (BVH nodes, spheres, materials) is staged
-//    once into LDS with coalesced 16-byte loads, next to a [level][lane] 16-bit traversal stack;
-//  * one lane = one PIXEL (the reference seeds its xorshift32 once per pixel and runs it through all of that
-//    pixel's samples, JOBS/SampleBatchJob.cs:91,132-157, so samples of a pixel are inherently sequential);
-//  * per-lane state machine with path regeneration: every trip of the main loop advances every live lane by
-//    exactly one path segment (traverse + shade); a lane whose path ended starts its next sample - or pulls its
-//    next pixel from a global ticket counter (wave-aggregated atomic) - in the same trip, so lanes never idle on
-//    a finished path;
-//  * closest-hit traversal, near child first, with t-pruning: equivalent to the reference's collect-all /
-//    sort / take [0] (JOBS/SampleBatchJob.cs:403-475, 205-209) because only element 0 is consumed when no
-//    ProbabilisticVolume exists;
-//  * the per-depth emission/attenuation stacks (JOBS/SampleBatchJob.cs:103-104,311,330) are kept as 16-bit
-//    material codes packed in VGPRs and re-expanded when the path is folded tail -> head (:384-396), which keeps the
-//    colour bit-identical to the reference's fold order without 2 x TraceDepth float3 of per-lane storage.
+// Shape of the kernel:
+//  * persistent: one 1024-lane workgroup per CU; the whole scene image (BVH nodes, primitives, materials) is staged once into LDS with
+//    coalesced 16-byte loads, next to a [level][lane] 16-bit traversal stack and an 8-entry candidate list per lane;
+//  * one lane = one PIXEL under the reference RNG policy (the reference seeds its generator once per pixel and runs it through all of
+//    that pixel's samples, JOBS/SampleBatchJob.cs:91,132-157), one lane = one (pixel, 16-sample group) unit under RTOW_RNG_PER_SAMPLE;
+//    pixel tickets are handed to waves in 64-pixel chunks, most expensive chunks first;
+//  * per-lane state machine REGEN -> TRAV -> TEST -> (VOL ->) HIT | SKY and a wave-level stage scheduler: a trip of the main loop runs the
+//    stages in pipeline order, each only if enough live lanes wait in it (ballot + popcount against thresholds); the box walk is
+//    resumable and sliced; depth-0 rays take their candidates from a per-pixel list of leaf-parent nodes instead of walking;
+//  * leaf boxes are the reference's own entity boxes with the reference's own slab test (a primitive is only tested when the ray passes
+//    its box, and that guard is part of the result); inner boxes are padded unions; exact primitive tests are deferred to TEST;
+//  * the per-depth emission/attenuation stacks (JOBS/SampleBatchJob.cs:103-104,311,330) are kept as 16-bit material codes packed in
+//    VGPRs and re-expanded when the path is folded tail -> head (:384-396), which keeps the colour bit-identical to the reference's
+//    fold order without 2 x TraceDepth float3 of per-lane storage (textured scenes keep per-depth colours in scratch instead);
+//  * template parameters: ALL_LDS (scene fully LDS resident), KIND (spheres / moving spheres / general entities / volumes / textured /
+//    both), HW (history words: trace depth <= 8 / 16 / 64), FULL_DIAG, NOISE (white / blue / STBN), PER_SAMPLE.
 //
 // Numerics: compiled with -ffp-contract=off; every expression below is written in the evaluation order of the C#
 // source (left to right, no fusion), with IEEE division and square root, and the deterministic transcendental
