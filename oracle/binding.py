@@ -86,6 +86,8 @@ def load(kind="strict"):
     lib.oracle_kat_unity_sort.restype = None
     lib.oracle_kat_hit_tie_order.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_int)]
     lib.oracle_kat_hit_tie_order.restype = C.c_int
+    lib.oracle_kat_leaf_boxes.argtypes = [C.POINTER(abi.SceneDesc), fp]
+    lib.oracle_kat_leaf_boxes.restype = C.c_int
     lib.oracle_kat_scatter.argtypes = [C.POINTER(abi.Material), fp, fp, C.c_float, fp, fp, C.c_float, C.POINTER(C.c_uint32), fp]
     lib.oracle_kat_get_ray.argtypes = [C.POINTER(abi.View), C.c_float, C.c_float, C.POINTER(C.c_uint32), fp]
     lib.oracle_kat_nearest_hit.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]

@@ -1681,6 +1681,19 @@ ORACLE_API int oracle_scene_set_stb_noise(void* scenePtr, const RtowStbNoiseDesc
     sc->stbRowStride = d->rowStride; sc->stbTextureCount = d->textureCount;
     return 0;
 }
+/* bounds of the reference leaf every entity sits in (out[entity * 6 .. +5] = min.xyz, max.xyz): its own box, or the union in a forced leaf */
+ORACLE_API int oracle_kat_leaf_boxes(const RtowSceneDesc* d, float* out)
+{
+    OracleScene sc;
+    sc.Build(d);
+    for (const BvhNode& n : sc.nodes)
+        if (n.IsLeaf())
+            for (int i = 0; i < n.EntityCount; i++) {
+                float* o = out + (size_t)sc.bvhEntities[n.EntitiesStart + i].SourceIndex * 6;
+                o[0] = n.Bounds.Min.x; o[1] = n.Bounds.Min.y; o[2] = n.Bounds.Min.z; o[3] = n.Bounds.Max.x; o[4] = n.Bounds.Max.y; o[5] = n.Bounds.Max.z;
+            }
+    return (int)sc.entities.size();
+}
 /* R2.Next(n) and the first `count` texel indices a PerPixelNoise(seed, (x, y), rowStride) visits */
 ORACLE_API void oracle_kat_r2(uint32_t n, float* out) { const float2 r = R2Next(n); out[0] = r.x; out[1] = r.y; }
 ORACLE_API void oracle_kat_per_pixel_noise(uint32_t seed, uint32_t x, uint32_t y, uint32_t rowStride, int count, uint32_t* out)

@@ -342,9 +342,26 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         }
     }
 
-    // tie order of hits at bit-identical distances: the entity's place in the reference tree's leaf order (rtow_reforder.h)
-    std::vector<uint32_t> ranks;
-    if (general) ranks = referenceLeafRanks(cullBoxes, n, desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32 /* prefab default */);
+    // What the reference's own tree contributes to the result (rtow_reforder.h): the order of hits at bit-identical distances (the entity's
+    // place in its leaf order), and the box that guards each entity's exact test - the bounds of the reference LEAF it sits in, which is the
+    // entity's own box except in leaves forced at MaxBvhDepth, where it is their union.
+    std::vector<float> guardBoxes;
+    const std::vector<uint32_t> ranks = referenceLeafRanks(cullBoxes, n, desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32 /* prefab default */, &guardBoxes);
+    for (int i = 0; i < n; i++) {
+        bool wider = false;
+        for (int a = 0; a < 3; a++) wider |= guardBoxes[(size_t)i * 8 + a] < cullBoxes[(size_t)i * 8 + a] || guardBoxes[(size_t)i * 8 + 4 + a] > cullBoxes[(size_t)i * 8 + 4 + a];
+        if (!wider) continue;
+        // a forced leaf: the GPU tree must enclose the (larger) guard box too, so that its inner boxes never cull what the reference tests
+        Box& bx = b.primBox[i];
+        for (int a = 0; a < 3; a++) {
+            const float lo = guardBoxes[(size_t)i * 8 + a], hi = guardBoxes[(size_t)i * 8 + 4 + a];
+            const float pad = 1e-5f * std::max(std::max(std::fabs(lo), std::fabs(hi)), 1.0f) + 1e-5f * (hi - lo);
+            bx.lo[a] = std::min(bx.lo[a], lo - pad);
+            bx.hi[a] = std::max(bx.hi[a], hi + pad);
+            b.centroid[a][i] = 0.5f * (bx.lo[a] + bx.hi[a]);
+        }
+    }
+    cullBoxes = guardBoxes;   // from here on: leaf-child boxes of the GPU tree and the backwards probe's guard
 
     // ---- SAH build, then breadth-first renumbering ----
     std::vector<int> idx(n);

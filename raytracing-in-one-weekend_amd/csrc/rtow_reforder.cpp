@@ -103,8 +103,9 @@ void referenceIndexSort(uint32_t* idx, int length, const float* key)
     IndexSorter{idx, key}.run(0, length - 1, 2 * levels);
 }
 
-std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth)
+std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth, std::vector<float>* leafBoxes)
 {
+    if (leafBoxes) leafBoxes->assign((size_t)n * 8, 0.0f);
     // The reference's recursion (UNITY/BvhNodeData.cs:122-213) sorts and splits sub-ranges of one array in place, left child =
     // the front part; the array it ends with IS the leaf order.  Only the range bookkeeping is repeated here.
     std::vector<uint32_t> order(n);
@@ -133,13 +134,19 @@ std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n,
             if (w > widest) { widest = w; axis = a; }
         }
         if (axis >= 0 && axis != r.sortedAxis) {                       // :146-151
-            for (int i = 0; i < n; i++) key[i] = boxes[(size_t)i * 8 + axis];
+            for (int i = r.begin; i < r.end; i++) key[order[i]] = boxes[(size_t)order[i] * 8 + axis];
             referenceIndexSort(order.data() + r.begin, count, key.data());
         }
         if (r.depth == maxDepth || count <= 1) {                       // leaf (:155-167)
             // a leaf's entities are appended to the candidate list front to back and the hit loop pops that list from its end
             // (JOBS/SampleBatchJob.cs:436-441,452-455): inside one leaf the hits come out back to front
             for (int i = r.begin, j = r.end - 1; i < j; i++, j--) std::swap(order[i], order[j]);
+            // the leaf's bounds (:161-166) guard every entity in it: a ray reaches an entity's exact test iff it passes THIS box
+            if (leafBoxes)
+                for (int i = r.begin; i < r.end; i++) {
+                    float* g = &(*leafBoxes)[(size_t)order[i] * 8];
+                    for (int a = 0; a < 3; a++) { g[a] = lo[a]; g[4 + a] = hi[a]; }
+                }
             continue;
         }
         // :170-196: the front part ends with the first entity that starts beyond, or is itself wider than, half the range

@@ -15,8 +15,9 @@
 namespace rtow {
 
 // boxes: float[8] {min.xyz, -, max.xyz, -} per entity, the reference's own fp32 entity boxes (UNITY/BvhNodeData.cs:23-81).
-// maxDepth: the host's MaxBvhDepth (leaves are forced at that depth).  Returns rank[entity] in 0..n-1.
-std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth);
+// maxDepth: the host's MaxBvhDepth (leaves are forced at that depth).  Returns rank[entity] in 0..n-1.  leafBoxes (optional, same layout
+// as boxes): the bounds of the reference leaf each entity ends up in - its own box, or the union of the boxes of a leaf forced at maxDepth.
+std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth, std::vector<float>* leafBoxes = nullptr);
 
 // The introsort of com.unity.collections 1.0.0-pre.6 (NativeSortExtension.Sort), on an index array with float keys and the
 // comparer `(int) sign(key[l] - key[r])` (UNITY/BvhNodeData.cs:240-250).  Exposed for the unit tests.

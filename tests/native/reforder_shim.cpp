@@ -10,3 +10,11 @@ extern "C" void shim_leaf_ranks(const float* boxes, int n, int maxDepth, uint32_
 }
 
 extern "C" void shim_index_sort(uint32_t* idx, int length, const float* key) { rtow::referenceIndexSort(idx, length, key); }
+
+extern "C" void shim_leaf_boxes(const float* boxes, int n, int maxDepth, float* out)
+{
+    const std::vector<float> b(boxes, boxes + (size_t)n * 8);
+    std::vector<float> leaf;
+    (void)rtow::referenceLeafRanks(b, n, maxDepth, &leaf);
+    for (size_t i = 0; i < leaf.size(); i++) out[i] = leaf[i];
+}

@@ -146,3 +146,22 @@ def test_whole_frames_of_the_other_kernel_variants_equal_the_oracle(rt, oracle, 
     for k in ("color", "normal", "albedo", "scw"):
         assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (name, k, int(np.any(gpu[k].view(np.uint32).reshape(w * h, -1) != ref[k].view(np.uint32).reshape(w * h, -1), axis=1).sum()))
     assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0])
+
+
+@pytest.mark.parametrize("name,max_depth", [("cover", 5), ("stress", 7), ("mixed", 2)])
+def test_whole_frames_with_forced_reference_leaves(rt, oracle, gpu_context, name, max_depth):
+    """Host trees cut at a small MaxBvhDepth: the reference then tests every entity of a forced leaf whenever the ray passes the LEAF's box
+    (UNITY/BvhNodeData.cs:155-167, JOBS/SampleBatchJob.cs:430-441), and orders ties by the cut tree.  Every pixel."""
+    S = rt.scenes
+    scene = {"cover": S.cover_scene, "mixed": S.mixed_scene, "stress": lambda: S.stress_scene(count=3000, max_tentatives=12000)}[name]()
+    desc = scene.desc(max_bvh_depth=max_depth)
+    gpu_context.upload_scene(desc)
+    w, h = 960, 540
+    p = S.make_params(scene, w, h, spp=3, trace_depth=8)
+    gpu = _device_render(rt, gpu_context, p, w * h, 4)
+    osc = oracle.OracleScene(desc)
+    ref = osc.sample_batch(p)
+    osc.close()
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
+    assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0])

@@ -32,6 +32,7 @@ def shim():
     lib = C.CDLL(so)
     lib.shim_leaf_ranks.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.shim_index_sort.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float)]
+    lib.shim_leaf_boxes.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]
     return lib
 
 
@@ -118,3 +119,22 @@ def test_product_leaf_order_equals_oracle_tree(shim, name, max_depth):
     shim.shim_leaf_ranks(boxes.ctypes.data_as(C.POINTER(C.c_float)), n, max_depth if max_depth > 0 else 32, ranks.ctypes.data_as(C.POINTER(C.c_uint32)))
     assert sorted(ranks.tolist()) == list(range(n))
     assert np.argsort(ranks).tolist() == list(order)
+
+
+@pytest.mark.parametrize("name,max_depth", [("cover", 0), ("cover", 4), ("mixed", 2), ("volumes", 1), ("stress", 7), ("stress", 0)])
+def test_product_guard_boxes_equal_the_reference_leaf_bounds(shim, name, max_depth):
+    """The box that guards an entity's exact test is the bounds of the reference leaf it sits in: its own box, or - in leaves forced at
+    MaxBvhDepth - the union of the leaf's entity boxes (UNITY/BvhNodeData.cs:155-167)."""
+    scene = {"volumes": S.volume_scene, "mixed": S.mixed_scene, "cover": S.cover_scene, "stress": lambda: S.stress_scene(2000)}[name]()
+    d = scene.desc(max_bvh_depth=max_depth)
+    n = d.entityCount
+    want = np.zeros((n, 6), dtype=np.float32)
+    assert ob.load().oracle_kat_leaf_boxes(C.byref(d), want.ctypes.data_as(C.POINTER(C.c_float))) == n
+    boxes = np.ascontiguousarray(_boxes(d))
+    got = np.zeros((n, 8), dtype=np.float32)
+    shim.shim_leaf_boxes(boxes.ctypes.data_as(C.POINTER(C.c_float)), n, max_depth if max_depth > 0 else 32, got.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(got[:, 0:3], want[:, 0:3]) and np.array_equal(got[:, 4:7], want[:, 3:6])
+    if max_depth == 0:
+        assert np.array_equal(got[:, 0:3], boxes[:, 0:3]) and np.array_equal(got[:, 4:7], boxes[:, 4:7])     # single-entity leaves: the entity's own box
+    else:
+        assert np.any(got[:, 4:7] - got[:, 0:3] > boxes[:, 4:7] - boxes[:, 0:3])                               # forced leaves: wider
