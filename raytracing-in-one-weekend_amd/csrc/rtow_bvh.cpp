@@ -426,7 +426,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? SCENE_KIND_TEXTURED : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     L.primOffset = off; if (general) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuPrim));
     L.cullOffset = off; if (hasVolumes) off = align16(off + (uint32_t)n * 32u);
-    L.rankOffset = off; if (general) off = align16(off + (uint32_t)n * 4u);
+    L.rankOffset = off; off = align16(off + (uint32_t)n * 4u);
     L.matIndexOffset = off; off = align16(off + (uint32_t)n * 4u);
     L.materialOffset = off; L.materialCount = (uint32_t)mats.size(); off = align16(off + L.materialCount * (uint32_t)sizeof(GpuMaterial));
     L.totalBytes = off;
@@ -438,7 +438,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     if (hasMotion) memcpy(out->blob.data() + L.motionOffset, motion.data(), motion.size() * sizeof(GpuMotion));
     if (general) memcpy(out->blob.data() + L.primOffset, prims.data(), prims.size() * sizeof(GpuPrim));
     if (hasVolumes) memcpy(out->blob.data() + L.cullOffset, cullBoxes.data(), cullBoxes.size() * 4u);
-    if (general) memcpy(out->blob.data() + L.rankOffset, ranks.data(), ranks.size() * 4u);
+    memcpy(out->blob.data() + L.rankOffset, ranks.data(), ranks.size() * 4u);
     memcpy(out->blob.data() + L.matIndexOffset, matIndex.data(), matIndex.size() * 4u);
     memcpy(out->blob.data() + L.materialOffset, mats.data(), mats.size() * sizeof(GpuMaterial));
     out->layout = L;

@@ -1040,7 +1040,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     } else {
                         V3 c; float r, t;
                         sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
-                        if (sphere_hit(sub(ro, c), rd, a, r, t) && t < best) { best = t; prim = i; }
+                        if (sphere_hit(sub(ro, c), rd, a, r, t) && t <= best) {
+                            // same tie rule as above (duplicate or exactly tangent spheres)
+                            const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
+                            if (t < best || (prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
+                        }
                     }
                 }
                 if (cur >= 0) st = ST_TRAV;        // the list was full: resume the walk, now pruned by `best`

@@ -493,6 +493,28 @@ def coplanar_scene():
     return s
 
 
+def twin_spheres_scene(moving=False):
+    """Sphere-only scene (the SPHERES / SPHERES_MOTION kernels) where spheres coincide exactly: twins and triplets with different
+    materials, added in different orders, so the nearest hit is a tie decided by the reference tree's leaf order."""
+    s = Scene("twin_spheres_moving" if moving else "twin_spheres")
+    s.add_sphere((0, -100.5, 0), 100, lambertian((0.6, 0.6, 0.6)))
+    mats = [lambertian((0.8, 0.2, 0.2)), metal((0.9, 0.9, 0.9), 0.0), dielectric(1.5), standard((0.1, 0.1, 0.1), 0.0, 0.0, emission=(2.0, 1.5, 1.0)),
+            lambertian((0.1, 0.7, 0.2)), metal((0.8, 0.6, 0.2), 0.4)]
+    rng = np.random.default_rng(5)
+    k = 0
+    for gx in range(-3, 4):
+        for gz in range(-2, 3):
+            pos = (gx * 1.1 + float(rng.uniform(-0.2, 0.2)), 0.0 + float(rng.uniform(0.0, 0.3)), gz * 1.1 + float(rng.uniform(-0.2, 0.2)))
+            r = float(rng.uniform(0.3, 0.5))
+            copies = 1 + (k % 3)                                   # single, twin, triplet
+            mv = dict(moving=True, dest_offset=(0.0, 0.4, 0.1), time_range=(0.0, 1.0)) if (moving and k % 2 == 0) else {}
+            for c in range(copies):
+                s.add_sphere(pos, r, mats[(k * 5 + c * (1 + k % 4)) % len(mats)], **mv)
+            k += 1
+    s.camera = {"position": [0.5, 3.0, 7.0], "target": [0.0, 0.2, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": 0.05 if moving else 0.0}
+    return s
+
+
 def _quad(s, p00, p10, p11, p01, material, uv0=(0.0, 0.0), uv1=(1.0, 1.0)):
     """Two triangles p00-p10-p11 / p00-p11-p01 with the texture coordinates of a [uv0, uv1] rectangle."""
     (u0, v0), (u1, v1) = uv0, uv1

@@ -27,8 +27,8 @@ def _compare(gpu, ref, check_diag=True):
         assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0]), "RayCount differs"
 
 
-def _run_both(rt, oracle, ctx, scene, w, h, spp, depth, inputs=None, **kw):
-    desc = scene.desc()
+def _run_both(rt, oracle, ctx, scene, w, h, spp, depth, inputs=None, max_bvh_depth=32, **kw):
+    desc = scene.desc(max_bvh_depth=max_bvh_depth)
     p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, **kw)
     ctx.upload_scene(desc)
     gpu = rt.sample_batch_host(ctx, p, inputs)
@@ -163,6 +163,15 @@ def test_nearest_hit_ties_between_coplanar_entities(rt, oracle, gpu_context):
     one that comes first in the reference tree's leaf order wins (JOBS/SampleBatchJob.cs:450-475, csrc/rtow_reforder.h)."""
     scene = rt.scenes.coplanar_scene()
     gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 64, 8, 8, focus=6.0, diagnostics_stride=16)
+    _compare(gpu, ref)
+
+
+@pytest.mark.parametrize("moving,max_depth", [(False, 32), (True, 32), (False, 3)])
+def test_nearest_hit_ties_between_coinciding_spheres(rt, oracle, gpu_context, moving, max_depth):
+    """Sphere-only scenes (the SPHERES / SPHERES_MOTION kernels): twins and triplets of the same sphere with different materials - the
+    reference's sorted hit list starts with the one first in its tree's leaf order (JOBS/SampleBatchJob.cs:450-475)."""
+    scene = rt.scenes.twin_spheres_scene(moving)
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 128, 72, 8, 8, diagnostics_stride=16, max_bvh_depth=max_depth)
     _compare(gpu, ref)
 
 

@@ -106,10 +106,10 @@ def _boxes(desc_holder):
     return boxes
 
 
-@pytest.mark.parametrize("name,max_depth", [("volumes", 0), ("volumes", 2), ("volume_ties", 0), ("volume_ties", 1), ("coplanar", 0), ("coplanar", 2), ("mixed", 0), ("mixed", 3), ("cover", 0), ("cover", 5), ("moving", 0), ("stress", 6)])
+@pytest.mark.parametrize("name,max_depth", [("volumes", 0), ("volumes", 2), ("volume_ties", 0), ("volume_ties", 1), ("coplanar", 0), ("coplanar", 2), ("mixed", 0), ("mixed", 3), ("cover", 0), ("cover", 5), ("moving", 0), ("stress", 6), ("twins", 0), ("twins", 3), ("twins_moving", 0)])
 def test_product_leaf_order_equals_oracle_tree(shim, name, max_depth):
     scene = {"volumes": S.volume_scene, "volume_ties": S.volume_tie_scene, "coplanar": S.coplanar_scene, "mixed": S.mixed_scene, "cover": S.cover_scene, "moving": S.moving_scene,
-             "stress": lambda: S.stress_scene(2000)}[name]()
+             "stress": lambda: S.stress_scene(2000), "twins": S.twin_spheres_scene, "twins_moving": lambda: S.twin_spheres_scene(True)}[name]()
     d = scene.desc(max_bvh_depth=max_depth)
     n = d.entityCount
     order = (C.c_int * n)()
