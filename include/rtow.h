@@ -54,7 +54,9 @@ typedef enum RtowResult {
     RTOW_ERROR_UNSUPPORTED = 5,       /* entity / material / noise kind not built yet           */
     RTOW_ERROR_LAUNCH_FAILURE = 6,    /* kernel launch or stream error (hipError in the log)    */
     RTOW_ERROR_CANCELLED = 7,         /* cancellation flag observed; outputs unspecified        */
-    RTOW_ERROR_CAPACITY = 8,          /* scene exceeds a compiled-in bound (traversal stack...) */
+    RTOW_ERROR_CAPACITY = 8,          /* a compiled-in bound was exceeded: at upload (entities, tree depth) or - reported by the host-buffer
+                                       * rtowSampleBatch, a cancellable rtowSampleBatchDevice or the next rtowSynchronize - by a ray of a
+                                       * volume scene that met more than 24 surfaces (the reference's hit list is unbounded) */
     RTOW_ERROR_INTERNAL = 99
 } RtowResult;
 

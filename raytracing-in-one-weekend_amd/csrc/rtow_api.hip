@@ -149,6 +149,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.ldsNodeCount = ctx->ldsNodeCount;
     a.workCounter = ctx->dWorkCounter;
     a.cancelFlag = useCancelFlag ? ctx->hCancel : nullptr;
+    a.overflowFlag = const_cast<uint32_t*>(ctx->hCancel) + 1;
     a.width = (int)p->size.x;
     a.height = (int)p->size.y;
     a.totalWork = (uint32_t)ownedRows(p) * (uint32_t)a.width;
@@ -359,6 +360,15 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     return RTOW_SUCCESS;
 }
 
+// A ray of a volume scene met more surfaces than the per-lane hit list holds (24): the batch's result is not the reference's.
+int takeOverflow(RtowContext ctx)
+{
+    if (ctx->hCancel[1] == 0u) return RTOW_SUCCESS;
+    ctx->hCancel[1] = 0u;
+    logf(ctx, 2, "rtow", "a ray hit more than 24 surfaces (hit-list capacity of volume scenes): results of this batch are invalid");
+    return RTOW_ERROR_CAPACITY;
+}
+
 // Block until the stop event completes while mirroring the caller's cancellation byte into the device-visible flag.
 int waitWithCancel(RtowContext ctx, const volatile uint8_t* cancel)
 {
@@ -377,7 +387,8 @@ int waitWithCancel(RtowContext ctx, const volatile uint8_t* cancel)
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     if (cancel && *cancel) cancelled = true;
-    return cancelled ? RTOW_ERROR_CANCELLED : RTOW_SUCCESS;
+    if (cancelled) return RTOW_ERROR_CANCELLED;
+    return takeOverflow(ctx);
 }
 
 int ensureStaging(RtowContext ctx, size_t pixels, size_t diagBytes)
@@ -451,7 +462,8 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     ok = ok && hipHostMalloc(&pinned, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (!ok) { rtowDestroyContext(ctx); return RTOW_ERROR_MEMORY_ALLOCATION; }
     ctx->hCancel = (volatile uint32_t*)pinned;
-    *ctx->hCancel = 0u;
+    ctx->hCancel[0] = 0u;
+    ctx->hCancel[1] = 0u;
     logf(ctx, 4, "rtow", "context on device %d (%s, %d CUs)", ordinal, prop.gcnArchName, ctx->cuCount);
     *outContext = ctx;
     return RTOW_SUCCESS;
@@ -522,7 +534,11 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     HIP_TRY(ctx, launchPrepareEntities(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     ctx->scene = std::move(compiled);
-    const uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);
+    uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);
+    if (const char* env = getenv("RTOW_LDS_BUDGET")) {       // development aid: run small scenes through the kernels that read the tree from HBM
+        const long v = atol(env);
+        if (v >= (long)sizeof(GpuNode) && (uint32_t)v < budget) budget = (uint32_t)v;
+    }
     if (ctx->scene.layout.totalBytes <= budget) {
         ctx->ldsSceneBytes = ctx->scene.layout.totalBytes;
         ctx->ldsNodeCount = ctx->scene.layout.nodeCount;
@@ -829,7 +845,7 @@ RTOW_API int rtowSynchronize(RtowContext ctx)
     if (!ctx) return RTOW_ERROR_INVALID_VALUE;
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
-    return RTOW_SUCCESS;
+    return takeOverflow(ctx);
 }
 
 } // extern "C"

@@ -52,6 +52,7 @@ struct SampleKernelArgs {
     const uint2* pixelCandidates;         // [width * height]: camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray
     int32_t probeOnly;                    // 1: cost probe - one sample per pixel, nothing stored but pixelCost
     const volatile uint32_t* cancelFlag;  // host-pinned, may be null
+    uint32_t* overflowFlag;               // host-pinned: set when a ray's hit list (volume scenes) exceeds the per-lane capacity
     uint32_t totalWork;                   // owned pixels = ownedRows * width
     int32_t width, height;
 

@@ -331,6 +331,70 @@ __device__ __forceinline__ float texture_scalar(const SampleKernelArgs& A, const
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// hitBuffer.Sort(DistanceComparer) (JOBS/SampleBatchJob.cs:473-474) for the hit list of a volume scene.
+// The reference sorts a list that starts in its tree's leaf order with a sort that is not stable, and hits at bit-identical
+// distances (coplanar faces) keep whatever order that leaves: put the hits in leaf order first (rank, rtow_reforder.h), then run
+// the same sort (NativeSortExtension: compare-exchange for 2 and 3 elements, insertion up to 16, above that median-of-three Hoare
+// partitions down to ranges of <= 16; the heap-sort fallback of the introsort is out of reach for <= 24 elements).
+// A real call on purpose (the lists live in scratch anyway): it keeps this rarely run code and its temporaries out of the
+// register allocation of the stage loop.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __noinline__ __attribute__((unused)) void sort_hit_list(float* hitT, float* hitTmin0, unsigned* hitCode, int nHits, const unsigned* rank)
+{
+    auto rankOf = [&](unsigned code) { return rank[code & 0xffffu]; };
+    auto swapHits = [&](int a, int b) {
+        const float t = hitT[a], tm = hitTmin0[a]; const unsigned c = hitCode[a];
+        hitT[a] = hitT[b]; hitTmin0[a] = hitTmin0[b]; hitCode[a] = hitCode[b];
+        hitT[b] = t; hitTmin0[b] = tm; hitCode[b] = c;
+    };
+    auto swapIfGreater = [&](int l, int r) { if (l != r && hitT[l] > hitT[r]) swapHits(l, r); };
+    for (int i = 1; i < nHits; i++) {                                   // leaf order; an entity's exit hit was recorded after its entry
+        const float t = hitT[i], tm = hitTmin0[i];
+        const unsigned c = hitCode[i], r = rankOf(c);
+        int j = i - 1;
+        while (j >= 0 && rankOf(hitCode[j]) > r) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
+        hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
+    }
+    // pending ranges of the introsort; a list of <= 24 hits needs at most four partition steps before every range is <= 16
+    int rangeLo[8], rangeHi[8], ranges = 1;
+    rangeLo[0] = 0; rangeHi[0] = nHits - 1;
+    while (ranges > 0) {
+        ranges--;
+        int lo = rangeLo[ranges], hi = rangeHi[ranges];
+        while (hi > lo) {
+            const int size = hi - lo + 1;
+            if (size == 2) { swapIfGreater(lo, hi); break; }
+            if (size == 3) { swapIfGreater(lo, hi - 1); swapIfGreater(lo, hi); swapIfGreater(hi - 1, hi); break; }
+            if (size <= 16) {
+                for (int i = lo + 1; i <= hi; i++) {
+                    const float t = hitT[i], tm = hitTmin0[i];
+                    const unsigned c = hitCode[i];
+                    int j = i - 1;
+                    while (j >= lo && t < hitT[j]) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
+                    hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
+                }
+                break;
+            }
+            // median-of-three Hoare partition; the right part is sorted on its own, the left part continues here
+            const int mid = lo + (hi - lo) / 2;
+            swapIfGreater(lo, mid); swapIfGreater(lo, hi); swapIfGreater(mid, hi);
+            const float pivot = hitT[mid];
+            swapHits(mid, hi - 1);
+            int left = lo, right = hi - 1;
+            while (left < right) {
+                while (pivot > hitT[++left]) {}
+                while (pivot < hitT[--right]) {}
+                if (left >= right) break;
+                swapHits(left, right);
+            }
+            swapHits(left, hi - 1);
+            rangeLo[ranges] = left + 1; rangeHi[ranges] = hi; ranges++;
+            hi = left - 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // scene access: LDS image first, HBM/L2 for whatever did not fit
 // ------------------------------------------------------------------------------------------------------------
 struct SceneRefs {
@@ -671,6 +735,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     constexpr int kMaxHits = VOLUMES ? 24 : 1;
     float hitT[kMaxHits], hitTmin0[kMaxHits];
     unsigned hitCode[kMaxHits];      // primitive | dot(normal, dir) < 0 -> bit 30 | dot > 0 -> bit 31
+    bool hitOverflow = false;
     int nHits = 0;
     int curVol = -1;
     float pendRE = 0;
@@ -758,6 +823,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         const unsigned rc = (unsigned)rayCount;
                         A.pixelCost[tick] = (unsigned short)(rc < 65535u ? rc : 65535u);
                     }
+                    if (VOLUMES && hitOverflow) { *A.overflowFlag = 1u; hitOverflow = false; }            // RTOW_ERROR_CAPACITY on the host side
                     if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
                     if (PER_SAMPLE && pix >= 0) {
                         // ---- unit done: its partial sums go to the record the fold kernel adds up in group order ----
@@ -1024,6 +1090,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                                 for (int k = 0; k < kMaxHits; k++)
                                     if (k == nHits) { hitT[k] = t; hitTmin0[k] = tmin; hitCode[k] = (unsigned)i | (dn < 0 ? 0x40000000u : 0u) | (dn > 0 ? 0x80000000u : 0u); }
                                 nHits++;
+                            } else {
+                                hitOverflow = true;                                      // more surfaces than the list holds: reported, not ignored
                             }
                             if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME || !(type == RTOW_ENTITY_BOX || type == RTOW_ENTITY_SPHERE)) break;
                             tmin = t + 0.001f;
@@ -1231,40 +1299,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 auto matOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (code & 0xffffu) * 4u); };
                 auto isVolume = [&](unsigned code) { return ((matOf(code) >> 16) & 3u) == MAT_CLASS_VOLUME; };
                 // ---- hitBuffer.Sort(DistanceComparer) (:473-474) ----
-                // The reference sorts a list that starts in its tree's leaf order with a sort that is not stable, and hits at
-                // bit-identical distances (coplanar faces) keep whatever order that leaves: put the hits in leaf order first
-                // (rank, rtow_reforder.h), then run the same small-array sort (NativeSortExtension: compare-exchange for 2 and 3,
-                // insertion above; lists longer than 16 - never seen - are insertion-sorted as well, exact unless they hold a tie).
-                {
-                    auto rankOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset) + (code & 0xffffu) * 4u); };
-                    auto swapHits = [&](int a, int b) {
-                        const float t = hitT[a], tm = hitTmin0[a]; const unsigned c = hitCode[a];
-                        hitT[a] = hitT[b]; hitTmin0[a] = hitTmin0[b]; hitCode[a] = hitCode[b];
-                        hitT[b] = t; hitTmin0[b] = tm; hitCode[b] = c;
-                    };
-                    for (int i = 1; i < nHits; i++) {                                   // leaf order; an entity's exit hit was recorded after its entry
-                        const float t = hitT[i], tm = hitTmin0[i];
-                        const unsigned c = hitCode[i], r = rankOf(c);
-                        int j = i - 1;
-                        while (j >= 0 && rankOf(hitCode[j]) > r) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
-                        hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
-                    }
-                    if (nHits == 2) {
-                        if (hitT[0] > hitT[1]) swapHits(0, 1);
-                    } else if (nHits == 3) {
-                        if (hitT[0] > hitT[1]) swapHits(0, 1);
-                        if (hitT[0] > hitT[2]) swapHits(0, 2);
-                        if (hitT[1] > hitT[2]) swapHits(1, 2);
-                    } else {
-                        for (int i = 1; i < nHits; i++) {
-                            const float t = hitT[i], tm = hitTmin0[i];
-                            const unsigned c = hitCode[i];
-                            int j = i - 1;
-                            while (j >= 0 && t < hitT[j]) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
-                            hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
-                        }
-                    }
-                }
+                if (nHits > 1) sort_hit_list(hitT, hitTmin0, hitCode, nHits, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
                 // ---- DetermineVolumeContainment (:477-508) ----
                 if (curVol < 0) {
                     for (int i = 0; i < nHits; i++) {

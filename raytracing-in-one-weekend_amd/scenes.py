@@ -473,6 +473,24 @@ def volume_tie_scene():
     return s
 
 
+def volume_stack_scene(slabs=10):
+    """Ten thin fog slabs stacked face to face along the view axis, in front of a wall lying in the last slab's back face: a camera ray
+    collects 21 hits (more than the 16 up to which the reference's sort is an insertion sort) of which ten pairs are at bit-identical
+    distances (camera and faces on dyadic coordinates), so the result depends on the partition steps of the unstable introsort."""
+    s = Scene("volume_stack")
+    white = lambertian((0.8, 0.8, 0.8))
+    up90 = quat_axis_angle((1, 0, 0), -90)
+    s.add_rect((0, -1.5, 0), (12, 12), white, rotation=up90)
+    s.add_rect((0, 0, -2.5), (3, 3), standard((0.0, 0.0, 0.0), 0.0, 0.0, emission=(3.0, 2.5, 2.0)))     # wall in the z = -2.5 face of the last slab
+    fogs = [volume((0.9, 0.5, 0.3), 0.12), volume((0.3, 0.6, 0.9), 0.2), volume((0.5, 0.9, 0.4), 0.08)]
+    for k in [k for k in (3, 7, 0, 9, 12, 4, 1, 10, 8, 5, 11, 2, 6) if k < slabs]:          # not in depth order
+        s.add_box((0.0, 0.0, -2.25 + 0.5 * k), (3, 3, 0.5), fogs[k % 3])
+    s.add_sphere((0.5, -0.25, 0.25), 0.5, dielectric(1.5))                                 # something solid inside the stack
+    s.camera = {"position": [0.25, 0.5, 6.0], "target": [0.0, 0.0, -2.0], "up": [0.0, 1.0, 0.0], "vfov": 35.0, "aperture": 0.0}
+    s.sky_bottom, s.sky_top = (0.4, 0.4, 0.4), (0.3, 0.4, 0.7)
+    return s
+
+
 def coplanar_scene():
     """No volumes: decals lying exactly IN the plane of a wall / the floor and boxes sharing faces - the nearest hit is a tie
     between two entities for many pixels, decided by the reference's hit-list order (leaf order of its tree)."""

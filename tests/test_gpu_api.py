@@ -103,6 +103,32 @@ def test_combine_interlace_lookaround_and_debug_colours(rt, oracle, gpu_context)
             assert np.array_equal(o.download(np.float32, (n, 3)).view(np.uint32), wv.view(np.uint32))
 
 
+def test_hit_list_overflow_is_reported(rt, gpu_context):
+    """The reference's hit list grows without bound; the kernel's holds 24 hits per ray (volume scenes).  A ray that meets more must not
+    pass silently: the batch reports RTOW_ERROR_CAPACITY, once, and the context stays usable."""
+    a = rt.abi
+    ctx = gpu_context
+    deep = rt.scenes.volume_stack_scene(slabs=13)                       # 13 hulls x (entry + exit) + the wall = 27 hits per camera ray
+    ctx.upload_scene(deep.desc())
+    p = rt.scenes.make_params(deep, 32, 32, spp=1, trace_depth=4)
+    with pytest.raises(rt.lib.RtowError) as e:
+        rt.sample_batch_host(ctx, p)
+    assert e.value.code == a.RTOW_ERROR_CAPACITY
+    fits = rt.scenes.volume_stack_scene(slabs=10)
+    ctx.upload_scene(fits.desc())
+    out = rt.sample_batch_host(ctx, rt.scenes.make_params(fits, 32, 32, spp=1, trace_depth=4))
+    assert out["color"][:, 3].sum() > 0
+    # device-buffer path: the flag surfaces at the next rtowSynchronize
+    ctx.upload_scene(deep.desc())
+    n = 32 * 32
+    bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+    acc = a.AccumBuffers(*[b.ptr for b in bufs])
+    lib = rt.lib.load()
+    assert lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(acc), C.byref(acc), None, None, None) == a.RTOW_SUCCESS
+    assert lib.rtowSynchronize(ctx.handle) == a.RTOW_ERROR_CAPACITY
+    assert lib.rtowSynchronize(ctx.handle) == a.RTOW_SUCCESS
+
+
 def test_error_codes(rt, gpu_context):
     lib = rt.lib.load()
     a = rt.abi

@@ -158,6 +158,15 @@ def test_volume_hits_at_identical_distances(rt, oracle, gpu_context):
     assert gpu["color"][:, 3].sum() > 0
 
 
+def test_volume_hit_lists_longer_than_sixteen_with_ties(rt, oracle, gpu_context):
+    """21 hits per camera ray, ten pairs of them at identical distances: above 16 elements the reference's sort partitions
+    (median of three, Hoare) before it insertion-sorts, and the order that leaves the ties in decides which hull is 'entered' first."""
+    scene = rt.scenes.volume_stack_scene()
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 96, 8, 12, diagnostics_stride=16)
+    _compare(gpu, ref)
+    assert gpu["color"][:, 3].sum() > 0
+
+
 def test_nearest_hit_ties_between_coplanar_entities(rt, oracle, gpu_context):
     """Decals in a wall's plane, boxes sharing a face, one sphere twice: the nearest hit is shared by two or three entities and the
     one that comes first in the reference tree's leaf order wins (JOBS/SampleBatchJob.cs:450-475, csrc/rtow_reforder.h)."""
