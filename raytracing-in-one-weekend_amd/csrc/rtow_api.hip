@@ -328,6 +328,14 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         for (int i = 0; i < 16; i++) fprintf(stderr, "[stats] %-16s %llu\n", names[i], h[i]);
         unsigned long long w[3];
         (void)hipMemcpy(w, a.stats + 16, sizeof(w), hipMemcpyDeviceToHost);
+        {
+            unsigned long long st[8];
+            (void)hipMemcpy(st, a.stats + 24, sizeof(st), hipMemcpyDeviceToHost);
+            static const char* stageNames[8] = {"regen", "walk", "test", "hit", "sky", "vol", "vol probe", "scheduler"};
+            unsigned long long total = 0;
+            for (int i = 0; i < 8; i++) total += st[i];
+            for (int i = 0; i < 8; i++) if (st[i]) fprintf(stderr, "[stats] wave time in %-10s %5.1f %%\n", stageNames[i], 100.0 * (double)st[i] / (double)(total ? total : 1));
+        }
         if (getenv("RTOW_DEBUG_PIXEL")) {
             std::vector<unsigned long long> t(8 * 500 + 8);
             (void)hipMemcpy(t.data(), a.stats + 5000, 8 * 500 * sizeof(unsigned long long), hipMemcpyDeviceToHost);

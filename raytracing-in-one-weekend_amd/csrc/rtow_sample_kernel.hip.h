@@ -602,11 +602,16 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 #define STAT_DECL unsigned long long stat[16] = {0}
 #define STAT_ADD(i, v) stat[i] += (unsigned long long)(v)
 #define STAT_LANES(i) stat[i] += 1ull
+// wall time (100 MHz ticks) per stage, wave level: the time since the previous mark belongs to the stage marked then (7 = scheduler)
+#define STAGE_DECL unsigned long long stageT[8] = {0}; unsigned long long stLast = wall_clock64(); int stCur = 7
+#define STAGE_MARK(k) do { const unsigned long long n_ = wall_clock64(); stageT[stCur] += n_ - stLast; stLast = n_; stCur = (k); } while (0)
 // per-segment trace of one pixel: {smp, depth, kind, prim, t bits, curVol, nHits, rng}
 #define DBG_TRACE(kind, primv, tv) do { if (A.stats && pix == A.debugPixel) { const unsigned long long k_ = atomicAdd(&A.stats[20], 1ull); if (k_ < 500) { unsigned long long* d_ = A.stats + 5000 + k_ * 8; d_[0] = smp; d_[1] = (unsigned)depth; d_[2] = (kind); d_[3] = (unsigned)(primv); d_[4] = __float_as_uint(tv); d_[5] = (unsigned)curVol; d_[6] = (unsigned)nHits; d_[7] = rng.trace_value(); } } } while (0)
 #else
 #define DBG_TRACE(kind, primv, tv)
 #define STAT_DECL
+#define STAGE_DECL
+#define STAGE_MARK(k)
 #define STAT_ADD(i, v)
 #define STAT_LANES(i)
 #endif
@@ -789,12 +794,14 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     uint2 pcand = make_uint2(kNoPrimaryList, 0u);   // this pixel's camera-ray candidate list (4 x 16 bit), or kNoPrimaryList in .x
     int force = -1;
     STAT_DECL;
+    STAGE_DECL;
 #ifdef RTOW_STATS
     const unsigned long long statT0 = wall_clock64();
     unsigned long long pixT0 = statT0;
 #endif
     for (;;) {
         STAT_ADD(0, 1);
+        STAGE_MARK(7);
         // Stages run in pipeline order; each one only if enough lanes wait in it, so a lane can still advance a whole path segment per
         // trip when the wave is dense, while sparse stages batch up.  A.tune[] holds the thresholds in 64ths of the wave's LIVE lanes
         // (lanes that still have pixels): 1 = "any lane", 48 = three quarters of them.  Depth-0 rays skip the box walk (camera-ray lists),
@@ -805,6 +812,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         bool ran = false;
         if ((int)__popcll(__ballot(st == ST_REGEN)) >= (force == ST_REGEN ? 1 : need(0))) {
             ran = true;
+            STAGE_MARK(0);
             // ================= next sample of this pixel, or next pixel =================
             STAT_ADD(1, 1);
             if (st == ST_REGEN) {
@@ -1013,6 +1021,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         }
         if ((int)__popcll(__ballot(st == ST_TRAV)) >= (force == ST_TRAV ? 1 : need(1))) {
             ran = true;
+            STAGE_MARK(1);
             // ================= box walk: FindHitCandidates (JOBS/SampleBatchJob.cs:403-448), resumable =================
             if (st == ST_TRAV) {
                 const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
@@ -1067,6 +1076,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         }
         if ((int)__popcll(__ballot(st == ST_TEST)) >= (force == ST_TEST ? 1 : need(2))) {
             ran = true;
+            STAGE_MARK(2);
             // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
             if (st == ST_TEST) {
                 const float a = dot(rd, rd);
@@ -1086,9 +1096,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             if (!general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, tmin, t, nl, rq)) break;
                             const float dn = dot(normalize(rotate(rq, nl)), rd);
                             if (nHits < kMaxHits) {
-#pragma unroll
-                                for (int k = 0; k < kMaxHits; k++)
-                                    if (k == nHits) { hitT[k] = t; hitTmin0[k] = tmin; hitCode[k] = (unsigned)i | (dn < 0 ? 0x40000000u : 0u) | (dn > 0 ? 0x80000000u : 0u); }
+                                hitT[nHits] = t; hitTmin0[nHits] = tmin; hitCode[nHits] = (unsigned)i | (dn < 0 ? 0x40000000u : 0u) | (dn > 0 ? 0x80000000u : 0u);
                                 nHits++;
                             } else {
                                 hitOverflow = true;                                      // more surfaces than the list holds: reported, not ignored
@@ -1121,6 +1129,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         }
         if ((int)__popcll(__ballot(st == ST_HIT)) >= (force == ST_HIT ? 1 : need(3))) {
             ran = true;
+            STAGE_MARK(3);
             // ================= surface hit: Entity.Hit record + Material.Scatter =================
             STAT_ADD(7, 1);
             if (st == ST_HIT) {
@@ -1293,122 +1302,127 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 else startRay();
             }
         }
-        if (VOLUMES && (int)__popcll(__ballot(st == ST_VOL)) >= 1) {
+        if (VOLUMES && (int)__popcll(__ballot(st == ST_VOL)) >= (force == ST_VOL ? 1 : need(5))) {
             ran = true;
+            STAGE_MARK(5);
             if (st == ST_VOL) {
                 auto matOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (code & 0xffffu) * 4u); };
                 auto isVolume = [&](unsigned code) { return ((matOf(code) >> 16) & 3u) == MAT_CLASS_VOLUME; };
-                // ---- hitBuffer.Sort(DistanceComparer) (:473-474) ----
-                if (nHits > 1) sort_hit_list(hitT, hitTmin0, hitCode, nHits, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
-                // ---- DetermineVolumeContainment (:477-508) ----
-                if (curVol < 0) {
-                    for (int i = 0; i < nHits; i++) {
-                        const unsigned c = hitCode[i];
-                        if (!isVolume(c)) continue;
-                        if (c & 0x40000000u) break;                                   // entry hit, early out
-                        // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
-                        const V3 bd = neg(rd);
-                        V3 einv = v3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);                    // math.rcp + "convert NaN to INFINITY" (:409-412)
-                        if (einv.x != einv.x) einv.x = __builtin_inff();
-                        if (einv.y != einv.y) einv.y = __builtin_inff();
-                        if (einv.z != einv.z) einv.z = __builtin_inff();
-                        const V3 binv = einv;                                                    // leaf boxes are exact: the walk needs the exact reciprocal too
-                        bool insideVolume = false;
-                        int bsp = 0, bcur = 0;
-                        while (bcur >= 0) {                                              // FindHitCandidates(backwardsRay): no pruning
-                            float4 q0, q1, q2;
-                            int c0, c1;
-                            load_node<ALL_LDS>(sc, L, bcur, q0, q1, q2, c0, c1);
-                            const float t0x = (q0.x - ro.x) * binv.x, t1x = (q1.z - ro.x) * binv.x, u0x = (q0.y - ro.x) * binv.x, u1x = (q1.w - ro.x) * binv.x;
-                            const float t0y = (q0.z - ro.y) * binv.y, t1y = (q2.x - ro.y) * binv.y, u0y = (q0.w - ro.y) * binv.y, u1y = (q2.y - ro.y) * binv.y;
-                            const float t0z = (q1.x - ro.z) * binv.z, t1z = (q2.z - ro.z) * binv.z, u0z = (q1.y - ro.z) * binv.z, u1z = (q2.w - ro.z) * binv.z;
-                            const bool h0 = vmax3(vmin(t0x, t1x), vmin(t0y, t1y), vmax(vmin(t0z, t1z), 0.0f)) <= vmin3(vmax(t0x, t1x), vmax(t0y, t1y), vmax(t0z, t1z));
-                            const bool h1 = vmax3(vmin(u0x, u1x), vmin(u0y, u1y), vmax(vmin(u0z, u1z), 0.0f)) <= vmin3(vmax(u0x, u1x), vmax(u0y, u1y), vmax(u0z, u1z)) && twoChildren;
-                            for (int side = 0; side < 2; side++) {
-                                const int cc = side ? c1 : c0;
-                                if (!(side ? h1 : h0) || cc >= 0) continue;
-                                const unsigned mw = matOf((unsigned)~cc);
-                                if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME) continue;    // AnyBackwardsVolumeEntryHit (:510-524)
-                                {
-                                    // The probe starts ON a surface with tMin = 0, so whether the hull is a candidate at all is decided by the
-                                    // reference's slab test (RT/HitTests.cs:9-21) on the reference tree's box of this entity; repeat it exactly.
-                                    const float4* cb = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.cullOffset) + (unsigned)~cc * 32u);
-                                    const float4 lo = cb[0], hi = cb[1];
-                                    const float a0x = (lo.x - ro.x) * einv.x, a1x = (hi.x - ro.x) * einv.x;
-                                    const float a0y = (lo.y - ro.y) * einv.y, a1y = (hi.y - ro.y) * einv.y;
-                                    const float a0z = (lo.z - ro.z) * einv.z, a1z = (hi.z - ro.z) * einv.z;
-                                    const float tn = um_max(0.0f, um_max(um_max(um_min(a0x, a1x), um_min(a0y, a1y)), um_min(a0z, a1z)));
-                                    const float tf = um_min(um_min(um_max(a0x, a1x), um_max(a0y, a1y)), um_max(a0z, a1z));
-                                    if (!(tn < tf)) continue;
+                // ---- hitBuffer.Sort(DistanceComparer) (:473-474) comes first (below); the rest of the stage reads the list through accessors ----
+                auto volumeLogic = [&](auto distAt, auto codeAt, auto tminAt) {
+                    // ---- DetermineVolumeContainment (:477-508) ----
+                    if (curVol < 0) {
+                        for (int i = 0; i < nHits; i++) {
+                            const unsigned c = codeAt(i);
+                            if (!isVolume(c)) continue;
+                            if (c & 0x40000000u) break;                                   // entry hit, early out
+                            // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
+                            const V3 bd = neg(rd);
+                            V3 einv = v3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);                    // math.rcp + "convert NaN to INFINITY" (:409-412)
+                            if (einv.x != einv.x) einv.x = __builtin_inff();
+                            if (einv.y != einv.y) einv.y = __builtin_inff();
+                            if (einv.z != einv.z) einv.z = __builtin_inff();
+                            const V3 binv = einv;                                                    // leaf boxes are exact: the walk needs the exact reciprocal too
+                            bool insideVolume = false;
+                            int bsp = 0, bcur = 0;
+                            while (bcur >= 0) {                                              // FindHitCandidates(backwardsRay): no pruning
+                                float4 q0, q1, q2;
+                                int c0, c1;
+                                load_node<ALL_LDS>(sc, L, bcur, q0, q1, q2, c0, c1);
+                                const float t0x = (q0.x - ro.x) * binv.x, t1x = (q1.z - ro.x) * binv.x, u0x = (q0.y - ro.x) * binv.x, u1x = (q1.w - ro.x) * binv.x;
+                                const float t0y = (q0.z - ro.y) * binv.y, t1y = (q2.x - ro.y) * binv.y, u0y = (q0.w - ro.y) * binv.y, u1y = (q2.y - ro.y) * binv.y;
+                                const float t0z = (q1.x - ro.z) * binv.z, t1z = (q2.z - ro.z) * binv.z, u0z = (q1.y - ro.z) * binv.z, u1z = (q2.w - ro.z) * binv.z;
+                                const bool h0 = vmax3(vmin(t0x, t1x), vmin(t0y, t1y), vmax(vmin(t0z, t1z), 0.0f)) <= vmin3(vmax(t0x, t1x), vmax(t0y, t1y), vmax(t0z, t1z));
+                                const bool h1 = vmax3(vmin(u0x, u1x), vmin(u0y, u1y), vmax(vmin(u0z, u1z), 0.0f)) <= vmin3(vmax(u0x, u1x), vmax(u0y, u1y), vmax(u0z, u1z)) && twoChildren;
+                                for (int side = 0; side < 2; side++) {
+                                    const int cc = side ? c1 : c0;
+                                    if (!(side ? h1 : h0) || cc >= 0) continue;
+                                    const unsigned mw = matOf((unsigned)~cc);
+                                    if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME) continue;    // AnyBackwardsVolumeEntryHit (:510-524)
+                                    {
+                                        // The probe starts ON a surface with tMin = 0, so whether the hull is a candidate at all is decided by the
+                                        // reference's slab test (RT/HitTests.cs:9-21) on the reference tree's box of this entity; repeat it exactly.
+                                        const float4* cb = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.cullOffset) + (unsigned)~cc * 32u);
+                                        const float4 lo = cb[0], hi = cb[1];
+                                        const float a0x = (lo.x - ro.x) * einv.x, a1x = (hi.x - ro.x) * einv.x;
+                                        const float a0y = (lo.y - ro.y) * einv.y, a1y = (hi.y - ro.y) * einv.y;
+                                        const float a0z = (lo.z - ro.z) * einv.z, a1z = (hi.z - ro.z) * einv.z;
+                                        const float tn = um_max(0.0f, um_max(um_max(um_min(a0x, a1x), um_min(a0y, a1y)), um_min(a0z, a1z)));
+                                        const float tf = um_min(um_min(um_max(a0x, a1x), um_max(a0y, a1y)), um_max(a0z, a1z));
+                                        if (!(tn < tf)) continue;
+                                    }
+                                    float t; V3 nl; float4 rq;
+                                    if (general_hit<ALL_LDS>(sc, L, ~cc, mw >> kPrimTypeShift, ro, bd, rtime, 0.0f, t, nl, rq) && dot(normalize(rotate(rq, nl)), bd) > 0) insideVolume = true;
                                 }
-                                float t; V3 nl; float4 rq;
-                                if (general_hit<ALL_LDS>(sc, L, ~cc, mw >> kPrimTypeShift, ro, bd, rtime, 0.0f, t, nl, rq) && dot(normalize(rotate(rq, nl)), bd) > 0) insideVolume = true;
+                                const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
+                                if (in0 && in1) { stack[bsp * kBlockThreads] = (unsigned short)c1; bsp++; bcur = c0; }
+                                else if (in0 || in1) bcur = in0 ? c0 : c1;
+                                else if (bsp > 0) { bsp--; bcur = stack[bsp * kBlockThreads]; }
+                                else bcur = -1;
                             }
-                            const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
-                            if (in0 && in1) { stack[bsp * kBlockThreads] = (unsigned short)c1; bsp++; bcur = c0; }
-                            else if (in0 || in1) bcur = in0 ? c0 : c1;
-                            else if (bsp > 0) { bsp--; bcur = stack[bsp * kBlockThreads]; }
-                            else bcur = -1;
+                            if (insideVolume) { curVol = (int)(matOf(c) & 0xffffu); break; }
                         }
-                        if (insideVolume) { curVol = (int)(matOf(c) & 0xffffu); break; }
                     }
-                }
-                for (int i = 0; i < nHits; i++) DBG_TRACE(10 + i, hitCode[i], hitT[i]);
-                DBG_TRACE(9, 0, 0.0f);
-                // ---- the hit loop of Sample with the volume branch (:205-303) ----
-                int hitIndex = 0;
-                int chosen = -1;
-                insideHit = false;
-                while (hitIndex < nHits) {
-                    const unsigned c = hitCode[hitIndex];
-                    const unsigned mw = matOf(c);
-                    if (curVol >= 0 || ((mw >> 16) & 3u) == MAT_CLASS_VOLUME) {
-                        const bool isEntryHit = curVol < 0;
-                        if (curVol < 0) curVol = (int)(mw & 0xffffu);
-                        int exitHitIndex = hitIndex, lastExitIndex = -1, sameMaterialEntries = 0;
-                        while (exitHitIndex < nHits) {
-                            const unsigned ec = hitCode[exitHitIndex];
-                            if ((int)(matOf(ec) & 0xffffu) == curVol) {
-                                if (ec & 0x40000000u) sameMaterialEntries++;
-                                else { sameMaterialEntries--; lastExitIndex = exitHitIndex; }
-                                if (sameMaterialEntries <= 0) break;
-                            } else
-                                break;
-                            exitHitIndex++;
-                        }
-                        if (sameMaterialEntries > 0 && lastExitIndex != -1) exitHitIndex = lastExitIndex;
-                        if (exitHitIndex < nHits) {
-                            float distanceInVolume = hitT[exitHitIndex];
-                            float entryDistance = 0;
-                            if (isEntryHit) { entryDistance = hitT[hitIndex]; distanceInVolume -= hitT[hitIndex]; }
-                            // Material.ProbabilisticHit (RT/Material.cs:49-65)
-                            const float density = *reinterpret_cast<const float*>(section<ALL_LDS>(sc, L.materialOffset) + (unsigned)curVol * 64u + 36u);
-                            pendRE++;
-                            const float volumeHitDistance = -(1 / um_max(density, 1.1920928955078125e-7f)) * det_log(rng.next(NoiseSite{&A, (unsigned)cx, (unsigned)cy}));
-                            if (volumeHitDistance < distanceInVolume) {
-                                best = entryDistance + volumeHitDistance;                    // we hit inside the volume
-                                insideHit = true;
+                    for (int i = 0; i < nHits; i++) DBG_TRACE(10 + i, codeAt(i), distAt(i));
+                    DBG_TRACE(9, 0, 0.0f);
+                    // ---- the hit loop of Sample with the volume branch (:205-303) ----
+                    int hitIndex = 0;
+                    int chosen = -1;
+                    insideHit = false;
+                    while (hitIndex < nHits) {
+                        const unsigned c = codeAt(hitIndex);
+                        const unsigned mw = matOf(c);
+                        if (curVol >= 0 || ((mw >> 16) & 3u) == MAT_CLASS_VOLUME) {
+                            const bool isEntryHit = curVol < 0;
+                            if (curVol < 0) curVol = (int)(mw & 0xffffu);
+                            int exitHitIndex = hitIndex, lastExitIndex = -1, sameMaterialEntries = 0;
+                            while (exitHitIndex < nHits) {
+                                const unsigned ec = codeAt(exitHitIndex);
+                                if ((int)(matOf(ec) & 0xffffu) == curVol) {
+                                    if (ec & 0x40000000u) sameMaterialEntries++;
+                                    else { sameMaterialEntries--; lastExitIndex = exitHitIndex; }
+                                    if (sameMaterialEntries <= 0) break;
+                                } else
+                                    break;
+                                exitHitIndex++;
+                            }
+                            if (sameMaterialEntries > 0 && lastExitIndex != -1) exitHitIndex = lastExitIndex;
+                            if (exitHitIndex < nHits) {
+                                float distanceInVolume = distAt(exitHitIndex);
+                                float entryDistance = 0;
+                                if (isEntryHit) { entryDistance = distAt(hitIndex); distanceInVolume -= distAt(hitIndex); }
+                                // Material.ProbabilisticHit (RT/Material.cs:49-65)
+                                const float density = *reinterpret_cast<const float*>(section<ALL_LDS>(sc, L.materialOffset) + (unsigned)curVol * 64u + 36u);
+                                pendRE++;
+                                const float volumeHitDistance = -(1 / um_max(density, 1.1920928955078125e-7f)) * det_log(rng.next(NoiseSite{&A, (unsigned)cx, (unsigned)cy}));
+                                if (volumeHitDistance < distanceInVolume) {
+                                    best = entryDistance + volumeHitDistance;                    // we hit inside the volume
+                                    insideHit = true;
+                                    break;
+                                }
+                                curVol = -1;                                                     // no hit inside the volume, exit it
+                                const unsigned xc = codeAt(exitHitIndex);
+                                if (isVolume(xc) && (xc & 0x80000000u)) { hitIndex = exitHitIndex + 1; continue; }   // volume exit: next hit
+                                chosen = exitHitIndex;                                           // obstacle
                                 break;
                             }
-                            curVol = -1;                                                     // no hit inside the volume, exit it
-                            const unsigned xc = hitCode[exitHitIndex];
-                            if (isVolume(xc) && (xc & 0x80000000u)) { hitIndex = exitHitIndex + 1; continue; }   // volume exit: next hit
-                            chosen = exitHitIndex;                                           // obstacle
+                            nHits = 0;                                                           // no more surfaces (volume has holes)
                             break;
                         }
-                        nHits = 0;                                                           // no more surfaces (volume has holes)
+                        chosen = hitIndex;
                         break;
                     }
-                    chosen = hitIndex;
-                    break;
-                }
-                if (insideHit) { prim = -1; st = ST_HIT; }
-                else if (chosen >= 0 && chosen < nHits) { best = hitT[chosen]; hitTmin = hitTmin0[chosen]; prim = (int)(hitCode[chosen] & 0xffffu); st = ST_HIT; }
-                else st = ST_SKY;
+                    if (insideHit) { prim = -1; st = ST_HIT; }
+                    else if (chosen >= 0 && chosen < nHits) { best = distAt(chosen); hitTmin = tminAt(chosen); prim = (int)(codeAt(chosen) & 0xffffu); st = ST_HIT; }
+                    else st = ST_SKY;
+                };
+                if (nHits > 1) sort_hit_list(hitT, hitTmin0, hitCode, nHits, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
+                volumeLogic([&](int i) { return hitT[i]; }, [&](int i) { return hitCode[i]; }, [&](int i) { return hitTmin0[i]; });
             }
         }
         if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : need(4))) {
             ran = true;
+            STAGE_MARK(4);
             // ================= sky (:341-374), then fold tail -> head (:384-396) =================
             STAT_ADD(15, 1);
             if (st == ST_SKY) {
@@ -1444,6 +1458,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 endSample(true, col);
             }
         }
+        STAGE_MARK(7);
         // nothing met its threshold: force the most populated stage next trip (or stop when every lane is dead)
         if (ran) {
             force = -1;
@@ -1460,6 +1475,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 #ifdef RTOW_STATS
     // every lane counted the same wave-level events for 'per-run' slots; lane-population slots were added by all active lanes.
     if (A.stats) for (int i = 0; i < 16; i++) atomicAdd(&A.stats[i], stat[i]);
+    if (A.stats && (threadIdx.x & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&A.stats[24 + i], stageT[i]);
     if (A.stats && (threadIdx.x & 63) == 0) {
         const unsigned long long dt = wall_clock64() - statT0;   // 100 MHz ticks this wave was resident
         atomicAdd(&A.stats[16], dt);
