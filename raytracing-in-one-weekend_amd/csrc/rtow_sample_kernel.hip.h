@@ -746,6 +746,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     float pendRE = 0;
     bool insideHit = false;          // the chosen "hit" is a scattering event inside the volume
     float hitTmin = 0;               // tMin of the test that produced the chosen hit (exit hits use entry + 0.001)
+    constexpr bool KEEP_NORMAL = KIND == SCENE_KIND_GENERAL;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
+    V3 keptNormal = v3(0, 0, 0);
 
     // per-ray traversal state (resumable across trips)
     V3 inv = v3(0, 0, 0);
@@ -1111,7 +1113,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             // two surfaces at the bit-identical distance: the reference's sorted hit list starts with the one that
                             // comes first in its tree's leaf order (rtow_reforder.h)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
-                            if (t < best || (t == best && prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
+                            if (t < best || (t == best && prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; if (KEEP_NORMAL) keptNormal = nl; }
                         }
                     } else {
                         V3 c; float r, t;
@@ -1150,9 +1152,16 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     cls = MAT_CLASS_VOLUME;
                 } else if (GENERAL) {
                     // re-run the winning primitive's test for its entity-space normal, then rotate it out (RT/Entity.cs:62-66)
-                    float t2; V3 nLocal; float4 rq;
-                    (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq, TEXTURED ? &hitUv : nullptr);
-                    N = normalize(rotate(rq, nLocal));
+                    if (KEEP_NORMAL) {
+                        // TEST kept the entity-space normal of this very hit; only the rotation is fetched again (GpuPrim: [6] for triangles, else [0])
+                        const float4* pp = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)prim * 128u);
+                        const float4 rq = pp[(mi >> kPrimTypeShift) == RTOW_ENTITY_TRIANGLE ? 6 : 0];
+                        N = normalize(rotate(rq, keptNormal));
+                    } else {
+                        float t2; V3 nLocal; float4 rq;
+                        (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq, TEXTURED ? &hitUv : nullptr);
+                        N = normalize(rotate(rq, nLocal));
+                    }
                 } else {
                     V3 c; float radius;
                     sphere_at<ALL_LDS, HAS_MOTION>(sc, L, prim, rtime, c, radius);
