@@ -24,6 +24,9 @@ def feature_cases(rt):
         "probabilistic_volumes": (S.volume_scene(), dict(width=40, height=40, spp=4, trace_depth=10, focus=6.5), None),
         "volume_ties": (S.volume_tie_scene(), dict(width=40, height=40, spp=4, trace_depth=10, focus=5.0), None),
         "coplanar_ties": (S.coplanar_scene(), dict(width=48, height=32, spp=4, trace_depth=6, focus=6.0), None),
+        "twin_sphere_ties": (S.twin_spheres_scene(), dict(width=48, height=27, spp=4, trace_depth=6), None),
+        "twin_sphere_ties_moving": (S.twin_spheres_scene(True), dict(width=48, height=27, spp=4, trace_depth=6), None),
+        "long_hit_lists_with_ties": (S.volume_stack_scene(), dict(width=32, height=32, spp=4, trace_depth=8), None),
         "image_textures": (S.textured_scene(), dict(width=48, height=32, spp=4, trace_depth=8), None),
         "textured_volumes": (S.textured_volume_scene(), dict(width=32, height=32, spp=4, trace_depth=10, focus=6.5), None),
         "cubemap_sky": (S.cover_scene(), dict(width=48, height=27, spp=4, trace_depth=8, sky_type=abi.SKY_CUBEMAP), lambda osc: osc.set_cubemap(sky.desc())),
