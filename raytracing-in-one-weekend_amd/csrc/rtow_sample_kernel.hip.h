@@ -1461,7 +1461,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         col = v3(col.x * att.x + texHist[i * 6 + 3], col.y * att.y + texHist[i * 6 + 4], col.z * att.z + texHist[i * 6 + 5]);
                         continue;
                     }
-                    const V3 att = white ? v3(1, 1, 1) : v3(m0.x, m0.y, m0.z);
+                    // attenuation = white ? 1 : albedo, as a bit merge rather than a select: a select on a loaded value is turned into a
+                    // branch around the load (with its own s_waitcnt lgkmcnt(0)), which serialises the LDS latencies of the unrolled fold
+                    const unsigned wmask = (unsigned)((int)(code << 16) >> 31);                     // all ones iff bit 15 (white) is set
+                    auto pick = [&](float albedo) { return __uint_as_float((__float_as_uint(albedo) & ~wmask) | (0x3f800000u & wmask)); };
+                    const V3 att = v3(pick(m0.x), pick(m0.y), pick(m0.z));
                     col = v3(col.x * att.x + m0.w, col.y * att.y + m1.x, col.z * att.z + m1.y);
                 }
                 endSample(true, col);
