@@ -1212,6 +1212,17 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 float randomEvents = VOLUMES ? pendRE : 0.0f;     // rng.RandomEvents may already hold ProbabilisticHit's increments
                 pendRE = 0;
 
+                // The first cosine-hemisphere draw around N of both Standard classes in one place: the scatter direction of the lambert class
+                // and the rough normal of the general class are the same code on each lane's own random stream, so the lanes of both classes
+                // run it together instead of one class after the other (the order of draws per lane is unchanged).
+                constexpr bool kSharedHemisphere = !TEXTURED;
+                V3 hemi = v3(0, 0, 0);
+                if (kSharedHemisphere) {
+                    bool want = cls == MAT_CLASS_LAMBERT;
+                    if (cls == MAT_CLASS_LAMBERT) rng.skip_cosine_hemisphere(at);                       // the unused rough-normal draw (see below)
+                    if (cls == MAT_CLASS_GENERAL) want = *reinterpret_cast<const float*>(mp + 44) > 0;  // roughness > 0
+                    if (want) hemi = rng.cosine_hemisphere(at, N);
+                }
                 if (VOLUMES && cls == MAT_CLASS_VOLUME) {
                     // ProbabilisticVolume (RT/Material.cs:163-168): isotropic scatter, ray time reset to 0, RandomEvents += 2
                     sdir = rng.direction(at);                          // NextFloat3Direction
@@ -1222,8 +1233,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     // Standard with glossiness == 0 and metallic == 0 (RT/Material.cs:75-119): roughness = 1, so the rough normal
                     // costs one cosine-hemisphere draw (two white-noise numbers) whose result is never used (reflectionChance = saturate(fresnel * 0 * g1) = 0, and the
                     // rough-metal branch needs metallic > 0); RandomEvents = 0 + 0 + 1 * 0 + 1 * 1.
-                    rng.skip_cosine_hemisphere(at);
-                    sdir = rng.cosine_hemisphere(at, N);
+                    if (kSharedHemisphere) sdir = hemi;
+                    else { rng.skip_cosine_hemisphere(at); sdir = rng.cosine_hemisphere(at, N); }
                     randomEvents += 1.0f;                          // 0 + 0 + 1 * 0 + 1 * 1 on top of whatever was pending
                 } else if (cls == MAT_CLASS_GENERAL) {                                        // RT/Material.cs:75-119
                     STAT_ADD(11, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(12);
@@ -1235,7 +1246,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     perfectSpecular = (__float_as_uint(m2.z) & MAT_FLAG_PERFECT_SPECULAR) != 0;
                     V3 roughN = N;
                     if (roughness > 0) {
-                        const V3 h = rng.cosine_hemisphere(at, N);
+                        const V3 h = kSharedHemisphere ? hemi : rng.cosine_hemisphere(at, N);
                         roughN = normalize(v3(N.x + roughness * (h.x - N.x), N.y + roughness * (h.y - N.y), N.z + roughness * (h.z - N.z)));
                     }
                     const float incidentCosine = -dot(rd, roughN);
