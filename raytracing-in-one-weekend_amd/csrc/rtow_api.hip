@@ -24,7 +24,7 @@
 // minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: any
 // threshold above 1 loses (waiting lanes cost more than the skipped stage saves); slicing the walk at 16 wins ~5 %.
 #ifndef RTOW_DEFAULT_TUNE
-#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 1, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4 of the live lanes; TEST, HIT, SKY at once; 16 node visits per walk slice */
+#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 1, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4 of the live lanes; TEST, HIT, SKY, VOL at once; 16 node visits per walk slice */
 #endif
 
 using namespace rtow;
