@@ -138,3 +138,28 @@ def test_product_guard_boxes_equal_the_reference_leaf_bounds(shim, name, max_dep
         assert np.array_equal(got[:, 0:3], boxes[:, 0:3]) and np.array_equal(got[:, 4:7], boxes[:, 4:7])     # single-entity leaves: the entity's own box
     else:
         assert np.any(got[:, 4:7] - got[:, 0:3] > boxes[:, 4:7] - boxes[:, 0:3])                               # forced leaves: wider
+
+
+def test_rank_rule_is_exact_up_to_16_hits_and_not_beyond():
+    """The kernels of scenes without volumes keep only the nearest hit and break a tie by leaf order ("the first of the tied minima wins").
+    That is what the reference's sort of the whole hit list leaves in front for lists of up to 16 hits (compare-exchange networks and a
+    stable insertion sort); from 17 hits on its partition steps move another tied hit to the front in almost half of the cases - the
+    documented limit of the rule."""
+    lib = ob.load()
+    rng = np.random.default_rng(1)
+
+    def first_minimum_wins(n, trials):
+        wins = 0
+        for _ in range(trials):
+            keys = (rng.random(n) * 10 + 5).astype(np.float32)
+            tied = rng.choice(n, int(rng.integers(2, 4)), replace=False)
+            keys[tied] = 1.0
+            ids = np.arange(n, dtype=np.int32)
+            lib.oracle_kat_unity_sort(keys.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_int)), n)
+            wins += int(ids[0] == tied.min())
+        return wins
+
+    for n in range(2, 17):
+        assert first_minimum_wins(n, 300) == 300, n
+    assert first_minimum_wins(17, 300) < 300
+    assert first_minimum_wins(24, 300) < 300
