@@ -152,7 +152,7 @@ def test_rank_rule_is_exact_up_to_16_hits_and_not_beyond():
         wins = 0
         for _ in range(trials):
             keys = (rng.random(n) * 10 + 5).astype(np.float32)
-            tied = rng.choice(n, int(rng.integers(2, 4)), replace=False)
+            tied = rng.choice(n, min(n, int(rng.integers(2, 4))), replace=False)
             keys[tied] = 1.0
             ids = np.arange(n, dtype=np.int32)
             lib.oracle_kat_unity_sort(keys.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_int)), n)
