@@ -560,8 +560,9 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     ctx->haveScene = true;
     ctx->sceneSerial++;
     ctx->orderValid = false;
-    logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
-         ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes);
+    logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)%s", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
+         ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes,
+         ctx->scene.layout.exactTies ? ", duplicate primitives: exact-tie kernels" : "");
     return RTOW_SUCCESS;
 }
 

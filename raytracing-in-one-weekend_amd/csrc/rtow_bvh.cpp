@@ -424,6 +424,33 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.hasMotion = hasMotion ? 1u : 0u;
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
     L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? SCENE_KIND_TEXTURED : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
+    // Does the scene hold the same primitive twice (same geometry, any material)?  Two such surfaces coincide everywhere - the same float
+    // program produces both distances - and tie at the nearest hit of whole image regions; then the kernel variant that settles nearest-hit
+    // ties through the reference's whole hit list is used (kExactTiesBit).  Without duplicates a tie needs two different
+    // float programs to agree to the last bit (faces in one plane, shared mesh edges) and the leaf-order rule stands, exact up to 16 hits
+    // per ray.  Volume scenes resolve every tie in their hit list anyway.
+    L.exactTies = 0u;
+    if (!hasVolumes) {
+        std::vector<std::array<uint32_t, 38>> keys(n);
+        for (int i = 0; i < n; i++) {
+            const RtowEntity& e = desc->entities[i];
+            float f[38] = {0};
+            f[0] = (float)e.type;
+            if (e.type == RTOW_ENTITY_TRIANGLE) {
+                memcpy(&f[1], &desc->triangles[e.contentIndex], 24 * sizeof(float));       // data, normals, texture coordinates
+            } else {
+                f[1] = e.position.x; f[2] = e.position.y; f[3] = e.position.z;
+                f[4] = e.rotation.x; f[5] = e.rotation.y; f[6] = e.rotation.z; f[7] = e.rotation.w;
+                f[8] = e.type == RTOW_ENTITY_SPHERE ? std::fabs(e.size.x) : e.size.x;       // a sphere and its negative-radius twin hit alike
+                f[9] = e.type == RTOW_ENTITY_SPHERE ? 0.0f : e.size.y;
+                f[10] = e.type == RTOW_ENTITY_BOX ? e.size.z : 0.0f;
+            }
+            if (e.moving) { f[30] = 1.0f; f[31] = e.destinationOffset.x; f[32] = e.destinationOffset.y; f[33] = e.destinationOffset.z; f[34] = e.timeRange.x; f[35] = e.timeRange.y; }
+            for (int k = 0; k < 38; k++) { f[k] += 0.0f; memcpy(&keys[i][k], &f[k], 4); }              // + 0: -0 and +0 are the same place
+        }
+        std::sort(keys.begin(), keys.end());
+        for (int i = 1; i < n; i++) if (keys[i] == keys[i - 1]) { L.exactTies = 1u; break; }
+    }
     L.primOffset = off; if (general) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuPrim));
     L.cullOffset = off; if (hasVolumes) off = align16(off + (uint32_t)n * 32u);
     L.rankOffset = off; off = align16(off + (uint32_t)n * 4u);

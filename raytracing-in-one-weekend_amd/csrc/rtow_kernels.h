@@ -108,6 +108,10 @@ struct KernelInfo {
 hipError_t launchSampleSpheres(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
 hipError_t launchSampleSpheresMotion(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
 hipError_t launchSampleGeneral(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleGeneralTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleTexturedTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleSpheresTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleSpheresMotionTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
 hipError_t launchSampleVolumes(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
 hipError_t launchSampleTextured(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
 hipError_t launchSampleVolumesTextured(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);

@@ -361,12 +361,12 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
     switch (args.layout.sceneKind) {
-        case SCENE_KIND_SPHERES: return launchSampleSpheres(args, numBlocks, ldsBytes, stream, allLds);
-        case SCENE_KIND_SPHERES_MOTION: return launchSampleSpheresMotion(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_SPHERES: return args.layout.exactTies ? launchSampleSpheresTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleSpheres(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_SPHERES_MOTION: return args.layout.exactTies ? launchSampleSpheresMotionTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleSpheresMotion(args, numBlocks, ldsBytes, stream, allLds);
         case SCENE_KIND_VOLUMES: return launchSampleVolumes(args, numBlocks, ldsBytes, stream, allLds);
-        case SCENE_KIND_TEXTURED: return launchSampleTextured(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_TEXTURED: return args.layout.exactTies ? launchSampleTexturedTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleTextured(args, numBlocks, ldsBytes, stream, allLds);
         case SCENE_KIND_VOLUMES_TEXTURED: return launchSampleVolumesTextured(args, numBlocks, ldsBytes, stream, allLds);
-        default: return launchSampleGeneral(args, numBlocks, ldsBytes, stream, allLds);
+        default: return args.layout.exactTies ? launchSampleGeneralTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleGeneral(args, numBlocks, ldsBytes, stream, allLds);
     }
 }
 

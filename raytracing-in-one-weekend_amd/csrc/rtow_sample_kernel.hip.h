@@ -673,6 +673,69 @@ enum : int {
     ST_COUNT = 6
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// Nearest-hit tie, the long way.  Scenes without volumes keep only the nearest hit and break a tie by leaf order - which is what the
+// reference's sort of the whole hit list leaves in front as long as the ray has at most 16 hits; beyond that its partition steps
+// decide.  When TEST saw a second surface at exactly the nearest distance, this runs the reference's own procedure for
+// that one ray: every hit of the ray (the walk again, not pruned, same box tests), in leaf order, through the same sort; element 0 wins.
+// A real call: it is rare, and its list lives in scratch.
+// ------------------------------------------------------------------------------------------------------------
+template <bool ALL_LDS, int KIND>
+__device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs& sc, const SceneLayout& L, V3 ro, V3 rd, float rtime, unsigned short* stack,
+                                                                       uint32_t* overflowFlag)
+{
+    constexpr int kMaxList = 24;
+    float hitT[kMaxList], hitDummy[kMaxList];
+    unsigned hitCode[kMaxList];
+    int n = 0;
+    V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                     // startRay's rayInvDirection
+    if (inv.x != inv.x) inv.x = __builtin_inff();
+    if (inv.y != inv.y) inv.y = __builtin_inff();
+    if (inv.z != inv.z) inv.z = __builtin_inff();
+    const bool twoChildren = L.sphereCount > 1u;
+    const float a = dot(rd, rd);
+    int sp = 0, cur = 0;
+    while (cur >= 0) {
+        float4 q0, q1, q2;
+        int c0, c1;
+        load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
+        // the walk's slab expressions (TRAV), one child at a time
+        const float t0x = (q0.x - ro.x) * inv.x, t1x = (q1.z - ro.x) * inv.x, u0x = (q0.y - ro.x) * inv.x, u1x = (q1.w - ro.x) * inv.x;
+        const float t0y = (q0.z - ro.y) * inv.y, t1y = (q2.x - ro.y) * inv.y, u0y = (q0.w - ro.y) * inv.y, u1y = (q2.y - ro.y) * inv.y;
+        const float t0z = (q1.x - ro.z) * inv.z, t1z = (q2.z - ro.z) * inv.z, u0z = (q1.y - ro.z) * inv.z, u1z = (q2.w - ro.z) * inv.z;
+        const float tmin0 = vmax3(vmin(t0x, t1x), vmin(t0y, t1y), vmax(vmin(t0z, t1z), 0.0f)), tfar0 = vmin3(vmax(t0x, t1x), vmax(t0y, t1y), vmax(t0z, t1z));
+        const float tmin1 = vmax3(vmin(u0x, u1x), vmin(u0y, u1y), vmax(vmin(u0z, u1z), 0.0f)), tfar1 = vmin3(vmax(u0x, u1x), vmax(u0y, u1y), vmax(u0z, u1z));
+        const bool hit0 = tmin0 <= tfar0, hit1 = tmin1 <= tfar1 && twoChildren;
+        for (int side = 0; side < 2; side++) {
+            const int cc = side ? c1 : c0;
+            if (cc >= 0 || !(side ? (hit1 && tmin1 < tfar1) : (hit0 && tmin0 < tfar0))) continue;     // leaf children: AxisAlignedBoundingBox.Hit, tMin < tMax
+            const int i = ~cc;
+            float t;
+            bool ok;
+            if (KIND >= SCENE_KIND_GENERAL) {
+                const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
+                V3 nl; float4 rq;
+                ok = general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq);
+            } else {
+                V3 c; float r;
+                sphere_at<ALL_LDS, KIND == SCENE_KIND_SPHERES_MOTION>(sc, L, i, rtime, c, r);
+                ok = sphere_hit(sub(ro, c), rd, a, r, t);
+            }
+            if (!ok) continue;
+            if (n < kMaxList) { hitT[n] = t; hitDummy[n] = 0.0f; hitCode[n] = (unsigned)i; n++; }
+            else *overflowFlag = 1u;                                                                       // RTOW_ERROR_CAPACITY on the host side
+        }
+        const bool in0 = hit0 && c0 >= 0, in1 = hit1 && c1 >= 0;
+        if (in0 && in1) { stack[sp * kBlockThreads] = (unsigned short)c1; sp++; cur = c0; }
+        else if (in0 || in1) cur = in0 ? c0 : c1;
+        else if (sp > 0) { sp--; cur = stack[sp * kBlockThreads]; }
+        else cur = -1;
+    }
+    if (n == 0) return -1;
+    if (n > 1) sort_hit_list(hitT, hitDummy, hitCode, n, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
+    return (int)(hitCode[0] & 0xffffu);
+}
+
 template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
 __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
 {
@@ -704,10 +767,14 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     // a one-entity scene has a root whose second child is a placeholder; its (inverted) box cannot be told from a real one by the
     // symmetric slab test, so it is masked explicitly (wave-uniform, costs one scalar AND per node visit)
     const bool twoChildren = L.sphereCount > 1u;
-    constexpr bool HAS_MOTION = KIND == SCENE_KIND_SPHERES_MOTION;
-    constexpr bool GENERAL = KIND >= SCENE_KIND_GENERAL;
-    constexpr bool VOLUMES = KIND == SCENE_KIND_VOLUMES || KIND == SCENE_KIND_VOLUMES_TEXTURED;   // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
-    constexpr bool TEXTURED = KIND == SCENE_KIND_TEXTURED || KIND == SCENE_KIND_VOLUMES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
+    // KIND = scene kind (SCENE_KIND_*) | kExactTiesBit: with the bit, a tie at the nearest hit is settled by the reference's whole procedure
+    // (resolve_nearest_tie, a call that costs the hot kernel ~10 % whether taken or not - hence a variant of its own, chosen at upload)
+    constexpr int BASE = KIND & 7;
+    constexpr bool EXACT_TIES = (KIND & kExactTiesBit) != 0;
+    constexpr bool HAS_MOTION = BASE == SCENE_KIND_SPHERES_MOTION;
+    constexpr bool GENERAL = BASE >= SCENE_KIND_GENERAL;
+    constexpr bool VOLUMES = BASE == SCENE_KIND_VOLUMES || BASE == SCENE_KIND_VOLUMES_TEXTURED;   // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
+    constexpr bool TEXTURED = BASE == SCENE_KIND_TEXTURED || BASE == SCENE_KIND_VOLUMES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
 
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
@@ -740,13 +807,14 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     constexpr int kMaxHits = VOLUMES ? 24 : 1;
     float hitT[kMaxHits], hitTmin0[kMaxHits];
     unsigned hitCode[kMaxHits];      // primitive | dot(normal, dir) < 0 -> bit 30 | dot > 0 -> bit 31
+    bool tieAtBest = false;          // scenes without volumes: a second surface at exactly the nearest distance was seen (resolve_nearest_tie)
     bool hitOverflow = false;
     int nHits = 0;
     int curVol = -1;
     float pendRE = 0;
     bool insideHit = false;          // the chosen "hit" is a scattering event inside the volume
     float hitTmin = 0;               // tMin of the test that produced the chosen hit (exit hits use entry + 0.001)
-    constexpr bool KEEP_NORMAL = KIND == SCENE_KIND_GENERAL;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
+    constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
     V3 keptNormal = v3(0, 0, 0);
 
     // per-ray traversal state (resumable across trips)
@@ -783,6 +851,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         if (inv.z != inv.z) inv.z = __builtin_inff();
         cur = 0; sp = 0; nc = 0; prim = -1;
         best = __builtin_inff();
+        tieAtBest = false;
         nHits = 0;
         st = ST_TRAV;
     };
@@ -1113,6 +1182,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             // two surfaces at the bit-identical distance: the reference's sorted hit list starts with the one that
                             // comes first in its tree's leaf order (rtow_reforder.h)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
+                            if (EXACT_TIES) { if (t == best && prim >= 0) tieAtBest = true; else if (t < best) tieAtBest = false; }
                             if (t < best || (t == best && prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; if (KEEP_NORMAL) keptNormal = nl; }
                         }
                     } else {
@@ -1121,6 +1191,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         if (sphere_hit(sub(ro, c), rd, a, r, t) && t <= best) {
                             // same tie rule as above (duplicate or exactly tangent spheres)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
+                            if (EXACT_TIES) tieAtBest = !(t < best) && prim >= 0;                    // t == best here
                             if (t < best || (prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
                         }
                     }
@@ -1137,6 +1208,19 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             if (st == ST_HIT) {
                 STAT_LANES(8);
                 DBG_TRACE(VOLUMES && insideHit ? 1 : 0, prim, best);
+                if (EXACT_TIES && !VOLUMES && tieAtBest) {
+                    // two surfaces at exactly this distance: let the reference's own procedure pick (rare; see resolve_nearest_tie)
+                    tieAtBest = false;
+                    const int winner = resolve_nearest_tie<ALL_LDS, BASE>(sc, L, ro, rd, rtime, stack, A.overflowFlag);
+                    if (winner >= 0 && winner != prim) {
+                        prim = winner;
+                        if (KEEP_NORMAL) {
+                            const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u) >> kPrimTypeShift;
+                            float t2; float4 rq;
+                            (void)general_hit<ALL_LDS>(sc, L, prim, type, ro, rd, rtime, 0.0f, t2, keptNormal, rq);
+                        }
+                    }
+                }
                 unsigned mi = 0;
                 if (!(VOLUMES && insideHit)) mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
                 unsigned matIdx = mi & 0xffffu;

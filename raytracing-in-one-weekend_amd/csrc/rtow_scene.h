@@ -115,6 +115,8 @@ enum : uint32_t {
     SCENE_KIND_TEXTURED = 4,       // GENERAL + at least one Image texture: materials are evaluated per hit at the hit's texture coordinates
     SCENE_KIND_VOLUMES_TEXTURED = 5, // both
 };
+// template flag OR-ed to the kind of the sample kernel: settle nearest-hit ties with the reference's whole procedure (SceneLayout::exactTies)
+constexpr int kExactTiesBit = 8;
 // materialIndex[] word: bits 0..15 material, 16..17 shading class, 18..20 RtowEntityType
 constexpr uint32_t kPrimTypeShift = 18;
 
@@ -128,6 +130,8 @@ struct SceneLayout {
     uint32_t totalBytes;                    // size of the blob
     uint32_t bvhDepth;                      // max number of inner nodes on a root->leaf path == stack bound
     uint32_t sceneKind;                     // SCENE_KIND_*
+    uint32_t exactTies;                     // scenes without volumes: two surfaces can coincide exactly (duplicate spheres; any non-sphere geometry), so the
+                                            // kernel variant that resolves nearest-hit ties through the reference's whole hit list is used
     uint32_t primOffset;                    // GpuPrim[sphereCount] when sceneKind == SCENE_KIND_GENERAL
     uint32_t cullOffset;                    // float[8] {min.xyz, -, max.xyz, -} per entity when sceneKind == SCENE_KIND_VOLUMES: the reference tree's entity box
     uint32_t rankOffset;                    // uint32 per entity when sceneKind >= SCENE_KIND_GENERAL: place in the reference tree's leaf order (rtow_reforder.h)

@@ -13,13 +13,22 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["spheres", "spheres_motion", "general", "volumes", "textured", "volumes_textured"]
+KINDS = ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "volumes", "textured", "textured_ties", "volumes_textured"]
 
 
 def _scene(rt, kind):
     S = rt.scenes
-    return {"spheres": S.twin_spheres_scene, "spheres_motion": S.tiny_scene, "general": S.coplanar_scene, "volumes": S.volume_tie_scene,
-            "textured": S.textured_scene, "volumes_textured": S.textured_volume_scene}[kind]()
+    # the *_ties kernels (duplicate spheres: nearest-hit ties go through resolve_nearest_tie) are chosen at upload when the scene holds duplicates
+    def textured_with_twins():
+        s = S.textured_scene()
+        s.add_sphere((0.4, 0.6, 0.3), 0.35, S.lambertian((0.8, 0.3, 0.2)))
+        s.add_sphere((0.4, 0.6, 0.3), 0.35, S.metal((0.9, 0.9, 0.9), 0.1))
+        return s
+
+    return {"spheres": lambda: S.cover_scene(60, 600), "spheres_ties": S.twin_spheres_scene, "spheres_motion": S.tiny_scene,
+            "spheres_motion_ties": lambda: S.twin_spheres_scene(True), "general": S.mixed_scene, "general_ties": S.coplanar_scene,
+            "volumes": S.volume_tie_scene, "textured": S.textured_scene, "textured_ties": textured_with_twins,
+            "volumes_textured": S.textured_volume_scene}[kind]()
 
 
 # (trace depth -> history width 4 / 8 / 32, noise, rng policy); the texture-driven noise sources only exist with history width 32
@@ -39,7 +48,8 @@ def test_every_kernel_variant(rt, oracle, kind, in_lds):
     abi = rt.abi
     scene = _scene(rt, kind)
     desc = scene.desc()
-    ctx = rt.Context(0)
+    log = []
+    ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: log.append(msg.decode()), log_level=4)
     old = os.environ.get("RTOW_LDS_BUDGET")
     try:
         if not in_lds:
@@ -51,6 +61,7 @@ def test_every_kernel_variant(rt, oracle, kind, in_lds):
         else:
             os.environ["RTOW_LDS_BUDGET"] = old
     assert bool(ctx.scene_info().sceneInLds) == in_lds
+    assert any("exact-tie kernels" in m for m in log) == kind.endswith("_ties"), log        # the scene really selects the variant it is meant to cover
     noise = rt.scenes.NoiseTextures(row_stride=8, count=2, seed=3)
     ctx.upload_blue_noise(noise.blue_desc())
     ctx.upload_stb_noise(noise.stb_desc())
