@@ -541,6 +541,10 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchPrepareEntities(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    if (const char* env = getenv("RTOW_EXACT_TIES")) {       // 1: exact-tie kernels for every scene without volumes (slower), 0: never
+        const bool volumes = compiled.layout.sceneKind == SCENE_KIND_VOLUMES || compiled.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
+        if (!volumes) compiled.layout.exactTies = atoi(env) != 0 ? 1u : 0u;
+    }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);
     if (const char* env = getenv("RTOW_LDS_BUDGET")) {       // development aid: run small scenes through the kernels that read the tree from HBM
@@ -562,7 +566,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     ctx->orderValid = false;
     logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)%s", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
          ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes,
-         ctx->scene.layout.exactTies ? ", duplicate primitives: exact-tie kernels" : "");
+         ctx->scene.layout.exactTies ? ", exact-tie kernels" : "");
     return RTOW_SUCCESS;
 }
 

@@ -129,6 +129,30 @@ def test_hit_list_overflow_is_reported(rt, gpu_context):
     assert lib.rtowSynchronize(ctx.handle) == a.RTOW_SUCCESS
 
 
+def test_exact_tie_kernels_can_be_forced(rt, oracle):
+    """RTOW_EXACT_TIES=1 (read at upload) selects the exact-tie kernels for a scene without duplicates; same image, bit for bit."""
+    import os
+    scene = rt.scenes.mixed_scene()
+    desc = scene.desc()
+    p = rt.scenes.make_params(scene, 64, 40, spp=4, trace_depth=8)
+    osc = oracle.OracleScene(desc)
+    ref = osc.sample_batch(p)
+    osc.close()
+    for forced in (False, True):
+        log = []
+        ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: log.append(msg.decode()), log_level=4)
+        try:
+            if forced:
+                os.environ["RTOW_EXACT_TIES"] = "1"
+            ctx.upload_scene(desc)
+        finally:
+            os.environ.pop("RTOW_EXACT_TIES", None)
+        assert any("exact-tie kernels" in m for m in log) == forced, log
+        got = rt.sample_batch_host(ctx, p)
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (forced, k)
+
+
 def test_error_codes(rt, gpu_context):
     lib = rt.lib.load()
     a = rt.abi
