@@ -65,7 +65,21 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0):
+# BASELINE.json configs the driver can time on one GPU (configs[0] is the reference's own CPU-runnable case: the cpu_baseline leg)
+CONFIGS = {
+    2: dict(scene="cover", width=1920, height=1080, spp=256, depth=8, label="configs[1]: cover scene 1920x1080, 256 spp, 8 bounces"),
+    3: dict(scene="cover", width=3840, height=2160, spp=1024, depth=16, label="configs[2]: cover scene 3840x2160, 1024 spp, 16 bounces"),
+    4: dict(scene="stress", width=1920, height=1080, spp=256, depth=8, label="configs[3]: 10k-sphere stress scene 1920x1080, 256 spp, 8 bounces"),
+    5: dict(scene="moving", width=1920, height=1080, spp=512, depth=8, label="configs[4]: moving spheres + defocus blur 1920x1080, 512 spp, 8 bounces"),
+}
+SCENE_TEXT = {
+    "cover": "cover scene (486 spheres, generated per Final Scene (Book 1).asset, seed 700)",
+    "stress": "stress scene (10 000 spheres dart-thrown on 100x100, seed 10000; tree does not fit LDS)",
+    "moving": "moving-spheres scene (Random With Movement (Book 2).asset: 80 % of the random spheres move, aperture 0.05)",
+}
+
+
+def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0, scene_name="cover", full_spp=256):
     """Time the CPU restatement of the reference Burst path (oracle, -O3 -ffast-math build) on this host's cores.
 
     Bounded sample of the SAME workload: the full 1920x1080 frame of the cover scene at a reduced spp, chosen from a
@@ -97,8 +111,8 @@ def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0):
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": "cover scene %dx%d, %d spp (of the 256-spp workload), %d bounces, 1 batch, best of 2; "
-                  "C++ restatement of the reference Burst path, -O3 -ffast-math, 1 task/pixel dynamic" % (width, height, spp, depth),
+        "sample": "%s scene %dx%d, %d spp (of the %d-spp workload), %d bounces, 1 batch, best of 2; "
+                  "C++ restatement of the reference Burst path, -O3 -ffast-math, 1 task/pixel dynamic" % (scene_name, width, height, spp, full_spp, depth),
         "mrays_per_s": round(rays / best / 1e6, 3),
         "seconds": round(best, 3),
     }
@@ -109,15 +123,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2,
+                    help="BASELINE.json config to time (1-based like SURVEY.md 8: 2 = configs[1], the headline; 3 = 4K/1024 spp/16 bounces; 4 = 10k spheres; 5 = moving + defocus)")
+    ap.add_argument("--scene", choices=sorted(SCENE_TEXT), default=None, help="override the config's scene")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--rng", choices=["reference", "per-sample"], default="reference",
                     help="reference: the reference's per-pixel generator (same seed, same image: the headline); per-sample: RTOW_RNG_PER_SAMPLE, a different stream")
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
     ap.add_argument("--partition", choices=("batches", "tiles"), default="batches", help="how N > 1 GPUs split a batch")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    overridden = [k for k in ("scene", "width", "height", "spp", "depth") if getattr(args, k) is not None]
+    for k in ("scene", "width", "height", "spp", "depth"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,8 +175,8 @@ def main():
 
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
     n = W * H
-    scene = rt.scenes.cover_scene()
-    ctx = rt.Context(local_rank)
+    scene = {"cover": rt.scenes.cover_scene, "stress": rt.scenes.stress_scene, "moving": rt.scenes.moving_scene}[args.scene]()
+    ctx = rt.Context(local_rank, scheduler_tune=[int(x) for x in args.tune.split(",")] if args.tune else None)
     ctx.upload_scene(scene.desc())
     info = ctx.scene_info()
 
@@ -263,7 +286,8 @@ def main():
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic, traffic_src, secondary = measured_hbm_traffic() if world == 1 else (None, None, {})
         out = {
-            "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce",
+            "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce" if (args.config == 2 and not overridden) else
+                      "Msamples/s, %s scene %dx%d %d-bounce" % (args.scene, W, H, depth),
             "value": round(total_samples / elapsed / 1e6, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -276,8 +300,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "cover scene (486 spheres, generated per Final Scene (Book 1).asset, seed 700), %dx%d, %d spp per batch, "
-                            "%d bounces, white noise, jitter on, %s" % (W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_PER_SAMPLE (NOT the reference stream; lane per 16-sample group)"),
+                "workload": "%s%s, %dx%d, %d spp per batch, "
+                            "%d bounces, white noise, jitter on, %s" % ("BASELINE.json " + cfg["label"] + " = " if not overridden else "", SCENE_TEXT[args.scene], W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_PER_SAMPLE (NOT the reference stream; lane per 16-sample group)"),
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
                               "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
                               if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch" % world),
@@ -304,7 +328,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rt, scene, W, H, depth)
+            out["cpu_baseline"] = cpu_baseline(rt, scene, W, H, depth, scene_name=args.scene, full_spp=spp)
         print(json.dumps(out), flush=True)
 
     ctx.close()

@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 4
+#define RTOW_API_VERSION 5
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -55,7 +55,7 @@ typedef enum RtowResult {
     RTOW_ERROR_LAUNCH_FAILURE = 6,    /* kernel launch or stream error (hipError in the log)    */
     RTOW_ERROR_CANCELLED = 7,         /* cancellation flag observed; outputs unspecified        */
     RTOW_ERROR_CAPACITY = 8,          /* a compiled-in bound was exceeded: at upload (entities, tree depth) or - reported by the host-buffer
-                                       * rtowSampleBatch, a cancellable rtowSampleBatchDevice or the next rtowSynchronize - by a ray of a
+                                       * rtowSampleBatch, a cancellable rtowSampleBatchDevice or the next rtowGetBatchStatus / rtowSynchronize - by a ray of a
                                        * volume scene that met more than 24 surfaces (the reference's hit list is unbounded) */
     RTOW_ERROR_INTERNAL = 99
 } RtowResult;
@@ -278,11 +278,31 @@ typedef struct RtowContext_t* RtowContext;
  * May be invoked from any thread (OptixApi.cs:145-152). */
 typedef void (*RtowLogCallback)(int32_t level, const char* tag, const char* message, void* userData);
 
+/* Behaviour switches of a context (RtowContextOptions.flags).  None of them changes what the library computes for a given scene and
+ * parameter block except where stated; nothing is read from the environment. */
+typedef enum RtowContextFlags {
+    RTOW_CONTEXT_EXACT_TIES_ALWAYS = 1u << 0,      /* settle every nearest-hit tie with the reference's whole procedure (walk again unpruned, sort the hit
+                                                    * list like NativeSortExtension.Sort, take [0]) in every scene without volumes; default: only in scenes
+                                                    * that hold the same primitive twice.  Closes the one documented deviation; slower */
+    RTOW_CONTEXT_EXACT_TIES_NEVER = 1u << 1,       /* never (the rank rule everywhere) */
+    RTOW_CONTEXT_REFERENCE_DIAGNOSTICS = 1u << 2,  /* FULL_DIAGNOSTICS records (diagnosticsStride 16): BoundsHitCount / CandidateCount count the REFERENCE's tree -
+                                                    * node boxes a ray passes and entities of the leaves it reaches in the tree RebuildBvh would build
+                                                    * (UNITY/BvhNodeData.cs:122-213, JOBS/SampleBatchJob.cs:427-440, UNITY/Raytracer.cs:54-64) - instead of the
+                                                    * library's own tree.  Costs a second, unpruned walk per ray in such batches */
+    RTOW_CONTEXT_NO_CAMERA_RAY_LISTS = 1u << 3,    /* development: walk the tree for camera rays too */
+    RTOW_CONTEXT_NO_CHUNK_ORDER = 1u << 4          /* development: hand out pixel chunks in row order, not most-expensive-first */
+} RtowContextFlags;
+
 typedef struct RtowContextOptions {
     int32_t deviceOrdinal;          /* HIP device ordinal */
     RtowLogCallback logCallback;    /* may be NULL */
     void* logCallbackData;
     int32_t logCallbackLevel;
+    uint32_t flags;                 /* RtowContextFlags, 0 = defaults */
+    int32_t ldsSceneBudgetBytes;    /* development: cap on the bytes of scene image staged into LDS (0 = all that fits); smaller scenes then run
+                                     * through the kernels that read the tree from HBM */
+    int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL - -) and the box-walk
+                                     * slice (node visits per trip); all zero = the built-in values */
 } RtowContextOptions;
 
 RTOW_API int rtowGetApiVersion(void);
@@ -329,6 +349,15 @@ RTOW_API int rtowSampleBatchDevice(RtowContext context, const RtowSampleParams* 
                                    const RtowAccumBuffers* in, const RtowAccumBuffers* out,
                                    void* diagnostics, void* stream, const volatile uint8_t* cancel);
 
+/* Pinned host buffers for rtowSampleBatch.  The host's accumulation buffers are long-lived pools (UNITY/Raytracer.cs:279-288,
+ * Allocator.Persistent); registering them once (hipHostRegister) lets rtowSampleBatch move the inputs with one pinned DMA and lets the
+ * kernel store the outputs and diagnostics straight into host memory, so the host-buffer form runs at the speed of the device-resident
+ * one.  Unregistered pointers keep working (pageable staging copies).  A registration covers [pointer, pointer + sizeInBytes) and must
+ * be dropped with rtowUnregisterHostBuffer before the memory is freed.  The reference's own plugin pattern is H2D -> work -> D2H per call
+ * (JOBS/DenoiseJobs.cs:75-117); this is that pattern with the copies taken off the critical path. */
+RTOW_API int rtowRegisterHostBuffer(RtowContext context, void* pointer, size_t sizeInBytes);
+RTOW_API int rtowUnregisterHostBuffer(RtowContext context, void* pointer);
+
 /* Device time (ms) of the most recent sample kernel of this context, measured with HIP events recorded on the
  * stream the kernel was launched on (the RecordTimeJob 0/1 bracket, JOBS/UtilJobs.cs:77-86). Synchronises on the end event. */
 RTOW_API int rtowGetLastSampleKernelMs(RtowContext context, float* outMs);
@@ -374,11 +403,37 @@ typedef enum RtowMemcpyKind {       /* CudaMemcpyKind, OptixApi.cs:33-40 */
     RTOW_MEMCPY_DEVICE_TO_HOST = 2,
     RTOW_MEMCPY_DEVICE_TO_DEVICE = 3
 } RtowMemcpyKind;
+/* ---- multi-GPU: one process per GPU, the frame row-interleaved with the reference's own slice contract ----
+ * Process g of G renders with sliceOffset = g, sliceDivider = G (JOBS/SampleBatchJob.cs:69-70: rows with row % G == g) and owns exactly
+ * those rows of every buffer; pixels are independent given (params, scene, Seed, global pixel index), so the gathered frame is
+ * bit-identical to the single-GPU frame.  The ONE collective of a batch is a gather of the owned rows to a root over RCCL (xGMI: every
+ * peer has its own link to the root).  RCCL is loaded on first use (dlopen of librccl.so), so single-GPU hosts never touch it.
+ *   rank 0:  rtowCommGetUniqueId(&id), hand the 128 bytes to the other processes by any host channel (the host's own IPC, a file, MPI ...)
+ *   all:     rtowCommInit(ctx, &id, rank, worldSize)            collective, blocks until every rank has joined
+ *   batch:   rtowSampleBatchDevice(...slice params...); rtowGatherRowsDevice(ctx, W, H, G, &mine, &frame, what, root, stream)
+ *   all:     rtowCommDestroy(ctx)
+ * rtowGatherRowsDevice: `mine` holds this rank's owned rows in place (full-frame buffers, other rows ignored); on the root `frame`
+ * receives every rank's rows in place (full-frame buffers; may be the same buffers as `mine`); on other ranks `frame` is ignored.
+ * `what` selects the buffers (RtowGatherMask); rows are packed, sent and unpacked on `stream` (NULL = the context's own), asynchronously. */
+typedef struct RtowCommId { char bytes[128]; } RtowCommId;        /* ncclUniqueId */
+typedef enum RtowGatherMask { RTOW_GATHER_COLOR = 1, RTOW_GATHER_NORMAL = 2, RTOW_GATHER_ALBEDO = 4, RTOW_GATHER_SAMPLE_COUNT_WEIGHT = 8, RTOW_GATHER_ALL = 15 } RtowGatherMask;
+RTOW_API int rtowCommGetUniqueId(RtowCommId* outId);
+RTOW_API int rtowCommInit(RtowContext context, const RtowCommId* id, int32_t rank, int32_t worldSize);
+RTOW_API int rtowCommDestroy(RtowContext context);
+RTOW_API int rtowGatherRowsDevice(RtowContext context, int32_t width, int32_t height, int32_t sliceDivider,
+                                  const RtowAccumBuffers* mine, const RtowAccumBuffers* frame, int32_t what, int32_t root, void* stream);
+
 RTOW_API int rtowDeviceAlloc(RtowContext context, size_t sizeInBytes, void** outPointer);
 RTOW_API int rtowDeviceFree(RtowContext context, void* pointer);
 RTOW_API int rtowDeviceCopy(RtowContext context, const void* source, void* destination, size_t sizeInBytes, int kind);
 RTOW_API int rtowDeviceMemset(RtowContext context, void* pointer, int value, size_t sizeInBytes);
+/* Waits for everything the context's own stream holds AND for the most recent sample batch wherever it was enqueued, then reports that
+ * batch history's status: RTOW_ERROR_CAPACITY if any batch since the last report met a ray with more than 24 surfaces (the flag is sticky
+ * until reported), else RTOW_SUCCESS. */
 RTOW_API int rtowSynchronize(RtowContext context);
+/* The same status query without draining the context's stream: blocks only until the most recent sample batch (on whatever stream it
+ * was given) has finished.  For callers of the asynchronous rtowSampleBatchDevice, which cannot return the batch's status itself. */
+RTOW_API int rtowGetBatchStatus(RtowContext context);
 
 #ifdef __cplusplus
 }

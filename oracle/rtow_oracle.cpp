@@ -2041,4 +2041,5 @@ ORACLE_API void oracle_abi_sizes(int* out)
     out[9] = (int)sizeof(RtowContextOptions); out[10] = (int)sizeof(RtowMetrics); out[11] = (int)sizeof(RtowCombineParams);
     out[12] = (int)sizeof(RtowTriangle); out[13] = (int)sizeof(RtowCubemapDesc);
     out[14] = (int)sizeof(RtowBlueNoiseDesc); out[15] = (int)sizeof(RtowStbNoiseDesc); out[16] = (int)sizeof(RtowImage);
+    out[17] = (int)sizeof(RtowCommId);
 }

@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 4
+RTOW_API_VERSION = 5
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -133,9 +133,19 @@ class AccumBuffers(C.Structure):
 LogCallback = C.CFUNCTYPE(None, C.c_int32, C.c_char_p, C.c_char_p, C.c_void_p)
 
 
+# RtowContextFlags
+CONTEXT_EXACT_TIES_ALWAYS, CONTEXT_EXACT_TIES_NEVER, CONTEXT_REFERENCE_DIAGNOSTICS, CONTEXT_NO_CAMERA_RAY_LISTS, CONTEXT_NO_CHUNK_ORDER = 1, 2, 4, 8, 16
+# RtowGatherMask
+GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_ALL = 1, 2, 4, 8, 15
+
+
 class ContextOptions(C.Structure):
     _fields_ = [("deviceOrdinal", C.c_int32), ("logCallback", LogCallback), ("logCallbackData", C.c_void_p),
-                ("logCallbackLevel", C.c_int32)]
+                ("logCallbackLevel", C.c_int32), ("flags", C.c_uint32), ("ldsSceneBudgetBytes", C.c_int32), ("schedulerTune", C.c_int32 * 9)]
+
+
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
 
 
 class Metrics(C.Structure):
@@ -152,5 +162,6 @@ EXPORTED_SYMBOLS = [
     "rtowGetApiVersion", "rtowErrorString", "rtowCreateContext", "rtowDestroyContext", "rtowUploadScene",
     "rtowUploadSkyCubemap", "rtowUploadBlueNoise", "rtowUploadStbNoise", "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
     "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
-    "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize",
+    "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize", "rtowGetBatchStatus", "rtowRegisterHostBuffer", "rtowUnregisterHostBuffer",
+    "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
 ]

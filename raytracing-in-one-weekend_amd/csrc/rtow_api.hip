@@ -5,6 +5,7 @@
 // and the post passes.  There is no CPU implementation behind any entry point: without a usable HIP device
 // rtowCreateContext fails with RTOW_ERROR_NO_DEVICE and nothing else can be called.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -88,6 +89,22 @@ struct RtowContext_t {
     size_t stagingPixels = 0, stagingDiagBytes = 0;
 
     MetricsPartial* dPartials = nullptr;
+
+    // RtowContextOptions: behaviour switches and development knobs (nothing is read from the environment)
+    uint32_t flags = 0;
+    uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
+    int tune[9] = {RTOW_DEFAULT_TUNE};
+
+    // rtowRegisterHostBuffer: pinned + device-mapped ranges of caller memory
+    struct HostRange { uint8_t* base; size_t size; uint8_t* device; };
+    std::vector<HostRange> hostRanges;
+
+    // rtowComm*: RCCL communicator of this rank (one process per GPU) and the packed-row staging of rtowGatherRowsDevice
+    void* comm = nullptr;                 // ncclComm_t
+    int commRank = 0, commWorld = 1;
+    float *dGatherSend = nullptr, *dGatherRecv = nullptr;
+    size_t gatherSendFloats = 0, gatherRecvFloats = 0;
+
     std::mutex mu;
 };
 
@@ -188,16 +205,9 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.cubemapFaceStride = ctx->cubemap.pixelStride * ctx->cubemap.faceWidth * ctx->cubemap.faceHeight;         // :168
     a.cubemapChannelType = ctx->cubemap.channelType;
 
-    // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice; RTOW_TUNE overrides for experiments
-    static const int kDefaultTune[9] = {RTOW_DEFAULT_TUNE};
-    int tune[9];
-    memcpy(tune, kDefaultTune, sizeof(tune));
-    if (const char* env = getenv("RTOW_TUNE")) {
-        int v[9];
-        if (sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[8]) == 8) { v[7] = 1; memcpy(tune, v, sizeof(tune)); }
-    }
-    for (int i = 0; i < 8; i++) a.tune[i] = tune[i] < 1 ? 1 : tune[i];
-    a.travSlice = tune[8] < 1 ? 1 : tune[8];
+    // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice (RtowContextOptions.schedulerTune overrides)
+    for (int i = 0; i < 8; i++) a.tune[i] = ctx->tune[i] < 1 ? 1 : ctx->tune[i];
+    a.travSlice = ctx->tune[8] < 1 ? 1 : ctx->tune[8];
     a.stats = nullptr;
 #ifdef RTOW_STATS
     static unsigned long long* dStats = nullptr;
@@ -207,6 +217,17 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.debugPixel = getenv("RTOW_DEBUG_PIXEL") ? atoi(getenv("RTOW_DEBUG_PIXEL")) : -2;
 #endif
     const uint32_t ownedPixels = a.totalWork;
+    if (ownedPixels == 0) {
+        // a slice that owns no row (SliceOffset >= height): Execute returns for every index (JOBS/SampleBatchJob.cs:69-70) - nothing is
+        // written, nothing is launched (a zero-sized grid is not a valid launch); the events still bracket "this batch"
+        if (ctx->haveBatchDone) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->evBatchDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipEventRecord(ctx->evStart, stream), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipEventRecord(ctx->evBatchDone, stream), RTOW_ERROR_LAUNCH_FAILURE);
+        ctx->haveBatchDone = true;
+        ctx->haveTiming = true;
+        return RTOW_SUCCESS;
+    }
     a.groupsPerPixel = 1;
     if (p->rngPolicy == RTOW_RNG_PER_SAMPLE) {
         // work units are (owned pixel, group of kSampleGroup samples); each leaves a record that fold_unit_records_kernel adds up
@@ -234,7 +255,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     if (ctx->haveBatchDone) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->evBatchDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
 
     // ---- camera-ray candidate lists: one conservative beam walk per pixel, reused by all its samples (and by later batches of the same view) ----
-    if (!getenv("RTOW_NO_PRIMARY_LISTS")) {
+    if (!(ctx->flags & RTOW_CONTEXT_NO_CAMERA_RAY_LISTS)) {
         const size_t pixels = (size_t)a.width * (size_t)a.height;
         if (pixels > ctx->pixCandCapacity) {
             if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
@@ -270,7 +291,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
 
     // ---- chunk order: most expensive 64-pixel chunks first, from the ray counts of the previous launch (or of a probe) ----
     a.chunkCount = (a.totalWork + 63u) / 64u;
-    const bool wantOrder = a.chunkCount >= (uint32_t)(4 * ctx->cuCount) && !getenv("RTOW_NO_CHUNK_ORDER");   // tiny frames: not worth it
+    const bool wantOrder = a.chunkCount >= (uint32_t)(4 * ctx->cuCount) && !(ctx->flags & RTOW_CONTEXT_NO_CHUNK_ORDER);   // tiny frames: not worth it
     if (wantOrder) {
         if (a.chunkCount > ctx->chunkCapacity) {
             if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
@@ -369,6 +390,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
 }
 
 // A ray of a volume scene met more surfaces than the per-lane hit list holds (24): the batch's result is not the reference's.
+// The flag is sticky: it is set by the kernel and cleared only here, so it covers every batch enqueued since the last report
+// (rtowSampleBatch, a cancellable rtowSampleBatchDevice, rtowGetBatchStatus, rtowSynchronize).
 int takeOverflow(RtowContext ctx)
 {
     if (ctx->hCancel[1] == 0u) return RTOW_SUCCESS;
@@ -386,6 +409,7 @@ int waitWithCancel(RtowContext ctx, const volatile uint8_t* cancel)
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) {
             logf(ctx, 2, "hip", "sample kernel failed: %s", hipGetErrorString(q));
+            ctx->hCancel[1] = 0u;
             return RTOW_ERROR_LAUNCH_FAILURE;
         }
         if (cancel && *cancel && !cancelled) {
@@ -395,8 +419,20 @@ int waitWithCancel(RtowContext ctx, const volatile uint8_t* cancel)
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     if (cancel && *cancel) cancelled = true;
-    if (cancelled) return RTOW_ERROR_CANCELLED;
+    if (cancelled) {
+        ctx->hCancel[1] = 0u;          // the cancelled batch's outputs are discarded; its overflow must not be blamed on the next batch
+        return RTOW_ERROR_CANCELLED;
+    }
     return takeOverflow(ctx);
+}
+
+// device-visible address of caller memory [p, p + bytes) if it lies inside a range given to rtowRegisterHostBuffer, else null
+uint8_t* mappedHost(RtowContext ctx, const void* p, size_t bytes)
+{
+    const uint8_t* q = (const uint8_t*)p;
+    for (const RtowContext_t::HostRange& r : ctx->hostRanges)
+        if (q >= r.base && q + bytes <= r.base + r.size) return r.device + (q - r.base);
+    return nullptr;
 }
 
 int ensureStaging(RtowContext ctx, size_t pixels, size_t diagBytes)
@@ -420,6 +456,60 @@ int ensureStaging(RtowContext ctx, size_t pixels, size_t diagBytes)
     }
     return RTOW_SUCCESS;
 }
+
+// ---- RCCL, loaded on first use: hosts that drive one GPU never map it, and a process that already holds a copy (PyTorch ships its own
+// librccl.so.1) shares that copy.  Only the point-to-point calls the row gather needs; types restated from <rccl/rccl.h> (ROCm 7.2:
+// NCCL_UNIQUE_ID_BYTES 128, ncclFloat32 = 7, ncclSuccess = 0) so that the library has no link-time dependency on RCCL. ----
+struct RcclUniqueId { char internal[128]; };
+static_assert(sizeof(RcclUniqueId) == sizeof(RtowCommId), "RtowCommId carries an ncclUniqueId");
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return handle && GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString; }
+};
+constexpr int kRcclFloat32 = 7;
+
+RcclApi* rccl()
+{
+    static std::mutex mu;
+    static RcclApi api;
+    std::lock_guard<std::mutex> lock(mu);
+    if (api.ok()) return &api;
+    static const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;     // a copy this process already holds
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return nullptr;
+    api.handle = h;
+    api.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
+    api.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    api.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    api.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+    api.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+    api.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+    api.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    return api.ok() ? &api : nullptr;
+}
+
+#define RCCL_TRY(ctx, api, expr)                                                                       \
+    do {                                                                                               \
+        const int _r = (expr);                                                                         \
+        if (_r != 0) {                                                                                 \
+            logf(ctx, 2, "rccl", "%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(_r), __FILE__, __LINE__); \
+            return RTOW_ERROR_LAUNCH_FAILURE;                                                          \
+        }                                                                                              \
+    } while (0)
+
+// rows of the frame owned by `rank` under the reference's interlacing (row % divider == rank, JOBS/SampleBatchJob.cs:69-70)
+unsigned rowsOwnedBy(int rank, int divider, int height) { return rank >= height ? 0u : (unsigned)((height - rank + divider - 1) / divider); }
 
 } // namespace
 
@@ -460,7 +550,15 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     if (!ctx) return RTOW_ERROR_MEMORY_ALLOCATION;
     ctx->device = ordinal;
     ctx->cuCount = prop.multiProcessorCount;
-    if (options) { ctx->logCb = options->logCallback; ctx->logData = options->logCallbackData; ctx->logLevel = options->logCallbackLevel; }
+    if (options) {
+        ctx->logCb = options->logCallback; ctx->logData = options->logCallbackData; ctx->logLevel = options->logCallbackLevel;
+        ctx->flags = options->flags;
+        if ((ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) && (ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER)) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
+        if (options->ldsSceneBudgetBytes > 0) ctx->ldsSceneBudget = (uint32_t)options->ldsSceneBudgetBytes;
+        bool anyTune = false;
+        for (int i = 0; i < 9; i++) anyTune = anyTune || options->schedulerTune[i] != 0;
+        if (anyTune) for (int i = 0; i < 9; i++) ctx->tune[i] = options->schedulerTune[i] < 1 ? 1 : options->schedulerTune[i];
+    }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->evStart) == hipSuccess && hipEventCreate(&ctx->evStop) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->evBatchDone, hipEventDisableTiming) == hipSuccess;
@@ -495,6 +593,11 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
     if (ctx->dDiag) (void)hipFree(ctx->dDiag);
+    if (ctx->comm) { if (RcclApi* api = rccl()) (void)api->CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    if (ctx->dGatherSend) (void)hipFree(ctx->dGatherSend);
+    if (ctx->dGatherRecv) (void)hipFree(ctx->dGatherRecv);
+    for (const RtowContext_t::HostRange& r : ctx->hostRanges) (void)hipHostUnregister(r.base);
+    ctx->hostRanges.clear();
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     if (ctx->evBatchDone) (void)hipEventDestroy(ctx->evBatchDone);
@@ -541,16 +644,13 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchPrepareEntities(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
-    if (const char* env = getenv("RTOW_EXACT_TIES")) {       // 1: exact-tie kernels for every scene without volumes (slower), 0: never
+    if (ctx->flags & (RTOW_CONTEXT_EXACT_TIES_ALWAYS | RTOW_CONTEXT_EXACT_TIES_NEVER)) {   // exact-tie kernels for every scene without volumes (slower), or never
         const bool volumes = compiled.layout.sceneKind == SCENE_KIND_VOLUMES || compiled.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
-        if (!volumes) compiled.layout.exactTies = atoi(env) != 0 ? 1u : 0u;
+        if (!volumes) compiled.layout.exactTies = (ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) ? 1u : 0u;
     }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);
-    if (const char* env = getenv("RTOW_LDS_BUDGET")) {       // development aid: run small scenes through the kernels that read the tree from HBM
-        const long v = atol(env);
-        if (v >= (long)sizeof(GpuNode) && (uint32_t)v < budget) budget = (uint32_t)v;
-    }
+    if (ctx->ldsSceneBudget >= sizeof(GpuNode) && ctx->ldsSceneBudget < budget) budget = ctx->ldsSceneBudget;   // development aid: small scenes through the tree-in-HBM kernels
     if (ctx->scene.layout.totalBytes <= budget) {
         ctx->ldsSceneBytes = ctx->scene.layout.totalBytes;
         ctx->ldsNodeCount = ctx->scene.layout.nodeCount;
@@ -589,6 +689,7 @@ RTOW_API int rtowUploadSkyCubemap(RtowContext ctx, const RtowCubemapDesc* cubema
     if (cubemap->pixelStride < minStride || cubemap->pixelStride > 64) return RTOW_ERROR_INVALID_VALUE;
     if (cubemap->channelType == RTOW_CUBEMAP_SIGNED_HALF && (cubemap->pixelStride & 1)) return RTOW_ERROR_INVALID_VALUE;
     const size_t bytes = (size_t)6 * (size_t)cubemap->faceWidth * (size_t)cubemap->faceHeight * (size_t)cubemap->pixelStride;
+    if (bytes > 0x7fffffffull) return RTOW_ERROR_CAPACITY;                                      // Cubemap.Sample's strides are int32 here as in the reference (RT/Texture.cs:146-148)
     HIP_TRY(ctx, hipDeviceSynchronize(), RTOW_ERROR_LAUNCH_FAILURE);                            // no batch may still be reading the old faces
     if (bytes > ctx->cubemapCapacity) {
         if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);
@@ -652,6 +753,7 @@ RTOW_API int rtowUploadStbNoise(RtowContext ctx, const RtowStbNoiseDesc* noise)
 RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
 {
     if (!ctx || !info) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
     info->entityCount = ctx->scene.entityCount;
     info->materialCount = ctx->scene.materialCount;
@@ -671,8 +773,8 @@ RTOW_API int rtowSampleBatchDevice(RtowContext ctx, const RtowSampleParams* para
     if (v != RTOW_SUCCESS) return v;
     if (!in->color || !in->normal || !in->albedo || !in->sampleCountWeight || !out->color || !out->normal || !out->albedo || !out->sampleCountWeight)
         return RTOW_ERROR_INVALID_VALUE;
-    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE); // called from a different worker thread each time
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     *ctx->hCancel = 0u;
@@ -690,8 +792,8 @@ RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, co
     if (v != RTOW_SUCCESS) return v;
     if (!in->color || !in->normal || !in->albedo || !in->sampleCountWeight || !out->color || !out->normal || !out->albedo || !out->sampleCountWeight)
         return RTOW_ERROR_INVALID_VALUE;
-    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     const int w = (int)params->size.x, h = (int)params->size.y;
     const size_t n = (size_t)w * (size_t)h;
@@ -699,21 +801,29 @@ RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, co
     int rc = ensureStaging(ctx, n, diagBytes);
     if (rc != RTOW_SUCCESS) return rc;
     hipStream_t s = ctx->stream;
+    // inputs: one DMA per buffer into the grow-only staging (pinned when the caller registered its pools, pageable otherwise)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dColor, in->color, n * 16, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dNormal, in->normal, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dAlbedo, in->albedo, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dScw, in->sampleCountWeight, n * 4, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
 
-    RtowAccumBuffers dev{ctx->dColor, ctx->dNormal, ctx->dAlbedo, ctx->dScw}; // in place: each lane reads its pixel before writing it
+    // outputs: when every output buffer (and the diagnostics) lies in registered host memory the kernel stores straight into it - each
+    // pixel's 48 + stride bytes leave over PCIe when that pixel finishes, spread over the whole batch, and there is no copy-back at all.
+    // Pixels skipped by the slice test are not touched either way (JOBS/SampleBatchJob.cs:69-70).
+    RtowAccumBuffers dev{ctx->dColor, ctx->dNormal, ctx->dAlbedo, ctx->dScw}; // staging is read and (copy-back path) written in place: each lane reads its pixel before writing it
+    RtowAccumBuffers direct{(float*)mappedHost(ctx, out->color, n * 16), (float*)mappedHost(ctx, out->normal, n * 12), (float*)mappedHost(ctx, out->albedo, n * 12),
+                            (float*)mappedHost(ctx, out->sampleCountWeight, n * 4)};
+    uint8_t* directDiag = diagnostics ? mappedHost(ctx, diagnostics, diagBytes) : nullptr;
+    const bool zeroCopyOut = direct.color && direct.normal && direct.albedo && direct.sampleCountWeight && (!diagnostics || directDiag);
     *ctx->hCancel = 0u;
-    rc = launchSample(ctx, params, &dev, &dev, diagnostics ? ctx->dDiag : nullptr, s, cancel != nullptr);
+    rc = launchSample(ctx, params, &dev, zeroCopyOut ? &direct : &dev, diagnostics ? (zeroCopyOut ? (void*)directDiag : (void*)ctx->dDiag) : nullptr, s, cancel != nullptr);
     if (rc != RTOW_SUCCESS) return rc;
     rc = waitWithCancel(ctx, cancel);
     if (rc != RTOW_SUCCESS) return rc;
 
     // copy back ONLY the rows this slice owns: skipped pixels write nothing (JOBS/SampleBatchJob.cs:69-70)
     const int rows = ownedRows(params);
-    if (rows > 0) {
+    if (rows > 0 && !zeroCopyOut) {
         const size_t D = (size_t)params->sliceDivider, O = (size_t)params->sliceOffset;
         auto copyRows = [&](void* dst, const void* src, size_t bytesPerPixel) -> hipError_t {
             const size_t rowBytes = (size_t)w * bytesPerPixel;
@@ -727,12 +837,47 @@ RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, co
         if (diagnostics) HIP_TRY(ctx, copyRows(diagnostics, ctx->dDiag, (size_t)params->diagnosticsStride), RTOW_ERROR_LAUNCH_FAILURE);
     }
     HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
+    if (ctx->haveBatchDone) HIP_TRY(ctx, hipEventSynchronize(ctx->evBatchDone), RTOW_ERROR_LAUNCH_FAILURE);
     return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowRegisterHostBuffer(RtowContext ctx, void* pointer, size_t sizeInBytes)
+{
+    if (!ctx || !pointer || sizeInBytes == 0) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    for (const RtowContext_t::HostRange& r : ctx->hostRanges)
+        if ((uint8_t*)pointer < r.base + r.size && r.base < (uint8_t*)pointer + sizeInBytes) return RTOW_ERROR_INVALID_VALUE;   // overlaps a live registration
+    HIP_TRY(ctx, hipHostRegister(pointer, sizeInBytes, hipHostRegisterMapped | hipHostRegisterPortable), RTOW_ERROR_MEMORY_ALLOCATION);
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, pointer, 0) != hipSuccess || !dev) {
+        (void)hipHostUnregister(pointer);
+        return RTOW_ERROR_MEMORY_ALLOCATION;
+    }
+    ctx->hostRanges.push_back(RtowContext_t::HostRange{(uint8_t*)pointer, sizeInBytes, (uint8_t*)dev});
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowUnregisterHostBuffer(RtowContext ctx, void* pointer)
+{
+    if (!ctx || !pointer) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    for (size_t i = 0; i < ctx->hostRanges.size(); i++)
+        if (ctx->hostRanges[i].base == (uint8_t*)pointer) {
+            if (ctx->haveBatchDone) (void)hipEventSynchronize(ctx->evBatchDone);      // no kernel may still be storing into it
+            (void)hipStreamSynchronize(ctx->stream);
+            HIP_TRY(ctx, hipHostUnregister(pointer), RTOW_ERROR_INVALID_VALUE);
+            ctx->hostRanges.erase(ctx->hostRanges.begin() + (long)i);
+            return RTOW_SUCCESS;
+        }
+    return RTOW_ERROR_INVALID_VALUE;
 }
 
 RTOW_API int rtowGetLastSampleKernelMs(RtowContext ctx, float* outMs)
 {
     if (!ctx || !outMs) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->haveTiming) return RTOW_ERROR_INVALID_VALUE;
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     HIP_TRY(ctx, hipEventSynchronize(ctx->evStop), RTOW_ERROR_LAUNCH_FAILURE);
@@ -811,6 +956,136 @@ RTOW_API int rtowAddAccumDevice(RtowContext ctx, int32_t pixelCount, const RtowA
     return RTOW_SUCCESS;
 }
 
+RTOW_API int rtowCommGetUniqueId(RtowCommId* outId)
+{
+    if (!outId) return RTOW_ERROR_INVALID_VALUE;
+    RcclApi* api = rccl();
+    if (!api) return RTOW_ERROR_UNSUPPORTED;                       // no librccl.so in this process or on the loader path
+    RcclUniqueId id;
+    if (api->GetUniqueId(&id) != 0) return RTOW_ERROR_LAUNCH_FAILURE;
+    memcpy(outId->bytes, id.internal, sizeof(id.internal));
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowCommInit(RtowContext ctx, const RtowCommId* id, int32_t rank, int32_t worldSize)
+{
+    if (!ctx || !id || worldSize < 1 || rank < 0 || rank >= worldSize) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->comm) return RTOW_ERROR_INVALID_VALUE;                // one communicator per context; rtowCommDestroy first
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    RcclApi* api = rccl();
+    if (!api) { logf(ctx, 2, "rccl", "librccl.so could not be loaded: %s", dlerror()); return RTOW_ERROR_UNSUPPORTED; }
+    RcclUniqueId uid;
+    memcpy(uid.internal, id->bytes, sizeof(uid.internal));
+    void* comm = nullptr;
+    RCCL_TRY(ctx, api, api->CommInitRank(&comm, worldSize, uid, rank));
+    ctx->comm = comm;
+    ctx->commRank = rank;
+    ctx->commWorld = worldSize;
+    logf(ctx, 4, "rccl", "rank %d of %d joined", rank, worldSize);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowCommDestroy(RtowContext ctx)
+{
+    if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->comm) return RTOW_SUCCESS;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    (void)hipDeviceSynchronize();
+    RcclApi* api = rccl();
+    if (api) (void)api->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->commRank = 0;
+    ctx->commWorld = 1;
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height, int32_t sliceDivider, const RtowAccumBuffers* mine,
+                                  const RtowAccumBuffers* frame, int32_t what, int32_t root, void* stream)
+{
+    if (!ctx || !mine || width <= 0 || height <= 0 || sliceDivider < 1 || (what & ~RTOW_GATHER_ALL) || !(what & RTOW_GATHER_ALL)) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int world = ctx->comm ? ctx->commWorld : 1, rank = ctx->comm ? ctx->commRank : 0;
+    if (sliceDivider != world || root < 0 || root >= world) return RTOW_ERROR_INVALID_VALUE;   // rank g owns the rows of slice g: one slice per rank
+    if (rank == root && !frame) return RTOW_ERROR_INVALID_VALUE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // the rows being gathered were written by the last sample batch, whatever stream that was enqueued on
+    if (ctx->haveBatchDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evBatchDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+
+    static const int kComponents[4] = {4, 3, 3, 1};
+    float* const mineBuf[4] = {mine->color, mine->normal, mine->albedo, mine->sampleCountWeight};
+    float* const frameBuf[4] = {frame ? frame->color : nullptr, frame ? frame->normal : nullptr, frame ? frame->albedo : nullptr, frame ? frame->sampleCountWeight : nullptr};
+    unsigned floatsPerPixel = 0;
+    for (int b = 0; b < 4; b++)
+        if (what & (1 << b)) {
+            if (!mineBuf[b] || (rank == root && !frameBuf[b])) return RTOW_ERROR_INVALID_VALUE;
+            floatsPerPixel += (unsigned)kComponents[b];
+        }
+    auto packedFloats = [&](int r) { return (size_t)rowsOwnedBy(r, world, height) * (size_t)width * floatsPerPixel; };
+
+    if (world == 1 || rank == root) {
+        // the root's own rows: already in place when frame == mine, else copied row by row on the device
+        const unsigned rows = rowsOwnedBy(rank, world, height);
+        for (int b = 0; b < 4; b++)
+            if ((what & (1 << b)) && frameBuf[b] != mineBuf[b]) {
+                const size_t rowBytes = (size_t)width * kComponents[b] * 4u;
+                HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t*)frameBuf[b] + (size_t)rank * rowBytes, (size_t)world * rowBytes, (const uint8_t*)mineBuf[b] + (size_t)rank * rowBytes,
+                                              (size_t)world * rowBytes, rowBytes, rows, hipMemcpyDeviceToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+            }
+        if (world == 1) return RTOW_SUCCESS;
+    }
+    RcclApi* api = rccl();
+    if (!api) return RTOW_ERROR_UNSUPPORTED;
+
+    if (rank != root) {
+        // pack this rank's rows of the selected buffers back to back, one send to the root over this GPU's own xGMI link to it
+        const size_t need = packedFloats(rank);
+        if (need > ctx->gatherSendFloats) {
+            if (ctx->dGatherSend) (void)hipFree(ctx->dGatherSend);
+            ctx->dGatherSend = nullptr; ctx->gatherSendFloats = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dGatherSend, need * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->gatherSendFloats = need;
+        }
+        size_t at = 0;
+        const unsigned rows = rowsOwnedBy(rank, world, height);
+        for (int b = 0; b < 4; b++)
+            if (what & (1 << b)) {
+                HIP_TRY(ctx, launchCopyRows(mineBuf[b], ctx->dGatherSend + at, (unsigned)(width * kComponents[b]), rows, (unsigned)rank, (unsigned)world, false, s), RTOW_ERROR_LAUNCH_FAILURE);
+                at += (size_t)rows * width * kComponents[b];
+            }
+        if (need) RCCL_TRY(ctx, api, api->Send(ctx->dGatherSend, need, kRcclFloat32, root, ctx->comm, s));
+        return RTOW_SUCCESS;
+    }
+
+    // root: one receive per peer into its own region of the staging block (posted as one group: all seven links run at once), then scatter
+    size_t total = 0;
+    std::vector<size_t> offset((size_t)world, 0);
+    for (int r = 0; r < world; r++) { offset[(size_t)r] = total; if (r != root) total += packedFloats(r); }
+    if (total > ctx->gatherRecvFloats) {
+        if (ctx->dGatherRecv) (void)hipFree(ctx->dGatherRecv);
+        ctx->dGatherRecv = nullptr; ctx->gatherRecvFloats = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->dGatherRecv, total * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
+        ctx->gatherRecvFloats = total;
+    }
+    RCCL_TRY(ctx, api, api->GroupStart());
+    for (int r = 0; r < world; r++)
+        if (r != root && packedFloats(r)) RCCL_TRY(ctx, api, api->Recv(ctx->dGatherRecv + offset[(size_t)r], packedFloats(r), kRcclFloat32, r, ctx->comm, s));
+    RCCL_TRY(ctx, api, api->GroupEnd());
+    for (int r = 0; r < world; r++) {
+        if (r == root) continue;
+        size_t at = offset[(size_t)r];
+        const unsigned rows = rowsOwnedBy(r, world, height);
+        for (int b = 0; b < 4; b++)
+            if (what & (1 << b)) {
+                HIP_TRY(ctx, launchCopyRows(frameBuf[b], ctx->dGatherRecv + at, (unsigned)(width * kComponents[b]), rows, (unsigned)r, (unsigned)world, true, s), RTOW_ERROR_LAUNCH_FAILURE);
+                at += (size_t)rows * width * kComponents[b];
+            }
+    }
+    return RTOW_SUCCESS;
+}
+
 RTOW_API int rtowDeviceAlloc(RtowContext ctx, size_t sizeInBytes, void** outPointer)
 {
     if (!ctx || !outPointer || sizeInBytes == 0) return RTOW_ERROR_INVALID_VALUE;
@@ -853,11 +1128,23 @@ RTOW_API int rtowDeviceMemset(RtowContext ctx, void* pointer, int value, size_t 
     return RTOW_SUCCESS;
 }
 
+RTOW_API int rtowGetBatchStatus(RtowContext ctx)
+{
+    if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    // the last batch may have been enqueued on a caller's stream: its end is evBatchDone, not the end of ctx->stream
+    if (ctx->haveBatchDone) HIP_TRY(ctx, hipEventSynchronize(ctx->evBatchDone), RTOW_ERROR_LAUNCH_FAILURE);
+    return takeOverflow(ctx);
+}
+
 RTOW_API int rtowSynchronize(RtowContext ctx)
 {
     if (!ctx) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    if (ctx->haveBatchDone) HIP_TRY(ctx, hipEventSynchronize(ctx->evBatchDone), RTOW_ERROR_LAUNCH_FAILURE);
     return takeOverflow(ctx);
 }
 

@@ -40,6 +40,8 @@ struct Builder {
     std::vector<Box> primBox;
     std::vector<float> centroid[3];
     std::vector<TmpNode> nodes;
+    std::vector<int> order;          // sweep scratch, grown once to the root's size
+    std::vector<double> rightArea;
     int maxDepthSeen = 0;
 
     // returns child code; box receives the subtree bounds. depthLeft = inner-node levels still allowed.
@@ -55,12 +57,17 @@ struct Builder {
 
         double bestCost = DBL_MAX;
         int bestAxis = -1, bestSplit = -1;
-        std::vector<int> order(n), bestOrder;
-        std::vector<double> rightArea(n);
+        // scratch is shared by the whole recursion (a node's sweep is over before its children start); only the winning (axis, split)
+        // is remembered during the sweep and the range is sorted once more along that axis afterwards - copying the sorted order on
+        // every cost improvement was O(n) copies of O(n) ints at the top of a 65 535-entity tree
+        if ((int)order.size() < n) { order.resize(n); rightArea.resize(n); }
+        auto sortAlong = [&](int axis, int* first, int* last) {
+            const std::vector<float>& c = centroid[axis];
+            std::sort(first, last, [&c](int a, int b) { return c[a] < c[b] || (c[a] == c[b] && a < b); });
+        };
         for (int axis = 0; axis < 3; axis++) {
             std::copy(idx.begin() + begin, idx.begin() + end, order.begin());
-            const std::vector<float>& c = centroid[axis];
-            std::sort(order.begin(), order.end(), [&c](int a, int b) { return c[a] < c[b] || (c[a] == c[b] && a < b); });
+            sortAlong(axis, order.data(), order.data() + n);
             Box acc;
             acc.reset();
             for (int i = n - 1; i >= 1; i--) { acc.grow(primBox[order[i]]); rightArea[i] = acc.area(); }
@@ -69,14 +76,11 @@ struct Builder {
                 acc.grow(primBox[order[i - 1]]);
                 if (i > cap || (n - i) > cap) continue; // keep both subtrees buildable within the depth bound
                 const double cost = acc.area() * i + rightArea[i] * (n - i);
-                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = i; bestOrder = order; }
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = i; }
             }
         }
-        if (bestAxis < 0) { // cannot happen while n <= 2^depthLeft; defensive median split
-            bestOrder.assign(idx.begin() + begin, idx.begin() + end);
-            bestSplit = n / 2;
-        }
-        std::copy(bestOrder.begin(), bestOrder.end(), idx.begin() + begin);
+        if (bestAxis < 0) bestSplit = n / 2; // cannot happen while n <= 2^depthLeft; defensive median split in the current order
+        else sortAlong(bestAxis, idx.data() + begin, idx.data() + end);   // the comparator is a total order: the same sequence the sweep saw
 
         const int self = (int)nodes.size();
         nodes.push_back(TmpNode{});

@@ -127,6 +127,8 @@ hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inN
                           uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, hipStream_t stream);
 
 hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t stream); // dst += src
+// rows first, first + step, ... (`rows` of them, `rowFloats` floats each) of a full-frame buffer -> / <- one contiguous block
+hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, bool toFrame, hipStream_t stream);
 
 // Per-block partial results of the metrics reduction; the host folds them in block order.
 struct MetricsPartial {

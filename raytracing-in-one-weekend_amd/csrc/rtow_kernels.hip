@@ -30,6 +30,9 @@ __global__ void __launch_bounds__(256) fold_unit_records_kernel(SampleKernelArgs
     const unsigned ticket = blockIdx.x * blockDim.x + threadIdx.x;       // owned pixel
     const unsigned pixels = A.totalWork / A.groupsPerPixel;
     if (ticket >= pixels) return;
+    // a cancelled batch leaves units that were never pulled with stale records: like the reference, whose cancelled Execute returns before
+    // any write (JOBS/SampleBatchJob.cs:61-62), nothing is folded then (the flag stays set until the next batch is enqueued)
+    if (A.cancelFlag && *A.cancelFlag != 0u) return;
     const int ownedRow = (int)(ticket / (unsigned)A.width);
     const int cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
     const int cy = A.sliceOffset + ownedRow * A.sliceDivider;
@@ -368,6 +371,30 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
         case SCENE_KIND_VOLUMES_TEXTURED: return launchSampleVolumesTextured(args, numBlocks, ldsBytes, stream, allLds);
         default: return args.layout.exactTies ? launchSampleGeneralTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleGeneral(args, numBlocks, ldsBytes, stream, allLds);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// rtowGatherRowsDevice: rows first, first + step, ... of a full-frame buffer <-> one contiguous block (what travels over xGMI).
+// HBM bound, 4 B read + 4 B written per float; at most 11 floats per owned pixel per batch.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy_rows_kernel(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, int toFrame)
+{
+    const size_t total = (size_t)rows * rowFloats;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = i / rowFloats, j = i - k * rowFloats;
+        const size_t f = ((size_t)first + k * step) * rowFloats + j;
+        if (toFrame) frame[f] = packed[i];
+        else packed[i] = frame[f];
+    }
+}
+
+hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, bool toFrame, hipStream_t stream)
+{
+    const size_t total = (size_t)rows * rowFloats;
+    if (total == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)(total < (size_t)256 * 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, stream, frame, packed, rowFloats, rows, first, step, toFrame ? 1 : 0);
+    return hipGetLastError();
 }
 
 hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream)

@@ -65,15 +65,59 @@ class DeviceBuffer:
 class Context:
     """RtowContext: one per GPU (one process per GPU in multi-GPU runs)."""
 
-    def __init__(self, device_ordinal=0, log=None, log_level=0):
+    def __init__(self, device_ordinal=0, log=None, log_level=0, flags=0, lds_scene_budget=0, scheduler_tune=None):
+        """flags: abi.CONTEXT_* (RtowContextFlags); lds_scene_budget / scheduler_tune: the development knobs of RtowContextOptions."""
         self._cb = abi.LogCallback(log) if log else abi.LogCallback()
-        opts = abi.ContextOptions(device_ordinal, self._cb, None, log_level)
+        opts = abi.ContextOptions(device_ordinal, self._cb, None, log_level, flags, lds_scene_budget)
+        if scheduler_tune is not None:
+            if len(scheduler_tune) != 9:
+                raise ValueError("scheduler_tune takes 8 stage thresholds + the box-walk slice")
+            for i, v in enumerate(scheduler_tune):
+                opts.schedulerTune[i] = int(v)
         self.handle = C.c_void_p()
         check(load().rtowCreateContext(C.byref(opts), C.byref(self.handle)), "rtowCreateContext")
         self._scene_keepalive = None
+        self._registered = []
+
+    def register_host_buffers(self, *arrays):
+        """Pin the host's long-lived accumulation pools (UNITY/Raytracer.cs:279-288) so that rtowSampleBatch runs without staging copies
+        on the output side; the arrays must stay alive until unregister_host_buffers() / close()."""
+        for a in arrays:
+            check(load().rtowRegisterHostBuffer(self.handle, a.ctypes.data, a.nbytes), "rtowRegisterHostBuffer")
+            self._registered.append(a)
+
+    def unregister_host_buffers(self):
+        for a in self._registered:
+            load().rtowUnregisterHostBuffer(self.handle, a.ctypes.data)
+        self._registered = []
+
+    def batch_status(self):
+        """Status of the batches enqueued since the last report (waits for the most recent one, wherever it was enqueued)."""
+        check(load().rtowGetBatchStatus(self.handle), "rtowGetBatchStatus")
+
+    # ---- multi-GPU: one process per GPU, rows gathered over RCCL behind the C ABI ----
+    @staticmethod
+    def comm_unique_id():
+        cid = abi.CommId()
+        check(load().rtowCommGetUniqueId(C.byref(cid)), "rtowCommGetUniqueId")
+        return C.string_at(C.addressof(cid), 128)       # all 128 bytes (a c_char array's .value would stop at the first NUL)
+
+    def comm_init(self, id_bytes, rank, world):
+        cid = abi.CommId()
+        C.memmove(C.addressof(cid), id_bytes, 128)
+        check(load().rtowCommInit(self.handle, C.byref(cid), rank, world), "rtowCommInit")
+
+    def comm_destroy(self):
+        check(load().rtowCommDestroy(self.handle), "rtowCommDestroy")
+
+    def gather_rows(self, width, height, divider, mine, frame, what=abi.GATHER_COLOR, root=0, stream=None):
+        """mine / frame: abi.AccumBuffers of device pointers (frame may be None on non-root ranks)."""
+        check(load().rtowGatherRowsDevice(self.handle, width, height, divider, C.byref(mine), C.byref(frame) if frame is not None else None, what, root, stream),
+              "rtowGatherRowsDevice")
 
     def close(self):
         if self.handle:
+            self._registered = []          # rtowDestroyContext drops the registrations
             load().rtowDestroyContext(self.handle)
             self.handle = C.c_void_p()
 

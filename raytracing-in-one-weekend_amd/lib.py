@@ -63,6 +63,13 @@ def load():
     lib.rtowDeviceCopy.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
     lib.rtowDeviceMemset.argtypes = [vp, vp, C.c_int, C.c_size_t]
     lib.rtowSynchronize.argtypes = [vp]
+    lib.rtowGetBatchStatus.argtypes = [vp]
+    lib.rtowRegisterHostBuffer.argtypes = [vp, vp, C.c_size_t]
+    lib.rtowUnregisterHostBuffer.argtypes = [vp, vp]
+    lib.rtowCommGetUniqueId.argtypes = [C.POINTER(abi.CommId)]
+    lib.rtowCommInit.argtypes = [vp, C.POINTER(abi.CommId), C.c_int32, C.c_int32]
+    lib.rtowCommDestroy.argtypes = [vp]
+    lib.rtowGatherRowsDevice.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, AB, AB, C.c_int32, C.c_int32, vp]
     for name in abi.EXPORTED_SYMBOLS:
         if name not in ("rtowErrorString",):
             getattr(lib, name).restype = C.c_int

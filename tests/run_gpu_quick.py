@@ -14,7 +14,8 @@ def main():
     w, h, spp, depth = [int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (1920, 1080, 32, 8))]
     name = sys.argv[5] if len(sys.argv) > 5 else "cover"
     scene = {"cover": rt.scenes.cover_scene, "moving": rt.scenes.moving_scene, "stress": rt.scenes.stress_scene, "mixed": rt.scenes.mixed_scene, "mesh": rt.scenes.mesh_scene, "volumes": rt.scenes.volume_scene, "textured": rt.scenes.textured_scene}[name]()
-    ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: print("[rtow]", tag.decode(), msg.decode()), log_level=4)
+    tune = [int(x) for x in sys.argv[6].split(",")] if len(sys.argv) > 6 else None      # RtowContextOptions.schedulerTune, 9 integers
+    ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: print("[rtow]", tag.decode(), msg.decode()), log_level=4, scheduler_tune=tune)
     ctx.upload_scene(scene.desc())
     info = ctx.scene_info()
     print("scene: nodes", info.bvhNodeCount, "depth", info.bvhDepth, "ldsBytes", info.ldsBytesScene, "inLds", info.sceneInLds)

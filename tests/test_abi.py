@@ -23,11 +23,11 @@ def test_library_loads_and_exports_every_declared_symbol(rt):
 
 
 def test_ctypes_mirror_matches_c_layout(rt, oracle):
-    sizes = (C.c_int * 17)()
+    sizes = (C.c_int * 18)()
     oracle.load().oracle_abi_sizes(sizes)  # sizeof() as g++ sees include/rtow.h
     a = rt.abi
     mirror = [a.Texture, a.Material, a.Entity, a.SceneDesc, a.SceneInfo, a.View, a.Environment, a.SampleParams, a.AccumBuffers,
-              a.ContextOptions, a.Metrics, a.CombineParams, a.Triangle, a.CubemapDesc, a.BlueNoiseDesc, a.StbNoiseDesc, a.Image]
+              a.ContextOptions, a.Metrics, a.CombineParams, a.Triangle, a.CubemapDesc, a.BlueNoiseDesc, a.StbNoiseDesc, a.Image, a.CommId]
     assert C.sizeof(a.Triangle) == 96  # float3x3 + float3x3 + float2x3 (RT/EntityTypes/Triangle.cs:8-12)
     assert [C.sizeof(t) for t in mirror] == list(sizes)
     assert C.sizeof(a.View) == 88  # 7 x float3 + float (RT/View.cs:8-14)

@@ -127,11 +127,72 @@ def test_hit_list_overflow_is_reported(rt, gpu_context):
     assert lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(acc), C.byref(acc), None, None, None) == a.RTOW_SUCCESS
     assert lib.rtowSynchronize(ctx.handle) == a.RTOW_ERROR_CAPACITY
     assert lib.rtowSynchronize(ctx.handle) == a.RTOW_SUCCESS
+    # a batch enqueued on a CALLER's stream: the status query waits for that batch (not for the context's own, idle stream), reports it
+    # once, and a cancelled batch does not leave its flag behind for the next one
+    import torch
+    side = torch.cuda.Stream()
+    assert lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(acc), C.byref(acc), None, side.cuda_stream, None) == a.RTOW_SUCCESS
+    assert lib.rtowGetBatchStatus(ctx.handle) == a.RTOW_ERROR_CAPACITY
+    assert lib.rtowGetBatchStatus(ctx.handle) == a.RTOW_SUCCESS
+    token = C.c_uint8(1)                                                # already cancelled: whatever the kernel flagged is discarded with the batch
+    big = rt.scenes.make_params(deep, 256, 256, spp=8, trace_depth=4)
+    nb = 256 * 256
+    bb = [rt.DeviceBuffer(ctx, nb * c * 4).zero() for c in (4, 3, 3, 1)]
+    accb = a.AccumBuffers(*[b.ptr for b in bb])
+    assert lib.rtowSampleBatchDevice(ctx.handle, C.byref(big), C.byref(accb), C.byref(accb), None, None, C.addressof(token)) == a.RTOW_ERROR_CANCELLED
+    assert lib.rtowGetBatchStatus(ctx.handle) == a.RTOW_SUCCESS
+    for b in bufs + bb:
+        b.free()
+
+
+def test_slice_that_owns_no_row_does_nothing(rt, gpu_context):
+    """SliceOffset >= height (tile-parallel with more ranks than rows): the reference's Execute returns for every index
+    (JOBS/SampleBatchJob.cs:69-70); the batch succeeds, writes nothing and can be timed."""
+    ctx = gpu_context
+    scene = rt.scenes.tiny_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 16, 4
+    p = rt.scenes.make_params(scene, w, h, spp=2, trace_depth=4, slice_offset=5, slice_divider=8)
+    ins = {"color": np.full((w * h, 4), 3.0, np.float32), "normal": np.full((w * h, 3), 4.0, np.float32),
+           "albedo": np.full((w * h, 3), 5.0, np.float32), "scw": np.full(w * h, 6.0, np.float32)}
+    out = rt.sample_batch_host(ctx, p, inputs=ins)
+    for k in ins:
+        assert np.array_equal(out[k], ins[k]), k
+    assert ctx.last_sample_kernel_ms() >= 0.0
+    # per-sample policy too (its fold kernel would be a zero-sized launch)
+    p.rngPolicy = rt.abi.RNG_PER_SAMPLE
+    out = rt.sample_batch_host(ctx, p, inputs=ins)
+    for k in ins:
+        assert np.array_equal(out[k], ins[k]), k
+
+
+def test_cancelled_per_sample_batch_leaves_the_accumulators_alone(rt, gpu_context):
+    """RTOW_RNG_PER_SAMPLE folds unit records into the accumulators after the sample kernel; after a cancellation the records of units
+    that never ran are stale, so nothing may be folded: in-place accumulators keep their input values (the reference's cancelled Execute
+    returns before any write, JOBS/SampleBatchJob.cs:61-62)."""
+    a = rt.abi
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 640, 360
+    n = w * h
+    p = rt.scenes.make_params(scene, w, h, spp=64, trace_depth=8, rng_policy=a.RNG_PER_SAMPLE)
+    bufs = [rt.DeviceBuffer(ctx, n * c * 4) for c in (4, 3, 3, 1)]
+    lib = rt.lib.load()
+    for b in bufs:
+        assert lib.rtowDeviceMemset(ctx.handle, b.handle, 0, b.nbytes) == 0
+    acc = a.AccumBuffers(*[b.ptr for b in bufs])
+    token = C.c_uint8(1)
+    assert lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(acc), C.byref(acc), None, None, C.addressof(token)) == a.RTOW_ERROR_CANCELLED
+    ctx.synchronize()
+    for b, c in zip(bufs, (4, 3, 3, 1)):
+        assert not b.download(np.float32, (n, c)).any(), "a cancelled batch folded stale unit records into the accumulators"
+        b.free()
 
 
 def test_exact_tie_kernels_can_be_forced(rt, oracle):
-    """RTOW_EXACT_TIES=1 (read at upload) selects the exact-tie kernels for a scene without duplicates; same image, bit for bit."""
-    import os
+    """RTOW_CONTEXT_EXACT_TIES_ALWAYS (a context option, applied at upload) selects the exact-tie kernels for a scene without duplicates;
+    same image, bit for bit."""
     scene = rt.scenes.mixed_scene()
     desc = scene.desc()
     p = rt.scenes.make_params(scene, 64, 40, spp=4, trace_depth=8)
@@ -140,17 +201,15 @@ def test_exact_tie_kernels_can_be_forced(rt, oracle):
     osc.close()
     for forced in (False, True):
         log = []
-        ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: log.append(msg.decode()), log_level=4)
-        try:
-            if forced:
-                os.environ["RTOW_EXACT_TIES"] = "1"
-            ctx.upload_scene(desc)
-        finally:
-            os.environ.pop("RTOW_EXACT_TIES", None)
+        ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: log.append(msg.decode()), log_level=4, flags=rt.abi.CONTEXT_EXACT_TIES_ALWAYS if forced else 0)
+        ctx.upload_scene(desc)
         assert any("exact-tie kernels" in m for m in log) == forced, log
         got = rt.sample_batch_host(ctx, p)
         for k in ("color", "normal", "albedo", "scw"):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (forced, k)
+        ctx.close()
+    with pytest.raises(rt.lib.RtowError):                                # contradictory switches
+        rt.Context(0, flags=rt.abi.CONTEXT_EXACT_TIES_ALWAYS | rt.abi.CONTEXT_EXACT_TIES_NEVER)
 
 
 def test_error_codes(rt, gpu_context):
@@ -353,7 +412,7 @@ def test_adaptive_sample_counts_match_oracle(rt, oracle, gpu_context):
     assert len(np.unique(r2["diag"][:, 0])) > 3
 
 
-def test_camera_ray_candidate_lists_are_conservative(rt, oracle, gpu_context, monkeypatch):
+def test_camera_ray_candidate_lists_are_conservative(rt, oracle, gpu_context):
     """Depth-0 rays take their candidates from a per-pixel list of leaf-parent nodes built by one conservative beam walk
     (primary_candidates_kernel) instead of walking the tree.  The frame must not change by a bit when the lists are switched off, and must equal the oracle, for the cases that
     stretch the beam: huge pixels (tiny frames), a wide lens, no jitter, interlaced slices, camera inside the geometry, a tree outside LDS."""
@@ -374,15 +433,14 @@ def test_camera_ray_candidate_lists_are_conservative(rt, oracle, gpu_context, mo
     cases.append((inside, dict(width=32, height=32, spp=8, trace_depth=6)))
     cases.append((rt.scenes.mixed_scene(), dict(width=48, height=32, spp=8, trace_depth=4)))
     cases.append((rt.scenes.stress_scene(count=3000, max_tentatives=12000), dict(width=60, height=34, spp=4, trace_depth=3)))
+    walker = rt.Context(0, flags=rt.abi.CONTEXT_NO_CAMERA_RAY_LISTS)     # a context that walks the tree for camera rays too
     for scene, kw in cases:
         desc = scene.desc()
         ctx.upload_scene(desc)
+        walker.upload_scene(desc)
         p = rt.scenes.make_params(scene, **kw)
-        monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS", raising=False)
         with_lists = rt.sample_batch_host(ctx, p)
-        monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
-        without = rt.sample_batch_host(ctx, p)
-        monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS", raising=False)
+        without = rt.sample_batch_host(walker, p)
         osc = oracle.OracleScene(desc)
         ref = osc.sample_batch(p)
         osc.close()
@@ -390,3 +448,4 @@ def test_camera_ray_candidate_lists_are_conservative(rt, oracle, gpu_context, mo
             assert np.array_equal(with_lists[k].view(np.uint32), without[k].view(np.uint32)), (scene.name, kw, k)
             assert np.array_equal(with_lists[k].view(np.uint32), ref[k].view(np.uint32)), (scene.name, kw, k)
         assert np.array_equal(with_lists["diag"][:, 0], ref["diag"][:, 0])
+    walker.close()

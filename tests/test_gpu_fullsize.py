@@ -62,51 +62,62 @@ def test_config2_cover_1080p_256spp(rt, oracle, gpu_context):
     _check_sparse(rt, oracle, gpu_context, rt.scenes.cover_scene(), 1920, 1080, 256, 8, count=600)
 
 
-def test_config3_cover_4k_16_bounces(rt, oracle, gpu_context):
-    """BASELINE.json configs[2] geometry (3840x2160, 16 bounces) at 64 spp per batch: exercises the 16-deep path history."""
-    _check_sparse(rt, oracle, gpu_context, rt.scenes.cover_scene(), 3840, 2160, 64, 16, count=500, seed=3)
+def test_config3_cover_4k_1024spp_16_bounces(rt, oracle, gpu_context):
+    """BASELINE.json configs[2] on one GPU: cover scene 3840x2160, 1024 spp in ONE batch (one generator runs through all 1024 samples of a
+    pixel), 16 bounces.  The 8-way tile split of the same config is test_config3_tile_split_slices_equal_the_whole_frame."""
+    _check_sparse(rt, oracle, gpu_context, rt.scenes.cover_scene(), 3840, 2160, 1024, 16, count=400, seed=3)
+
+
+def test_config3_tile_split_slices_equal_the_whole_frame(rt, gpu_context):
+    """BASELINE.json configs[2] partition: the 4K frame as 8 row-interleaved slices (SliceDivider = 8, JOBS/SampleBatchJob.cs:69-70), each
+    rendered on its own into a NaN-filled frame, must reassemble into the whole-frame render bit for bit (16 spp: the property is per pixel)."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h, spp, depth, G = 3840, 2160, 16, 16, 8
+    whole = _device_render(rt, ctx, rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=11), w * h, 4)
+    rows = np.arange(w * h) // w
+    for g in range(G):
+        part = _device_render(rt, ctx, rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=11, slice_offset=g, slice_divider=G), w * h, 4)
+        own = rows % G == g
+        for k in ("color", "normal", "albedo", "scw", "diag"):
+            assert np.array_equal(part[k][own].view(np.uint32), whole[k][own].view(np.uint32)), (g, k)
+            assert np.all(part[k][~own].view(np.uint32) == 0xFFFFFFFF) or k == "diag", (g, k, "a pixel outside the slice was written")
 
 
 def test_config4_stress_10k_spheres(rt, oracle, gpu_context):
-    """BASELINE.json configs[3]: 10 000-sphere scene (deep BVH, image larger than LDS) at 1920x1080, 32 spp."""
+    """BASELINE.json configs[3]: 10 000-sphere scene (deep BVH, image larger than LDS) at 1920x1080, 256 spp."""
     scene = rt.scenes.stress_scene()
     assert scene.entity_count == 10000
-    gpu = _check_sparse(rt, oracle, gpu_context, scene, 1920, 1080, 32, 8, count=500, seed=5)
+    gpu = _check_sparse(rt, oracle, gpu_context, scene, 1920, 1080, 256, 8, count=500, seed=5)
     info = gpu_context.scene_info()
     assert info.sceneInLds == 0 and info.bvhNodeCount == 9999
 
 
 def test_config5_moving_defocus_1080p(rt, oracle, gpu_context):
-    """BASELINE.json configs[4]: moving spheres + aperture 0.05 at 1920x1080, 64 spp."""
-    _check_sparse(rt, oracle, gpu_context, rt.scenes.moving_scene(), 1920, 1080, 64, 8, count=500, seed=7, stride=16)
+    """BASELINE.json configs[4]: moving spheres + aperture 0.05 at 1920x1080, 512 spp."""
+    _check_sparse(rt, oracle, gpu_context, rt.scenes.moving_scene(), 1920, 1080, 512, 8, count=400, seed=7, stride=16)
 
 
 @pytest.mark.parametrize("name", ["cover", "moving", "stress", "mixed"])
-def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, monkeypatch, name):
+def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, name):
     """Results-neutral machinery at full size: camera-ray candidate lists on / off, longest-chunk-first ordering on / off (first launch =
-    probe order, second = measured order) and different stage thresholds must all give the same 1080p frame, bit for bit."""
-    ctx = gpu_context
+    probe order, second = measured order) and different stage thresholds (RtowContextOptions) must all give the same 1080p frame, bit for bit."""
+    a = rt.abi
     scene = {"cover": rt.scenes.cover_scene, "moving": rt.scenes.moving_scene, "stress": lambda: rt.scenes.stress_scene(count=6000, max_tentatives=30000),
              "mixed": rt.scenes.mixed_scene}[name]()
-    ctx.upload_scene(scene.desc())
+    desc = scene.desc()
     w, h, spp = 1920, 1080, 6
     p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=8)
-    for var in ("RTOW_NO_PRIMARY_LISTS", "RTOW_NO_CHUNK_ORDER", "RTOW_TUNE"):
-        monkeypatch.delenv(var, raising=False)
-    base = _device_render(rt, ctx, p, w * h, 4)
-    again = _device_render(rt, ctx, p, w * h, 4)              # chunk order now comes from the first launch's cost map
-    variants = {"second launch": again}
-    monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
-    variants["no camera-ray lists"] = _device_render(rt, ctx, p, w * h, 4)
-    monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
-    monkeypatch.setenv("RTOW_NO_CHUNK_ORDER", "1")
-    variants["row-order tickets"] = _device_render(rt, ctx, p, w * h, 4)
-    monkeypatch.delenv("RTOW_NO_CHUNK_ORDER")
-    monkeypatch.setenv("RTOW_TUNE", "1,1,1,1,1,1,1,16")
-    variants["every stage at once"] = _device_render(rt, ctx, p, w * h, 4)
-    monkeypatch.setenv("RTOW_TUNE", "32,64,16,16,16,1,1,5")
-    variants["heavy thresholds, 5-visit walk slices"] = _device_render(rt, ctx, p, w * h, 4)
-    monkeypatch.delenv("RTOW_TUNE")
+    gpu_context.upload_scene(desc)
+    base = _device_render(rt, gpu_context, p, w * h, 4)
+    variants = {"second launch": _device_render(rt, gpu_context, p, w * h, 4)}   # chunk order now comes from the first launch's cost map
+    for what, kw in (("no camera-ray lists", dict(flags=a.CONTEXT_NO_CAMERA_RAY_LISTS)), ("row-order tickets", dict(flags=a.CONTEXT_NO_CHUNK_ORDER)),
+                     ("every stage at once", dict(scheduler_tune=(1, 1, 1, 1, 1, 1, 1, 1, 16))),
+                     ("heavy thresholds, 5-visit walk slices", dict(scheduler_tune=(32, 64, 16, 16, 16, 1, 1, 1, 5)))):
+        with rt.Context(0, **kw) as ctx:
+            ctx.upload_scene(desc)
+            variants[what] = _device_render(rt, ctx, p, w * h, 4)
     for what, r in variants.items():
         for k in ("color", "normal", "albedo", "scw", "diag"):
             assert np.array_equal(base[k].view(np.uint32), r[k].view(np.uint32)), (name, what, k)

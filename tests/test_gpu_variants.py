@@ -49,17 +49,9 @@ def test_every_kernel_variant(rt, oracle, kind, in_lds):
     scene = _scene(rt, kind)
     desc = scene.desc()
     log = []
-    ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: log.append(msg.decode()), log_level=4)
-    old = os.environ.get("RTOW_LDS_BUDGET")
-    try:
-        if not in_lds:
-            os.environ["RTOW_LDS_BUDGET"] = "1024"                      # 16 nodes in LDS, everything else read through L2
-        ctx.upload_scene(desc)
-    finally:
-        if old is None:
-            os.environ.pop("RTOW_LDS_BUDGET", None)
-        else:
-            os.environ["RTOW_LDS_BUDGET"] = old
+    # RtowContextOptions.ldsSceneBudgetBytes = 1024: 16 nodes in LDS, everything else read through L2
+    ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: log.append(msg.decode()), log_level=4, lds_scene_budget=0 if in_lds else 1024)
+    ctx.upload_scene(desc)
     assert bool(ctx.scene_info().sceneInLds) == in_lds
     assert any("exact-tie kernels" in m for m in log) == kind.endswith("_ties"), log        # the scene really selects the variant it is meant to cover
     noise = rt.scenes.NoiseTextures(row_stride=8, count=2, seed=3)
