@@ -11,16 +11,22 @@ ping-pong buffers with a fresh seed, exactly like the reference's successive bat
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
+N = 1: the K timed steps are enqueued as chains of `--chain` successive batches (rtowSampleBatchChainDevice; the reference itself keeps
+two batches in flight, Raytracer.cs:586-593): one launch per chain, in which a pixel chunk's next batch starts as soon as its previous
+batch is stored.  The same K steps as plain one-launch-per-batch calls and the host-buffer form (rtowSampleBatch on pinned host arrays)
+are measured after the timed region and reported next to `value` (`plain_batches`, `host_buffer_ms_per_step`).
+
 N > 1: one process per GPU, no data-path collective inside a batch; the batch's results are combined over RCCL afterwards.  The total work is fixed
-(same frame, same spp), so scaling is "strong".  Two partitions (raytracing-in-one-weekend_amd/multigpu.py):
-  --partition batches (default)  every rank renders the whole frame with spp/N samples and its own seed from zeroed
-                                 accumulators; the partials are exchanged (all-to-all), every rank folds one slice of the frame in
-                                 rank order, and the frame is gathered on rank 0 (the reference's batch accumulation,
-                                 Raytracer.cs:656-661,798-802, run concurrently; bit-identical to folding on one rank);
-  --partition tiles              the frame is row-interleaved with the reference's slice contract (SliceOffset = rank,
-                                 SliceDivider = N, JOBS/SampleBatchJob.cs:69-70) and the colour rows are gathered;
-                                 bit-identical to the single-GPU frame but limited by lane-per-pixel granularity
-                                 (measured 3.2x at 8 slices of 1080p), which is why it is not the default.
+(same frame, same spp), so scaling is "strong".  `value` is the TILE partition north_star names:
+  tiles    the frame is row-interleaved with the reference's slice contract (SliceOffset = rank, SliceDivider = N,
+           JOBS/SampleBatchJob.cs:69-70) and the colour rows are gathered on rank 0 by ONE RCCL gather per batch behind the C ABI
+           (rtowCommInit / rtowGatherRowsDevice); bit-identical to the single-GPU frame; limited by lane-per-pixel granularity under
+           the reference RNG stream (a GPU with one pixel per lane finishes when its slowest pixel does);
+and the line also carries, measured in the same run (`partitions`):
+  batches  every rank renders the whole frame with spp/N samples and its own seed from zeroed accumulators; the partials are
+           exchanged (all-to-all), every rank folds one slice of the frame in rank order, and the frame is gathered on rank 0
+           (the reference's batch accumulation, Raytracer.cs:656-661,798-802, run concurrently; raytracing-in-one-weekend_amd/multigpu.py);
+  tiles under --rng per-sample (RTOW_RNG_PER_SAMPLE, NOT the reference's random stream: a pixel's samples become independent units).
 
 Rank 0 prints ONE JSON line (see the task contract) that also carries `roofline` and `cpu_baseline`.
 """
@@ -133,8 +139,10 @@ def main():
                     help="reference: the reference's per-pixel generator (same seed, same image: the headline); per-sample: RTOW_RNG_PER_SAMPLE, a different stream")
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (plain batches, host-buffer form, other partitions)")
+    ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default 8 on one GPU, 1 on several (one gather per batch)")
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
-    ap.add_argument("--partition", choices=("batches", "tiles"), default="batches", help="how N > 1 GPUs split a batch")
+    ap.add_argument("--partition", choices=("tiles", "batches"), default="tiles", help="which N > 1 partition `value` reports (the other is reported beside it)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     overridden = [k for k in ("scene", "width", "height", "spp", "depth") if getattr(args, k) is not None]
@@ -149,6 +157,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.chain is None:
+        args.chain = 8 if world == 1 else 1
+    args.chain = max(1, args.chain)
 
     import torch  # device memory, streams, torch.distributed (RCCL); loaded before the HIP library on purpose
 
@@ -179,111 +190,169 @@ def main():
     ctx = rt.Context(local_rank, scheduler_tune=[int(x) for x in args.tune.split(",")] if args.tune else None)
     ctx.upload_scene(scene.desc())
     info = ctx.scene_info()
-
-    # accumulators resident in HBM (torch tensors are only the allocation + stream plumbing); each set of four buffers is a
-    # view of one flat [11 * n] tensor so that a rank's partial result can travel in one collective
     mg = importlib.import_module("raytracing-in-one-weekend_amd.multigpu")
-    batches = world > 1 and args.partition == "batches"
-
-    def flat():
-        # batches: padded so that the flat accumulator splits into `world` equal slices of whole 11-float units (multigpu.slice_floats)
-        return torch.zeros(mg.padded_floats(n, world) if batches else mg.ACCUM_FLOATS * n, device=dev)
-
-    ping_flat, pong_flat = flat(), flat()
-    ping, pong = mg.accum_views(ping_flat, n), mg.accum_views(pong_flat, n)
-    zero_flat = flat() if batches else None           # never written: the input of every rank's sub-batch
-    # batches: the running accumulation is distributed - this rank's slice of it, the all-to-all receive buffer, and (rank 0) the gathered frame
-    acc_slice = torch.zeros(mg.slice_floats(n, world), device=dev) if batches else None
-    exchange = flat() if batches else None
-    frame_flat = ping_flat if batches else None
-    diag = torch.zeros(n, device=dev)
-    # parameter block built once (View ctor + auto-focus probe are host work outside the path); only Seed changes per step
-    if batches:
-        base = rt.scenes.make_params(scene, W, H, spp=mg.batch_split(spp, rank, world), trace_depth=depth)
-    else:
-        base = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, slice_offset=rank, slice_divider=world)
-
-    def params_for(seed):
-        p = abi.SampleParams.from_buffer_copy(base)
-        p.seed = seed
-        p.rngPolicy = abi.RNG_PER_SAMPLE if args.rng == "per-sample" else abi.RNG_REFERENCE
-        return p
 
     import ctypes as C
     lib = rt.lib.load()
     stream = torch.cuda.current_stream(dev)
-    kernel_ms = []
 
-    def add_flat(dst, src):
-        # dst += src over a flat slice of 11 * k floats, as the 4-buffer device add over k "pixels" (element for element the same adds)
-        k = dst.numel() // mg.ACCUM_FLOATS
-        d = abi.AccumBuffers(*[dst.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
-        s_ = abi.AccumBuffers(*[src.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
-        rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, k, C.byref(d), C.byref(s_), stream.cuda_stream), "rtowAddAccumDevice")
+    # the C-ABI communicator of the tile partition: rank 0 makes the id, torch.distributed is only the host channel that carries its 128 bytes
+    have_comm = False
+    if world > 1 and not shared_gpu:
+        box = [rt.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], rank, world)
+        have_comm = True
 
-    def launch(p, src, dst):
-        bi = abi.AccumBuffers(*[t.data_ptr() for t in src])
-        bo = abi.AccumBuffers(*[t.data_ptr() for t in dst])
-        rt.lib.check(lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(bi), C.byref(bo), diag.data_ptr(), stream.cuda_stream, None),
-                     "rtowSampleBatchDevice")
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
-    def step(i, record=False):
-        nonlocal ping, pong, ping_flat, pong_flat
-        if batches:
-            # every rank: whole frame, its share of the samples, its own seed, zeroed inputs; all-to-all + ordered fold of the slices; gather of the frame
-            p = params_for(mg.batch_seed(i + 1, rank, world))
-
-            def render_full():
-                launch(p, mg.accum_views(zero_flat, n), pong)
-                return pong_flat
-
-            mg.render_batches(render_full, acc_slice, n, rank, world, add_flat, exchange=exchange, frame=frame_flat)   # ping = this batch's frame (rank 0)
-        else:
-            p = params_for(i + 1)
-            launch(p, ping, pong)
-            if world > 1:
-                # the one collective of the tile path: colour rows of every rank -> rank 0 (RCCL gather)
-                mg.gather_frame(mg.pack_owned(pong[0].view(H, W, 4), rank, world), H, rank, world)
-            ping, pong, ping_flat, pong_flat = pong, ping, pong_flat, ping_flat
-        if record:
-            kernel_ms.append(ctx.last_sample_kernel_ms())  # HIP events on the launch stream (synchronises)
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, record=True)
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def max_over_ranks(x):
+        if not dist:
+            return x
+        t = torch.tensor([x], device=dev if not shared_gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        kt = torch.tensor([sum(kernel_ms) / max(len(kernel_ms), 1)], device=dev, dtype=torch.float64)
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-        avg_kernel_ms = float(kt.item())
-    else:
-        avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        return float(t.item())
 
+    def measure(partition, rng, chain, steps, warmup):
+        """Time `steps` batches (after `warmup` untimed ones) under one partition / RNG policy / chain length; max over ranks.
+        Returns wall seconds, mean kernel ms per step, and the buffers of the last batch (for the ray / success statistics)."""
+        batches = world > 1 and partition == "batches"
+
+        def flat():
+            # batches: padded so that the flat accumulator splits into `world` equal slices of whole 11-float units (multigpu.slice_floats)
+            return torch.zeros(mg.padded_floats(n, world) if batches else mg.ACCUM_FLOATS * n, device=dev)
+
+        state = {"ping_flat": flat(), "pong_flat": flat()}
+        state["ping"], state["pong"] = mg.accum_views(state["ping_flat"], n), mg.accum_views(state["pong_flat"], n)
+        zero_flat = flat() if batches else None           # never written: the input of every rank's sub-batch
+        acc_slice = torch.zeros(mg.slice_floats(n, world), device=dev) if batches else None
+        exchange = flat() if batches else None
+        diags = [torch.zeros(n, device=dev) for _ in range(max(1, chain))]
+        if batches:
+            base = rt.scenes.make_params(scene, W, H, spp=mg.batch_split(spp, rank, world), trace_depth=depth)
+        else:
+            base = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, slice_offset=rank, slice_divider=world)
+        kernel_ms = []
+
+        def params_for(seed):
+            p = abi.SampleParams.from_buffer_copy(base)
+            p.seed = seed
+            p.rngPolicy = abi.RNG_PER_SAMPLE if rng == "per-sample" else abi.RNG_REFERENCE
+            return p
+
+        def add_flat(dst, src):
+            # dst += src over a flat slice of 11 * k floats, as the 4-buffer device add over k "pixels" (element for element the same adds)
+            k = dst.numel() // mg.ACCUM_FLOATS
+            d = abi.AccumBuffers(*[dst.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
+            s_ = abi.AccumBuffers(*[src.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
+            rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, k, C.byref(d), C.byref(s_), stream.cuda_stream), "rtowAddAccumDevice")
+
+        def launch(plist, src, dst):
+            bi = abi.AccumBuffers(*[t.data_ptr() for t in src])
+            bo = abi.AccumBuffers(*[t.data_ptr() for t in dst])
+            if len(plist) == 1:
+                rt.lib.check(lib.rtowSampleBatchDevice(ctx.handle, C.byref(plist[0]), C.byref(bi), C.byref(bo), diags[0].data_ptr(), stream.cuda_stream, None),
+                             "rtowSampleBatchDevice")
+            else:
+                arr = (abi.SampleParams * len(plist))(*plist)
+                dptr = (C.c_void_p * len(plist))(*[diags[k].data_ptr() for k in range(len(plist))])
+                rt.lib.check(lib.rtowSampleBatchChainDevice(ctx.handle, len(plist), arr, C.byref(bi), C.byref(bo), dptr, stream.cuda_stream, None),
+                             "rtowSampleBatchChainDevice")
+
+        def run(first, count, record):
+            i = first
+            while i < first + count:
+                c = min(chain, first + count - i)
+                if batches:
+                    # every rank: whole frame, its share of the samples, its own seed, zeroed inputs; all-to-all + ordered fold of the slices; gather of the frame
+                    p = params_for(mg.batch_seed(i + 1, rank, world))
+                    c = 1
+
+                    def render_full():
+                        launch([p], mg.accum_views(zero_flat, n), state["pong"])
+                        return state["pong_flat"]
+
+                    mg.render_batches(render_full, acc_slice, n, rank, world, add_flat, exchange=exchange, frame=state["ping_flat"])   # ping = this batch's frame (rank 0)
+                else:
+                    launch([params_for(i + 1 + k) for k in range(c)], state["ping"], state["pong"])
+                    if world > 1:
+                        # the one collective of the tile path: colour rows of every rank -> rank 0
+                        if have_comm:
+                            mine = abi.AccumBuffers(*[t.data_ptr() for t in state["pong"]])
+                            ctx.gather_rows(W, H, world, mine, mine if rank == 0 else None, what=abi.GATHER_COLOR, root=0, stream=stream.cuda_stream)
+                        else:
+                            mg.gather_frame(mg.pack_owned(state["pong"][0].view(H, W, 4), rank, world), H, rank, world)
+                    state["ping"], state["pong"], state["ping_flat"], state["pong_flat"] = state["pong"], state["ping"], state["pong_flat"], state["ping_flat"]
+                if record:
+                    kernel_ms.append(ctx.last_sample_kernel_ms())  # HIP events on the launch stream (synchronises); one launch = c steps
+                i += c
+
+        run(0, warmup, False)
+        barrier()
+        t0 = time.perf_counter()
+        run(warmup, steps, True)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        ctx.batch_status()                                  # the asynchronous batches report here (hit-list capacity)
+        avg_kernel_ms = max_over_ranks(sum(kernel_ms) / max(steps, 1))
+        launches = len(kernel_ms)
+        return {"elapsed": elapsed, "kernel_ms_per_step": avg_kernel_ms, "launches": launches, "last": state["ping"], "diag": diags[0 if batches else ((steps % chain) or min(chain, steps)) - 1],
+                "batches": batches, "base": base}
+
+    main_partition = args.partition if world > 1 else "single"
+    m = measure(args.partition, args.rng, args.chain, args.steps, args.warmup)
+    batches = m["batches"]
+
+    def summary(mm):
+        return {"value": round(float(n) * spp * args.steps / mm["elapsed"] / 1e6, 2), "ms_per_step": round(mm["elapsed"] / args.steps * 1e3, 3),
+                "kernel_ms_per_step": round(mm["kernel_ms_per_step"], 3)}
+
+    extras = {}
+    host_ms = None
+    if not args.no_extras:
+        if world == 1:
+            if args.chain > 1:
+                extras["plain_batches"] = dict(summary(measure("tiles", args.rng, 1, args.steps, 1)), note="the same steps as one launch per batch (rtowSampleBatchDevice)")
+            # the drop-in form of INTEGRATION.md: rtowSampleBatch on the host's own (pinned, registered) accumulation arrays
+            import numpy as np
+            pool = [np.zeros((n, c), np.float32) for c in (4, 3, 3)] + [np.zeros(n, np.float32)]
+            hdiag = np.zeros(n, np.float32)
+            ctx.register_host_buffers(*pool, hdiag)
+            hb = abi.AccumBuffers(*[a.ctypes.data for a in pool])
+            times = []
+            for i in range(4):
+                p = abi.SampleParams.from_buffer_copy(m["base"])
+                p.seed = 1000 + i
+                t = time.perf_counter()
+                rt.lib.check(lib.rtowSampleBatch(ctx.handle, C.byref(p), C.byref(hb), C.byref(hb), hdiag.ctypes.data, None), "rtowSampleBatch")
+                times.append(time.perf_counter() - t)
+            ctx.unregister_host_buffers()
+            host_ms = round(min(times[1:]) * 1e3, 3)
+        else:
+            other = "batches" if args.partition == "tiles" else "tiles"
+            extras["partitions"] = {args.partition: summary(m), other: summary(measure(other, args.rng, 1, args.steps, 1))}
+            if args.rng == "reference":
+                extras["partitions"]["tiles, RTOW_RNG_PER_SAMPLE (not the reference stream)"] = summary(measure("tiles", "per-sample", 1, args.steps, 1))
+
+    elapsed, avg_kernel_ms = m["elapsed"], m["kernel_ms_per_step"]
     if rank == 0:
         total_samples = float(n) * spp * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         # metrics of the last batch (rays per sample, success ratio) - outside the timed region
-        last = ping
-        rays = float(diag.sum().item()) * (world if world > 1 else 1)  # every rank traces a statistically equal share
+        last = m["last"]
+        rays = float(m["diag"].sum().item()) * (world if world > 1 else 1)  # every rank traces a statistically equal share
         # algorithmic HBM bytes per launch of the sample kernel (SURVEY.md 8(d)): 44 B read + 44 B write + 4 B diagnostics per
-        # owned pixel, plus the scene image once
+        # owned pixel AND batch of the launch, plus the scene image once
         owned_pixels = n if (batches or world == 1) else len(range(rank, H, world)) * W
         rank_spp = mg.batch_split(spp, rank, world) if batches else spp
-        alg_bytes = owned_pixels * 92 + int(info.sceneBytesDevice)
-        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        steps_per_launch = args.steps / max(m["launches"], 1)
+        alg_bytes = int(owned_pixels * 92 * steps_per_launch) + int(info.sceneBytesDevice)
+        launch_ms = avg_kernel_ms * steps_per_launch
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         traffic, traffic_src, secondary = measured_hbm_traffic() if world == 1 else (None, None, {})
         out = {
             "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce" if (args.config == 2 and not overridden) else
@@ -304,14 +373,17 @@ def main():
                             "%d bounces, white noise, jitter on, %s" % ("BASELINE.json " + cfg["label"] + " = " if not overridden else "", SCENE_TEXT[args.scene], W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_PER_SAMPLE (NOT the reference stream; lane per 16-sample group)"),
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
                               "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
-                              if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch" % world),
+                              if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),
+                "batches_per_launch": args.chain if not batches else 1,
+                "launches": m["launches"],
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds),
             },
             "kernel_ms_per_step": round(avg_kernel_ms, 3),
+            "kernel_ms_per_launch": round(launch_ms, 3),
             "msamples_per_s_kernel_only": round(owned_pixels * rank_spp * world / (avg_kernel_ms * 1e-3) / 1e6, 2),
             "mrays_per_s": round(rays / (avg_kernel_ms * 1e-3) / 1e6, 1),
             "rays_per_sample": round(rays / (float(n) * spp), 4),
-            "successful_sample_ratio": round(float(last[0][:, 3].sum().item()) * (world if world > 1 else 1) / (float(n) * spp * (args.steps + args.warmup)), 4) if world == 1 else None,
+            "successful_sample_ratio": round(float(last[0][:, 3].sum().item()) / (float(n) * spp * (args.steps + args.warmup)), 4) if world == 1 else None,
             "roofline": {
                 "bound": "hbm",
                 "achieved": round(achieved, 4),
@@ -323,14 +395,20 @@ def main():
                 "kernel": "sample_batch_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "secondary": secondary,   # what actually limits the kernel: from the same committed PMC summary as `traffic`
-                "note": "graph-traversal path: algorithmic HBM traffic is 92 B/pixel per launch, so the HBM fraction is tiny by construction; "
-                        "the kernel is VALU/LDS-latency bound (see DESIGN.md, profiles/)",
+                "note": "graph-traversal path: algorithmic HBM traffic is 92 B/pixel per batch, so the HBM fraction is tiny by construction; "
+                        "the kernel is VALU-issue / divergence bound (see DESIGN.md, profiles/)",
             },
         }
+        out.update(extras)
+        if host_ms is not None:
+            out["host_buffer_ms_per_step"] = host_ms
+            out["host_buffer_note"] = "rtowSampleBatch on pinned host arrays registered with rtowRegisterHostBuffer: inputs by one DMA, outputs stored by the kernel straight into host memory (best of 3 after 1 warm-up)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, W, H, depth, scene_name=args.scene, full_spp=spp)
         print(json.dumps(out), flush=True)
 
+    if have_comm:
+        ctx.comm_destroy()
     ctx.close()
     if dist:
         dist.destroy_process_group()

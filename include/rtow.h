@@ -349,6 +349,19 @@ RTOW_API int rtowSampleBatchDevice(RtowContext context, const RtowSampleParams* 
                                    const RtowAccumBuffers* in, const RtowAccumBuffers* out,
                                    void* diagnostics, void* stream, const volatile uint8_t* cancel);
 
+/* `count` successive batches of ONE frame, enqueued together: exactly what
+ *     rtowSampleBatchDevice(params[0], in, out, diagnostics[0]); rtowSampleBatchDevice(params[k], out, out, diagnostics[k]) for k = 1 .. count-1
+ * computes, bit for bit - the reference keeps two such batches in flight, the second scheduled with a dependency on the first
+ * (UNITY/Raytracer.cs:586-593 "kick if needed (with double-buffering)", :798-811).  When the batches differ in nothing but `seed`
+ * (successive batches of a frame, :656-661) they run as ONE launch in which every 64-pixel chunk of batch k + 1 starts as soon as that chunk
+ * of batch k is stored, so the CUs that run out of batch-k pixels do not idle until its slowest pixel ends (the reference stream makes a
+ * pixel's samples one indivisible unit of work; a batch on its own ends with a tail of about one pixel-time).  `diagnostics`: `count`
+ * device pointers (or NULL), one record buffer per batch.  `cancel` as for rtowSampleBatchDevice.  rtowGetLastSampleKernelMs then
+ * reports the last launch (all its batches). */
+RTOW_API int rtowSampleBatchChainDevice(RtowContext context, int32_t count, const RtowSampleParams* params /* [count] */,
+                                        const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                                        void* const* diagnostics /* [count] or NULL */, void* stream, const volatile uint8_t* cancel);
+
 /* Pinned host buffers for rtowSampleBatch.  The host's accumulation buffers are long-lived pools (UNITY/Raytracer.cs:279-288,
  * Allocator.Persistent); registering them once (hipHostRegister) lets rtowSampleBatch move the inputs with one pinned DMA and lets the
  * kernel store the outputs and diagnostics straight into host memory, so the host-buffer form runs at the speed of the device-resident

@@ -53,6 +53,9 @@ struct RtowContext_t {
     // work distribution / cancellation
     unsigned int* dWorkCounter = nullptr;
     // chunk cost map -> launch order (longest chunks first); valid for one (width, height, slice, scene) configuration
+    unsigned int* dChunkDone = nullptr;   // chained batches: pixels stored per chunk
+    ChainBatch* dChainBatches = nullptr;  // chained batches: per-batch seed / diagnostics table of the launch being enqueued
+    uint32_t chunkDoneCapacity = 0;
     unsigned int *dChunkCost = nullptr, *dChunkOrder = nullptr;
     unsigned short* dPixelCost = nullptr;
     uint32_t chunkCapacity = 0;
@@ -63,6 +66,9 @@ struct RtowContext_t {
     float* dUnitRecords = nullptr;
     size_t unitRecordCapacity = 0;
     uint32_t orderGroups = 1;     // groups per pixel the chunk cost map was recorded with
+    // RTOW_CONTEXT_REFERENCE_DIAGNOSTICS: the reference's own tree of the current scene (CompiledScene.refTree), HBM only
+    uint8_t* dRefTree = nullptr;
+    size_t refTreeCapacity = 0;
     // Image-texture blob of the current scene (CompiledScene.texBlob), HBM only
     uint8_t* dTexBlob = nullptr;
     size_t texBlobCapacity = 0;
@@ -152,8 +158,12 @@ int ownedRows(const RtowSampleParams* p)
     return (h - p->sliceOffset + p->sliceDivider - 1) / p->sliceDivider;
 }
 
+// chain (optional): {count, seeds[count], diagnostics[count]} - `count` successive batches of the frame in this one launch (seeds[0] / diags[0] are
+// batch 0's; p->seed and diag are ignored then)
+struct ChainSpec { int count; const uint32_t* seeds; void* const* diags; };
+
 int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuffers* in, const RtowAccumBuffers* out, void* diag,
-                 hipStream_t stream, bool useCancelFlag)
+                 hipStream_t stream, bool useCancelFlag, const ChainSpec* chain = nullptr)
 {
     SampleKernelArgs a{};
     a.inColor = in->color; a.inNormal = in->normal; a.inAlbedo = in->albedo; a.inScw = in->sampleCountWeight;
@@ -172,7 +182,12 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.totalWork = (uint32_t)ownedRows(p) * (uint32_t)a.width;
     a.sizeX = p->size.x; a.sizeY = p->size.y;
     a.sliceOffset = p->sliceOffset; a.sliceDivider = p->sliceDivider;
-    a.seed = p->seed;
+    a.seed = chain ? chain->seeds[0] : p->seed;
+    a.chainCount = chain ? (uint32_t)chain->count : 1u;
+    if (chain) {
+        if (diag == nullptr && chain->diags) diag = chain->diags[0];
+        a.diagnostics = (uint8_t*)diag;
+    }
     a.view = p->view;
     a.environment = p->environment;
     a.sampleCountMin = p->sampleCountRange[0];
@@ -181,6 +196,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.subPixelJitter = p->subPixelJitter;
     a.extremaX = p->sampleCountWeightExtrema.x;
     a.extremaY = p->sampleCountWeightExtrema.y;
+    a.refTree = (ctx->flags & RTOW_CONTEXT_REFERENCE_DIAGNOSTICS) ? ctx->dRefTree : nullptr;
     a.texBlob = ctx->dTexBlob;
     a.texLayout = ctx->scene.texLayout;
     a.noiseColor = p->noiseColor;
@@ -320,6 +336,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             probe.probeOnly = 1;
             probe.chunkOrder = nullptr;
             probe.cancelFlag = nullptr;
+            probe.chainCount = 1;                                // one pass over the pixels, whatever the launch it prepares
             HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
             HIP_TRY(ctx, hipMemsetAsync(ctx->dPixelCost, 0, (size_t)a.chunkCount * 64 * sizeof(unsigned short), stream), RTOW_ERROR_LAUNCH_FAILURE);   // the last chunk's tail
             HIP_TRY(ctx, launchSampleBatch(probe, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
@@ -330,6 +347,26 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         a.chunkOrder = haveOrder ? ctx->dChunkOrder : nullptr;
     }
 
+    if (a.chainCount > 1u) {
+        // per-chunk hand-off counters of the chain: pixels stored so far (all batches); batch b of a chunk waits for b x its pixels
+        if (a.chunkCount > ctx->chunkDoneCapacity) {
+            if (ctx->dChunkDone) (void)hipFree(ctx->dChunkDone);
+    if (ctx->dChainBatches) (void)hipFree(ctx->dChainBatches);
+            ctx->dChunkDone = nullptr;
+            ctx->chunkDoneCapacity = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dChunkDone, (size_t)a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->chunkDoneCapacity = a.chunkCount;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkDone, 0, (size_t)a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+        a.chunkDone = ctx->dChunkDone;
+        // what differs between the chain's batches, indexed per lane by the kernel: a small table in device memory, written in stream order
+        // (the previous chain's kernel may still be reading its own table: this copy is enqueued behind it)
+        if (!ctx->dChainBatches) HIP_TRY(ctx, hipMalloc(&ctx->dChainBatches, sizeof(ChainBatch) * kMaxChain), RTOW_ERROR_MEMORY_ALLOCATION);
+        ChainBatch table[kMaxChain] = {};
+        for (int b = 0; b < chain->count; b++) { table[b].seed = chain->seeds[b]; table[b].diagnostics = chain->diags ? (uint8_t*)chain->diags[b] : nullptr; }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dChainBatches, table, sizeof(ChainBatch) * (size_t)chain->count, hipMemcpyHostToDevice, stream), RTOW_ERROR_LAUNCH_FAILURE);
+        a.chainBatches = ctx->dChainBatches;
+    }
     HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStart, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
@@ -583,11 +620,14 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dScene) (void)hipFree(ctx->dScene);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
+    if (ctx->dChunkDone) (void)hipFree(ctx->dChunkDone);
+    if (ctx->dChainBatches) (void)hipFree(ctx->dChainBatches);
     if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
     if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);
     if (ctx->dBlueNoise) (void)hipFree(ctx->dBlueNoise);
     if (ctx->dStbNoise) (void)hipFree(ctx->dStbNoise);
     if (ctx->dTexBlob) (void)hipFree(ctx->dTexBlob);
+    if (ctx->dRefTree) (void)hipFree(ctx->dRefTree);
     if (ctx->dUnitRecords) (void)hipFree(ctx->dUnitRecords);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
@@ -641,6 +681,20 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         compiled.texBlob.clear();
         compiled.texBlob.shrink_to_fit();                                     // the host copy is not needed again
     }
+    if (ctx->flags & RTOW_CONTEXT_REFERENCE_DIAGNOSTICS) {
+        // the counters' walk keeps one stack entry per level of the reference tree (+1): 64 entries of scratch
+        if (compiled.refTreeDepth > 62) { logf(ctx, 2, "scene", "RTOW_CONTEXT_REFERENCE_DIAGNOSTICS supports MaxBvhDepth <= 62"); return RTOW_ERROR_CAPACITY; }
+        if (compiled.refTree.size() > ctx->refTreeCapacity) {
+            if (ctx->dRefTree) (void)hipFree(ctx->dRefTree);
+            ctx->dRefTree = nullptr;
+            ctx->refTreeCapacity = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dRefTree, compiled.refTree.size()), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->refTreeCapacity = compiled.refTree.size();
+        }
+        HIP_TRY(ctx, hipMemcpy(ctx->dRefTree, compiled.refTree.data(), compiled.refTree.size(), hipMemcpyHostToDevice), RTOW_ERROR_LAUNCH_FAILURE);
+    }
+    compiled.refTree.clear();
+    compiled.refTree.shrink_to_fit();
     HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchPrepareEntities(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
@@ -782,6 +836,51 @@ RTOW_API int rtowSampleBatchDevice(RtowContext ctx, const RtowSampleParams* para
     if (rc != RTOW_SUCCESS) return rc;
     if (cancel) return waitWithCancel(ctx, cancel);
     return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowSampleBatchChainDevice(RtowContext ctx, int32_t count, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                                        void* const* diagnostics, void* stream, const volatile uint8_t* cancel)
+{
+    if (!ctx || !in || !out || !params || count < 1) return RTOW_ERROR_INVALID_VALUE;
+    for (int b = 0; b < count; b++) {
+        const int v = validateParams(&params[b]);
+        if (v != RTOW_SUCCESS) return v;
+    }
+    if (!in->color || !in->normal || !in->albedo || !in->sampleCountWeight || !out->color || !out->normal || !out->albedo || !out->sampleCountWeight)
+        return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    *ctx->hCancel = 0u;
+
+    // One launch needs batches that differ in nothing but Seed (the reference's successive batches of a frame: UNITY/Raytracer.cs:656-661),
+    // the reference RNG policy (per-sample units fold through records) and a frame of fewer than 2^27 padded pixels.  Anything else runs as
+    // what the chain is defined to equal: the batches one after the other, batch b + 1 reading what batch b wrote.
+    bool fusable = params[0].rngPolicy == RTOW_RNG_REFERENCE;
+    for (int b = 1; b < count && fusable; b++) {
+        RtowSampleParams q = params[b];
+        q.seed = params[0].seed;
+        fusable = memcmp(&q, &params[0], sizeof(q)) == 0;
+    }
+    const uint64_t paddedPixels = ((uint64_t)ownedRows(&params[0]) * (uint64_t)(int)params[0].size.x + 63u) & ~63ull;
+    if (paddedPixels >= (1ull << 27)) fusable = false;
+    int rc = RTOW_SUCCESS;
+    for (int first = 0; first < count && rc == RTOW_SUCCESS;) {
+        const int n = fusable ? std::min(count - first, (int)kMaxChain) : 1;
+        const RtowAccumBuffers* src = first == 0 ? in : out;
+        if (n == 1) {
+            rc = launchSample(ctx, &params[first], src, out, diagnostics ? diagnostics[first] : nullptr, s, cancel != nullptr);
+        } else {
+            uint32_t seeds[kMaxChain];
+            for (int b = 0; b < n; b++) seeds[b] = params[first + b].seed;
+            const ChainSpec chain{n, seeds, diagnostics ? diagnostics + first : nullptr};
+            rc = launchSample(ctx, &params[first], src, out, nullptr, s, cancel != nullptr, &chain);
+        }
+        if (rc == RTOW_SUCCESS && cancel) rc = waitWithCancel(ctx, cancel);
+        first += n;
+    }
+    return rc;
 }
 
 RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out,

@@ -350,7 +350,10 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     // place in its leaf order), and the box that guards each entity's exact test - the bounds of the reference LEAF it sits in, which is the
     // entity's own box except in leaves forced at MaxBvhDepth, where it is their union.
     std::vector<float> guardBoxes;
-    const std::vector<uint32_t> ranks = referenceLeafRanks(cullBoxes, n, desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32 /* prefab default */, &guardBoxes);
+    std::vector<RefTreeNode> refTree;      // the tree RebuildBvh would build: only its FULL_DIAGNOSTICS counters need it on the device
+    const std::vector<uint32_t> ranks = referenceLeafRanks(cullBoxes, n, desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32 /* prefab default */, &guardBoxes, &refTree);
+    out->refTree.assign(reinterpret_cast<const uint8_t*>(refTree.data()), reinterpret_cast<const uint8_t*>(refTree.data()) + refTree.size() * sizeof(RefTreeNode));
+    out->refTreeDepth = desc->maxBvhDepth > 0 ? desc->maxBvhDepth : 32;
     for (int i = 0; i < n; i++) {
         bool wider = false;
         for (int a = 0; a < 3; a++) wider |= guardBoxes[(size_t)i * 8 + a] < cullBoxes[(size_t)i * 8 + a] || guardBoxes[(size_t)i * 8 + 4 + a] > cullBoxes[(size_t)i * 8 + 4 + a];

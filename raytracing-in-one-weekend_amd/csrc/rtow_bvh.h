@@ -22,6 +22,8 @@ struct CompiledScene {
     int materialCount = 0;
     std::vector<uint8_t> texBlob; // Image-texture blob (HBM only), see TexLayout; empty when the scene has no Image texture
     TexLayout texLayout{};
+    std::vector<uint8_t> refTree; // the reference's own tree (rtow_reforder.h RefTreeNode[], node 0 = root): uploaded only for RTOW_CONTEXT_REFERENCE_DIAGNOSTICS
+    int refTreeDepth = 0;         // its depth bound (the host's MaxBvhDepth)
 };
 
 // Returns an RtowResult; *err describes failures.

@@ -22,7 +22,15 @@ constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting 
 constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane]
 constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: first slot empty, second not - "no list, walk the tree"
 constexpr unsigned kSampleGroup = 16;   // RTOW_RNG_PER_SAMPLE: samples per work unit (part of that policy's definition: partial sums are per group)
-constexpr int kQueueBytes = 256;   // per-wave {next, end} pixel-ticket chunk (16 waves x 8 B, padded)
+constexpr int kQueueBytes = 256;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B)
+constexpr int kMaxChain = 16;      // successive batches one launch can run (rtowSampleBatchChainDevice)
+
+// Per-batch fields of a chained launch (rtowSampleBatchChainDevice): everything else is shared by the chain's batches.
+struct ChainBatch {
+    uint8_t* diagnostics;   // of this batch, may be null
+    uint32_t seed;          // Seed (JOBS/SampleBatchJob.cs:28,91)
+    uint32_t pad;
+};
 
 // Everything the sample kernel needs, passed by value (kernarg segment).
 struct SampleKernelArgs {
@@ -89,6 +97,16 @@ struct SampleKernelArgs {
     const uint8_t* cubemapData;
     int32_t cubemapHalfW, cubemapHalfH, cubemapW1, cubemapH1;   // halfFaceSize, faceSizeMinusOne
     int32_t cubemapPixelStride, cubemapRowStride, cubemapFaceStride, cubemapChannelType;
+
+    // RTOW_CONTEXT_REFERENCE_DIAGNOSTICS: the reference's own tree (RefTreeNode[], HBM only); when set, BoundsHitCount / CandidateCount of the
+    // 16-byte diagnostics count THAT tree's boxes and leaves (JOBS/SampleBatchJob.cs:427-440), one extra unpruned walk per ray
+    const uint8_t* refTree;
+
+    // chained batches (rtowSampleBatchChainDevice): this launch runs chainCount successive batches of the same frame; batch b of a
+    // 64-pixel chunk starts as soon as batch b - 1 of that chunk is stored (chunkDone), whichever CU traced it
+    uint32_t chainCount;                  // >= 1; 1 = a plain batch
+    const ChainBatch* chainBatches;       // [chainCount] what differs between the batches of the chain (device memory: indexed per lane)
+    unsigned int* chunkDone;              // [chunkCount] pixels stored so far, all batches of this launch; zeroed before the launch
 
     // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice
     int32_t tune[8];

@@ -103,17 +103,18 @@ void referenceIndexSort(uint32_t* idx, int length, const float* key)
     IndexSorter{idx, key}.run(0, length - 1, 2 * levels);
 }
 
-std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth, std::vector<float>* leafBoxes)
+std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth, std::vector<float>* leafBoxes, std::vector<RefTreeNode>* tree)
 {
     if (leafBoxes) leafBoxes->assign((size_t)n * 8, 0.0f);
+    if (tree) { tree->clear(); tree->push_back(RefTreeNode{}); }
     // The reference's recursion (UNITY/BvhNodeData.cs:122-213) sorts and splits sub-ranges of one array in place, left child =
     // the front part; the array it ends with IS the leaf order.  Only the range bookkeeping is repeated here.
     std::vector<uint32_t> order(n);
     for (int i = 0; i < n; i++) order[i] = (uint32_t)i;
     std::vector<float> key(n);
-    struct Range { int begin, end, depth, sortedAxis; };
+    struct Range { int begin, end, depth, sortedAxis, node; };
     std::vector<Range> todo;
-    todo.push_back(Range{0, n, 0, -1});
+    todo.push_back(Range{0, n, 0, -1, 0});
     while (!todo.empty()) {
         const Range r = todo.back();
         todo.pop_back();
@@ -126,6 +127,11 @@ std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n,
                 if (b[a] < lo[a]) lo[a] = b[a];
                 if (b[4 + a] > hi[a]) hi[a] = b[4 + a];
             }
+        }
+        if (tree) {
+            // BvhNodeData.Bounds: a leaf encloses its entities (:161-166), an inner node its two children (:198) - min / max, the same box either way
+            RefTreeNode& t = (*tree)[(size_t)r.node];
+            for (int a = 0; a < 3; a++) { t.lo[a] = lo[a]; t.hi[a] = hi[a]; }
         }
         int axis = -1;
         float widest = -FLT_MAX;
@@ -141,6 +147,7 @@ std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n,
             // a leaf's entities are appended to the candidate list front to back and the hit loop pops that list from its end
             // (JOBS/SampleBatchJob.cs:436-441,452-455): inside one leaf the hits come out back to front
             for (int i = r.begin, j = r.end - 1; i < j; i++, j--) std::swap(order[i], order[j]);
+            if (tree) { (*tree)[(size_t)r.node].left = ~count; (*tree)[(size_t)r.node].right = 0; }
             // the leaf's bounds (:161-166) guard every entity in it: a ray reaches an entity's exact test iff it passes THIS box
             if (leafBoxes)
                 for (int i = r.begin; i < r.end; i++) {
@@ -158,8 +165,17 @@ std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n,
             if (b[axis] - start > widest / 2 || b[4 + axis] - b[axis] > widest / 2) break;
         }
         if (front == count) front--;
-        todo.push_back(Range{r.begin + front, r.end, r.depth + 1, axis});
-        todo.push_back(Range{r.begin, r.begin + front, r.depth + 1, axis});
+        int leftNode = 0, rightNode = 0;
+        if (tree) {
+            leftNode = (int)tree->size();
+            rightNode = leftNode + 1;
+            tree->push_back(RefTreeNode{});
+            tree->push_back(RefTreeNode{});
+            (*tree)[(size_t)r.node].left = leftNode;
+            (*tree)[(size_t)r.node].right = rightNode;
+        }
+        todo.push_back(Range{r.begin + front, r.end, r.depth + 1, axis, rightNode});
+        todo.push_back(Range{r.begin, r.begin + front, r.depth + 1, axis, leftNode});
     }
     std::vector<uint32_t> rank(n);
     for (int i = 0; i < n; i++) rank[order[i]] = (uint32_t)i;

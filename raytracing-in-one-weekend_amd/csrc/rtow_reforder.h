@@ -17,7 +17,17 @@ namespace rtow {
 // boxes: float[8] {min.xyz, -, max.xyz, -} per entity, the reference's own fp32 entity boxes (UNITY/BvhNodeData.cs:23-81).
 // maxDepth: the host's MaxBvhDepth (leaves are forced at that depth).  Returns rank[entity] in 0..n-1.  leafBoxes (optional, same layout
 // as boxes): the bounds of the reference leaf each entity ends up in - its own box, or the union of the boxes of a leaf forced at maxDepth.
-std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth, std::vector<float>* leafBoxes = nullptr);
+// tree (optional): the reference tree itself, node 0 = root, for the FULL_DIAGNOSTICS counters that count ITS boxes and ITS leaves
+// (JOBS/SampleBatchJob.cs:427-440): bounds, two child indices, or - for a leaf - the number of entities it holds.
+struct RefTreeNode {
+    float lo[3];
+    int32_t left;      // >= 0: inner node, index of Left; < 0: leaf holding ~left entities
+    float hi[3];
+    int32_t right;     // inner node: index of Right
+};
+static_assert(sizeof(RefTreeNode) == 32, "RefTreeNode is read by the kernel as two float4");
+std::vector<uint32_t> referenceLeafRanks(const std::vector<float>& boxes, int n, int maxDepth, std::vector<float>* leafBoxes = nullptr,
+                                         std::vector<RefTreeNode>* tree = nullptr);
 
 // The introsort of com.unity.collections 1.0.0-pre.6 (NativeSortExtension.Sort), on an index array with float keys and the
 // comparer `(int) sign(key[l] - key[r])` (UNITY/BvhNodeData.cs:240-250).  Exposed for the unit tests.

@@ -156,9 +156,9 @@ struct Rng;
 template <>
 struct Rng<RTOW_NOISE_WHITE> {
     unsigned s;
-    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned pix)
+    __device__ __forceinline__ void begin_pixel(const NoiseSite&, unsigned pix, unsigned seed)
     {
-        s = (at.A->seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u);   // :91; the Random ctor then discards one NextState()
+        s = (seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u);   // :91; the Random ctor then discards one NextState()
         (void)rng_next(s);
     }
     // RTOW_RNG_PER_SAMPLE: sample `smp` of the pixel gets its own generator (include/rtow.h)
@@ -187,7 +187,7 @@ struct Rng<RTOW_NOISE_WHITE> {
 template <>
 struct Rng<RTOW_NOISE_BLUE> {
     unsigned s;                                                   // PerPixelNoise.n
-    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = at.A->seed + 1u; }   // n = seed; Advance() (:17-25)
+    __device__ __forceinline__ void begin_pixel(const NoiseSite&, unsigned, unsigned seed) { s = seed + 1u; }   // n = seed; Advance() (:17-25)
     __device__ __forceinline__ void begin_sample(const NoiseSite&, unsigned, unsigned) {}
     __device__ __forceinline__ void texel(const NoiseSite& at, float& x, float& y)
     {
@@ -214,7 +214,7 @@ struct Rng<RTOW_NOISE_BLUE> {
 template <>
 struct Rng<RTOW_NOISE_SPATIOTEMPORAL_BLUE> {
     unsigned s, v2, cs, u2, u3;                                   // n of perPixelScalar / Vector2 / CosineUnitVector3 / UnitVector2 / UnitVector3
-    __device__ __forceinline__ void begin_pixel(const NoiseSite& at, unsigned) { s = v2 = cs = u2 = u3 = at.A->seed + 1u; }
+    __device__ __forceinline__ void begin_pixel(const NoiseSite&, unsigned, unsigned seed) { s = v2 = cs = u2 = u3 = seed + 1u; }
     __device__ __forceinline__ void begin_sample(const NoiseSite&, unsigned, unsigned) {}
     __device__ __forceinline__ float next(const NoiseSite& at)                                                           // STBN :61
     {
@@ -656,6 +656,19 @@ template <> struct Hist<8> {
 };
 
 // ------------------------------------------------------------------------------------------------------------
+// Chained batches: accumulators handed from one batch to the next INSIDE a running kernel, possibly between workgroups on different XCDs
+// (eight L2s).  Measured on the part (profiles/calib/coherence_probe.hip): plain accesses read stale lines every time; a release /
+// acquire fence pair at agent scope is correct but writes the whole L2 back (4 us per release); relaxed agent-scope atomic accesses
+// (sc1: each one coherent at the device's coherence point) ordered by s_waitcnt are correct and cost what a plain access costs.
+// So under a chain every accumulator / diagnostics access is one of these, and a chunk is published by: stores (sc1) -> workgroup-scope
+// release (s_waitcnt vmcnt(0), keeps the compiler from reordering) -> relaxed agent-scope add on the chunk's counter.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr unsigned kChainShift = 27;                       // ticket = batch << 27 | owned-pixel number (chains need fewer than 2^27 padded pixels)
+constexpr unsigned kChainTicketMask = (1u << kChainShift) - 1u;
+
+// ------------------------------------------------------------------------------------------------------------
 // the megakernel
 // ------------------------------------------------------------------------------------------------------------
 // Lane states.  Every trip of the main loop the wavefront takes a population vote (__ballot + popcount per state) and
@@ -670,7 +683,8 @@ enum : int {
     ST_SKY = 4,      // missed everything: sky + fold
     ST_VOL = 5,      // VOLUMES scenes: all hits collected -> sort, containment probe, volume logic (JOBS/SampleBatchJob.cs:194-303)
     ST_DEAD = 6,
-    ST_COUNT = 6
+    ST_COUNT = 6,
+    ST_IDLE = 7      // chained batches: the lane's next pixel belongs to a chunk whose previous batch is not stored yet; it asks again every few trips
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -736,6 +750,40 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
     return (int)(hitCode[0] & 0xffffu);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// FULL_DIAGNOSTICS as the reference counts them (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS): FindHitCandidates walks the tree RebuildBvh built
+// and counts every node whose box the ray passes and every entity of the leaves it reaches (JOBS/SampleBatchJob.cs:403-448, counters
+// :427-440; consumed by the heat-map views, UNITY/Raytracer.cs:1015-1031).  The product walks its own, pruned tree, so in this mode the
+// reference's tree (rtow_reforder.h: RefTreeNode, from HBM through L2) is walked a second time, unpruned, only to count.
+// AxisAlignedBoundingBox.Hit as in the reference (RT/HitTests.cs:9-21).  A real call: only batches that asked for it pay.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __noinline__ __attribute__((unused)) void reference_counts(const uint8_t* tree, V3 ro, V3 rd, float* boundsHits, float* candidates)
+{
+    V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                     // rcp(ray.Direction), NaN -> +INF (:406-412)
+    if (inv.x != inv.x) inv.x = __builtin_inff();
+    if (inv.y != inv.y) inv.y = __builtin_inff();
+    if (inv.z != inv.z) inv.z = __builtin_inff();
+    int stack[64];
+    int sp = 0;
+    stack[sp++] = 0;
+    float bh = 0, cc = 0;
+    while (sp > 0) {
+        const int node = stack[--sp];
+        const float4 a = reinterpret_cast<const float4*>(tree)[2 * node], b = reinterpret_cast<const float4*>(tree)[2 * node + 1];
+        const float t0x = (a.x - ro.x) * inv.x, t0y = (a.y - ro.y) * inv.y, t0z = (a.z - ro.z) * inv.z;
+        const float t1x = (b.x - ro.x) * inv.x, t1y = (b.y - ro.y) * inv.y, t1z = (b.z - ro.z) * inv.z;
+        const float tMin = um_max(0.0f, um_max(um_max(um_min(t0x, t1x), um_min(t0y, t1y)), um_min(t0z, t1z)));
+        const float tMax = um_min(um_min(um_max(t0x, t1x), um_max(t0y, t1y)), um_max(t0z, t1z));
+        if (!(tMin < tMax)) continue;
+        bh += 1.0f;                                                          // diagnostics.BoundsHitCount++
+        const int left = __float_as_int(a.w);
+        if (left < 0) cc += (float)(~left);                                  // diagnostics.CandidateCount += entityCount
+        else if (sp <= 62) { stack[sp++] = left; stack[sp++] = __float_as_int(b.w); }     // Push(Left); Push(Right)
+    }
+    *boundsHits += bh;
+    *candidates += cc;
+}
+
 template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
 __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
 {
@@ -747,9 +795,10 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     // touch 32 different dwords (= banks) whatever level each of them is at
     unsigned short* const stack = reinterpret_cast<unsigned short*>(smem) + (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
     unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;                // [slot][lane] leaf candidates
-    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytes) + (tid >> 6) * 2;  // {next, end} ticket chunk of this wave
+    // {next, end} ticket chunk of this wave; chains: {.., needDone, chunk} = the chunk may only be handed out once chunkDone[chunk] >= needDone
+    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytes) + (tid >> 6) * 4;
     uint8_t* const ldsScene = smem + kStackBytes + kQueueBytes;
-    if ((tid & 63) == 0) { waveQueue[0] = 0; waveQueue[1] = 0; }
+    if ((tid & 63) == 0) { waveQueue[0] = 0; waveQueue[1] = 0; waveQueue[2] = 0; waveQueue[3] = 0; }
     {
         const uint4* src = reinterpret_cast<const uint4*>(A.sceneBlob);
         uint4* dst = reinterpret_cast<uint4*>(ldsScene);
@@ -764,6 +813,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     sc.ldsNodeCount = A.ldsNodeCount;
     const SceneLayout L = A.layout;
     const int traceDepth = A.traceDepth;
+    const bool refDiag = FULL_DIAG && A.refTree != nullptr;   // BoundsHitCount / CandidateCount count the reference's tree (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS)
+    const bool chained = A.chainCount > 1u;      // several successive batches in this launch (wave-uniform): coherent accumulator accesses, per-chunk hand-off
     // a one-entity scene has a root whose second child is a placeholder; its (inverted) box cannot be told from a real one by the
     // symmetric slab test, so it is masked explicitly (wave-uniform, costs one scalar AND per node visit)
     const bool twoChildren = L.sphereCount > 1u;
@@ -835,8 +886,13 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         } else if (smp == 0 && !A.probeOnly) {
             // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
             // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
-            A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
-            A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
+            if (chained) {
+                coherent_store(A.outNormal + 3 * (size_t)pix + 0, sampleNormal.x); coherent_store(A.outNormal + 3 * (size_t)pix + 1, sampleNormal.y); coherent_store(A.outNormal + 3 * (size_t)pix + 2, sampleNormal.z);
+                coherent_store(A.outAlbedo + 3 * (size_t)pix + 0, sampleAlbedo.x); coherent_store(A.outAlbedo + 3 * (size_t)pix + 1, sampleAlbedo.y); coherent_store(A.outAlbedo + 3 * (size_t)pix + 2, sampleAlbedo.z);
+            } else {
+                A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
+                A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
+            }
         }
         smp++;
         st = ST_REGEN;
@@ -854,6 +910,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         tieAtBest = false;
         nHits = 0;
         st = ST_TRAV;
+        if (FULL_DIAG) { if (refDiag) reference_counts(A.refTree, ro, rd, &boundsHits, &candidates); }   // FindHitCandidates(ray, ...) of this segment (:186)
     };
     // traversal finished: classify the result
     auto classify = [&]() {
@@ -864,6 +921,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 
     uint2 pcand = make_uint2(kNoPrimaryList, 0u);   // this pixel's camera-ray candidate list (4 x 16 bit), or kNoPrimaryList in .x
     int force = -1;
+    unsigned trip = 0;          // chained batches only: paces the polls of parked lanes
     STAT_DECL;
     STAGE_DECL;
 #ifdef RTOW_STATS
@@ -878,7 +936,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         // (lanes that still have pixels): 1 = "any lane", 48 = three quarters of them.  Depth-0 rays skip the box walk (camera-ray lists),
         // so without a threshold the walk would run every trip for the ~60 % of lanes on a bounce segment; holding it back until
         // most live lanes want it lets the camera segments (REGEN -> TEST -> HIT) of the others catch up first.
-        const int live = (int)__popcll(__ballot(st != ST_DEAD));
+        // chained batches: parked lanes (ST_IDLE) ask for their pixel again every 8th trip - a poll is a round trip to memory that the
+        // wave's working lanes would otherwise pay on every trip - and do not count as live: the thresholds below are fractions of the
+        // lanes that have work, and a stage that cannot make progress must never keep the others from being forced
+        if (chained) { trip++; if ((trip & 7u) == 0u && st == ST_IDLE) st = ST_REGEN; }
+        const int live = (int)__popcll(__ballot(st != ST_DEAD && st != ST_IDLE));
         auto need = [&](int k) { const int t = (live * A.tune[k] + 63) >> 6; return t < 1 ? 1 : t; };
         bool ran = false;
         if ((int)__popcll(__ballot(st == ST_REGEN)) >= (force == ST_REGEN ? 1 : need(0))) {
@@ -889,6 +951,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             if (st == ST_REGEN) {
                 STAT_LANES(2);
                 while (smp >= nsamp) {
+                    const unsigned tk = chained ? (tick & kChainTicketMask) : tick;      // owned-pixel (unit) number inside its batch
+                    const unsigned batch = chained ? (tick >> kChainShift) : 0u;         // which batch of the chain the finished pixel belongs to
 #ifdef RTOW_STATS
                     if (pix >= 0 && A.stats) {
                         // last pixel this wave finished: {end, start, rays, tick} (100 MHz ticks since the wave started); later stores overwrite earlier ones
@@ -900,7 +964,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         // cost map for the next launch's chunk order: this pixel's ray count, in ticket order (a plain 2-byte store that
                         // merges in L2 with its chunk's other 63; per-chunk atomics cost a memory-side transaction each)
                         const unsigned rc = (unsigned)rayCount;
-                        A.pixelCost[tick] = (unsigned short)(rc < 65535u ? rc : 65535u);
+                        A.pixelCost[tk] = (unsigned short)(rc < 65535u ? rc : 65535u);
                     }
                     if (VOLUMES && hitOverflow) { *A.overflowFlag = 1u; hitOverflow = false; }            // RTOW_ERROR_CAPACITY on the host side
                     if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
@@ -912,6 +976,29 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         rec[1] = fallback ? make_float4(fbNormal.x, fbNormal.y, fbNormal.z, rayCount) : make_float4(normalAcc.x, normalAcc.y, normalAcc.z, rayCount);
                         rec[2] = fallback ? make_float4(fbAlbedo.x, fbAlbedo.y, fbAlbedo.z, scwAcc) : make_float4(albedoAcc.x, albedoAcc.y, albedoAcc.z, scwAcc);
                         rec[3] = make_float4(boundsHits, candidates, 0, 0);
+                        pix = -1;
+                    }
+                    if (pix >= 0 && chained) {
+                        // ---- pixel done, chained batches: the same stores (:159-163) as device-coherent accesses, then publish the pixel ----
+                        float* oc = A.outColor + 4 * (size_t)pix;
+                        coherent_store(oc + 0, colorAcc.x); coherent_store(oc + 1, colorAcc.y); coherent_store(oc + 2, colorAcc.z); coherent_store(oc + 3, (float)sampleCount);
+                        if (sampleCount != 0 || nsamp == 0) {
+                            const V3 on = sampleCount != 0 ? normalAcc : v3(0, 0, 0), oa = sampleCount != 0 ? albedoAcc : v3(0, 0, 0);
+                            coherent_store(A.outNormal + 3 * (size_t)pix + 0, on.x); coherent_store(A.outNormal + 3 * (size_t)pix + 1, on.y); coherent_store(A.outNormal + 3 * (size_t)pix + 2, on.z);
+                            coherent_store(A.outAlbedo + 3 * (size_t)pix + 0, oa.x); coherent_store(A.outAlbedo + 3 * (size_t)pix + 1, oa.y); coherent_store(A.outAlbedo + 3 * (size_t)pix + 2, oa.z);
+                        }
+                        coherent_store(A.outScw + pix, scwAcc);
+                        uint8_t* dg = A.chainBatches[batch].diagnostics;
+                        if (dg) {
+                            if (FULL_DIAG)
+                                *reinterpret_cast<float4*>(dg + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
+                            else
+                                *reinterpret_cast<float*>(dg + (size_t)pix * 4u) = rayCount;
+                        }
+                        // every store above has reached the coherence point before the chunk's counter moves (release at workgroup scope =
+                        // s_waitcnt vmcnt(0) + no compiler reordering; the stores themselves are device-coherent)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __hip_atomic_fetch_add(A.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pix = -1;
                     }
                     if (pix >= 0) {
@@ -940,6 +1027,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     // by a single CU within about one pixel-time and coalesces in that XCD's L2 instead of being fetched and
                     // written back once per pixel from eight different L2s.
                     unsigned ticket = 0xffffffffu;
+                    bool parked = false;
                     for (bool got = false; !got;) {
                         const unsigned long long need = __ballot(1);                  // lanes asking right now (all still in this loop)
                         const int lane = tid & 63;
@@ -952,23 +1040,41 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                                 bool cancelled = false;
                                 if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
                                 const unsigned slot = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
-                                if (slot >= A.chunkCount) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
+                                if (slot >= A.chunkCount * A.chainCount) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
                                 else {
+                                    // chains: slots run batch after batch, each batch in the same chunk order
+                                    unsigned b = 0u, within = slot;
+                                    if (chained) { b = slot / A.chunkCount; within = slot - b * A.chunkCount; }
                                     // most expensive chunks first (cost map of the previous launch, or of a 1-spp probe), so that the
                                     // chunks handed out last - the ones that decide when a wave can retire - are the cheap ones
-                                    const unsigned base = (A.chunkOrder ? A.chunkOrder[slot] : slot) * 64u;
-                                    waveQueue[0] = base;
-                                    waveQueue[1] = (A.totalWork - base < 64u) ? A.totalWork : base + 64u;
+                                    const unsigned chunk = A.chunkOrder ? A.chunkOrder[within] : within;
+                                    const unsigned base = chunk * 64u;
+                                    const unsigned last = (A.totalWork - base < 64u) ? A.totalWork : base + 64u;
+                                    waveQueue[2] = b * (last - base);                // pixels of this chunk that must be stored before batch b may read them
+                                    waveQueue[3] = chunk;
+                                    waveQueue[0] = base | (b << kChainShift);
+                                    waveQueue[1] = last | (b << kChainShift);
                                 }
                             }
                             continue;
+                        }
+                        if (chained) {
+                            // batch b of a chunk reads what batch b - 1 of the same chunk stored, possibly on another CU / XCD, possibly in other
+                            // lanes of this very wave: never spin here - lanes that cannot be served leave and ask again on the next trip
+                            if (waveQueue[2] != 0u) {
+                                if (lane == leader && __hip_atomic_load(A.chunkDone + waveQueue[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= waveQueue[2]) waveQueue[2] = 0u;
+                                if (waveQueue[2] != 0u) { parked = true; break; }
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            }
                         }
                         const unsigned take = (unsigned)__popcll(need) < end - next ? (unsigned)__popcll(need) : end - next;
                         if ((unsigned)rank < take) { ticket = next + (unsigned)rank; got = true; }
                         if (lane == leader) waveQueue[0] = next + take;
                     }
-                    if (ticket == 0xffffffffu) { st = ST_DEAD; break; }
+                    if (ticket == 0xffffffffu) { st = parked ? ST_IDLE : ST_DEAD; break; }
                     tick = ticket;
+                    const unsigned newBatch = chained ? (ticket >> kChainShift) : 0u;
+                    if (chained) ticket &= kChainTicketMask;
                     if (PER_SAMPLE) { unitGroup = ticket % A.groupsPerPixel; ticket = ticket / A.groupsPerPixel; }   // unit = (owned pixel, sample group)
 #ifdef RTOW_STATS
                     pixT0 = wall_clock64();
@@ -983,6 +1089,15 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         // a unit only needs what decides the pixel's sample count (:118-126); the fold kernel reads the accumulators
                         last.w = A.inColor[4 * (size_t)pix + 3];
                         scwAcc = A.inScw[pix];
+                    } else if (chained) {
+                        // batch 0 reads the launch's inputs, every later batch what the batch before it stored for this pixel (device-coherent loads)
+                        const float* ic = (newBatch == 0u ? A.inColor : A.outColor) + 4 * (size_t)pix;
+                        const float* in_ = (newBatch == 0u ? A.inNormal : A.outNormal) + 3 * (size_t)pix;
+                        const float* ia = (newBatch == 0u ? A.inAlbedo : A.outAlbedo) + 3 * (size_t)pix;
+                        last = make_float4(coherent_load(ic), coherent_load(ic + 1), coherent_load(ic + 2), coherent_load(ic + 3));
+                        normalAcc = v3(coherent_load(in_), coherent_load(in_ + 1), coherent_load(in_ + 2));
+                        albedoAcc = v3(coherent_load(ia), coherent_load(ia + 1), coherent_load(ia + 2));
+                        scwAcc = coherent_load((newBatch == 0u ? A.inScw : A.outScw) + pix);
                     } else if (!A.probeOnly) {
                         last = reinterpret_cast<const float4*>(A.inColor)[pix];                           // :72-78
                         normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
@@ -995,7 +1110,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const int countIn = sampleCount;
 
                     // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
-                    rng.begin_pixel(NoiseSite{&A, (unsigned)cx, (unsigned)cy}, (unsigned)pix);
+                    rng.begin_pixel(NoiseSite{&A, (unsigned)cx, (unsigned)cy}, (unsigned)pix, chained ? A.chainBatches[newBatch].seed : A.seed);
 
                     // :118-126
                     const float w = scwIn / (float)countIn;
@@ -1022,7 +1137,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     // the pixel's camera-ray candidates (primary_candidates_kernel): up to 4 primitive indices, 0xFFFF = none
                     pcand = A.pixelCandidates ? A.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u);
                 }
-                if (st != ST_DEAD) {
+                if (st == ST_REGEN) {
                     // ---- camera ray (:134-135, RT/View.cs:38-48) ----
                     const V3 viewRight = v3(A.view.right), viewUp = v3(A.view.up);
                     const V3 viewLLC = v3(A.view.lowerLeftCorner), viewH = v3(A.view.horizontal), viewV = v3(A.view.vertical);
@@ -1079,7 +1194,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             const float tfar1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmax(tlz.y, thz.y));
                             const bool leaf0 = c0 < 0 && tmin0 < tfar0;                        // AxisAlignedBoundingBox.Hit on the entity's own box
                             const bool leaf1 = c1 < 0 && tmin1 < tfar1 && twoChildren;
-                            if (FULL_DIAG) boundsHits += (leaf0 ? 1.0f : 0.0f) + (leaf1 ? 1.0f : 0.0f);
+                            if (FULL_DIAG && !refDiag) boundsHits += (leaf0 ? 1.0f : 0.0f) + (leaf1 ? 1.0f : 0.0f);
                             cand[nc * kBlockThreads] = (unsigned short)~c0;
                             nc += leaf0 ? 1 : 0;
                             cand[nc * kBlockThreads] = (unsigned short)~c1;
@@ -1124,7 +1239,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const bool hit0 = tmin0 <= vmin(tfar0, best);
                     const bool hit1 = tmin1 <= vmin(tfar1, best) && twoChildren;
                     const bool leaf0 = c0 < 0 && hit0 && tmin0 < tfar0, leaf1 = c1 < 0 && hit1 && tmin1 < tfar1;
-                    if (FULL_DIAG) boundsHits += ((c0 < 0 ? leaf0 : hit0) ? 1.0f : 0.0f) + ((c1 < 0 ? leaf1 : hit1) ? 1.0f : 0.0f);
+                    if (FULL_DIAG && !refDiag) boundsHits += ((c0 < 0 ? leaf0 : hit0) ? 1.0f : 0.0f) + ((c1 < 0 ? leaf1 : hit1) ? 1.0f : 0.0f);
                     cand[nc * kBlockThreads] = (unsigned short)~c0;
                     nc += leaf0 ? 1 : 0;
                     cand[nc * kBlockThreads] = (unsigned short)~c1;
@@ -1151,7 +1266,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
             if (st == ST_TEST) {
                 const float a = dot(rd, rd);
-                if (FULL_DIAG) candidates += (float)nc;
+                if (FULL_DIAG && !refDiag) candidates += (float)nc;
                 while (nc > 0) {
                     STAT_ADD(5, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0);
                     STAT_LANES(6);
@@ -1422,6 +1537,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             if (c & 0x40000000u) break;                                   // entry hit, early out
                             // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
                             const V3 bd = neg(rd);
+                            if (FULL_DIAG) { if (refDiag) reference_counts(A.refTree, ro, bd, &boundsHits, &candidates); }   // FindHitCandidates(backwardsRay, ...) counts too (:495)
                             V3 einv = v3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);                    // math.rcp + "convert NaN to INFINITY" (:409-412)
                             if (einv.x != einv.x) einv.x = __builtin_inff();
                             if (einv.y != einv.y) einv.y = __builtin_inff();
@@ -1577,7 +1693,13 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 const int n = (int)__popcll(__ballot(st == k));
                 if (n > top) { top = n; force = k; }
             }
-            if (top == 0) break;
+            if (top == 0) {
+                if (!chained || __ballot(st == ST_IDLE) == 0ull) break;
+                // every lane of this wave that is not done is parked behind pixels other waves are still tracing: wait a little, ask again
+                __builtin_amdgcn_s_sleep(64);
+                if (st == ST_IDLE) st = ST_REGEN;
+                force = ST_REGEN;
+            }
         }
     }
 #ifdef RTOW_STATS

@@ -246,6 +246,20 @@ class SampleBatchJob:
         return JobHandle(rc)
 
 
+def sample_batch_chain_device(context, params_list, ins, outs, diags=None, stream=None, cancel=None):
+    """rtowSampleBatchChainDevice: `len(params_list)` successive batches of one frame enqueued together (the reference keeps two in flight,
+    UNITY/Raytracer.cs:586-593); batch 0 reads `ins`, every later batch reads what its predecessor wrote to `outs`.
+    ins / outs: four DeviceBuffers each; diags: one DeviceBuffer (or None) per batch."""
+    count = len(params_list)
+    arr = (abi.SampleParams * count)(*params_list)
+    bi = _buffers(*[b.ptr for b in ins])
+    bo = _buffers(*[b.ptr for b in outs])
+    dptr = None
+    if diags is not None:
+        dptr = (C.c_void_p * count)(*[d.ptr if d is not None else None for d in diags])
+    return load().rtowSampleBatchChainDevice(context.handle, count, arr, C.byref(bi), C.byref(bo), dptr, stream, cancel)
+
+
 def sample_batch_host(context, params, inputs=None, want_diag=True):
     """Convenience used by tests/bench: run one batch with host buffers; returns dict like the oracle binding."""
     w, h = int(params.size.x), int(params.size.y)

@@ -16,3 +16,15 @@ extern "C" int shim_compile_scene(const RtowSceneDesc* desc, int maxDepth, uint8
     memcpy(blobOut, cs.blob.data(), cs.blob.size());
     return 0;
 }
+
+// the reference's own tree as the product replays it (rtow_reforder.h RefTreeNode[]): 8 int32 / float words per node
+extern "C" int shim_reference_tree(const RtowSceneDesc* desc, uint8_t* out, uint32_t capacityBytes)
+{
+    rtow::CompiledScene cs;
+    std::string err;
+    const int rc = rtow::compileScene(desc, 24, &cs, &err);
+    if (rc != RTOW_SUCCESS) return -rc;
+    if (cs.refTree.size() > capacityBytes) return -1000;
+    memcpy(out, cs.refTree.data(), cs.refTree.size());
+    return (int)(cs.refTree.size() / 32);
+}

@@ -129,9 +129,10 @@ def test_hit_list_overflow_is_reported(rt, gpu_context):
     assert lib.rtowSynchronize(ctx.handle) == a.RTOW_SUCCESS
     # a batch enqueued on a CALLER's stream: the status query waits for that batch (not for the context's own, idle stream), reports it
     # once, and a cancelled batch does not leave its flag behind for the next one
-    import torch
-    side = torch.cuda.Stream()
-    assert lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(acc), C.byref(acc), None, side.cuda_stream, None) == a.RTOW_SUCCESS
+    hip = C.CDLL("libamdhip64.so")                                     # a caller-owned stream, created through the HIP runtime the library itself uses
+    side = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(side)) == 0
+    assert lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(acc), C.byref(acc), None, side, None) == a.RTOW_SUCCESS
     assert lib.rtowGetBatchStatus(ctx.handle) == a.RTOW_ERROR_CAPACITY
     assert lib.rtowGetBatchStatus(ctx.handle) == a.RTOW_SUCCESS
     token = C.c_uint8(1)                                                # already cancelled: whatever the kernel flagged is discarded with the batch
@@ -143,6 +144,8 @@ def test_hit_list_overflow_is_reported(rt, gpu_context):
     assert lib.rtowGetBatchStatus(ctx.handle) == a.RTOW_SUCCESS
     for b in bufs + bb:
         b.free()
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    assert hip.hipStreamDestroy(side) == 0
 
 
 def test_slice_that_owns_no_row_does_nothing(rt, gpu_context):
@@ -449,3 +452,94 @@ def test_camera_ray_candidate_lists_are_conservative(rt, oracle, gpu_context):
             assert np.array_equal(with_lists[k].view(np.uint32), ref[k].view(np.uint32)), (scene.name, kw, k)
         assert np.array_equal(with_lists["diag"][:, 0], ref["diag"][:, 0])
     walker.close()
+
+
+def test_registered_host_buffers_give_the_same_results(rt, oracle, gpu_context):
+    """rtowRegisterHostBuffer: with the host's pools pinned, rtowSampleBatch lets the kernel store outputs and diagnostics straight into host
+    memory (no copy-back).  Same bits as the staged path and the oracle; in-place (in == out) accumulation over two batches; a slice
+    leaves the rows it does not own alone; unregistered memory keeps working next to registered memory."""
+    a = rt.abi
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    w, h = 80, 45
+    n = w * h
+    osc = oracle.OracleScene(desc)
+    # one pool per buffer kind, like UNITY/Raytracer.cs:279-288; page-unaligned on purpose (numpy gives 64-byte alignment at best)
+    pool = {k: np.zeros((n, c), np.float32) for k, c in (("color", 4), ("normal", 3), ("albedo", 3))}
+    pool["scw"] = np.zeros(n, np.float32)
+    diag = np.zeros((n, 4), np.float32)
+    ctx.register_host_buffers(pool["color"], pool["normal"], pool["albedo"], pool["scw"], diag)
+    lib = rt.lib.load()
+    assert lib.rtowRegisterHostBuffer(ctx.handle, pool["color"].ctypes.data + 16, 64) == a.RTOW_ERROR_INVALID_VALUE      # overlaps a live registration
+    ref = None
+    for batch in range(2):
+        p = rt.scenes.make_params(scene, w, h, spp=3, trace_depth=6, seed=21 + batch, diagnostics_stride=16)
+        job = rt.SampleBatchJob(ctx, p)
+        job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = pool["color"], pool["normal"], pool["albedo"], pool["scw"]
+        job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = pool["color"], pool["normal"], pool["albedo"], pool["scw"]
+        job.OutputDiagnostics = diag
+        assert job.Schedule(n, 1).Complete() == 0
+        ref = osc.sample_batch(p, ref if ref is None else {k: ref[k] for k in ("color", "normal", "albedo", "scw")})
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(pool[k].reshape(-1).view(np.uint32), ref[k].reshape(-1).view(np.uint32)), (batch, k)
+        assert np.array_equal(diag[:, 0], ref["diag"][:, 0])
+    # a slice through the zero-copy path: rows it does not own keep their bytes
+    before = {k: v.copy() for k, v in pool.items()}
+    p = rt.scenes.make_params(scene, w, h, spp=2, trace_depth=6, seed=40, slice_offset=1, slice_divider=3)
+    job = rt.SampleBatchJob(ctx, p)
+    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = pool["color"], pool["normal"], pool["albedo"], pool["scw"]
+    job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = pool["color"], pool["normal"], pool["albedo"], pool["scw"]
+    assert job.Schedule(n, 1).Complete() == 0
+    rows = np.arange(n) // w
+    refs = osc.sample_batch(p, before)
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(pool[k][rows % 3 != 1], before[k][rows % 3 != 1]), k
+        assert np.array_equal(pool[k].reshape(n, -1)[rows % 3 == 1].view(np.uint32), refs[k].reshape(n, -1)[rows % 3 == 1].view(np.uint32)), k
+    # mixed: registered inputs, unregistered outputs -> staged copy-back
+    outs = {k: np.zeros_like(v) for k, v in pool.items()}
+    p = rt.scenes.make_params(scene, w, h, spp=2, trace_depth=6, seed=41)
+    job = rt.SampleBatchJob(ctx, p)
+    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = pool["color"], pool["normal"], pool["albedo"], pool["scw"]
+    job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = outs["color"], outs["normal"], outs["albedo"], outs["scw"]
+    assert job.Schedule(n, 1).Complete() == 0
+    refm = osc.sample_batch(p, pool)
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(outs[k].reshape(-1).view(np.uint32), refm[k].reshape(-1).view(np.uint32)), k
+    osc.close()
+    ctx.unregister_host_buffers()
+    assert lib.rtowUnregisterHostBuffer(ctx.handle, pool["color"].ctypes.data) == a.RTOW_ERROR_INVALID_VALUE             # already dropped
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth,max_bvh_depth", [("cover", 160, 90, 4, 8, 32), ("cover", 96, 54, 3, 6, 5), ("moving", 120, 68, 3, 6, 32),
+                                                               ("mixed", 96, 64, 3, 6, 32), ("volumes", 96, 54, 3, 8, 32), ("stress", 120, 68, 2, 5, 32)])
+def test_reference_identical_full_diagnostics(rt, oracle, name, w, h, spp, depth, max_bvh_depth):
+    """RTOW_CONTEXT_REFERENCE_DIAGNOSTICS: the FULL_DIAGNOSTICS record {RayCount, BoundsHitCount, CandidateCount, SampleCountWeight}
+    (UNITY/Raytracer.cs:54-64) as the REFERENCE produces it - BoundsHitCount / CandidateCount count the boxes and leaf entities of the tree
+    RebuildBvh builds (JOBS/SampleBatchJob.cs:427-440), including the backwards containment probes of volume scenes (:495) and leaves
+    forced at MaxBvhDepth.  All four columns against the oracle, which walks that very tree; colours unchanged."""
+    S = rt.scenes
+    scene = {"cover": S.cover_scene, "moving": S.moving_scene, "mixed": S.mixed_scene, "volumes": S.volume_scene,
+             "stress": lambda: S.stress_scene(count=3000, max_tentatives=12000)}[name]()
+    desc = scene.desc(max_bvh_depth=max_bvh_depth)
+    p = S.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=17, diagnostics_stride=16, focus=6.0 if name != "cover" else None)
+    osc = oracle.OracleScene(desc)
+    ref = osc.sample_batch(p)
+    osc.close()
+    with rt.Context(0, flags=rt.abi.CONTEXT_REFERENCE_DIAGNOSTICS) as ctx:
+        ctx.upload_scene(desc)
+        got = rt.sample_batch_host(ctx, p)
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+        for col, what in enumerate(("RayCount", "BoundsHitCount", "CandidateCount", "SampleCountWeight")):
+            assert np.array_equal(got["diag"][:, col].view(np.uint32), ref["diag"][:, col].view(np.uint32)), (name, what, got["diag"][:4], ref["diag"][:4])
+        # the per-sample RNG policy sums the same counters through its unit records
+        p.rngPolicy = rt.abi.RNG_PER_SAMPLE
+        got2 = rt.sample_batch_host(ctx, p)
+        assert got2["diag"][:, 1].sum() > 0 and got2["diag"][:, 2].sum() > 0
+    with rt.Context(0) as plain:                                        # without the option: the library's own tree, different numbers, same RayCount
+        plain.upload_scene(desc)
+        own = rt.sample_batch_host(plain, S.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=17, diagnostics_stride=16, focus=6.0 if name != "cover" else None))
+        assert np.array_equal(own["diag"][:, 0], ref["diag"][:, 0])
+        assert not np.array_equal(own["diag"][:, 1], ref["diag"][:, 1])

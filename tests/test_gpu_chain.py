@@ -1,0 +1,130 @@
+"""GPU: chained batches (rtowSampleBatchChainDevice, include/rtow.h).
+
+The reference keeps two sample batches in flight, the second depending on the first (UNITY/Raytracer.cs:586-593); the chain entry point
+takes `count` such batches at once and - when they differ only in Seed - runs them as ONE launch in which batch k + 1 of a 64-pixel chunk
+starts as soon as batch k of that chunk is stored.  Defined result: the batches one after the other.  Every test compares the chain, bit
+for bit, with that sequence (and one with the oracle), across workgroups / XCDs handing accumulators to each other inside the kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KEYS = (("color", 4), ("normal", 3), ("albedo", 3), ("scw", 1))
+
+
+def _zero_bufs(rt, ctx, n):
+    return [rt.DeviceBuffer(ctx, n * c * 4).zero() for _, c in KEYS]
+
+
+def _download(bufs, n):
+    return {k: b.download(np.float32, (n, c)) for (k, c), b in zip(KEYS, bufs)}
+
+
+def _params(rt, scene, w, h, spp, depth, seeds, **kw):
+    return [rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=s, **kw) for s in seeds]
+
+
+def _sequential(rt, ctx, plist, n, stride, start=None):
+    bufs = _zero_bufs(rt, ctx, n) if start is None else start
+    diags = []
+    for p in plist:
+        d = rt.DeviceBuffer(ctx, n * stride).zero()
+        job = rt.SampleBatchJob(ctx, p)
+        job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = bufs
+        job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = bufs
+        job.OutputDiagnostics = d
+        assert job.Schedule().Complete() == 0
+        diags.append(d)
+    ctx.synchronize()
+    out = _download(bufs, n)
+    out["diag"] = [d.download(np.float32, (n, stride // 4)) for d in diags]
+    for b in bufs + diags:
+        b.free()
+    return out
+
+
+def _chained(rt, ctx, plist, n, stride, separate_input=False):
+    outs = _zero_bufs(rt, ctx, n)
+    ins = _zero_bufs(rt, ctx, n) if separate_input else outs
+    diags = [rt.DeviceBuffer(ctx, n * stride).zero() for _ in plist]
+    assert rt.sample_batch_chain_device(ctx, plist, ins, outs, diags) == 0
+    ctx.synchronize()
+    out = _download(outs, n)
+    out["diag"] = [d.download(np.float32, (n, stride // 4)) for d in diags]
+    for b in set(outs + ins + diags):
+        b.free()
+    return out
+
+
+def _same(a, b, what):
+    for k, _ in KEYS:
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (what, k, int((a[k].view(np.uint32) != b[k].view(np.uint32)).any(axis=-1).sum()))
+    assert len(a["diag"]) == len(b["diag"])
+    for i, (x, y) in enumerate(zip(a["diag"], b["diag"])):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (what, "diagnostics of batch", i)
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth,count", [("cover", 1920, 1080, 4, 8, 3), ("cover", 96, 54, 6, 8, 16), ("moving", 640, 360, 5, 8, 4),
+                                                       ("mixed", 320, 200, 4, 6, 5), ("volumes", 256, 144, 3, 10, 4), ("textured", 256, 144, 3, 6, 3),
+                                                       ("stress", 960, 540, 3, 8, 3)])
+def test_chain_equals_the_batches_one_after_the_other(rt, gpu_context, name, w, h, spp, depth, count):
+    S = rt.scenes
+    scene = {"cover": S.cover_scene, "moving": S.moving_scene, "mixed": S.mixed_scene, "volumes": S.volume_scene, "textured": S.textured_scene,
+             "stress": lambda: S.stress_scene(count=6000, max_tentatives=30000)}[name]()
+    ctx = gpu_context
+    ctx.upload_scene(scene.desc())
+    n = w * h
+    plist = _params(rt, scene, w, h, spp, depth, [100 + 7 * k for k in range(count)], diagnostics_stride=16, focus=6.0 if name != "cover" else None)
+    seq = _sequential(rt, ctx, plist, n, 16)
+    for attempt in range(2):                                      # second attempt: chunk order from the measured cost map
+        _same(_chained(rt, ctx, plist, n, 16, separate_input=attempt == 1), seq, (name, attempt))
+    assert seq["color"][:, 3].max() == spp * count
+
+
+def test_chain_of_slices_and_the_oracle(rt, oracle, gpu_context):
+    """Interlaced slice (rows the chain must not touch), 4-byte diagnostics, and the CPU oracle as the referee of the accumulated result."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    w, h, spp, depth = 128, 72, 3, 8
+    n = w * h
+    plist = _params(rt, scene, w, h, spp, depth, [5, 6, 7, 8], slice_offset=2, slice_divider=3)
+    got = _chained(rt, ctx, plist, n, 4)
+    osc = oracle.OracleScene(desc)
+    ref = None
+    for i, p in enumerate(plist):
+        ref = osc.sample_batch(p, None if ref is None else {k: ref[k] for k, _ in KEYS})
+        assert np.array_equal(got["diag"][i][(np.arange(n) // w) % 3 == 2, 0], ref["diag"][(np.arange(n) // w) % 3 == 2, 0]), i
+    osc.close()
+    for k, _ in KEYS:
+        assert np.array_equal(got[k].reshape(-1).view(np.uint32), ref[k].reshape(-1).view(np.uint32)), k
+
+
+def test_chain_falls_back_when_batches_differ_or_are_too_many(rt, gpu_context):
+    """Batches that differ in more than Seed (here: samples per pixel), more batches than one launch holds (16), and the per-sample RNG policy
+    all run as the sequence the chain is defined to equal."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 160, 90
+    n = w * h
+    mixed = [rt.scenes.make_params(scene, w, h, spp=s, trace_depth=6, seed=30 + s) for s in (2, 3, 2)]
+    _same(_chained(rt, ctx, mixed, n, 4), _sequential(rt, ctx, mixed, n, 4), "differing spp")
+    many = _params(rt, scene, w, h, 1, 6, list(range(1, 20)))
+    _same(_chained(rt, ctx, many, n, 4), _sequential(rt, ctx, many, n, 4), "19 batches")
+    per_sample = _params(rt, scene, w, h, 20, 6, [3, 4], rng_policy=rt.abi.RNG_PER_SAMPLE)
+    _same(_chained(rt, ctx, per_sample, n, 4), _sequential(rt, ctx, per_sample, n, 4), "per-sample policy")
+
+
+def test_chain_with_adaptive_sample_counts(rt, gpu_context):
+    """SampleCountRange.x != .y: batch k + 1's per-pixel sample count depends on what batch k accumulated (JOBS/SampleBatchJob.cs:118-126) -
+    the hand-off must deliver exactly those accumulators."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 200, 120
+    n = w * h
+    plist = _params(rt, scene, w, h, 2, 8, [11, 12, 13, 14, 15], spp_max=9, extrema=(0.2, 1.4), diagnostics_stride=16)
+    _same(_chained(rt, ctx, plist, n, 16), _sequential(rt, ctx, plist, n, 16), "adaptive")

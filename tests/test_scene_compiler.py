@@ -117,3 +117,34 @@ def test_largest_scene_builds_in_seconds(shim):
     L, _ = compile_scene(shim, d)
     assert L["nodeCount"] == 65534 and L["bvhDepth"] <= STACK_CAPACITY
     assert time.time() - t < 20.0
+
+
+@pytest.mark.parametrize("name,max_depth", [("cover", 32), ("cover", 5), ("moving", 32), ("mixed", 32), ("mixed", 2), ("volumes", 32), ("mesh", 32), ("mesh", 7)])
+def test_replayed_reference_tree_matches_the_oracles(shim, name, max_depth):
+    """RTOW_CONTEXT_REFERENCE_DIAGNOSTICS counts the boxes and leaves of the tree RebuildBvh would build (UNITY/BvhNodeData.cs:122-213).  The
+    product replays that builder's range bookkeeping (csrc/rtow_reforder.cpp); the oracle restates the builder itself.  Same node count,
+    every entity in exactly one leaf, leaves only forced at MaxBvhDepth, children enclosed by their parent."""
+    from oracle import binding as ob
+    scene = {"cover": S.cover_scene, "moving": S.moving_scene, "mixed": S.mixed_scene, "volumes": S.volume_scene, "mesh": S.mesh_scene}[name]()
+    desc = scene.desc(max_bvh_depth=max_depth)
+    buf = (C.c_uint8 * (8 << 20))()
+    count = shim.shim_reference_tree(C.byref(desc), buf, len(buf))
+    assert count > 0, count
+    raw = np.frombuffer(buf, dtype=np.uint8, count=count * 32)
+    f = raw.view(np.float32).reshape(-1, 8)
+    i = raw.view(np.int32).reshape(-1, 8)
+    lo, left, hi, right = f[:, 0:3], i[:, 3], f[:, 4:7], i[:, 7]
+    osc = ob.OracleScene(desc)
+    assert count == ob.load().oracle_scene_node_count(osc.handle)
+    osc.close()
+    leaves = left < 0
+    assert int((~left[leaves]).sum()) == scene.entity_count
+    depth = np.zeros(count, np.int64)
+    for k in range(count):
+        if left[k] >= 0:
+            for c in (left[k], right[k]):
+                assert c > k
+                depth[c] = depth[k] + 1
+                assert np.all(lo[k] <= lo[c]) and np.all(hi[k] >= hi[c])
+    assert depth.max() <= max_depth
+    assert np.all((~left[leaves] == 1) | (depth[leaves] == max_depth))          # a leaf holds one entity unless MaxBvhDepth forced it
