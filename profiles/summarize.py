@@ -74,7 +74,16 @@ def main():
     if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         cycles = c["GRBM_GUI_ACTIVE"] / 8  # 8 XCDs
         d["gpu_cycles_per_launch"] = cycles
+        # Units pinned with pure instruction streams (profiles/calib/valu_calib.hip, r02_valu_calibration.json): SQ_INSTS_VALU and
+        # SQ_ACTIVE_INST_VALU both count INSTRUCTIONS (the latter 2 per transcendental), not busy cycles.  A wave64 instruction occupies its
+        # SIMD for 2 cycles if it is full rate (mul / add / fma / logic / mov), ~2.8 if half rate (min / max / compare / select / shift /
+        # convert, 3-operand encodings, packed fp32) and ~5.3 if transcendental.  So:
+        #   valu_issue_utilisation      = INSTS x 2 / SIMD-cycles: the fraction of issue slots used IF every instruction were full rate (a floor)
+        #   simd_cycles_per_valu_inst   = SIMD-cycles / INSTS: compare with ~2.7, what this kernel's instruction mix costs at full issue
+        #   valu_pipe_busy_estimate     = 2.7 / simd_cycles_per_valu_inst
         d["valu_issue_utilisation"] = c["SQ_INSTS_VALU"] * 2 / (cycles * 1024)  # wave64 on SIMD32: 2 cycles/instr, 1024 SIMDs
+        d["simd_cycles_per_valu_inst"] = cycles * 1024 / c["SQ_INSTS_VALU"]
+        d["valu_pipe_busy_estimate"] = min(1.0, 2.7 / d["simd_cycles_per_valu_inst"])
     if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
         d["lds_busy_fraction"] = c["SQ_LDS_IDX_ACTIVE"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256)
     if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:

@@ -429,6 +429,20 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.nodeOffset = off; L.nodeCount = (uint32_t)gnodes.size(); off = align16(off + L.nodeCount * (uint32_t)sizeof(GpuNode));
     L.sphereOffset = off; L.sphereCount = (uint32_t)n; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuSphere));
     L.hasMotion = hasMotion ? 1u : 0u;
+    if (hasMotion) {
+        // do all moving entities share one TimeRange?  (bit comparison: the hoisted expression must be the very same float program)
+        bool first = true, same = true;
+        uint32_t t0 = 0, t1 = 0;
+        for (int i = 0; i < n && same; i++) {
+            const RtowEntity& e = desc->entities[i];
+            if (!e.moving) continue;
+            uint32_t a, b;
+            memcpy(&a, &e.timeRange.x, 4); memcpy(&b, &e.timeRange.y, 4);
+            if (first) { t0 = a; t1 = b; first = false; }
+            else same = a == t0 && b == t1;
+        }
+        if (same && !first) { L.commonTimeRange = 1u; memcpy(&L.commonT0, &t0, 4); memcpy(&L.commonT1, &t1, 4); }
+    }
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
     L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? SCENE_KIND_TEXTURED : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     // Does the scene hold the same primitive twice (same geometry, any material)?  Two such surfaces coincide everywhere - the same float

@@ -20,7 +20,8 @@
 //    VGPRs and re-expanded when the path is folded tail -> head (:384-396), which keeps the colour bit-identical to the reference's
 //    fold order without 2 x TraceDepth float3 of per-lane storage (textured scenes keep per-depth colours in scratch instead);
 //  * template parameters: ALL_LDS (scene fully LDS resident), KIND (spheres / moving spheres / general entities / volumes / textured /
-//    both), HW (history words: trace depth <= 8 / 16 / 64), FULL_DIAG, NOISE (white / blue / STBN), PER_SAMPLE.
+//    both), HW (history words: trace depth <= 8 / 16 / 64), FULL_DIAG (the FULL_DIAGNOSTICS counters are kept), NOISE (white / blue / STBN),
+//    PER_SAMPLE; launchByDiag (end of this file) says which of the 144 instantiations serves which batch.
 //
 // Numerics: compiled with -ffp-contract=off; every expression below is written in the evaluation order of the C#
 // source (left to right, no fusion), with IEEE division and square root, and the deterministic transcendental
@@ -29,6 +30,20 @@
 #include "rtow_kernels.h"
 
 #include "rtow_detmath.hip.h"
+#include "rtow_exactmath.hip.h"
+
+// IEEE 1 / x and sqrt(x) of the path's float program: the exhaustively checked short forms of rtow_exactmath.hip.h (same result for every
+// operand; RTOW_EXACT_MATH=0 builds the compiler's expansions instead, for A/B timing).
+#ifndef RTOW_EXACT_MATH
+#define RTOW_EXACT_MATH 1
+#endif
+#if RTOW_EXACT_MATH
+#define RTOW_RCP(x) rtow::exact_rcp(x)
+#define RTOW_SQRT(x) rtow::exact_sqrt(x)
+#else
+#define RTOW_RCP(x) (1.0f / (x))
+#define RTOW_SQRT(x) __builtin_sqrtf(x)
+#endif
 
 namespace rtow {
 
@@ -47,7 +62,7 @@ __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ V3 scale(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // math.normalize(v) = rsqrt(dot(v, v)) * v with rsqrt(x) = 1 / sqrt(x)
-__device__ __forceinline__ V3 normalize(V3 v) { const float r = 1.0f / __builtin_sqrtf(dot(v, v)); return scale(r, v); }
+__device__ __forceinline__ V3 normalize(V3 v) { const float r = RTOW_RCP(RTOW_SQRT(dot(v, v))); return scale(r, v); }
 // math.reflect(i, n) = i - 2f * n * dot(i, n)
 __device__ __forceinline__ V3 reflect(V3 i, V3 n)
 {
@@ -95,7 +110,7 @@ __device__ __forceinline__ float half_bits_to_float(unsigned h)
 __device__ __forceinline__ V3 tangent_to_world(float tx, float ty, float tz, V3 n)
 {
     const float s = n.z >= 0 ? 1.0f : -1.0f;
-    const float a = -1 / (s + n.z);
+    const float a = -RTOW_RCP(s + n.z);      // -1 / x == -(1 / x): rounding to nearest is symmetric
     const float b = n.x * n.y * a;
     const V3 tangent = v3(1 + s * n.x * n.x * a, s * b, -s * n.x);
     const V3 bitangent = v3(b, s + n.y * n.y * a, -n.y);
@@ -107,19 +122,19 @@ __device__ __forceinline__ V3 tangent_to_world(float tx, float ty, float tz, V3 
 // RandomSource.OnCosineWeightedHemisphere (RT/RandomSource.cs:63-89) from its two uniform numbers
 __device__ __forceinline__ V3 cosine_hemisphere_uv(float u, float v, V3 n)
 {
-    const float radius = __builtin_sqrtf(u);
+    const float radius = RTOW_SQRT(u);
     const float theta = v * 2 * kPi;
     float sinT, cosT;
     det_sincos(theta, sinT, cosT);
     const float tx = radius * cosT, tz = radius * sinT;
-    const float ty = __builtin_sqrtf(1 - u);
+    const float ty = RTOW_SQRT(1 - u);
     return tangent_to_world(tx, ty, tz, n);
 }
 // RandomSource.NextFloat3Direction (RT/RandomSource.cs:113-128) from its two uniform numbers
 __device__ __forceinline__ V3 direction_uv(float r0, float r1)
 {
     const float z = r0 * 2.0f - 1.0f;
-    const float rr = __builtin_sqrtf(um_max(1.0f - z * z, 0.0f));
+    const float rr = RTOW_SQRT(um_max(1.0f - z * z, 0.0f));
     const float angle = r1 * kPi * 2.0f;
     float sn, cs;
     det_sincos(angle, sn, cs);
@@ -173,7 +188,7 @@ struct Rng<RTOW_NOISE_WHITE> {
     __device__ __forceinline__ void in_unit_disk(const NoiseSite&, float& x, float& y)       // RT/RandomSource.cs:40-61
     {
         const float theta = rng_next(s) * (2.0f * kPi - 0.0f) + 0.0f;                        // NextFloat(0, 2 * PI)
-        const float radius = __builtin_sqrtf(rng_next(s));
+        const float radius = RTOW_SQRT(rng_next(s));
         float sinT, cosT;
         det_sincos(theta, sinT, cosT);
         x = radius * cosT; y = radius * sinT;
@@ -200,7 +215,7 @@ struct Rng<RTOW_NOISE_BLUE> {
     __device__ __forceinline__ void in_unit_disk(const NoiseSite& at, float& x, float& y)
     {
         const float theta = next(at) * 2 * kPi;
-        const float radius = __builtin_sqrtf(next(at));
+        const float radius = RTOW_SQRT(next(at));
         float sinT, cosT;
         det_sincos(theta, sinT, cosT);
         x = radius * cosT; y = radius * sinT;
@@ -257,7 +272,7 @@ __device__ __forceinline__ float smith_g1(V3 w, V3 n, float alpha /* = Roughness
     const float cosTheta = dot(n, w);
     const float sqCos = cosTheta * cosTheta;
     const float sqSin = um_max(0.0f, 1 - sqCos);
-    const float sinTheta = __builtin_sqrtf(sqSin);
+    const float sinTheta = RTOW_SQRT(sqSin);
     const float tanTheta = sinTheta / cosTheta;
     const float absTan = __builtin_fabsf(tanTheta);
     float lambda;
@@ -265,9 +280,9 @@ __device__ __forceinline__ float smith_g1(V3 w, V3 n, float alpha /* = Roughness
         lambda = 0;
     } else {
         const float a2t2 = (alpha * absTan) * (alpha * absTan);
-        lambda = (-1 + __builtin_sqrtf(1 + a2t2)) / 2;
+        lambda = (-1 + RTOW_SQRT(1 + a2t2)) / 2;
     }
-    return 1 / (1 + lambda);
+    return RTOW_RCP(1 + lambda);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -435,7 +450,9 @@ __device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout
         const float4 m0 = *reinterpret_cast<const float4*>(mp);      // dx dy dz t0
         const float2 m1 = *reinterpret_cast<const float2*>(mp + 16); // t1 moving
         if (__float_as_int(m1.y) != 0) {
-            const float f = um_max(0.0f, um_min(1.0f, (time - m0.w) / (m1.x - m0.w))); // clamp(unlerp(t0, t1, t), 0, 1)
+            // clamp(unlerp(t0, t1, t), 0, 1); when every moving entity shares one TimeRange (L.commonTimeRange) `time` already IS that value:
+            // the sample's ray time goes through the expression once, in REGEN, instead of once per sphere test (same operands, same result)
+            const float f = L.commonTimeRange ? time : um_max(0.0f, um_min(1.0f, (time - m0.w) / (m1.x - m0.w)));
             c = v3(c.x + m0.x * f, c.y + m0.y * f, c.z + m0.z * f);
         }
     }
@@ -451,7 +468,7 @@ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, f
         // t = (-b -+ sq) / a with a = dot(d, d) >= 0: a numerator that is not positive gives a quotient that is not positive (or NaN) and
         // fails `t > 0` whatever a is, so its IEEE division is skipped - bit-identical, and the common "sphere behind the origin" case
         // (every ray leaving the ground sphere) costs no division at all.
-        const float sq = __builtin_sqrtf(disc);
+        const float sq = RTOW_SQRT(disc);
         const float n0 = -b - sq;
         if (n0 > 0) {
             const float t = n0 / a;
@@ -473,7 +490,7 @@ __device__ __forceinline__ bool sphere_hit_tmin(V3 oc, V3 d, float a, float radi
     const float c = dot(oc, oc) - radius * radius;
     const float disc = b * b - a * c;
     if (disc > 0) {
-        const float sq = __builtin_sqrtf(disc);                    // tMin >= 0 here: the numerator shortcut of sphere_hit applies unchanged
+        const float sq = RTOW_SQRT(disc);                    // tMin >= 0 here: the numerator shortcut of sphere_hit applies unchanged
         const float n0 = -b - sq;
         if (n0 > 0) {
             const float t = n0 / a;
@@ -519,7 +536,7 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
         const V3 pvec = cross(rd, e0);
         const float det = dot(e1, pvec);
         if (det == 0) return false;
-        const float invDet = 1 / det;
+        const float invDet = RTOW_RCP(det);
         const V3 tvec = sub(ro, v0);
         const float u = dot(tvec, pvec) * invDet;
         if (u < 0 || u > 1) return false;
@@ -702,7 +719,7 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
     float hitT[kMaxList], hitDummy[kMaxList];
     unsigned hitCode[kMaxList];
     int n = 0;
-    V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                     // startRay's rayInvDirection
+    V3 inv = v3(RTOW_RCP(rd.x), RTOW_RCP(rd.y), RTOW_RCP(rd.z));                     // startRay's rayInvDirection
     if (inv.x != inv.x) inv.x = __builtin_inff();
     if (inv.y != inv.y) inv.y = __builtin_inff();
     if (inv.z != inv.z) inv.z = __builtin_inff();
@@ -759,7 +776,7 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
 // ------------------------------------------------------------------------------------------------------------
 __device__ __noinline__ __attribute__((unused)) void reference_counts(const uint8_t* tree, V3 ro, V3 rd, float* boundsHits, float* candidates)
 {
-    V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);                     // rcp(ray.Direction), NaN -> +INF (:406-412)
+    V3 inv = v3(RTOW_RCP(rd.x), RTOW_RCP(rd.y), RTOW_RCP(rd.z));                     // rcp(ray.Direction), NaN -> +INF (:406-412)
     if (inv.x != inv.x) inv.x = __builtin_inff();
     if (inv.y != inv.y) inv.y = __builtin_inff();
     if (inv.z != inv.z) inv.z = __builtin_inff();
@@ -901,7 +918,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     auto startRay = [&]() {
         // rayInvDirection = rcp(ray.Direction), NaN -> +INF (JOBS/SampleBatchJob.cs:408-412).  The IEEE quotient, not v_rcp_f32: the leaf
         // children of the tree carry the reference's own entity boxes and must pass or fail the reference's own slab test (RT/HitTests.cs:9-21)
-        inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        inv = v3(RTOW_RCP(rd.x), RTOW_RCP(rd.y), RTOW_RCP(rd.z));
         if (inv.x != inv.x) inv.x = __builtin_inff();
         if (inv.y != inv.y) inv.y = __builtin_inff();
         if (inv.z != inv.z) inv.z = __builtin_inff();
@@ -990,7 +1007,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         coherent_store(A.outScw + pix, scwAcc);
                         uint8_t* dg = A.chainBatches[batch].diagnostics;
                         if (dg) {
-                            if (FULL_DIAG)
+                            if (FULL_DIAG && A.diagnosticsStride >= 16)
                                 *reinterpret_cast<float4*>(dg + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
                             else
                                 *reinterpret_cast<float*>(dg + (size_t)pix * 4u) = rayCount;
@@ -1014,7 +1031,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         } // else: sample 0 failed and its AOVs were stored as the fallback by endSample
                         A.outScw[pix] = scwAcc;
                         if (A.diagnostics) {
-                            if (FULL_DIAG)
+                            if (FULL_DIAG && A.diagnosticsStride >= 16)
                                 *reinterpret_cast<float4*>(A.diagnostics + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
                             else
                                 *reinterpret_cast<float*>(A.diagnostics + (size_t)pix * 4u) = rayCount;
@@ -1161,6 +1178,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                                       viewLLC.y - offset.y + u * viewH.y + v * viewV.y,
                                       viewLLC.z - offset.z + u * viewH.z + v * viewV.z));
                     rtime = rng.next(at);
+                    // moving-sphere scenes whose entities share one TimeRange: carry clamp(unlerp(t0, t1, Time), 0, 1) instead of Time (see sphere_at);
+                    // only sphere_at reads it in this scene kind, and scattered rays inherit the ray's time unchanged (RT/Material.cs:94,102,107,153)
+                    if (HAS_MOTION) { if (L.commonTimeRange) rtime = um_max(0.0f, um_min(1.0f, (rtime - L.commonT0) / (L.commonT1 - L.commonT0))); }
 
                     depth = 0;
                     hist.clear();
@@ -1394,7 +1414,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         } else {
                             roughness = 1 - glossiness;
                             ior = m2hit.y;
-                            invIor = 1 / ior;
+                            invIor = RTOW_RCP(ior);
                         }
                         float r0 = (1 - ior) / (1 + ior);
                         r0 *= r0;
@@ -1487,7 +1507,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const float disc = 1 - niOverNt * niOverNt * (1 - dt * dt);
                     bool refractOk = false;
                     if (disc > 0) {
-                        const float sq = __builtin_sqrtf(disc);
+                        const float sq = RTOW_SQRT(disc);
                         const V3 refracted = v3(niOverNt * (rd.x - outwardN.x * dt) - outwardN.x * sq,
                                                 niOverNt * (rd.y - outwardN.y * dt) - outwardN.y * sq,
                                                 niOverNt * (rd.z - outwardN.z * dt) - outwardN.z * sq);
@@ -1538,7 +1558,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
                             const V3 bd = neg(rd);
                             if (FULL_DIAG) { if (refDiag) reference_counts(A.refTree, ro, bd, &boundsHits, &candidates); }   // FindHitCandidates(backwardsRay, ...) counts too (:495)
-                            V3 einv = v3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);                    // math.rcp + "convert NaN to INFINITY" (:409-412)
+                            V3 einv = v3(RTOW_RCP(bd.x), RTOW_RCP(bd.y), RTOW_RCP(bd.z));                    // math.rcp + "convert NaN to INFINITY" (:409-412)
                             if (einv.x != einv.x) einv.x = __builtin_inff();
                             if (einv.y != einv.y) einv.y = __builtin_inff();
                             if (einv.z != einv.z) einv.z = __builtin_inff();
@@ -1614,7 +1634,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                                 // Material.ProbabilisticHit (RT/Material.cs:49-65)
                                 const float density = *reinterpret_cast<const float*>(section<ALL_LDS>(sc, L.materialOffset) + (unsigned)curVol * 64u + 36u);
                                 pendRE++;
-                                const float volumeHitDistance = -(1 / um_max(density, 1.1920928955078125e-7f)) * det_log(rng.next(NoiseSite{&A, (unsigned)cx, (unsigned)cy}));
+                                const float volumeHitDistance = -(RTOW_RCP(um_max(density, 1.1920928955078125e-7f))) * det_log(rng.next(NoiseSite{&A, (unsigned)cx, (unsigned)cy}));
                                 if (volumeHitDistance < distanceInVolume) {
                                     best = entryDistance + volumeHitDistance;                    // we hit inside the volume
                                     insideHit = true;
@@ -1726,27 +1746,27 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t lds
     return hipGetLastError();
 }
 
-template <bool ALL_LDS, int KIND, bool FULL_DIAG>
-hipError_t launchByDepth(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
-{
-    // the texture-driven noise sources are not the hot configuration: one (generic-history) variant each keeps the build small
-    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_BLUE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.unitRecords) {      // RTOW_RNG_PER_SAMPLE
-        if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
-        if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
-        return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
-    }
-    if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-    return launchVariant<ALL_LDS, KIND, 32, FULL_DIAG, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-}
-
+// Which instantiation serves a batch.  The kernel is specialised where it pays - the reference stream and the per-sample policy at trace
+// depth <= 8 (4 history words), the reference stream at depth <= 16 (8 words), both without the FULL_DIAGNOSTICS counters - and generic
+// elsewhere: ONE variant with the full history (32 words) and the counters switched on serves every deeper path, every 16-byte
+// diagnostics record, the texture-driven noise sources and the per-sample policy beyond depth 8 (the counters cost ~2 % there; the record
+// format is chosen at run time from diagnosticsStride).  Scenes that need the exact-tie resolver (kExactTiesBit) are rare: depth <= 16 shares
+// the 8-word variant.  144 instantiations instead of 320 (tests/test_gpu_variants.py runs every one of them on every build).
 template <bool ALL_LDS, int KIND>
 hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    if (args.diagnostics && args.diagnosticsStride >= 16) return launchByDepth<ALL_LDS, KIND, true>(args, numBlocks, ldsBytes, stream);
-    return launchByDepth<ALL_LDS, KIND, false>(args, numBlocks, ldsBytes, stream);
+    constexpr bool TIES = (KIND & kExactTiesBit) != 0;
+    const bool fullDiag = args.diagnostics && args.diagnosticsStride >= 16;
+    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_BLUE, false>(args, numBlocks, ldsBytes, stream);
+    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false>(args, numBlocks, ldsBytes, stream);
+    if (args.unitRecords) {      // RTOW_RNG_PER_SAMPLE
+        if constexpr (!TIES) if (!fullDiag && args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
+        return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
+    }
+    if (fullDiag) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
+    if constexpr (!TIES) if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
+    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
+    return launchVariant<ALL_LDS, KIND, 32, false, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
 }
 
 } // namespace

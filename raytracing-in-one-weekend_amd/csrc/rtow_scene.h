@@ -135,7 +135,9 @@ struct SceneLayout {
     uint32_t primOffset;                    // GpuPrim[sphereCount] when sceneKind == SCENE_KIND_GENERAL
     uint32_t cullOffset;                    // float[8] {min.xyz, -, max.xyz, -} per entity when sceneKind == SCENE_KIND_VOLUMES: the reference tree's entity box
     uint32_t rankOffset;                    // uint32 per entity when sceneKind >= SCENE_KIND_GENERAL: place in the reference tree's leaf order (rtow_reforder.h)
-    uint32_t pad[1];
+    uint32_t commonTimeRange;               // 1: every moving entity has the same TimeRange (the generated scenes: (0, 1)); then the kernel evaluates
+    float commonT0, commonT1;               //    clamp(unlerp(t0, t1, ray.Time), 0, 1) (RT/Entity.cs:124-127) once per sample instead of once per sphere test
+    uint32_t pad[3];
 };
 
 } // namespace rtow

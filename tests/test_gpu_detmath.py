@@ -20,3 +20,20 @@ def test_device_detmath_matches_oracle_bit_for_bit():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches" in r.stdout
+
+
+def test_exact_rcp_and_sqrt_equal_ieee_for_every_operand():
+    """rtow::exact_rcp / exact_sqrt (csrc/rtow_exactmath.hip.h) are the path's `1 / x` and `sqrt(x)`: a hardware approximation plus one
+    fused residual step where that is provably enough, the compiler's IEEE expansion elsewhere.  'Provably' = enumerated: all 2^32 float
+    operands, on the device, against `1.0f / x`, `__builtin_sqrtf(x)` and their composition in normalize."""
+    src = os.path.join(ROOT, "tests", "native", "exactmath_parity.hip")
+    hdr = os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc", "rtow_exactmath.hip.h")
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "exactmath_parity")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-x", "hip", src, "-o", exe],
+                       check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rcp 0 mismatches" in r.stdout and "sqrt 0 " in r.stdout and "rcp(sqrt) 0 " in r.stdout, r.stdout
