@@ -864,8 +864,10 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     int depth = 0;
     Hist<HW> hist;
     hist.clear();
-    V3 sampleNormal = v3(0, 0, 0), sampleAlbedo = v3(0, 0, 0);
-    bool firstNonSpecular = false;
+    V3 sampleNormal = v3(0, 0, 0);
+    // sampleAlbedo (:316-328,366-370) is not carried in registers: it is emission + reflectance of the first hit that is not perfectly specular -
+    // which the path history already names (depth firstNs) - or the sky colour, or 0; endSample rebuilds it with the same additions
+    int firstNs = -1;
     float randomEventsLocal = 0;
 
     // VOLUMES only: all hits of the current ray (FindHits' hitRecordBuffer, JOBS/SampleBatchJob.cs:450-475), the volume the path
@@ -891,7 +893,24 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     float best = 0;
 
     // end of a sample (JOBS/SampleBatchJob.cs:137-156)
-    auto endSample = [&](bool ok, V3 sampleColor) {
+    auto endSample = [&](bool ok, V3 sampleColor, V3 skyColor) {
+        // the sample's albedo AOV: first non-specular hit (emission + reflectance, reflectance overridden to 1 by a specular reflection), else
+        // the sky the path ended in, else the default 0 (a path cut off at TraceDepth that only met perfect mirrors / glass)
+        V3 sampleAlbedo = ok ? skyColor : v3(0, 0, 0);
+        if (firstNs >= 0) {
+            const unsigned code = hist.get(firstNs);
+            const bool white = (code & 0x8000u) != 0;
+            if (TEXTURED) {
+                const V3 refl = white ? v3(1, 1, 1) : v3(texHist[firstNs * 6 + 0], texHist[firstNs * 6 + 1], texHist[firstNs * 6 + 2]);
+                sampleAlbedo = add(v3(texHist[firstNs * 6 + 3], texHist[firstNs * 6 + 4], texHist[firstNs * 6 + 5]), refl);
+            } else {
+                const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + (code & 0x7fffu) * 64u;
+                const float4 m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
+                const float2 m1 = *reinterpret_cast<const float2*>(mp + 16);  // emission.yz
+                const V3 refl = white ? v3(1, 1, 1) : v3(m0.x, m0.y, m0.z);
+                sampleAlbedo = add(v3(m0.w, m1.x, m1.y), refl);
+            }
+        }
         if (ok) {                                                                         // :145-149, :398
             scwAcc += randomEventsLocal;
             colorAcc = add(colorAcc, sampleColor);
@@ -968,27 +987,37 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             if (st == ST_REGEN) {
                 STAT_LANES(2);
                 while (smp >= nsamp) {
+                    // Pixel boundaries are rare (one per `spp` samples) and touch two dozen launch constants nothing else needs - buffer pointers,
+                    // slice and sample-count parameters.  Read through a laundered pointer to the kernarg segment they are s_load-ed here, on
+                    // use, instead of sitting in SGPRs (and, past 102 of them, in VGPR lanes read back with v_readlane) through every stage.
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const SampleKernelArgs* coldArgs = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // the struct is the kernel's only argument
+                    asm volatile("" : "+s"(coldArgs));
+#else
+                    const SampleKernelArgs* coldArgs = &A;                                                                // host pass of the HIP compiler: never executed
+#endif
+                    const SampleKernelArgs& C = *coldArgs;
                     const unsigned tk = chained ? (tick & kChainTicketMask) : tick;      // owned-pixel (unit) number inside its batch
                     const unsigned batch = chained ? (tick >> kChainShift) : 0u;         // which batch of the chain the finished pixel belongs to
 #ifdef RTOW_STATS
-                    if (pix >= 0 && A.stats) {
+                    if (pix >= 0 && C.stats) {
                         // last pixel this wave finished: {end, start, rays, tick} (100 MHz ticks since the wave started); later stores overwrite earlier ones
-                        unsigned long long* rec = A.stats + 9000 + (size_t)(blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)) * 4;
+                        unsigned long long* rec = C.stats + 9000 + (size_t)(blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)) * 4;
                         rec[0] = wall_clock64() - statT0; rec[1] = pixT0 - statT0; rec[2] = (unsigned long long)rayCount; rec[3] = tick;
                     }
 #endif
-                    if (pix >= 0 && A.pixelCost) {
+                    if (pix >= 0 && C.pixelCost) {
                         // cost map for the next launch's chunk order: this pixel's ray count, in ticket order (a plain 2-byte store that
                         // merges in L2 with its chunk's other 63; per-chunk atomics cost a memory-side transaction each)
                         const unsigned rc = (unsigned)rayCount;
-                        A.pixelCost[tk] = (unsigned short)(rc < 65535u ? rc : 65535u);
+                        C.pixelCost[tk] = (unsigned short)(rc < 65535u ? rc : 65535u);
                     }
-                    if (VOLUMES && hitOverflow) { *A.overflowFlag = 1u; hitOverflow = false; }            // RTOW_ERROR_CAPACITY on the host side
-                    if (pix >= 0 && A.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
+                    if (VOLUMES && hitOverflow) { *C.overflowFlag = 1u; hitOverflow = false; }            // RTOW_ERROR_CAPACITY on the host side
+                    if (pix >= 0 && C.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
                     if (PER_SAMPLE && pix >= 0) {
                         // ---- unit done: its partial sums go to the record the fold kernel adds up in group order ----
                         const bool fallback = unitGroup == 0 && sampleCount == 0;       // then sample 0 failed: the record carries its AOVs instead of sums
-                        float4* rec = reinterpret_cast<float4*>(A.unitRecords) + (size_t)tick * 4u;
+                        float4* rec = reinterpret_cast<float4*>(C.unitRecords) + (size_t)tick * 4u;
                         rec[0] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
                         rec[1] = fallback ? make_float4(fbNormal.x, fbNormal.y, fbNormal.z, rayCount) : make_float4(normalAcc.x, normalAcc.y, normalAcc.z, rayCount);
                         rec[2] = fallback ? make_float4(fbAlbedo.x, fbAlbedo.y, fbAlbedo.z, scwAcc) : make_float4(albedoAcc.x, albedoAcc.y, albedoAcc.z, scwAcc);
@@ -997,17 +1026,17 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     }
                     if (pix >= 0 && chained) {
                         // ---- pixel done, chained batches: the same stores (:159-163) as device-coherent accesses, then publish the pixel ----
-                        float* oc = A.outColor + 4 * (size_t)pix;
+                        float* oc = C.outColor + 4 * (size_t)pix;
                         coherent_store(oc + 0, colorAcc.x); coherent_store(oc + 1, colorAcc.y); coherent_store(oc + 2, colorAcc.z); coherent_store(oc + 3, (float)sampleCount);
                         if (sampleCount != 0 || nsamp == 0) {
                             const V3 on = sampleCount != 0 ? normalAcc : v3(0, 0, 0), oa = sampleCount != 0 ? albedoAcc : v3(0, 0, 0);
-                            coherent_store(A.outNormal + 3 * (size_t)pix + 0, on.x); coherent_store(A.outNormal + 3 * (size_t)pix + 1, on.y); coherent_store(A.outNormal + 3 * (size_t)pix + 2, on.z);
-                            coherent_store(A.outAlbedo + 3 * (size_t)pix + 0, oa.x); coherent_store(A.outAlbedo + 3 * (size_t)pix + 1, oa.y); coherent_store(A.outAlbedo + 3 * (size_t)pix + 2, oa.z);
+                            coherent_store(C.outNormal + 3 * (size_t)pix + 0, on.x); coherent_store(C.outNormal + 3 * (size_t)pix + 1, on.y); coherent_store(C.outNormal + 3 * (size_t)pix + 2, on.z);
+                            coherent_store(C.outAlbedo + 3 * (size_t)pix + 0, oa.x); coherent_store(C.outAlbedo + 3 * (size_t)pix + 1, oa.y); coherent_store(C.outAlbedo + 3 * (size_t)pix + 2, oa.z);
                         }
-                        coherent_store(A.outScw + pix, scwAcc);
-                        uint8_t* dg = A.chainBatches[batch].diagnostics;
+                        coherent_store(C.outScw + pix, scwAcc);
+                        uint8_t* dg = C.chainBatches[batch].diagnostics;
                         if (dg) {
-                            if (FULL_DIAG && A.diagnosticsStride >= 16)
+                            if (FULL_DIAG && C.diagnosticsStride >= 16)
                                 *reinterpret_cast<float4*>(dg + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
                             else
                                 *reinterpret_cast<float*>(dg + (size_t)pix * 4u) = rayCount;
@@ -1015,26 +1044,26 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         // every store above has reached the coherence point before the chunk's counter moves (release at workgroup scope =
                         // s_waitcnt vmcnt(0) + no compiler reordering; the stores themselves are device-coherent)
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __hip_atomic_fetch_add(A.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(C.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pix = -1;
                     }
                     if (pix >= 0) {
                         // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
-                        reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
+                        reinterpret_cast<float4*>(C.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
                         if (sampleCount != 0) {
-                            A.outNormal[3 * (size_t)pix + 0] = normalAcc.x; A.outNormal[3 * (size_t)pix + 1] = normalAcc.y; A.outNormal[3 * (size_t)pix + 2] = normalAcc.z;
-                            A.outAlbedo[3 * (size_t)pix + 0] = albedoAcc.x; A.outAlbedo[3 * (size_t)pix + 1] = albedoAcc.y; A.outAlbedo[3 * (size_t)pix + 2] = albedoAcc.z;
+                            C.outNormal[3 * (size_t)pix + 0] = normalAcc.x; C.outNormal[3 * (size_t)pix + 1] = normalAcc.y; C.outNormal[3 * (size_t)pix + 2] = normalAcc.z;
+                            C.outAlbedo[3 * (size_t)pix + 0] = albedoAcc.x; C.outAlbedo[3 * (size_t)pix + 1] = albedoAcc.y; C.outAlbedo[3 * (size_t)pix + 2] = albedoAcc.z;
                         } else if (nsamp == 0) {
                             // no sample ran: the fallbacks keep their default (0) value (:115)
-                            A.outNormal[3 * (size_t)pix + 0] = 0; A.outNormal[3 * (size_t)pix + 1] = 0; A.outNormal[3 * (size_t)pix + 2] = 0;
-                            A.outAlbedo[3 * (size_t)pix + 0] = 0; A.outAlbedo[3 * (size_t)pix + 1] = 0; A.outAlbedo[3 * (size_t)pix + 2] = 0;
+                            C.outNormal[3 * (size_t)pix + 0] = 0; C.outNormal[3 * (size_t)pix + 1] = 0; C.outNormal[3 * (size_t)pix + 2] = 0;
+                            C.outAlbedo[3 * (size_t)pix + 0] = 0; C.outAlbedo[3 * (size_t)pix + 1] = 0; C.outAlbedo[3 * (size_t)pix + 2] = 0;
                         } // else: sample 0 failed and its AOVs were stored as the fallback by endSample
-                        A.outScw[pix] = scwAcc;
-                        if (A.diagnostics) {
-                            if (FULL_DIAG && A.diagnosticsStride >= 16)
-                                *reinterpret_cast<float4*>(A.diagnostics + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
+                        C.outScw[pix] = scwAcc;
+                        if (C.diagnostics) {
+                            if (FULL_DIAG && C.diagnosticsStride >= 16)
+                                *reinterpret_cast<float4*>(C.diagnostics + (size_t)pix * 16u) = make_float4(rayCount, boundsHits, candidates, scw0);
                             else
-                                *reinterpret_cast<float*>(A.diagnostics + (size_t)pix * 4u) = rayCount;
+                                *reinterpret_cast<float*>(C.diagnostics + (size_t)pix * 4u) = rayCount;
                         }
                         pix = -1;
                     }
@@ -1055,18 +1084,18 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         if (next == end) {
                             if (lane == leader) {
                                 bool cancelled = false;
-                                if (A.cancelFlag) cancelled = *A.cancelFlag != 0u;
-                                const unsigned slot = cancelled ? 0xffffffffu : atomicAdd(A.workCounter, 1u);
-                                if (slot >= A.chunkCount * A.chainCount) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
+                                if (C.cancelFlag) cancelled = *C.cancelFlag != 0u;
+                                const unsigned slot = cancelled ? 0xffffffffu : atomicAdd(C.workCounter, 1u);
+                                if (slot >= C.chunkCount * C.chainCount) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
                                 else {
                                     // chains: slots run batch after batch, each batch in the same chunk order
                                     unsigned b = 0u, within = slot;
-                                    if (chained) { b = slot / A.chunkCount; within = slot - b * A.chunkCount; }
+                                    if (chained) { b = slot / C.chunkCount; within = slot - b * C.chunkCount; }
                                     // most expensive chunks first (cost map of the previous launch, or of a 1-spp probe), so that the
                                     // chunks handed out last - the ones that decide when a wave can retire - are the cheap ones
-                                    const unsigned chunk = A.chunkOrder ? A.chunkOrder[within] : within;
+                                    const unsigned chunk = C.chunkOrder ? C.chunkOrder[within] : within;
                                     const unsigned base = chunk * 64u;
-                                    const unsigned last = (A.totalWork - base < 64u) ? A.totalWork : base + 64u;
+                                    const unsigned last = (C.totalWork - base < 64u) ? C.totalWork : base + 64u;
                                     waveQueue[2] = b * (last - base);                // pixels of this chunk that must be stored before batch b may read them
                                     waveQueue[3] = chunk;
                                     waveQueue[0] = base | (b << kChainShift);
@@ -1079,7 +1108,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             // batch b of a chunk reads what batch b - 1 of the same chunk stored, possibly on another CU / XCD, possibly in other
                             // lanes of this very wave: never spin here - lanes that cannot be served leave and ask again on the next trip
                             if (waveQueue[2] != 0u) {
-                                if (lane == leader && __hip_atomic_load(A.chunkDone + waveQueue[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= waveQueue[2]) waveQueue[2] = 0u;
+                                if (lane == leader && __hip_atomic_load(C.chunkDone + waveQueue[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= waveQueue[2]) waveQueue[2] = 0u;
                                 if (waveQueue[2] != 0u) { parked = true; break; }
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                             }
@@ -1092,34 +1121,34 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     tick = ticket;
                     const unsigned newBatch = chained ? (ticket >> kChainShift) : 0u;
                     if (chained) ticket &= kChainTicketMask;
-                    if (PER_SAMPLE) { unitGroup = ticket % A.groupsPerPixel; ticket = ticket / A.groupsPerPixel; }   // unit = (owned pixel, sample group)
+                    if (PER_SAMPLE) { unitGroup = ticket % C.groupsPerPixel; ticket = ticket / C.groupsPerPixel; }   // unit = (owned pixel, sample group)
 #ifdef RTOW_STATS
                     pixT0 = wall_clock64();
 #endif
-                    const int ownedRow = (int)(ticket / (unsigned)A.width);
-                    cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
-                    cy = A.sliceOffset + ownedRow * A.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
-                    pix = cy * A.width + cx;
+                    const int ownedRow = (int)(ticket / (unsigned)C.width);
+                    cx = (int)(ticket - (unsigned)ownedRow * (unsigned)C.width);
+                    cy = C.sliceOffset + ownedRow * C.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
+                    pix = cy * C.width + cx;
 
                     float4 last = make_float4(0, 0, 0, 0);
                     if (PER_SAMPLE) {
                         // a unit only needs what decides the pixel's sample count (:118-126); the fold kernel reads the accumulators
-                        last.w = A.inColor[4 * (size_t)pix + 3];
-                        scwAcc = A.inScw[pix];
+                        last.w = C.inColor[4 * (size_t)pix + 3];
+                        scwAcc = C.inScw[pix];
                     } else if (chained) {
                         // batch 0 reads the launch's inputs, every later batch what the batch before it stored for this pixel (device-coherent loads)
-                        const float* ic = (newBatch == 0u ? A.inColor : A.outColor) + 4 * (size_t)pix;
-                        const float* in_ = (newBatch == 0u ? A.inNormal : A.outNormal) + 3 * (size_t)pix;
-                        const float* ia = (newBatch == 0u ? A.inAlbedo : A.outAlbedo) + 3 * (size_t)pix;
+                        const float* ic = (newBatch == 0u ? C.inColor : C.outColor) + 4 * (size_t)pix;
+                        const float* in_ = (newBatch == 0u ? C.inNormal : C.outNormal) + 3 * (size_t)pix;
+                        const float* ia = (newBatch == 0u ? C.inAlbedo : C.outAlbedo) + 3 * (size_t)pix;
                         last = make_float4(coherent_load(ic), coherent_load(ic + 1), coherent_load(ic + 2), coherent_load(ic + 3));
                         normalAcc = v3(coherent_load(in_), coherent_load(in_ + 1), coherent_load(in_ + 2));
                         albedoAcc = v3(coherent_load(ia), coherent_load(ia + 1), coherent_load(ia + 2));
-                        scwAcc = coherent_load((newBatch == 0u ? A.inScw : A.outScw) + pix);
-                    } else if (!A.probeOnly) {
-                        last = reinterpret_cast<const float4*>(A.inColor)[pix];                           // :72-78
-                        normalAcc = v3(A.inNormal[3 * (size_t)pix], A.inNormal[3 * (size_t)pix + 1], A.inNormal[3 * (size_t)pix + 2]);
-                        albedoAcc = v3(A.inAlbedo[3 * (size_t)pix], A.inAlbedo[3 * (size_t)pix + 1], A.inAlbedo[3 * (size_t)pix + 2]);
-                        scwAcc = A.inScw[pix];
+                        scwAcc = coherent_load((newBatch == 0u ? C.inScw : C.outScw) + pix);
+                    } else if (!C.probeOnly) {
+                        last = reinterpret_cast<const float4*>(C.inColor)[pix];                           // :72-78
+                        normalAcc = v3(C.inNormal[3 * (size_t)pix], C.inNormal[3 * (size_t)pix + 1], C.inNormal[3 * (size_t)pix + 2]);
+                        albedoAcc = v3(C.inAlbedo[3 * (size_t)pix], C.inAlbedo[3 * (size_t)pix + 1], C.inAlbedo[3 * (size_t)pix + 2]);
+                        scwAcc = C.inScw[pix];
                     }
                     colorAcc = v3(last.x, last.y, last.z);
                     sampleCount = (int)last.w;
@@ -1127,18 +1156,18 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const int countIn = sampleCount;
 
                     // :91  new Random((Seed * 0x8C4CA03Fu) ^ (uint)(index * 0x7383ED49u)); the ctor discards one NextState()
-                    rng.begin_pixel(NoiseSite{&A, (unsigned)cx, (unsigned)cy}, (unsigned)pix, chained ? A.chainBatches[newBatch].seed : A.seed);
+                    rng.begin_pixel(NoiseSite{&A, (unsigned)cx, (unsigned)cy}, (unsigned)pix, chained ? C.chainBatches[newBatch].seed : C.seed);
 
                     // :118-126
                     const float w = scwIn / (float)countIn;
                     if (w == 0) {
-                        nsamp = A.sampleCountMin;
+                        nsamp = C.sampleCountMin;
                     } else {
-                        const float nw = um_saturate((w - A.extremaX) / (A.extremaY - A.extremaX));
-                        const float lo = (float)A.sampleCountMin, hi = (float)A.sampleCountMax;
+                        const float nw = um_saturate((w - C.extremaX) / (C.extremaY - C.extremaX));
+                        const float lo = (float)C.sampleCountMin, hi = (float)C.sampleCountMax;
                         nsamp = (unsigned)__builtin_rintf(lo + nw * (hi - lo));
                     }
-                    if (A.probeOnly) nsamp = 1;
+                    if (C.probeOnly) nsamp = 1;
                     scw0 = w;
                     smp = 0;
                     if (PER_SAMPLE) {
@@ -1152,7 +1181,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     }
                     rayCount = 0; boundsHits = 0; candidates = 0;
                     // the pixel's camera-ray candidates (primary_candidates_kernel): up to 4 primitive indices, 0xFFFF = none
-                    pcand = A.pixelCandidates ? A.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u);
+                    pcand = C.pixelCandidates ? C.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u);
                 }
                 if (st == ST_REGEN) {
                     // ---- camera ray (:134-135, RT/View.cs:38-48) ----
@@ -1185,8 +1214,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     depth = 0;
                     hist.clear();
                     sampleNormal = v3(0, 0, 0);
-                    sampleAlbedo = v3(0, 0, 0);
-                    firstNonSpecular = false;
+                    firstNs = -1;
                     randomEventsLocal = 0;
                     curVol = -1;
                     pendRE = 0;
@@ -1525,10 +1553,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 
                 hist.set(depth, (white ? 0x8000u : 0u) | matIdx);                             // :311,330 (re-expanded at the fold)
                 if (depth == 0) sampleNormal = N;                                             // :313-314
-                if (!firstNonSpecular && !perfectSpecular) {                                  // :316-328
-                    sampleAlbedo = add(emission, reflectance);
+                if (firstNs < 0 && !perfectSpecular) {                                        // :316-328: sampleAlbedo = emission + reflectance of THIS hit (see endSample)
                     sampleNormal = N;
-                    firstNonSpecular = true;
+                    firstNs = depth;
                 }
                 randomEventsLocal += randomEvents * inv_pow2(depth);                          // RandomEvents / pow(2, depth), :332
 
@@ -1537,7 +1564,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 ro = v3(P.x + 0.001f * offN.x, P.y + 0.001f * offN.y, P.z + 0.001f * offN.z);
                 rd = sdir;
                 depth++;
-                if (depth == traceDepth) endSample(false, v3(0, 0, 0));                       // :379-381
+                if (depth == traceDepth) endSample(false, v3(0, 0, 0), v3(0, 0, 0));                       // :379-381
                 else startRay();
             }
         }
@@ -1678,7 +1705,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 // randomEventsLocalAcc += rng.RandomEvents / pow(2, depth) (:363): RandomEvents is 0 here unless a ProbabilisticHit
                 // that found nothing left its increment pending
                 if (VOLUMES) { randomEventsLocal += pendRE * inv_pow2(depth); pendRE = 0; }
-                if (!firstNonSpecular) { sampleAlbedo = sky; sampleNormal = neg(rd); }
+                if (firstNs < 0) sampleNormal = neg(rd);                                      // and sampleAlbedo = the sky colour (endSample)
 
                 V3 col = sky; // 0 * 1 + sky
                 for (int i = depth - 1; i >= 0; i--) {
@@ -1699,7 +1726,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const V3 att = v3(pick(m0.x), pick(m0.y), pick(m0.z));
                     col = v3(col.x * att.x + m0.w, col.y * att.y + m1.x, col.z * att.z + m1.y);
                 }
-                endSample(true, col);
+                endSample(true, col, sky);
             }
         }
         STAGE_MARK(7);
