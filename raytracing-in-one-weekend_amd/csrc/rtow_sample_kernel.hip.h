@@ -682,6 +682,35 @@ template <> struct Hist<8> {
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The same accesses 16 and 12 bytes wide (what the compiler emits for an agent-scope atomic is `sc1` on a one-dword access; there is no
+// builtin for a wider one).  A write-through store is its own memory transaction: dword by dword a pixel's 44 bytes became eleven 32-byte
+// writes (rocprofv3 WRITE_SIZE: 789 MB per batch against 99 MB algorithmic), as four wide stores they are four.  The loads wait for their
+// own data and coherent_flush() for the stores: the compiler's wait-count bookkeeping does not see into inline assembly.
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef float fvec3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void coherent_store4(float* p, float x, float y, float z, float w)
+{
+    const fvec4 v = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void coherent_store3(float* p, V3 a)
+{
+    const fvec3 v = {a.x, a.y, a.z};
+    asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void coherent_flush() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+__device__ __forceinline__ float4 coherent_load4(const float* p)
+{
+    fvec4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ V3 coherent_load3(const float* p)
+{
+    fvec3 v;
+    asm volatile("global_load_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v3(v.x, v.y, v.z);
+}
 constexpr unsigned kChainShift = 27;                       // ticket = batch << 27 | owned-pixel number (chains need fewer than 2^27 padded pixels)
 constexpr unsigned kChainTicketMask = (1u << kChainShift) - 1u;
 
@@ -923,8 +952,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
             // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
             if (chained) {
-                coherent_store(A.outNormal + 3 * (size_t)pix + 0, sampleNormal.x); coherent_store(A.outNormal + 3 * (size_t)pix + 1, sampleNormal.y); coherent_store(A.outNormal + 3 * (size_t)pix + 2, sampleNormal.z);
-                coherent_store(A.outAlbedo + 3 * (size_t)pix + 0, sampleAlbedo.x); coherent_store(A.outAlbedo + 3 * (size_t)pix + 1, sampleAlbedo.y); coherent_store(A.outAlbedo + 3 * (size_t)pix + 2, sampleAlbedo.z);
+                coherent_store3(A.outNormal + 3 * (size_t)pix, sampleNormal);
+                coherent_store3(A.outAlbedo + 3 * (size_t)pix, sampleAlbedo);
             } else {
                 A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
                 A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
@@ -1026,12 +1055,10 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     }
                     if (pix >= 0 && chained) {
                         // ---- pixel done, chained batches: the same stores (:159-163) as device-coherent accesses, then publish the pixel ----
-                        float* oc = C.outColor + 4 * (size_t)pix;
-                        coherent_store(oc + 0, colorAcc.x); coherent_store(oc + 1, colorAcc.y); coherent_store(oc + 2, colorAcc.z); coherent_store(oc + 3, (float)sampleCount);
+                        coherent_store4(C.outColor + 4 * (size_t)pix, colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
                         if (sampleCount != 0 || nsamp == 0) {
-                            const V3 on = sampleCount != 0 ? normalAcc : v3(0, 0, 0), oa = sampleCount != 0 ? albedoAcc : v3(0, 0, 0);
-                            coherent_store(C.outNormal + 3 * (size_t)pix + 0, on.x); coherent_store(C.outNormal + 3 * (size_t)pix + 1, on.y); coherent_store(C.outNormal + 3 * (size_t)pix + 2, on.z);
-                            coherent_store(C.outAlbedo + 3 * (size_t)pix + 0, oa.x); coherent_store(C.outAlbedo + 3 * (size_t)pix + 1, oa.y); coherent_store(C.outAlbedo + 3 * (size_t)pix + 2, oa.z);
+                            coherent_store3(C.outNormal + 3 * (size_t)pix, sampleCount != 0 ? normalAcc : v3(0, 0, 0));
+                            coherent_store3(C.outAlbedo + 3 * (size_t)pix, sampleCount != 0 ? albedoAcc : v3(0, 0, 0));
                         }
                         coherent_store(C.outScw + pix, scwAcc);
                         uint8_t* dg = C.chainBatches[batch].diagnostics;
@@ -1043,6 +1070,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         }
                         // every store above has reached the coherence point before the chunk's counter moves (release at workgroup scope =
                         // s_waitcnt vmcnt(0) + no compiler reordering; the stores themselves are device-coherent)
+                        coherent_flush();
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __hip_atomic_fetch_add(C.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pix = -1;
@@ -1140,9 +1168,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         const float* ic = (newBatch == 0u ? C.inColor : C.outColor) + 4 * (size_t)pix;
                         const float* in_ = (newBatch == 0u ? C.inNormal : C.outNormal) + 3 * (size_t)pix;
                         const float* ia = (newBatch == 0u ? C.inAlbedo : C.outAlbedo) + 3 * (size_t)pix;
-                        last = make_float4(coherent_load(ic), coherent_load(ic + 1), coherent_load(ic + 2), coherent_load(ic + 3));
-                        normalAcc = v3(coherent_load(in_), coherent_load(in_ + 1), coherent_load(in_ + 2));
-                        albedoAcc = v3(coherent_load(ia), coherent_load(ia + 1), coherent_load(ia + 2));
+                        last = coherent_load4(ic);
+                        normalAcc = coherent_load3(in_);
+                        albedoAcc = coherent_load3(ia);
                         scwAcc = coherent_load((newBatch == 0u ? C.inScw : C.outScw) + pix);
                     } else if (!C.probeOnly) {
                         last = reinterpret_cast<const float4*>(C.inColor)[pix];                           // :72-78
