@@ -44,16 +44,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 
 def measured_hbm_traffic():
-    """HBM bytes per launch of the sample kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
+    """HBM bytes PER BATCH of the sample kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
     FETCH_SIZE and WRITE_SIZE from separate --pmc passes of this same bench command, KiB -> bytes, read side doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside the timed run."""
+    MI355X_MICROARCH.md prescribes for gfx950; the profiled launch held `batches_per_launch` batches).  PMC counters cannot be
+    collected from inside the timed run."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     for f in reversed(files):
         try:
             d = json.load(open(f))
-            secondary = {k: round(float(d["derived"][k]), 4) for k in ("valu_issue_utilisation", "valu_lane_utilisation", "lds_busy_fraction") if k in d["derived"]}
-            return float(d["derived"]["hbm_traffic_bytes"]), os.path.basename(f), secondary
+            keys = ("valu_issue_utilisation", "valu_lane_utilisation", "simd_cycles_per_valu_inst", "valu_pipe_busy_estimate", "lds_busy_fraction")
+            secondary = {k: round(float(d["derived"][k]), 4) for k in keys if k in d["derived"]}
+            per_launch = int(d.get("bench_line_under_profiler", {}).get("config", {}).get("batches_per_launch", 1) or 1)
+            return float(d["derived"]["hbm_traffic_bytes"]) / per_launch, os.path.basename(f), secondary
         except (KeyError, ValueError, OSError):
             continue
     return None, None, {}
@@ -354,6 +357,8 @@ def main():
         launch_ms = avg_kernel_ms * steps_per_launch
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         traffic, traffic_src, secondary = measured_hbm_traffic() if world == 1 else (None, None, {})
+        if traffic is not None:
+            traffic = round(traffic * steps_per_launch)      # per launch, like `achieved`: the committed profile's per-batch traffic x this run's batches per launch
         out = {
             "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce" if (args.config == 2 and not overridden) else
                       "Msamples/s, %s scene %dx%d %d-bounce" % (args.scene, W, H, depth),
