@@ -84,3 +84,26 @@ def test_make_params_defaults_follow_the_benchmark_contract(rt):
     assert p.environment.skyType == rt.abi.SKY_GRADIENT
     assert p.environment.skyBottomColor.tuple() == (1.0, 1.0, 1.0)
     assert np.allclose(p.environment.skyTopColor.tuple(), (0.5, 0.7, 1.0))
+
+
+def test_bench_configs_are_the_baseline_configs():
+    """bench.py --config N times BASELINE.json configs[N-1]: the sizes, sample counts and bounce counts quoted there."""
+    import importlib.util
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert sorted(bench.CONFIGS) == [2, 3, 4, 5]
+    for n, cfg in bench.CONFIGS.items():
+        text = base["configs"][n - 1]
+        m = re.search(r"(\d+)×(\d+)", text)
+        assert (int(m.group(1)), int(m.group(2))) == (cfg["width"], cfg["height"]), text
+        assert int(re.search(r"(\d+) spp", text).group(1)) == cfg["spp"], text
+        b = re.search(r"(\d+) bounces", text)
+        assert cfg["depth"] == (int(b.group(1)) if b else 8), text             # configs 4 and 5 do not name a bounce count: the metric's 8
+    assert "10k-sphere" in base["configs"][3] and bench.CONFIGS[4]["scene"] == "stress"
+    assert "Moving spheres" in base["configs"][4] and bench.CONFIGS[5]["scene"] == "moving"
