@@ -1416,6 +1416,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 if (!(VOLUMES && insideHit)) mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
                 unsigned matIdx = mi & 0xffffu;
                 unsigned cls = (mi >> 16) & 3u;                                // shading class packed by the scene compiler
+#ifdef RTOW_EXPERIMENT_ALL_LAMBERT
+                // TIMING EXPERIMENT ONLY (wrong image): every surface shades as lambert, i.e. the general-Standard and dielectric bodies cost nothing.
+                // The speed of this build is the ceiling of what ANY regrouping of those two classes could reach (DESIGN.md 4.1 "Regrouping").
+                if (cls != MAT_CLASS_VOLUME) cls = MAT_CLASS_LAMBERT;
+#endif
                 const float t = best;
                 const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
                 V3 N;
