@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (plain batches, host-buffer form, other partitions)")
     ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default 8 on one GPU, 1 on several (one gather per batch)")
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
+    ap.add_argument("--context-flags", type=int, default=0, help="development: RtowContextOptions.flags (e.g. 1 = exact-tie kernels always)")
     ap.add_argument("--partition", choices=("tiles", "batches"), default="tiles", help="which N > 1 partition `value` reports (the other is reported beside it)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -190,7 +191,7 @@ def main():
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
     n = W * H
     scene = {"cover": rt.scenes.cover_scene, "stress": rt.scenes.stress_scene, "moving": rt.scenes.moving_scene}[args.scene]()
-    ctx = rt.Context(local_rank, scheduler_tune=[int(x) for x in args.tune.split(",")] if args.tune else None)
+    ctx = rt.Context(local_rank, flags=args.context_flags, scheduler_tune=[int(x) for x in args.tune.split(",")] if args.tune else None)
     ctx.upload_scene(scene.desc())
     info = ctx.scene_info()
     mg = importlib.import_module("raytracing-in-one-weekend_amd.multigpu")
