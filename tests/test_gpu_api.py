@@ -507,6 +507,16 @@ def test_registered_host_buffers_give_the_same_results(rt, oracle, gpu_context):
     refm = osc.sample_batch(p, pool)
     for k in ("color", "normal", "albedo", "scw"):
         assert np.array_equal(outs[k].reshape(-1).view(np.uint32), refm[k].reshape(-1).view(np.uint32)), k
+    # the per-sample RNG policy folds its unit records with a second kernel: that one stores into the registered arrays too
+    before = {k: v.copy() for k, v in pool.items()}
+    p = rt.scenes.make_params(scene, w, h, spp=20, trace_depth=6, seed=43, rng_policy=a.RNG_PER_SAMPLE)
+    job = rt.SampleBatchJob(ctx, p)
+    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = pool["color"], pool["normal"], pool["albedo"], pool["scw"]
+    job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = pool["color"], pool["normal"], pool["albedo"], pool["scw"]
+    assert job.Schedule(n, 1).Complete() == 0
+    refp = osc.sample_batch(p, before)
+    for k in ("color", "normal", "albedo", "scw"):
+        assert np.array_equal(pool[k].reshape(-1).view(np.uint32), refp[k].reshape(-1).view(np.uint32)), ("per-sample", k)
     osc.close()
     ctx.unregister_host_buffers()
     assert lib.rtowUnregisterHostBuffer(ctx.handle, pool["color"].ctypes.data) == a.RTOW_ERROR_INVALID_VALUE             # already dropped

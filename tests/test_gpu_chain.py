@@ -128,3 +128,49 @@ def test_chain_with_adaptive_sample_counts(rt, gpu_context):
     n = w * h
     plist = _params(rt, scene, w, h, 2, 8, [11, 12, 13, 14, 15], spp_max=9, extrema=(0.2, 1.4), diagnostics_stride=16)
     _same(_chained(rt, ctx, plist, n, 16), _sequential(rt, ctx, plist, n, 16), "adaptive")
+
+
+def test_chain_under_texture_driven_noise_cubemap_sky_and_reference_diagnostics(rt, oracle):
+    """The per-batch Seed also seeds the blue / STBN texture walks (RT/PerPixelNoise.cs), the sky may be the cubemap, and with
+    RTOW_CONTEXT_REFERENCE_DIAGNOSTICS every batch of the chain writes the reference's own FULL_DIAGNOSTICS record to its own buffer:
+    chain == sequence, and the last batch's counters == the oracle's."""
+    a, S = rt.abi, rt.scenes
+    scene = S.cover_scene()
+    desc = scene.desc()
+    noise = S.NoiseTextures(row_stride=16, count=2, seed=4)
+    sky = S.synthetic_sky(size=32)
+    w, h, spp, depth = 112, 63, 3, 6
+    n = w * h
+    with rt.Context(0, flags=a.CONTEXT_REFERENCE_DIAGNOSTICS) as ctx:
+        ctx.upload_scene(desc)
+        ctx.upload_blue_noise(noise.blue_desc())
+        ctx.upload_stb_noise(noise.stb_desc())
+        ctx.upload_sky_cubemap(sky.desc())
+        for what, kw in (("blue", dict(noise_color=a.NOISE_BLUE, noise_texture_index=1)), ("stbn", dict(noise_color=a.NOISE_SPATIOTEMPORAL_BLUE)),
+                         ("white + cubemap", dict(sky_type=a.SKY_CUBEMAP))):
+            plist = _params(rt, scene, w, h, spp, depth, [3, 4, 5], diagnostics_stride=16, **kw)
+            seq = _sequential(rt, ctx, plist, n, 16)
+            got = _chained(rt, ctx, plist, n, 16)
+            _same(got, seq, what)
+            osc = oracle.OracleScene(desc)
+            osc.set_blue_noise(noise.blue_desc())
+            osc.set_stb_noise(noise.stb_desc())
+            osc.set_cubemap(sky.desc())
+            ref = None
+            for p in plist:
+                ref = osc.sample_batch(p, None if ref is None else {k: ref[k] for k, _ in KEYS})
+            osc.close()
+            for k, _ in KEYS:
+                assert np.array_equal(got[k].reshape(-1).view(np.uint32), ref[k].reshape(-1).view(np.uint32)), (what, k)
+            assert np.array_equal(got["diag"][-1].view(np.uint32), ref["diag"].view(np.uint32)), (what, "FULL_DIAGNOSTICS of the last batch")
+
+
+def test_chain_of_a_slice_that_owns_no_row(rt, gpu_context):
+    ctx = gpu_context
+    scene = rt.scenes.tiny_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 16, 4
+    plist = _params(rt, scene, w, h, 2, 4, [1, 2, 3], slice_offset=6, slice_divider=8)
+    got = _chained(rt, ctx, plist, w * h, 4)
+    for k, _ in KEYS:
+        assert not got[k].any(), k

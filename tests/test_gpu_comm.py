@@ -2,7 +2,8 @@
 
 One process per GPU, the frame row-interleaved with the reference's slice contract (JOBS/SampleBatchJob.cs:69-70), one gather of the owned
 rows to the root per batch.  The box these tests run on has ONE GPU: the two-rank test puts both ranks on it (two processes, two contexts,
-one RCCL communicator); the collective, the packing and the assembly are the same code an 8-GPU node runs."""
+one RCCL communicator) - which RCCL 2.27 refuses, so there the test skips with that reason; on a box with two or more GPUs each rank takes
+its own and the test runs.  The collective, the packing and the assembly are the same code an 8-GPU node runs."""
 import ctypes as C
 import importlib
 import os
@@ -49,7 +50,11 @@ sys.path.insert(0, sys.argv[1])
 rank, world, idfile, outfile = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
 rt = importlib.import_module("raytracing-in-one-weekend_amd")
 a = rt.abi
-ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: print("[rank %d] %s: %s" % (rank, tag.decode(), msg.decode()), flush=True), log_level=4)   # every rank on the box's one GPU
+import ctypes
+count = ctypes.c_int(0)
+ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(count))
+device = rank if count.value > rank else 0           # one GPU per rank where the box has them; else every rank on the one GPU
+ctx = rt.Context(device, log=lambda lvl, tag, msg, ud: print("[rank %d] %s: %s" % (rank, tag.decode(), msg.decode()), flush=True), log_level=4)
 if rank == 0:
     uid = rt.Context.comm_unique_id()
     open(idfile + ".tmp", "wb").write(uid)
