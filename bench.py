@@ -334,8 +334,22 @@ def main():
                 t = time.perf_counter()
                 rt.lib.check(lib.rtowSampleBatch(ctx.handle, C.byref(p), C.byref(hb), C.byref(hb), hdiag.ctypes.data, None), "rtowSampleBatch")
                 times.append(time.perf_counter() - t)
-            ctx.unregister_host_buffers()
             host_ms = round(min(times[1:]) * 1e3, 3)
+            # and the host-buffer chain: the same arrays, `chain` batches per call (inputs travel once, the batches accumulate on the device)
+            if args.chain > 1:
+                arr = (abi.SampleParams * args.chain)()
+                for k in range(args.chain):
+                    arr[k] = abi.SampleParams.from_buffer_copy(m["base"])
+                    arr[k].seed = 2000 + k
+                hdiags = [np.zeros(n, np.float32) for _ in range(args.chain)]
+                dptr = (C.c_void_p * args.chain)(*[d.ctypes.data for d in hdiags])
+                ctimes = []
+                for i in range(2):
+                    t = time.perf_counter()
+                    rt.lib.check(lib.rtowSampleBatchChain(ctx.handle, args.chain, arr, C.byref(hb), C.byref(hb), dptr, None), "rtowSampleBatchChain")
+                    ctimes.append(time.perf_counter() - t)
+                extras["host_buffer_chain_ms_per_step"] = round(min(ctimes) / args.chain * 1e3, 3)
+            ctx.unregister_host_buffers()
         else:
             other = "batches" if args.partition == "tiles" else "tiles"
             extras["partitions"] = {args.partition: summary(m), other: summary(measure(other, args.rng, 1, args.steps, 1))}
@@ -408,7 +422,8 @@ def main():
         out.update(extras)
         if host_ms is not None:
             out["host_buffer_ms_per_step"] = host_ms
-            out["host_buffer_note"] = "rtowSampleBatch on pinned host arrays registered with rtowRegisterHostBuffer: inputs by one DMA, outputs stored by the kernel straight into host memory (best of 3 after 1 warm-up)"
+            out["host_buffer_note"] = ("rtowSampleBatch on pinned host arrays registered with rtowRegisterHostBuffer: inputs by one DMA, outputs stored by the kernel straight into "
+                                       "host memory (best of 3 after 1 warm-up); host_buffer_chain_ms_per_step: rtowSampleBatchChain on the same arrays, batches_per_launch batches per call")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, W, H, depth, scene_name=args.scene, full_spp=spp)
         print(json.dumps(out), flush=True)

@@ -362,6 +362,13 @@ RTOW_API int rtowSampleBatchChainDevice(RtowContext context, int32_t count, cons
                                         const RtowAccumBuffers* in, const RtowAccumBuffers* out,
                                         void* const* diagnostics /* [count] or NULL */, void* stream, const volatile uint8_t* cancel);
 
+/* The same chain with HOST buffers, blocking like rtowSampleBatch: the inputs travel once, the batches accumulate in place on the device, the
+ * final accumulators (rows this slice owns) and each batch's diagnostics travel back.  All batches share size, slice and diagnosticsStride.
+ * For hosts that keep their accumulators in NativeArrays and have more than one batch queued. */
+RTOW_API int rtowSampleBatchChain(RtowContext context, int32_t count, const RtowSampleParams* params /* [count] */,
+                                  const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                                  void* const* diagnostics /* [count] host pointers or NULL */, const volatile uint8_t* cancel);
+
 /* Pinned host buffers for rtowSampleBatch.  The host's accumulation buffers are long-lived pools (UNITY/Raytracer.cs:279-288,
  * Allocator.Persistent); registering them once (hipHostRegister) lets rtowSampleBatch move the inputs with one pinned DMA and lets the
  * kernel store the outputs and diagnostics straight into host memory, so the host-buffer form runs at the speed of the device-resident

@@ -163,5 +163,5 @@ EXPORTED_SYMBOLS = [
     "rtowUploadSkyCubemap", "rtowUploadBlueNoise", "rtowUploadStbNoise", "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
     "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize", "rtowGetBatchStatus", "rtowRegisterHostBuffer", "rtowUnregisterHostBuffer",
-    "rtowSampleBatchChainDevice", "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
+    "rtowSampleBatchChainDevice", "rtowSampleBatchChain", "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
 ]

@@ -548,6 +548,40 @@ RcclApi* rccl()
 // rows of the frame owned by `rank` under the reference's interlacing (row % divider == rank, JOBS/SampleBatchJob.cs:69-70)
 unsigned rowsOwnedBy(int rank, int divider, int height) { return rank >= height ? 0u : (unsigned)((height - rank + divider - 1) / divider); }
 
+// `count` successive batches (batch 0 reads `in`, every later one what its predecessor wrote to `out`), enqueued on `stream`: as ONE launch per
+// group of up to kMaxChain batches when they differ in nothing but Seed, else one after the other (what the chain is defined to equal).
+// The caller holds ctx->mu and has validated params / buffers.
+int enqueueChain(RtowContext ctx, int count, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out, void* const* diagnostics,
+                 hipStream_t s, const volatile uint8_t* cancel)
+{
+    // One launch needs batches that differ in nothing but Seed (the reference's successive batches of a frame: UNITY/Raytracer.cs:656-661),
+    // the reference RNG policy (per-sample units fold through records) and a frame of fewer than 2^27 padded pixels.
+    bool fusable = params[0].rngPolicy == RTOW_RNG_REFERENCE;
+    for (int b = 1; b < count && fusable; b++) {
+        RtowSampleParams q = params[b];
+        q.seed = params[0].seed;
+        fusable = memcmp(&q, &params[0], sizeof(q)) == 0;
+    }
+    const uint64_t paddedPixels = ((uint64_t)ownedRows(&params[0]) * (uint64_t)(int)params[0].size.x + 63u) & ~63ull;
+    if (paddedPixels >= (1ull << 27)) fusable = false;
+    int rc = RTOW_SUCCESS;
+    for (int first = 0; first < count && rc == RTOW_SUCCESS;) {
+        const int n = fusable ? std::min(count - first, (int)kMaxChain) : 1;
+        const RtowAccumBuffers* src = first == 0 ? in : out;
+        if (n == 1) {
+            rc = launchSample(ctx, &params[first], src, out, diagnostics ? diagnostics[first] : nullptr, s, cancel != nullptr);
+        } else {
+            uint32_t seeds[kMaxChain];
+            for (int b = 0; b < n; b++) seeds[b] = params[first + b].seed;
+            const ChainSpec chain{n, seeds, diagnostics ? diagnostics + first : nullptr};
+            rc = launchSample(ctx, &params[first], src, out, nullptr, s, cancel != nullptr, &chain);
+        }
+        if (rc == RTOW_SUCCESS && cancel) rc = waitWithCancel(ctx, cancel);
+        first += n;
+    }
+    return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -853,34 +887,63 @@ RTOW_API int rtowSampleBatchChainDevice(RtowContext ctx, int32_t count, const Rt
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     *ctx->hCancel = 0u;
+    return enqueueChain(ctx, count, params, in, out, diagnostics, s, cancel);
+}
 
-    // One launch needs batches that differ in nothing but Seed (the reference's successive batches of a frame: UNITY/Raytracer.cs:656-661),
-    // the reference RNG policy (per-sample units fold through records) and a frame of fewer than 2^27 padded pixels.  Anything else runs as
-    // what the chain is defined to equal: the batches one after the other, batch b + 1 reading what batch b wrote.
-    bool fusable = params[0].rngPolicy == RTOW_RNG_REFERENCE;
-    for (int b = 1; b < count && fusable; b++) {
-        RtowSampleParams q = params[b];
-        q.seed = params[0].seed;
-        fusable = memcmp(&q, &params[0], sizeof(q)) == 0;
+RTOW_API int rtowSampleBatchChain(RtowContext ctx, int32_t count, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out,
+                                  void* const* diagnostics, const volatile uint8_t* cancel)
+{
+    if (!ctx || !in || !out || !params || count < 1) return RTOW_ERROR_INVALID_VALUE;
+    for (int b = 0; b < count; b++) {
+        const int v = validateParams(&params[b]);
+        if (v != RTOW_SUCCESS) return v;
+        // one staging set serves the whole chain: the batches share the frame and the record format
+        if ((int)params[b].size.x != (int)params[0].size.x || (int)params[b].size.y != (int)params[0].size.y || params[b].diagnosticsStride != params[0].diagnosticsStride ||
+            params[b].sliceOffset != params[0].sliceOffset || params[b].sliceDivider != params[0].sliceDivider)
+            return RTOW_ERROR_INVALID_VALUE;
     }
-    const uint64_t paddedPixels = ((uint64_t)ownedRows(&params[0]) * (uint64_t)(int)params[0].size.x + 63u) & ~63ull;
-    if (paddedPixels >= (1ull << 27)) fusable = false;
-    int rc = RTOW_SUCCESS;
-    for (int first = 0; first < count && rc == RTOW_SUCCESS;) {
-        const int n = fusable ? std::min(count - first, (int)kMaxChain) : 1;
-        const RtowAccumBuffers* src = first == 0 ? in : out;
-        if (n == 1) {
-            rc = launchSample(ctx, &params[first], src, out, diagnostics ? diagnostics[first] : nullptr, s, cancel != nullptr);
-        } else {
-            uint32_t seeds[kMaxChain];
-            for (int b = 0; b < n; b++) seeds[b] = params[first + b].seed;
-            const ChainSpec chain{n, seeds, diagnostics ? diagnostics + first : nullptr};
-            rc = launchSample(ctx, &params[first], src, out, nullptr, s, cancel != nullptr, &chain);
-        }
-        if (rc == RTOW_SUCCESS && cancel) rc = waitWithCancel(ctx, cancel);
-        first += n;
+    if (!in->color || !in->normal || !in->albedo || !in->sampleCountWeight || !out->color || !out->normal || !out->albedo || !out->sampleCountWeight)
+        return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    const int w = (int)params[0].size.x, h = (int)params[0].size.y;
+    const size_t n = (size_t)w * (size_t)h;
+    const size_t diagBytes = n * (size_t)params[0].diagnosticsStride;
+    int rc = ensureStaging(ctx, n, diagnostics ? diagBytes * (size_t)count : 0);
+    if (rc != RTOW_SUCCESS) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dColor, in->color, n * 16, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dNormal, in->normal, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dAlbedo, in->albedo, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dScw, in->sampleCountWeight, n * 4, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+    // the chain accumulates in place in the staging buffers (its batches read what their predecessors wrote there); only the final
+    // accumulators and each batch's diagnostics travel back
+    RtowAccumBuffers dev{ctx->dColor, ctx->dNormal, ctx->dAlbedo, ctx->dScw};
+    std::vector<void*> devDiag((size_t)count, nullptr);
+    if (diagnostics) for (int b = 0; b < count; b++) devDiag[(size_t)b] = diagnostics[b] ? ctx->dDiag + (size_t)b * diagBytes : nullptr;
+    *ctx->hCancel = 0u;
+    rc = enqueueChain(ctx, count, params, &dev, &dev, diagnostics ? devDiag.data() : nullptr, s, cancel);
+    if (rc != RTOW_SUCCESS) return rc;
+    if (!cancel) { rc = waitWithCancel(ctx, nullptr); if (rc != RTOW_SUCCESS) return rc; }
+    const int rows = ownedRows(&params[0]);
+    if (rows > 0) {
+        const size_t D = (size_t)params[0].sliceDivider, O = (size_t)params[0].sliceOffset;
+        auto copyRows = [&](void* dst, const void* src, size_t bytesPerPixel) -> hipError_t {
+            const size_t rowBytes = (size_t)w * bytesPerPixel;
+            return hipMemcpy2DAsync((uint8_t*)dst + O * rowBytes, D * rowBytes, (const uint8_t*)src + O * rowBytes, D * rowBytes, rowBytes, (size_t)rows,
+                                    hipMemcpyDeviceToHost, s);
+        };
+        HIP_TRY(ctx, copyRows(out->color, ctx->dColor, 16), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, copyRows(out->normal, ctx->dNormal, 12), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, copyRows(out->albedo, ctx->dAlbedo, 12), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, copyRows(out->sampleCountWeight, ctx->dScw, 4), RTOW_ERROR_LAUNCH_FAILURE);
+        if (diagnostics)
+            for (int b = 0; b < count; b++)
+                if (diagnostics[b]) HIP_TRY(ctx, copyRows(diagnostics[b], devDiag[(size_t)b], (size_t)params[0].diagnosticsStride), RTOW_ERROR_LAUNCH_FAILURE);
     }
-    return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
 }
 
 RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out,

@@ -260,6 +260,27 @@ def sample_batch_chain_device(context, params_list, ins, outs, diags=None, strea
     return load().rtowSampleBatchChainDevice(context.handle, count, arr, C.byref(bi), C.byref(bo), dptr, stream, cancel)
 
 
+def sample_batch_chain_host(context, params_list, inputs=None, want_diag=True):
+    """rtowSampleBatchChain: `len(params_list)` successive batches on HOST buffers in one blocking call; returns the final accumulators like
+    sample_batch_host, with out["diag"] = one record array per batch."""
+    count = len(params_list)
+    w, h = int(params_list[0].size.x), int(params_list[0].size.y)
+    n = w * h
+    if inputs is None:
+        inputs = {"color": np.zeros((n, 4), np.float32), "normal": np.zeros((n, 3), np.float32),
+                  "albedo": np.zeros((n, 3), np.float32), "scw": np.zeros(n, np.float32)}
+    ins = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in inputs.items()}
+    out = {k: np.array(v, dtype=np.float32, copy=True) for k, v in ins.items()}
+    diags = [np.zeros((n, params_list[0].diagnosticsStride // 4), np.float32) for _ in range(count)] if want_diag else None
+    arr = (abi.SampleParams * count)(*params_list)
+    bi = _buffers(*[ins[k].ctypes.data for k in ("color", "normal", "albedo", "scw")])
+    bo = _buffers(*[out[k].ctypes.data for k in ("color", "normal", "albedo", "scw")])
+    dptr = (C.c_void_p * count)(*[d.ctypes.data for d in diags]) if want_diag else None
+    check(load().rtowSampleBatchChain(context.handle, count, arr, C.byref(bi), C.byref(bo), dptr, None), "rtowSampleBatchChain")
+    out["diag"] = diags
+    return out
+
+
 def sample_batch_host(context, params, inputs=None, want_diag=True):
     """Convenience used by tests/bench: run one batch with host buffers; returns dict like the oracle binding."""
     w, h = int(params.size.x), int(params.size.y)

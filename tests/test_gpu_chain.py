@@ -174,3 +174,29 @@ def test_chain_of_a_slice_that_owns_no_row(rt, gpu_context):
     got = _chained(rt, ctx, plist, w * h, 4)
     for k, _ in KEYS:
         assert not got[k].any(), k
+
+
+def test_host_buffer_chain_equals_host_batches_one_after_the_other(rt, gpu_context):
+    """rtowSampleBatchChain (host arrays in, final accumulators + per-batch diagnostics out, one blocking call) against rtowSampleBatch called
+    per batch with the outputs fed back as inputs - the reference's own accumulation (UNITY/Raytracer.cs:798-802); whole frame and a slice."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 144, 81
+    n = w * h
+    rng = np.random.default_rng(8)
+    start = {"color": rng.random((n, 4)).astype(np.float32), "normal": rng.normal(size=(n, 3)).astype(np.float32),
+             "albedo": rng.random((n, 3)).astype(np.float32), "scw": rng.random(n).astype(np.float32)}
+    start["color"][:, 3] = rng.integers(0, 5, n)
+    for kw in ({}, {"slice_offset": 1, "slice_divider": 4}):
+        plist = _params(rt, scene, w, h, 3, 6, [9, 10, 11, 12], diagnostics_stride=16, **kw)
+        acc, diags = start, []
+        for p in plist:
+            acc = rt.sample_batch_host(ctx, p, inputs={k: acc[k] for k, _ in KEYS})
+            diags.append(acc["diag"])
+        got = rt.sample_batch_chain_host(ctx, plist, inputs=start)
+        for k, _ in KEYS:
+            assert np.array_equal(got[k].reshape(-1).view(np.uint32), acc[k].reshape(-1).view(np.uint32)), (kw, k)
+        rows = (np.arange(n) // w) % kw.get("slice_divider", 1) == kw.get("slice_offset", 0)
+        for i, (x, y) in enumerate(zip(got["diag"], diags)):
+            assert np.array_equal(x[rows].view(np.uint32), y[rows].view(np.uint32)), (kw, "diagnostics of batch", i)
