@@ -25,6 +25,19 @@ __device__ __forceinline__ float exact_rcp(float x)
     return 1.0f / x;
 }
 
+// rcp(x) with NaN -> +INF, the reference's rayInvDirection (JOBS/SampleBatchJob.cs:406-412: `select(rcp, INFINITY, isnan(rcp))`).  The fast path
+// cannot produce a NaN (finite, normal operand), so only the fallback looks for one.
+__device__ __forceinline__ float exact_rcp_nan_to_inf(float x)
+{
+    if (__builtin_expect(((__float_as_uint(x) & 0x7f800000u) - 0x01000000u) <= 0x7d000000u, 1)) {
+        const float y = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, y, 1.0f);
+        return __builtin_fmaf(e, y, y);
+    }
+    const float r = 1.0f / x;
+    return r != r ? __builtin_inff() : r;
+}
+
 // RN(sqrt(x))
 __device__ __forceinline__ float exact_sqrt(float x)
 {

@@ -39,9 +39,11 @@
 #endif
 #if RTOW_EXACT_MATH
 #define RTOW_RCP(x) rtow::exact_rcp(x)
+#define RTOW_RCP_NAN_TO_INF(x) rtow::exact_rcp_nan_to_inf(x)
 #define RTOW_SQRT(x) rtow::exact_sqrt(x)
 #else
 #define RTOW_RCP(x) (1.0f / (x))
+#define RTOW_RCP_NAN_TO_INF(x) ([](float r_) { return r_ != r_ ? __builtin_inff() : r_; }(1.0f / (x)))
 #define RTOW_SQRT(x) __builtin_sqrtf(x)
 #endif
 
@@ -966,10 +968,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     auto startRay = [&]() {
         // rayInvDirection = rcp(ray.Direction), NaN -> +INF (JOBS/SampleBatchJob.cs:408-412).  The IEEE quotient, not v_rcp_f32: the leaf
         // children of the tree carry the reference's own entity boxes and must pass or fail the reference's own slab test (RT/HitTests.cs:9-21)
-        inv = v3(RTOW_RCP(rd.x), RTOW_RCP(rd.y), RTOW_RCP(rd.z));
-        if (inv.x != inv.x) inv.x = __builtin_inff();
-        if (inv.y != inv.y) inv.y = __builtin_inff();
-        if (inv.z != inv.z) inv.z = __builtin_inff();
+        inv = v3(RTOW_RCP_NAN_TO_INF(rd.x), RTOW_RCP_NAN_TO_INF(rd.y), RTOW_RCP_NAN_TO_INF(rd.z));
         cur = 0; sp = 0; nc = 0; prim = -1;
         best = __builtin_inff();
         tieAtBest = false;

@@ -17,7 +17,7 @@ __global__ void sweep(unsigned long long* bad, unsigned* firstBad)
 {
     const unsigned stride = gridDim.x * blockDim.x;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned b0 = 0, b1 = 0, b2 = 0;
+    unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     for (unsigned k = 0; k < (unsigned)((1ull << 32) / stride); k++, i += stride) {     // the grid size (2^20 threads) divides 2^32
         const float x = __uint_as_float(i);
         volatile float vx = x;                                      // keep the reference expressions from being folded with the candidates
@@ -26,10 +26,13 @@ __global__ void sweep(unsigned long long* bad, unsigned* firstBad)
         if (!same(rtow::exact_sqrt(x), r1)) { if (!b1) atomicCAS(&firstBad[1], 0u, i); b1++; }
         const float r2 = 1.0f / r1;
         if (!same(rtow::exact_rcp(rtow::exact_sqrt(x)), r2)) { if (!b2) atomicCAS(&firstBad[2], 0u, i); b2++; }
+        const float r3 = r0 != r0 ? __builtin_inff() : r0;         // rayInvDirection: rcp, NaN -> +INF
+        if (__float_as_uint(rtow::exact_rcp_nan_to_inf(x)) != __float_as_uint(r3)) { if (!b3) atomicCAS(&firstBad[3], 0u, i); b3++; }
     }
     if (b0) atomicAdd(&bad[0], (unsigned long long)b0);
     if (b1) atomicAdd(&bad[1], (unsigned long long)b1);
     if (b2) atomicAdd(&bad[2], (unsigned long long)b2);
+    if (b3) atomicAdd(&bad[3], (unsigned long long)b3);
 }
 
 int main()
@@ -39,9 +42,10 @@ int main()
     hipMemset(bad, 0, 32); hipMemset(first, 0, 16);
     // 2^32 operands over 2^20 threads: 4096 operands each (the grid size divides 2^32)
     hipLaunchKernelGGL(sweep, dim3(4096), dim3(256), 0, 0, bad, first);
-    unsigned long long h[3]; unsigned f[3];
+    unsigned long long h[4]; unsigned f[4];
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
     hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost); hipMemcpy(f, first, sizeof(f), hipMemcpyDeviceToHost);
-    printf("exactmath parity over 2^32 operands: rcp %llu mismatches (first 0x%08x), sqrt %llu (first 0x%08x), rcp(sqrt) %llu (first 0x%08x)\n", h[0], f[0], h[1], f[1], h[2], f[2]);
-    return (h[0] || h[1] || h[2]) ? 1 : 0;
+    printf("exactmath parity over 2^32 operands: rcp %llu mismatches (first 0x%08x), sqrt %llu (first 0x%08x), rcp(sqrt) %llu (first 0x%08x), rcp with NaN -> inf %llu (first 0x%08x)\n",
+           h[0], f[0], h[1], f[1], h[2], f[2], h[3], f[3]);
+    return (h[0] || h[1] || h[2] || h[3]) ? 1 : 0;
 }
