@@ -11,7 +11,7 @@ ping-pong buffers with a fresh seed, exactly like the reference's successive bat
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N = 1: the K timed steps are enqueued as chains of `--chain` successive batches (rtowSampleBatchChainDevice; the reference itself keeps
+N = 1: the K timed steps are enqueued as equally long chains of at most 16 successive batches (`--chain`) (rtowSampleBatchChainDevice; the reference itself keeps
 two batches in flight, Raytracer.cs:586-593): one launch per chain, in which a pixel chunk's next batch starts as soon as its previous
 batch is stored.  The same K steps as plain one-launch-per-batch calls and the host-buffer form (rtowSampleBatch on pinned host arrays)
 are measured after the timed region and reported next to `value` (`plain_batches`, `host_buffer_ms_per_step`).
@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (plain batches, host-buffer form, other partitions)")
-    ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default 8 on one GPU, 1 on several (one gather per batch)")
+    ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default: on one GPU the steps split into equal chains of at most 16, on several 1 (one gather per batch)")
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
     ap.add_argument("--context-flags", type=int, default=0, help="development: RtowContextOptions.flags (e.g. 1 = exact-tie kernels always)")
     ap.add_argument("--partition", choices=("tiles", "batches"), default="tiles", help="which N > 1 partition `value` reports (the other is reported beside it)")
@@ -162,8 +162,10 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     if args.chain is None:
-        args.chain = 8 if world == 1 else 1
-    args.chain = max(1, args.chain)
+        # one GPU: the K timed steps as equally long chains of at most 16 batches (the most one launch holds): 20 steps -> 10 + 10
+        launches = -(-args.steps // 16)
+        args.chain = -(-args.steps // launches) if world == 1 else 1
+    args.chain = max(1, min(16, args.chain))
 
     import torch  # device memory, streams, torch.distributed (RCCL); loaded before the HIP library on purpose
 

@@ -9,9 +9,10 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the default bench command line (chains of 8 batches per launch); the counter passes profile ONE chain launch (8 batches) after the probe
-BENCH="python $REPO/bench.py --steps 16 --warmup 0 --no-cpu-baseline --no-extras"
-ONE="python $REPO/bench.py --steps 8 --warmup 0 --no-cpu-baseline --no-extras"
+# bench.py with chains of 8 batches per launch (its default splits the steps into equal chains of at most 16); the counter passes profile ONE
+# chain launch (8 batches) after the probe
+BENCH="python $REPO/bench.py --steps 16 --warmup 0 --chain 8 --no-cpu-baseline --no-extras"
+ONE="python $REPO/bench.py --steps 8 --warmup 0 --chain 8 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $ONE > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $ONE > $OUT/pmc_write.log 2>&1
