@@ -1,6 +1,6 @@
 // rtow_sample_kernel.hip.h - the sample-batch megakernel (hand-written gfx950 / CDNA4) and the device helpers shared with the small
-// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_*.hip): the kernel has ~190
-// template instantiations and compiling them side by side keeps the build under a minute.
+// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_*.hip): the kernel has 144
+// template instantiations and compiling them side by side keeps the build at half a minute.
 //
 // sample_batch_kernel replaces SampleBatchJob.Execute + Sample + FindHitCandidates + FindHits + Entity.Hit +
 // Sphere.Hit + Material.Scatter + View.GetRay + RandomSource (JOBS/SampleBatchJob.cs:59-475, RT/*.cs).
@@ -19,13 +19,16 @@
 //  * the per-depth emission/attenuation stacks (JOBS/SampleBatchJob.cs:103-104,311,330) are kept as 16-bit material codes packed in
 //    VGPRs and re-expanded when the path is folded tail -> head (:384-396), which keeps the colour bit-identical to the reference's
 //    fold order without 2 x TraceDepth float3 of per-lane storage (textured scenes keep per-depth colours in scratch instead);
+//  * several successive batches of a frame can run in ONE launch (chained batches, rtowSampleBatchChainDevice): batch b of a 64-pixel chunk is
+//    handed out once batch b - 1 of that chunk is stored (per-chunk counters, device-coherent accumulator accesses), so lanes that run out
+//    of one batch's pixels take the next batch's instead of idling through the batch's tail;
 //  * template parameters: ALL_LDS (scene fully LDS resident), KIND (spheres / moving spheres / general entities / volumes / textured /
 //    both), HW (history words: trace depth <= 8 / 16 / 64), FULL_DIAG (the FULL_DIAGNOSTICS counters are kept), NOISE (white / blue / STBN),
 //    PER_SAMPLE; launchByDiag (end of this file) says which of the 144 instantiations serves which batch.
 //
 // Numerics: compiled with -ffp-contract=off; every expression below is written in the evaluation order of the C#
-// source (left to right, no fusion), with IEEE division and square root, and the deterministic transcendental
-// functions of rtow_detmath.hip.h.  No MFMA: there is no dense contraction anywhere on this path.
+// source (left to right, no fusion), with IEEE division and square root (1 / x and sqrt(x) through the exhaustively checked short forms
+// of rtow_exactmath.hip.h), and the deterministic transcendental functions of rtow_detmath.hip.h.  No MFMA: there is no dense contraction anywhere on this path.
 #pragma once
 #include "rtow_kernels.h"
 

@@ -1,10 +1,10 @@
 """GPU: every compiled variant of the sample kernel, one by one.
 
-The kernel is instantiated per (tree in LDS | in HBM) x scene kind x history width x diagnostics x noise source x RNG policy - 192
-kernels, the spilling ones compiled under heavy register pressure.  During development one of them (VOLUMES, spatio-temporal noise,
+The kernel is instantiated per (tree in LDS | in HBM) x scene kind x the (history width, diagnostics, noise source, RNG policy) combinations
+`launchByDiag` (end of csrc/rtow_sample_kernel.hip.h) dispatches to - 144 kernels, the spilling ones compiled under heavy register pressure.  During development one of them (VOLUMES, spatio-temporal noise,
 short diagnostics) was once MISCOMPILED by hipcc (ROCm 7.2): a VGPR spill store was scheduled in front of the `s_or_b64 exec` of a join
 block, so the lanes that had skipped the region kept a stale spill slot and later reloaded it - their ray-count diagnostic came out 0
-while the colours were right.  Any source change reshuffles the register allocation of all 192, so every build
+while the colours were right.  Any source change reshuffles the register allocation of all of them, so every build
 renders a small, divergent frame through each of them and compares every output with the oracle, bit for bit."""
 import os
 
