@@ -1291,6 +1291,13 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
                 const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
                 int budget = A.travSlice;
+                // Pruning bound.  A subtree whose box the ray enters beyond the nearest hit so far cannot hold a nearer one - but it can hold an
+                // EQUAL one: the twin of the sphere that set `best`.  The two distances come from different float programs (slab entry of the
+                // twin's box against the quadratic's root), and where the ray meets the sphere at a point that touches its box they differ by
+                // rounding only; one ulp the wrong way pruned the twin, TEST never saw the tie, and the resolver was never asked (twin spheres
+                // moving, 1 pixel in 42.8 M rays: tests/soak_frames.py at 2.5x).  Scenes that need exact ties therefore prune with 2^-12 of slack
+                // (the entry distance is good to an ulp, the root to a few where the two can meet); TEST still compares against `best` itself.
+                const float bestPrune = EXACT_TIES ? best * 1.000244140625f : best;
                 // Branch-free node visit: every LDS access of the iteration is issued up front (node, plus the stack slot a
                 // pop would need), candidate / stack slots are written unconditionally and only the counters are predicated,
                 // so the wave's EXEC mask changes only at the loop test.
@@ -1314,8 +1321,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     // inner child (padded box): conservative, pruned by the nearest hit so far.  Leaf child (the reference's own entity box):
                     // AxisAlignedBoundingBox.Hit itself, tMin < tMax (RT/HitTests.cs:15-20) - pruning by `best` on top (<=, so that a tie at
                     // exactly `best` is still tested) cannot change which hit is nearest.
-                    const bool hit0 = tmin0 <= vmin(tfar0, best);
-                    const bool hit1 = tmin1 <= vmin(tfar1, best) && twoChildren;
+                    const bool hit0 = tmin0 <= vmin(tfar0, bestPrune);
+                    const bool hit1 = tmin1 <= vmin(tfar1, bestPrune) && twoChildren;
                     const bool leaf0 = c0 < 0 && hit0 && tmin0 < tfar0, leaf1 = c1 < 0 && hit1 && tmin1 < tfar1;
                     if (FULL_DIAG && !refDiag) boundsHits += ((c0 < 0 ? leaf0 : hit0) ? 1.0f : 0.0f) + ((c1 < 0 ? leaf1 : hit1) ? 1.0f : 0.0f);
                     cand[nc * kBlockThreads] = (unsigned short)~c0;
