@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None)
-    ap.add_argument("--rng", choices=["reference", "per-sample"], default="reference",
+    ap.add_argument("--rng", choices=["reference", "per-sample", "per-sample-xoroshiro"], default="reference",
                     help="reference: the reference's per-pixel generator (same seed, same image: the headline); per-sample: RTOW_RNG_PER_SAMPLE, a different stream")
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,7 +247,7 @@ def main():
         def params_for(seed):
             p = abi.SampleParams.from_buffer_copy(base)
             p.seed = seed
-            p.rngPolicy = abi.RNG_PER_SAMPLE if rng == "per-sample" else abi.RNG_REFERENCE
+            p.rngPolicy = {"per-sample": abi.RNG_PER_SAMPLE, "per-sample-xoroshiro": abi.RNG_PER_SAMPLE_XOROSHIRO}.get(rng, abi.RNG_REFERENCE)
             return p
 
         def add_flat(dst, src):
@@ -392,7 +392,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s%s, %dx%d, %d spp per batch, "
-                            "%d bounces, white noise, jitter on, %s" % ("BASELINE.json " + cfg["label"] + " = " if not overridden else "", SCENE_TEXT[args.scene], W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_PER_SAMPLE (NOT the reference stream; lane per 16-sample group)"),
+                            "%d bounces, white noise, jitter on, %s" % ("BASELINE.json " + cfg["label"] + " = " if not overridden else "", SCENE_TEXT[args.scene], W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_%s (NOT the reference stream; lane per 16-sample group)" % args.rng.upper().replace("-", "_")),
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
                               "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
                               if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),

@@ -206,8 +206,11 @@ typedef struct RtowView {
  *                        and advanced once like the Random ctor does; samples are taken in groups of 16, every group summed from zero
  *                        in sample order, and the groups added to the accumulators in group order (colour, normal, albedo, successes,
  *                        sample-count weight; the fallback AOVs are sample 0's).  A pixel's samples become independent units of work:
- *                        no long tail at the end of a batch, and a frame can be split over GPUs by rows without starving lanes. */
-typedef enum RtowRngPolicy { RTOW_RNG_REFERENCE = 0, RTOW_RNG_PER_SAMPLE = 1 } RtowRngPolicy;
+ *                        no long tail at the end of a batch, and a frame can be split over GPUs by rows without starving lanes.
+ *   RTOW_RNG_PER_SAMPLE_XOROSHIRO  the same policy (units, groups, fold order) with the generator north_star names: xoroshiro64** (Blackman & Vigna,
+ *                        two 32-bit words per lane).  s0 = the RTOW_RNG_PER_SAMPLE seed of the sample, s1 = s0 * 0x85EBCA6B ^ 0xC2B2AE35 (0x9E3779B9 if both
+ *                        are 0), one output discarded; NextFloat() takes the top 23 bits of an output exactly like Unity's (asfloat(0x3f800000 | (x >> 9)) - 1). */
+typedef enum RtowRngPolicy { RTOW_RNG_REFERENCE = 0, RTOW_RNG_PER_SAMPLE = 1, RTOW_RNG_PER_SAMPLE_XOROSHIRO = 2 } RtowRngPolicy;
 
 typedef enum RtowCubemapChannelType { RTOW_CUBEMAP_UNSIGNED_BYTE = 0, RTOW_CUBEMAP_SIGNED_HALF = 1 } RtowCubemapChannelType;
 typedef struct RtowCubemapDesc {

@@ -53,6 +53,7 @@ def load(kind="strict"):
     lib.oracle_finalize.argtypes = [C.c_int] + [C.c_void_p] * 6
     lib.oracle_reduce_metrics.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(abi.Metrics)]
     lib.oracle_kat_rng.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    lib.oracle_kat_xoroshiro.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     lib.oracle_kat_pixel_seed.restype = C.c_uint32
     lib.oracle_kat_pixel_seed.argtypes = [C.c_uint32, C.c_int]
     lib.oracle_kat_sincos.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -131,15 +131,37 @@ const float UM_EPSILON = 1.1920928955078125e-7f;
  * NextState(): t = state; state ^= state << 13; state ^= state >> 17; state ^= state << 5; return t. */
 struct UmRandom {
     uint32_t state;
+    /* RTOW_RNG_PER_SAMPLE_XOROSHIRO (include/rtow.h; not the reference): xoroshiro64** - state words (state, s1), output rotl(s0 * 0x9E3779BB, 5) * 5,
+     * then s1 ^= s0; s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9); s1 = rotl(s1, 13) (Blackman & Vigna, public domain reference implementation restated) */
+    uint32_t s1 = 0;
+    bool xoroshiro = false;
+    static uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
     uint32_t NextState()
     {
+        if (xoroshiro) {
+            const uint32_t s0 = state;
+            uint32_t t1 = s1;
+            const uint32_t result = rotl(s0 * 0x9E3779BBu, 5) * 5u;
+            t1 ^= s0;
+            state = rotl(s0, 26) ^ t1 ^ (t1 << 9);
+            s1 = rotl(t1, 13);
+            return result;
+        }
         const uint32_t t = state;
         state ^= state << 13;
         state ^= state >> 17;
         state ^= state << 5;
         return t;
     }
-    void Init(uint32_t seed) { state = seed; NextState(); }
+    void Init(uint32_t seed) { xoroshiro = false; state = seed; NextState(); }
+    void InitXoroshiro(uint32_t seed)
+    {
+        xoroshiro = true;
+        state = seed;
+        s1 = (seed * 0x85EBCA6Bu) ^ 0xC2B2AE35u;
+        if ((state | s1) == 0u) s1 = 0x9E3779B9u;
+        NextState();
+    }
     float NextFloat() { return dm_asfloat(0x3f800000u | (NextState() >> 9)) - 1.0f; }
     float2 NextFloat2() { float2 r; r.x = NextFloat(); r.y = NextFloat(); return r; }
     float NextFloat(float mn, float mx) { return NextFloat() * (mx - mn) + mn; }
@@ -1539,7 +1561,7 @@ struct Job {
 
         /* RTOW_RNG_PER_SAMPLE (include/rtow.h; NOT the reference): every sample has its own generator; groups of 16 samples are summed
          * from zero in sample order and the groups added to the accumulators in group order */
-        const bool perSample = p.rngPolicy == RTOW_RNG_PER_SAMPLE;
+        const bool perSample = p.rngPolicy == RTOW_RNG_PER_SAMPLE || p.rngPolicy == RTOW_RNG_PER_SAMPLE_XOROSHIRO;
         float3 gColor = f3(0), gNormal = f3(0), gAlbedo = f3(0);
         float gWeight = 0;
         int gCount = 0;
@@ -1555,8 +1577,8 @@ struct Job {
             if (tracePixel) fprintf(stderr, "[otrace] sample %u\n", smp);
             if (perSample) {
                 uint32_t state = ((p.seed * 0x8C4CA03Fu) ^ ((uint32_t)index * 0x7383ED49u)) ^ ((smp + 1u) * 0x9E3779B9u);
-                if (state == 0) state = 0x9E3779B9u;
-                rng.whiteNoise.Init(state);
+                if (p.rngPolicy == RTOW_RNG_PER_SAMPLE_XOROSHIRO) rng.whiteNoise.InitXoroshiro(state);
+                else { if (state == 0) state = 0x9E3779B9u; rng.whiteNoise.Init(state); }
                 rng.RandomEvents = 0;
             }
             float2 jitter;
@@ -1745,7 +1767,7 @@ static int sample_impl(void* scenePtr, const RtowSampleParams* params,
 {
     if (!scenePtr || !params) return 1;
     if (params->noiseColor < RTOW_NOISE_WHITE || params->noiseColor > RTOW_NOISE_SPATIOTEMPORAL_BLUE) return 1;
-    if (params->rngPolicy != RTOW_RNG_REFERENCE && !(params->rngPolicy == RTOW_RNG_PER_SAMPLE && params->noiseColor == RTOW_NOISE_WHITE)) return 1;
+    if (params->rngPolicy != RTOW_RNG_REFERENCE && !((params->rngPolicy == RTOW_RNG_PER_SAMPLE || params->rngPolicy == RTOW_RNG_PER_SAMPLE_XOROSHIRO) && params->noiseColor == RTOW_NOISE_WHITE)) return 1;
     if (params->sliceDivider < 1 || params->traceDepth < 0) return 1;
     const OracleScene* scene = (const OracleScene*)scenePtr;
     Job job;
@@ -1887,6 +1909,12 @@ ORACLE_API void oracle_kat_rng(uint32_t seed, int n, uint32_t* states, float* fl
     UmRandom a; a.Init(seed);
     UmRandom b; b.Init(seed);
     for (int i = 0; i < n; i++) { states[i] = a.NextState(); floats[i] = b.NextFloat(); }
+}
+ORACLE_API void oracle_kat_xoroshiro(uint32_t seed, int n, uint32_t* outputs, float* floats)
+{
+    UmRandom a; a.InitXoroshiro(seed);
+    UmRandom b; b.InitXoroshiro(seed);
+    for (int i = 0; i < n; i++) { outputs[i] = a.NextState(); floats[i] = b.NextFloat(); }
 }
 ORACLE_API uint32_t oracle_kat_pixel_seed(uint32_t seed, int index) { return (seed * 0x8C4CA03Fu) ^ ((uint32_t)index * 0x7383ED49u); }
 ORACLE_API void oracle_kat_sincos(int n, const float* x, float* s, float* c) { for (int i = 0; i < n; i++) dm_sincosf(x[i], &s[i], &c[i]); }

@@ -96,7 +96,7 @@ class View(C.Structure):
 
 
 CUBEMAP_UNSIGNED_BYTE, CUBEMAP_SIGNED_HALF = 0, 1
-RNG_REFERENCE, RNG_PER_SAMPLE = 0, 1
+RNG_REFERENCE, RNG_PER_SAMPLE, RNG_PER_SAMPLE_XOROSHIRO = 0, 1, 2
 
 
 class CubemapDesc(C.Structure):

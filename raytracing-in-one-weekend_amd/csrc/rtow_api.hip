@@ -144,8 +144,8 @@ int validateParams(const RtowSampleParams* p)
     if (p->sliceDivider < 1 || p->sliceOffset < 0 || p->sliceOffset >= p->sliceDivider) return RTOW_ERROR_INVALID_VALUE;
     if (p->traceDepth < 1 || p->traceDepth > 64) return p->traceDepth < 1 ? RTOW_ERROR_INVALID_VALUE : RTOW_ERROR_CAPACITY;
     if (p->noiseColor < RTOW_NOISE_WHITE || p->noiseColor > RTOW_NOISE_SPATIOTEMPORAL_BLUE) return RTOW_ERROR_INVALID_VALUE;
-    if (p->rngPolicy != RTOW_RNG_REFERENCE && p->rngPolicy != RTOW_RNG_PER_SAMPLE) return RTOW_ERROR_INVALID_VALUE;
-    if (p->rngPolicy == RTOW_RNG_PER_SAMPLE && p->noiseColor != RTOW_NOISE_WHITE) return RTOW_ERROR_INVALID_VALUE;   // the texture walks are per pixel by construction
+    if (p->rngPolicy != RTOW_RNG_REFERENCE && p->rngPolicy != RTOW_RNG_PER_SAMPLE && p->rngPolicy != RTOW_RNG_PER_SAMPLE_XOROSHIRO) return RTOW_ERROR_INVALID_VALUE;
+    if (p->rngPolicy != RTOW_RNG_REFERENCE && p->noiseColor != RTOW_NOISE_WHITE) return RTOW_ERROR_INVALID_VALUE;   // the texture walks are per pixel by construction
     if (p->environment.skyType < RTOW_SKY_NONE || p->environment.skyType > RTOW_SKY_CUBEMAP) return RTOW_ERROR_INVALID_VALUE;
     if (p->diagnosticsStride != 4 && p->diagnosticsStride != 16) return RTOW_ERROR_INVALID_VALUE;
     return RTOW_SUCCESS;
@@ -245,7 +245,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         return RTOW_SUCCESS;
     }
     a.groupsPerPixel = 1;
-    if (p->rngPolicy == RTOW_RNG_PER_SAMPLE) {
+    a.xoroshiro = p->rngPolicy == RTOW_RNG_PER_SAMPLE_XOROSHIRO ? 1 : 0;
+    if (p->rngPolicy != RTOW_RNG_REFERENCE) {
         // work units are (owned pixel, group of kSampleGroup samples); each leaves a record that fold_unit_records_kernel adds up
         uint32_t groups = (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
         groups = (groups + kSampleGroup - 1) / kSampleGroup;

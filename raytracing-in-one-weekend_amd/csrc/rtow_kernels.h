@@ -78,6 +78,7 @@ struct SampleKernelArgs {
     // RTOW_RNG_PER_SAMPLE: work units are (owned pixel, group of kSampleGroup samples); totalWork counts units
     float* unitRecords;                   // [totalWork] x 16 floats, null = reference policy (units are pixels)
     uint32_t groupsPerPixel;              // ceil(sampleCountMax / kSampleGroup), 1 under the reference policy
+    int32_t xoroshiro;                    // per-sample policies: 1 = xoroshiro64** (RTOW_RNG_PER_SAMPLE_XOROSHIRO), 0 = Unity's xorshift32 reseeded per sample
 
     // Image textures (SCENE_KIND_TEXTURED): GpuTexMaterial / GpuImage tables and pixels, in HBM
     const uint8_t* texBlob;

@@ -32,6 +32,8 @@
 #pragma once
 #include "rtow_kernels.h"
 
+#include <type_traits>
+
 #include "rtow_detmath.hip.h"
 #include "rtow_exactmath.hip.h"
 
@@ -201,6 +203,54 @@ struct Rng<RTOW_NOISE_WHITE> {
     __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite&, V3 n) { const float u = rng_next(s), v = rng_next(s); return cosine_hemisphere_uv(u, v, n); }
     __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite&) { (void)rng_next(s); (void)rng_next(s); }
     __device__ __forceinline__ V3 direction(const NoiseSite&) { const float r0 = rng_next(s), r1 = rng_next(s); return direction_uv(r0, r1); }
+    __device__ __forceinline__ unsigned trace_value() const { return s; }
+};
+
+// The per-sample policies (include/rtow.h RtowRngPolicy; not the reference's stream): every sample has its own white-noise generator -
+// Unity's xorshift32 reseeded per sample (RTOW_RNG_PER_SAMPLE) or xoroshiro64** (RTOW_RNG_PER_SAMPLE_XOROSHIRO, the generator north_star names:
+// output rotl(s0 * 0x9E3779BB, 5) * 5; s1 ^= s0; s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9); s1 = rotl(s1, 13)).  One kernel variant serves both: the
+// choice is a launch constant, and a second state word costs these variants nothing they notice.
+struct RngPerSample {
+    unsigned s, s1;
+    __device__ __forceinline__ static unsigned rotl(unsigned x, unsigned k) { return __builtin_amdgcn_alignbit(x, x, 32u - k); }
+    __device__ __forceinline__ float draw(const NoiseSite& at)
+    {
+        if (at.A->xoroshiro) {
+            const unsigned s0 = s;
+            unsigned t1 = s1;
+            const unsigned result = rotl(s0 * 0x9E3779BBu, 5u) * 5u;
+            t1 ^= s0;
+            s = rotl(s0, 26u) ^ t1 ^ (t1 << 9);
+            s1 = rotl(t1, 13u);
+            return __uint_as_float(0x3f800000u | (result >> 9)) - 1.0f;
+        }
+        return rng_next(s);
+    }
+    __device__ __forceinline__ void begin_pixel(const NoiseSite&, unsigned, unsigned) { s = 1u; s1 = 0u; }     // every sample reseeds (begin_sample)
+    __device__ __forceinline__ void begin_sample(const NoiseSite& at, unsigned pix, unsigned smp)
+    {
+        s = ((at.A->seed * 0x8C4CA03Fu) ^ (pix * 0x7383ED49u)) ^ ((smp + 1u) * 0x9E3779B9u);
+        if (at.A->xoroshiro) {
+            s1 = (s * 0x85EBCA6Bu) ^ 0xC2B2AE35u;
+            if ((s | s1) == 0u) s1 = 0x9E3779B9u;
+        } else if (s == 0u) {
+            s = 0x9E3779B9u;                                      // Random needs a non-zero state
+        }
+        (void)draw(at);                                           // like the Random ctor: one output discarded
+    }
+    __device__ __forceinline__ float next(const NoiseSite& at) { return draw(at); }
+    __device__ __forceinline__ void next2(const NoiseSite& at, float& a, float& b) { a = draw(at); b = draw(at); }
+    __device__ __forceinline__ void in_unit_disk(const NoiseSite& at, float& x, float& y)
+    {
+        const float theta = draw(at) * (2.0f * kPi - 0.0f) + 0.0f;
+        const float radius = RTOW_SQRT(draw(at));
+        float sinT, cosT;
+        det_sincos(theta, sinT, cosT);
+        x = radius * cosT; y = radius * sinT;
+    }
+    __device__ __forceinline__ V3 cosine_hemisphere(const NoiseSite& at, V3 n) { const float u = draw(at), v = draw(at); return cosine_hemisphere_uv(u, v, n); }
+    __device__ __forceinline__ void skip_cosine_hemisphere(const NoiseSite& at) { (void)draw(at); (void)draw(at); }
+    __device__ __forceinline__ V3 direction(const NoiseSite& at) { const float r0 = draw(at), r1 = draw(at); return direction_uv(r0, r1); }
     __device__ __forceinline__ unsigned trace_value() const { return s; }
 };
 
@@ -882,7 +932,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     int st = ST_REGEN;
     int pix = -1;
     unsigned tick = 0;          // ticket (owned-pixel number) of the current pixel
-    Rng<NOISE> rng{};
+    typename std::conditional<PER_SAMPLE && NOISE == RTOW_NOISE_WHITE, RngPerSample, Rng<NOISE>>::type rng{};
     V3 fbNormal = v3(0, 0, 0), fbAlbedo = v3(0, 0, 0);   // PER_SAMPLE: AOVs of the batch's sample 0 (the fallback when nothing succeeds)
     unsigned unitGroup = 0;                                // PER_SAMPLE: which 16-sample group of its pixel this lane works on
     unsigned smp = 0, nsamp = 0;

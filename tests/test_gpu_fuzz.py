@@ -95,7 +95,7 @@ def test_random_scene(rt, oracle, gpu_context, seed):
     ctx = gpu_context
     ctx.upload_scene(desc)
     noise_color = int(rng.choice([abi.NOISE_WHITE, abi.NOISE_WHITE, abi.NOISE_BLUE, abi.NOISE_SPATIOTEMPORAL_BLUE]))
-    policy = int(rng.choice([abi.RNG_REFERENCE, abi.RNG_PER_SAMPLE])) if noise_color == abi.NOISE_WHITE else abi.RNG_REFERENCE
+    policy = int(rng.choice([abi.RNG_REFERENCE, abi.RNG_REFERENCE, abi.RNG_PER_SAMPLE, abi.RNG_PER_SAMPLE_XOROSHIRO])) if noise_color == abi.NOISE_WHITE else abi.RNG_REFERENCE
     div = int(rng.choice([1, 1, 2, 3]))
     big = 3 if os.environ.get("RTOW_FUZZ_HEAVY") else 1
     p = rt.scenes.make_params(scene, int(rng.integers(8, 48 * big)), int(rng.integers(8, 36 * big)), spp=int(rng.integers(1, 20)), trace_depth=int(rng.choice([1, 2, 5, 8, 12, 17, 40])),

@@ -265,13 +265,14 @@ def test_image_textures_with_probabilistic_volumes(rt, oracle, gpu_context):
     assert gpu["color"][:, 3].sum() > 0
 
 
-def test_per_sample_rng_policy(rt, oracle, gpu_context):
-    """RTOW_RNG_PER_SAMPLE (include/rtow.h): NOT the reference's stream - every sample has its own generator, work units are (pixel, group
+@pytest.mark.parametrize("policy", ["xorshift", "xoroshiro"])
+def test_per_sample_rng_policy(rt, oracle, gpu_context, policy):
+    """RTOW_RNG_PER_SAMPLE / RTOW_RNG_PER_SAMPLE_XOROSHIRO (include/rtow.h): NOT the reference's stream - every sample has its own generator, work units are (pixel, group
     of 16 samples), a fold kernel adds the groups in order.  Defined by the oracle's restatement of that definition; bit-exact against it
     for sample counts that are / are not multiples of 16, adaptive counts, slices, all history widths, both diagnostics layouts, and on
     top of existing accumulators."""
     ctx = gpu_context
-    PS = rt.abi.RNG_PER_SAMPLE
+    PS = rt.abi.RNG_PER_SAMPLE if policy == "xorshift" else rt.abi.RNG_PER_SAMPLE_XOROSHIRO      # north_star's per-lane xoroshiro generator
     cases = [(rt.scenes.cover_scene(), dict(width=64, height=36, spp=40, trace_depth=8)),
              (rt.scenes.cover_scene(), dict(width=48, height=27, spp=16, trace_depth=12, diagnostics_stride=16)),
              (rt.scenes.cover_scene(), dict(width=48, height=27, spp=5, trace_depth=20, slice_offset=1, slice_divider=2)),

@@ -37,6 +37,8 @@ def _modes(abi):
     for depth in (5, 12, 20):
         out.append((depth, abi.NOISE_WHITE, abi.RNG_REFERENCE))
         out.append((depth, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE))
+    out.append((5, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE_XOROSHIRO))
+    out.append((12, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE_XOROSHIRO))
     out.append((6, abi.NOISE_BLUE, abi.RNG_REFERENCE))
     out.append((6, abi.NOISE_SPATIOTEMPORAL_BLUE, abi.RNG_REFERENCE))
     return out

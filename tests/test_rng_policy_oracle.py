@@ -43,3 +43,52 @@ def test_samples_are_independent_units_of_work():
     with pytest.raises(RuntimeError):
         osc.sample_batch(bad)
     osc.close()
+
+
+def _xoroshiro64ss(s0, s1, n):
+    """xoroshiro64** 1.0 (Blackman & Vigna, public domain), written out from its published definition: the pin of the oracle's restatement."""
+    rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & 0xFFFFFFFF
+    out = []
+    for _ in range(n):
+        out.append((rotl((s0 * 0x9E3779BB) & 0xFFFFFFFF, 5) * 5) & 0xFFFFFFFF)
+        s1 ^= s0
+        s0 = rotl(s0, 26) ^ s1 ^ ((s1 << 9) & 0xFFFFFFFF)
+        s1 = rotl(s1, 13)
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 700, 0x9E3779B9, 0xFFFFFFFF, 0])
+def test_xoroshiro_known_answers(seed):
+    """RTOW_RNG_PER_SAMPLE_XOROSHIRO: s0 = seed, s1 = seed * 0x85EBCA6B ^ 0xC2B2AE35 (0x9E3779B9 if both are 0), one output discarded, NextFloat =
+    asfloat(0x3f800000 | (output >> 9)) - 1.  Also the generator's published test vector style check: state (1, 2) gives a fixed first output."""
+    import ctypes as C
+    n = 32
+    outs = (C.c_uint32 * n)()
+    floats = (C.c_float * n)()
+    ob.load().oracle_kat_xoroshiro(seed, n, outs, floats)
+    s1 = ((seed * 0x85EBCA6B) & 0xFFFFFFFF) ^ 0xC2B2AE35
+    if (seed | s1) == 0:
+        s1 = 0x9E3779B9
+    expect = _xoroshiro64ss(seed, s1, n + 1)[1:]
+    assert list(outs) == expect
+    for o, f in zip(expect, floats):
+        assert np.float32(f) == np.frombuffer(np.uint32(0x3F800000 | (o >> 9)).tobytes(), np.float32)[0] - np.float32(1.0)
+    assert _xoroshiro64ss(1, 2, 1)[0] == ((((0x9E3779BB << 5) | (0x9E3779BB >> 27)) & 0xFFFFFFFF) * 5) & 0xFFFFFFFF
+
+
+def test_xoroshiro_policy_is_the_per_sample_policy_with_another_generator():
+    sc = S.cover_scene()
+    osc = ob.OracleScene(sc.desc())
+    ref = osc.sample_batch(S.make_params(sc, 64, 36, spp=64, trace_depth=8))
+    x = osc.sample_batch(S.make_params(sc, 64, 36, spp=64, trace_depth=8, rng_policy=abi.RNG_PER_SAMPLE_XOROSHIRO))
+    y = osc.sample_batch(S.make_params(sc, 64, 36, spp=64, trace_depth=8, rng_policy=abi.RNG_PER_SAMPLE_XOROSHIRO), nthreads=3)
+    ps = osc.sample_batch(S.make_params(sc, 64, 36, spp=64, trace_depth=8, rng_policy=abi.RNG_PER_SAMPLE))
+    assert np.array_equal(x["color"].view(np.uint32), y["color"].view(np.uint32))
+    assert not np.array_equal(x["color"], ps["color"]) and not np.array_equal(x["color"], ref["color"])
+    mean_ref = ref["color"][:, :3].sum(0) / ref["color"][:, 3].sum()
+    mean_x = x["color"][:, :3].sum(0) / x["color"][:, 3].sum()
+    assert np.all(np.abs(mean_x - mean_ref) / mean_ref < 0.02)
+    bad = S.make_params(sc, 8, 8, spp=1, trace_depth=2, rng_policy=abi.RNG_PER_SAMPLE_XOROSHIRO, noise_color=abi.NOISE_BLUE)
+    with pytest.raises(RuntimeError):
+        osc.sample_batch(bad)
+    osc.close()
