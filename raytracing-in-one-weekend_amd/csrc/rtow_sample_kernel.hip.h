@@ -1345,9 +1345,10 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 // EQUAL one: the twin of the sphere that set `best`.  The two distances come from different float programs (slab entry of the
                 // twin's box against the quadratic's root), and where the ray meets the sphere at a point that touches its box they differ by
                 // rounding only; one ulp the wrong way pruned the twin, TEST never saw the tie, and the resolver was never asked (twin spheres
-                // moving, 1 pixel in 42.8 M rays: tests/soak_frames.py at 2.5x).  Scenes that need exact ties therefore prune with 2^-12 of slack
+                // moving, 1 pixel in 42.8 M rays: tests/soak_frames.py at 2.5x).  So the walk prunes with 2^-12 of slack - in every variant: one multiply per slice, and
+                // without duplicates the same margin keeps a root that errs a few ulps below its own box entry from being dropped
                 // (the entry distance is good to an ulp, the root to a few where the two can meet); TEST still compares against `best` itself.
-                const float bestPrune = EXACT_TIES ? best * 1.000244140625f : best;
+                const float bestPrune = best * 1.000244140625f;
                 // Branch-free node visit: every LDS access of the iteration is issued up front (node, plus the stack slot a
                 // pop would need), candidate / stack slots are written unconditionally and only the counters are predicated,
                 // so the wave's EXEC mask changes only at the loop test.
