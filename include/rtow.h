@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 5
+#define RTOW_API_VERSION 6
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -54,9 +54,9 @@ typedef enum RtowResult {
     RTOW_ERROR_UNSUPPORTED = 5,       /* entity / material / noise kind not built yet           */
     RTOW_ERROR_LAUNCH_FAILURE = 6,    /* kernel launch or stream error (hipError in the log)    */
     RTOW_ERROR_CANCELLED = 7,         /* cancellation flag observed; outputs unspecified        */
-    RTOW_ERROR_CAPACITY = 8,          /* a compiled-in bound was exceeded: at upload (entities, tree depth) or - reported by the host-buffer
-                                       * rtowSampleBatch, a cancellable rtowSampleBatchDevice or the next rtowGetBatchStatus / rtowSynchronize - by a ray of a
-                                       * volume scene that met more than 24 surfaces (the reference's hit list is unbounded) */
+    RTOW_ERROR_CAPACITY = 8,          /* a bound was exceeded: at upload (entities, tree depth) or - reported by the host-buffer rtowSampleBatch, a
+                                       * cancellable rtowSampleBatchDevice or the next rtowGetBatchStatus / rtowSynchronize - by a ray that met more
+                                       * surfaces than RtowContextOptions.hitListCapacity (the reference's hit list grows without bound) */
     RTOW_ERROR_INTERNAL = 99
 } RtowResult;
 
@@ -306,6 +306,11 @@ typedef struct RtowContextOptions {
                                      * through the kernels that read the tree from HBM */
     int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL - -) and the box-walk
                                      * slice (node visits per trip); all zero = the built-in values */
+    int32_t hitListCapacity;        /* most surfaces one ray may meet where every hit of a ray is kept (scenes with ProbabilisticVolume materials, and
+                                     * the exact-tie procedure): the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71);
+                                     * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per
+                                     * entry, sized at rtowUploadScene to min(this, the most the scene can produce: 2 per entity with volumes, else 1).
+                                     * 0 = 1024.  A ray beyond it makes the batch report RTOW_ERROR_CAPACITY */
 } RtowContextOptions;
 
 RTOW_API int rtowGetApiVersion(void);
@@ -451,7 +456,7 @@ RTOW_API int rtowDeviceFree(RtowContext context, void* pointer);
 RTOW_API int rtowDeviceCopy(RtowContext context, const void* source, void* destination, size_t sizeInBytes, int kind);
 RTOW_API int rtowDeviceMemset(RtowContext context, void* pointer, int value, size_t sizeInBytes);
 /* Waits for everything the context's own stream holds AND for the most recent sample batch wherever it was enqueued, then reports that
- * batch history's status: RTOW_ERROR_CAPACITY if any batch since the last report met a ray with more than 24 surfaces (the flag is sticky
+ * batch history's status: RTOW_ERROR_CAPACITY if any batch since the last report met a ray beyond the hit-list capacity (the flag is sticky
  * until reported), else RTOW_SUCCESS. */
 RTOW_API int rtowSynchronize(RtowContext context);
 /* The same status query without draining the context's stream: blocks only until the most recent sample batch (on whatever stream it

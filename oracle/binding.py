@@ -85,6 +85,10 @@ def load(kind="strict"):
     lib.oracle_kat_half_to_float.restype = C.c_float
     lib.oracle_kat_unity_sort.argtypes = [fp, C.POINTER(C.c_int), C.c_int]
     lib.oracle_kat_unity_sort.restype = None
+    lib.oracle_kat_unity_sort_heapsorts.argtypes = []
+    lib.oracle_kat_unity_sort_heapsorts.restype = C.c_int
+    lib.oracle_kat_unity_sort_killer.argtypes = [C.c_int, fp]
+    lib.oracle_kat_unity_sort_killer.restype = None
     lib.oracle_kat_hit_tie_order.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_int)]
     lib.oracle_kat_hit_tie_order.restype = C.c_int
     lib.oracle_kat_leaf_boxes.argtypes = [C.POINTER(abi.SceneDesc), fp]

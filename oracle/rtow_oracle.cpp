@@ -193,6 +193,7 @@ struct Entity;
  * leaves equal keys in is part of the reference's behaviour (hits at bit-identical distances, entities
  * with equal Bounds.Min on the split axis).  `cmp(a, b)` returns the IComparer<T>.Compare integer.
  * =================================================================================================== */
+static std::atomic<int> g_heapSortCalls{0};   /* test instrumentation: how often the depth limit was reached (oracle_kat_unity_sort_heapsorts) */
 template <class T, class Cmp>
 struct UnitySort {
     T* a;
@@ -221,6 +222,7 @@ struct UnitySort {
     }
     void HeapSort(int lo, int hi)
     {
+        g_heapSortCalls.fetch_add(1, std::memory_order_relaxed);
         const int n = hi - lo + 1;
         for (int i = n / 2; i >= 1; i--) Heapify(i, n, lo);
         for (int i = n; i > 1; i--) { std::swap(a[lo], a[lo + i - 1]); Heapify(1, i - 1, lo); }
@@ -1954,6 +1956,24 @@ ORACLE_API void oracle_kat_unity_sort(float* keys, int* ids, int n)
     for (int i = 0; i < n; i++) v[i] = KV{keys[i], ids[i]};
     unity_sort(v.data(), n, [](const KV& x, const KV& y) { return float_compare_to(x.k, y.k); });
     for (int i = 0; i < n; i++) { keys[i] = v[i].k; ids[i] = v[i].id; }
+}
+/* HeapSort calls since the last query: lets a test prove that an input drove the introsort to its depth limit */
+ORACLE_API int oracle_kat_unity_sort_heapsorts(void) { return g_heapSortCalls.exchange(0); }
+/* An input of n distinct keys that defeats THIS introsort's median-of-three partitions (M. D. McIlroy, "A Killer Adversary for Quicksort",
+ * 1999: the comparator decides the keys while the sort runs), so that sorting it again reaches the 2*floor(log2(n)) depth limit. */
+ORACLE_API void oracle_kat_unity_sort_killer(int n, float* keysOut)
+{
+    std::vector<int> val(n, n), items(n);
+    int solid = 0, candidate = 0;
+    for (int i = 0; i < n; i++) items[i] = i;
+    auto cmp = [&](int x, int y) {
+        if (val[x] == n && val[y] == n) { if (x == candidate) val[x] = solid++; else val[y] = solid++; }
+        if (val[x] == n) candidate = x; else if (val[y] == n) candidate = y;
+        return val[x] - val[y];
+    };
+    unity_sort(items.data(), n, cmp);
+    for (int i = 0; i < n; i++) keysOut[i] = (float)(val[i] == n ? solid++ : val[i]);
+    (void)g_heapSortCalls.exchange(0);
 }
 /* the order in which hits of equal distance start out: source indices of the re-ordered entity array, leaf by leaf, each
  * leaf back to front (candidates are pushed front to back and popped from the end) */

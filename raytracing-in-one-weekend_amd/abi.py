@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 5
+RTOW_API_VERSION = 6
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -141,7 +141,8 @@ GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_A
 
 class ContextOptions(C.Structure):
     _fields_ = [("deviceOrdinal", C.c_int32), ("logCallback", LogCallback), ("logCallbackData", C.c_void_p),
-                ("logCallbackLevel", C.c_int32), ("flags", C.c_uint32), ("ldsSceneBudgetBytes", C.c_int32), ("schedulerTune", C.c_int32 * 9)]
+                ("logCallbackLevel", C.c_int32), ("flags", C.c_uint32), ("ldsSceneBudgetBytes", C.c_int32), ("schedulerTune", C.c_int32 * 9),
+                ("hitListCapacity", C.c_int32)]
 
 
 class CommId(C.Structure):

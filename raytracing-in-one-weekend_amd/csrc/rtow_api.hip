@@ -69,6 +69,11 @@ struct RtowContext_t {
     // RTOW_CONTEXT_REFERENCE_DIAGNOSTICS: the reference's own tree of the current scene (CompiledScene.refTree), HBM only
     uint8_t* dRefTree = nullptr;
     size_t refTreeCapacity = 0;
+    // hit lists beyond the 24 entries a lane holds itself (volume scenes, exact-tie kernels): [entry][lane] columns, grow-only
+    uint4* dHitSpill = nullptr;
+    uint32_t hitSpillEntries = 0;         // of the current scene (<= hitSpillCapacity)
+    uint32_t hitSpillCapacity = 0;        // entries per lane the allocation holds
+    uint32_t hitListCapacity = 0;         // RtowContextOptions.hitListCapacity (0 = default)
     // Image-texture blob of the current scene (CompiledScene.texBlob), HBM only
     uint8_t* dTexBlob = nullptr;
     size_t texBlobCapacity = 0;
@@ -197,6 +202,9 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.extremaX = p->sampleCountWeightExtrema.x;
     a.extremaY = p->sampleCountWeightExtrema.y;
     a.refTree = (ctx->flags & RTOW_CONTEXT_REFERENCE_DIAGNOSTICS) ? ctx->dRefTree : nullptr;
+    a.hitSpill = ctx->hitSpillEntries ? ctx->dHitSpill : nullptr;
+    a.hitSpillEntries = ctx->hitSpillEntries;
+    a.hitSpillStride = (uint32_t)ctx->cuCount * (uint32_t)kBlockThreads;
     a.texBlob = ctx->dTexBlob;
     a.texLayout = ctx->scene.texLayout;
     a.noiseColor = p->noiseColor;
@@ -352,7 +360,6 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         // per-chunk hand-off counters of the chain: pixels stored so far (all batches); batch b of a chunk waits for b x its pixels
         if (a.chunkCount > ctx->chunkDoneCapacity) {
             if (ctx->dChunkDone) (void)hipFree(ctx->dChunkDone);
-    if (ctx->dChainBatches) (void)hipFree(ctx->dChainBatches);
             ctx->dChunkDone = nullptr;
             ctx->chunkDoneCapacity = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkDone, (size_t)a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
@@ -427,7 +434,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     return RTOW_SUCCESS;
 }
 
-// A ray of a volume scene met more surfaces than the per-lane hit list holds (24): the batch's result is not the reference's.
+// A ray met more surfaces than the context's hit-list capacity (RtowContextOptions.hitListCapacity; volume scenes and exact-tie kernels keep
+// every hit of a ray): the batch's result is not the reference's.
 // The flag is sticky: it is set by the kernel and cleared only here, so it covers every batch enqueued since the last report
 // (rtowSampleBatch, a cancellable rtowSampleBatchDevice, rtowGetBatchStatus, rtowSynchronize).
 int takeOverflow(RtowContext ctx)
@@ -600,7 +608,7 @@ RTOW_API const char* rtowErrorString(int result)
         case RTOW_ERROR_UNSUPPORTED: return "feature not built yet";
         case RTOW_ERROR_LAUNCH_FAILURE: return "kernel launch or stream failure";
         case RTOW_ERROR_CANCELLED: return "cancelled";
-        case RTOW_ERROR_CAPACITY: return "compiled-in capacity exceeded";
+        case RTOW_ERROR_CAPACITY: return "capacity exceeded";
         case RTOW_ERROR_INTERNAL: return "internal error";
     }
     return "unknown error";
@@ -627,6 +635,8 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
         ctx->flags = options->flags;
         if ((ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) && (ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER)) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
         if (options->ldsSceneBudgetBytes > 0) ctx->ldsSceneBudget = (uint32_t)options->ldsSceneBudgetBytes;
+        if (options->hitListCapacity < 0) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
+        ctx->hitListCapacity = (uint32_t)options->hitListCapacity;
         bool anyTune = false;
         for (int i = 0; i < 9; i++) anyTune = anyTune || options->schedulerTune[i] != 0;
         if (anyTune) for (int i = 0; i < 9; i++) ctx->tune[i] = options->schedulerTune[i] < 1 ? 1 : options->schedulerTune[i];
@@ -663,6 +673,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dStbNoise) (void)hipFree(ctx->dStbNoise);
     if (ctx->dTexBlob) (void)hipFree(ctx->dTexBlob);
     if (ctx->dRefTree) (void)hipFree(ctx->dRefTree);
+    if (ctx->dHitSpill) (void)hipFree(ctx->dHitSpill);
     if (ctx->dUnitRecords) (void)hipFree(ctx->dUnitRecords);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
@@ -736,6 +747,25 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     if (ctx->flags & (RTOW_CONTEXT_EXACT_TIES_ALWAYS | RTOW_CONTEXT_EXACT_TIES_NEVER)) {   // exact-tie kernels for every scene without volumes (slower), or never
         const bool volumes = compiled.layout.sceneKind == SCENE_KIND_VOLUMES || compiled.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
         if (!volumes) compiled.layout.exactTies = (ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) ? 1u : 0u;
+    }
+    {
+        // Rays whose hit list outgrows a lane's own 24 entries (every hit is kept in volume scenes and by the exact-tie procedure) continue in
+        // HBM.  An entity yields at most two hits per ray (a volume hull's entry and exit, JOBS/SampleBatchJob.cs:457-469), one in scenes
+        // without volumes, so that bound - capped by RtowContextOptions.hitListCapacity - is all a scene can need.
+        const bool volumes = compiled.layout.sceneKind == SCENE_KIND_VOLUMES || compiled.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
+        uint64_t most = (volumes || compiled.layout.exactTies) ? (uint64_t)compiled.entityCount * (volumes ? 2u : 1u) : 0u;
+        const uint64_t cap = ctx->hitListCapacity ? ctx->hitListCapacity : kDefaultHitListCapacity;
+        if (most > cap) most = cap;
+        const uint32_t entries = most > (uint64_t)kLocalHitEntries ? (uint32_t)(most - kLocalHitEntries) : 0u;
+        if (entries > ctx->hitSpillCapacity) {
+            if (ctx->dHitSpill) (void)hipFree(ctx->dHitSpill);
+            ctx->dHitSpill = nullptr;
+            ctx->hitSpillCapacity = 0;
+            ctx->hitSpillEntries = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dHitSpill, (size_t)entries * (size_t)ctx->cuCount * kBlockThreads * sizeof(uint4)), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->hitSpillCapacity = entries;
+        }
+        ctx->hitSpillEntries = entries;
     }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);

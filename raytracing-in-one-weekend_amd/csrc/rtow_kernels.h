@@ -24,6 +24,8 @@ constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: fi
 constexpr unsigned kSampleGroup = 16;   // RTOW_RNG_PER_SAMPLE: samples per work unit (part of that policy's definition: partial sums are per group)
 constexpr int kQueueBytes = 256;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B)
 constexpr int kMaxChain = 16;      // successive batches one launch can run (rtowSampleBatchChainDevice)
+constexpr int kLocalHitEntries = 24;                // entries of a ray's hit list a lane holds itself; longer lists continue in SampleKernelArgs.hitSpill
+constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0
 
 // Per-batch fields of a chained launch (rtowSampleBatchChainDevice): everything else is shared by the chain's batches.
 struct ChainBatch {
@@ -102,6 +104,11 @@ struct SampleKernelArgs {
     // RTOW_CONTEXT_REFERENCE_DIAGNOSTICS: the reference's own tree (RefTreeNode[], HBM only); when set, BoundsHitCount / CandidateCount of the
     // 16-byte diagnostics count THAT tree's boxes and leaves (JOBS/SampleBatchJob.cs:427-440), one extra unpruned walk per ray
     const uint8_t* refTree;
+
+    // hit lists longer than the 24 entries a lane holds itself (volume scenes, exact-tie kernels; the reference's HybridList grows on the heap,
+    // UTIL/HybridCollections.cs:65-71): entry e >= 24 of lane l of workgroup g is hitSpill[(e - 24) * hitSpillStride + g * 1024 + l]
+    uint4* hitSpill;                      // null = none
+    uint32_t hitSpillEntries, hitSpillStride;
 
     // chained batches (rtowSampleBatchChainDevice): this launch runs chainCount successive batches of the same frame; batch b of a
     // 64-pixel chunk starts as soon as batch b - 1 of that chunk is stored (chunkDone), whichever CU traced it

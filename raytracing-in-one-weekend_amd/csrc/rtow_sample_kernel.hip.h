@@ -400,6 +400,7 @@ __device__ __forceinline__ float texture_scalar(const SampleKernelArgs& A, const
     return 0.0f;
 }
 
+// [hit-list sorts: begin]  (tests/test_hitsort_host.py compiles the text between the two markers for the host and checks it against the oracle)
 // ------------------------------------------------------------------------------------------------------------
 // hitBuffer.Sort(DistanceComparer) (JOBS/SampleBatchJob.cs:473-474) for the hit list of a volume scene.
 // The reference sorts a list that starts in its tree's leaf order with a sort that is not stable, and hits at bit-identical
@@ -421,9 +422,9 @@ __device__ __noinline__ __attribute__((unused)) void sort_hit_list(float* hitT, 
     for (int i = 1; i < nHits; i++) {                                   // leaf order; an entity's exit hit was recorded after its entry
         const float t = hitT[i], tm = hitTmin0[i];
         const unsigned c = hitCode[i], r = rankOf(c);
-        int j = i - 1;
-        while (j >= 0 && rankOf(hitCode[j]) > r) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
-        hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
+        int j = i;                                                       // the hole: no index is ever formed from a negative value (see hit_spill_entry)
+        while (j > 0 && rankOf(hitCode[j - 1]) > r) { hitT[j] = hitT[j - 1]; hitTmin0[j] = hitTmin0[j - 1]; hitCode[j] = hitCode[j - 1]; j--; }
+        hitT[j] = t; hitTmin0[j] = tm; hitCode[j] = c;
     }
     // pending ranges of the introsort; a list of <= 24 hits needs at most four partition steps before every range is <= 16
     int rangeLo[8], rangeHi[8], ranges = 1;
@@ -439,9 +440,9 @@ __device__ __noinline__ __attribute__((unused)) void sort_hit_list(float* hitT, 
                 for (int i = lo + 1; i <= hi; i++) {
                     const float t = hitT[i], tm = hitTmin0[i];
                     const unsigned c = hitCode[i];
-                    int j = i - 1;
-                    while (j >= lo && t < hitT[j]) { hitT[j + 1] = hitT[j]; hitTmin0[j + 1] = hitTmin0[j]; hitCode[j + 1] = hitCode[j]; j--; }
-                    hitT[j + 1] = t; hitTmin0[j + 1] = tm; hitCode[j + 1] = c;
+                    int j = i;
+                    while (j > lo && t < hitT[j - 1]) { hitT[j] = hitT[j - 1]; hitTmin0[j] = hitTmin0[j - 1]; hitCode[j] = hitCode[j - 1]; j--; }
+                    hitT[j] = t; hitTmin0[j] = tm; hitCode[j] = c;
                 }
                 break;
             }
@@ -464,6 +465,128 @@ __device__ __noinline__ __attribute__((unused)) void sort_hit_list(float* hitT, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Hit lists longer than a lane holds itself.  The reference's hitRecordBuffer is a HybridList that grows on the heap
+// (UTIL/HybridCollections.cs:65-71), so a ray may meet any number of surfaces; here entries [0, kLocalHits) stay in the lane's own
+// arrays (scratch) and entry e >= kLocalHits lives in the lane's column of a spill area in HBM (SampleKernelArgs.hitSpill,
+// [entry][lane] so that a wave's accesses coalesce).  Only lists that long pay for it.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kLocalHits = kLocalHitEntries;
+
+struct HitSpill {
+    uint4* column;       // this lane's entry kLocalHits; null when the context holds no spill area
+    uint32_t stride;     // uint4s between successive entries of one lane
+    uint32_t entries;    // entries per lane beyond kLocalHits
+};
+
+__device__ __forceinline__ HitSpill hit_spill_of(const SampleKernelArgs& A)
+{
+    return HitSpill{A.hitSpill ? A.hitSpill + (size_t)blockIdx.x * kBlockThreads + threadIdx.x : nullptr, A.hitSpillStride, A.hitSpill ? A.hitSpillEntries : 0u};
+}
+
+struct HitRec { float t, tmin0; unsigned code; };
+
+// Index arithmetic of the sorts below: no index is ever formed by adding a constant to a value that can be negative.  The natural
+// insertion loop (`j = i - 1; while (j >= lo && ...) { a[j + 1] = a[j]; j--; } a[j + 1] = x;`) reaches j = -1, and hipcc 7.2 at -O2 and
+// above turned `a[j + 1]` into zext(j) * 4 + 4 (separate-const-offset-from-gep, pass 2598 of the device compile by opt-bisect; -O1 and
+// a host build of the same source are correct): an address 16 GB past the array, outside every aperture, whenever an element moved to
+// the front of its range (tests/test_gpu_hitsort.py).  The loops therefore track the hole (j >= lo >= 0) instead, and the spill entry
+// index is formed in unsigned arithmetic.
+__device__ __forceinline__ uint4* hit_spill_entry(const HitSpill& sp, int i)
+{
+    const unsigned e = (unsigned)i - (unsigned)kLocalHits;
+    return sp.column + (size_t)e * (size_t)sp.stride;
+}
+
+__device__ __forceinline__ HitRec hit_get(const float* hitT, const float* hitTmin0, const unsigned* hitCode, const HitSpill& sp, int i)
+{
+    if (i < kLocalHits) return HitRec{hitT[i], hitTmin0[i], hitCode[i]};
+    const uint4 v = *hit_spill_entry(sp, i);
+    return HitRec{__uint_as_float(v.x), __uint_as_float(v.y), v.z};
+}
+
+__device__ __forceinline__ void hit_set(float* hitT, float* hitTmin0, unsigned* hitCode, const HitSpill& sp, int i, HitRec r)
+{
+    if (i < kLocalHits) { hitT[i] = r.t; hitTmin0[i] = r.tmin0; hitCode[i] = r.code; }
+    else *hit_spill_entry(sp, i) = make_uint4(__float_as_uint(r.t), __float_as_uint(r.tmin0), r.code, 0u);
+}
+
+// sort_hit_list for a list of any length: leaf order first, then the whole NativeSortExtension introsort - the partition steps as above,
+// plus the heap sort it falls back to once 2 * floor(log2(n)) partition levels are used up (within reach from 25 elements on).
+__device__ __noinline__ __attribute__((unused)) void sort_hit_list_spilled(float* hitT, float* hitTmin0, unsigned* hitCode, HitSpill sp, int nHits, const unsigned* rank)
+{
+    auto get = [&](int i) { return hit_get(hitT, hitTmin0, hitCode, sp, i); };
+    auto set = [&](int i, HitRec r) { hit_set(hitT, hitTmin0, hitCode, sp, i, r); };
+    auto rankOf = [&](unsigned code) { return rank[code & 0xffffu]; };
+    auto swapHits = [&](int a, int b) { const HitRec x = get(a), y = get(b); set(a, y); set(b, x); };
+    auto swapIfGreater = [&](int l, int r) { if (l != r && get(l).t > get(r).t) swapHits(l, r); };
+    for (int i = 1; i < nHits; i++) {                                   // leaf order; an entity's exit hit was recorded after its entry
+        const HitRec h = get(i);
+        const unsigned r = rankOf(h.code);
+        int j = i;                                                       // the hole; see the note on index arithmetic above
+        while (j > 0) { const HitRec o = get(j - 1); if (!(rankOf(o.code) > r)) break; set(j, o); j--; }
+        set(j, h);
+    }
+    auto insertionSort = [&](int lo, int hi) {
+        for (int i = lo + 1; i <= hi; i++) {
+            const HitRec h = get(i);
+            int j = i;
+            while (j > lo) { const HitRec o = get(j - 1); if (!(h.t < o.t)) break; set(j, o); j--; }
+            set(j, h);
+        }
+    };
+    auto heapify = [&](int i, int n, int lo) {
+        const HitRec val = get(lo + i - 1);
+        while (i <= n / 2) {
+            int child = 2 * i;
+            HitRec c = get(lo + child - 1);
+            if (child < n) { const HitRec c2 = get(lo + child); if (c.t < c2.t) { child++; c = c2; } }
+            if (c.t < val.t) break;
+            set(lo + i - 1, c);
+            i = child;
+        }
+        set(lo + i - 1, val);
+    };
+    auto heapSort = [&](int lo, int hi) {
+        const int n = hi - lo + 1;
+        for (int i = n / 2; i >= 1; i--) heapify(i, n, lo);
+        for (int i = n; i > 1; i--) { swapHits(lo, lo + i - 1); heapify(1, i - 1, lo); }
+    };
+    // pending ranges: every partition step pushes one and uses up one of the 2 * floor(log2(n)) levels
+    constexpr int kRanges = 40;
+    int rangeLo[kRanges], rangeHi[kRanges], rangeDepth[kRanges], ranges = 1;
+    int log2floor = 0;
+    while ((nHits >> (log2floor + 1)) != 0) log2floor++;
+    rangeLo[0] = 0; rangeHi[0] = nHits - 1; rangeDepth[0] = 2 * log2floor;
+    while (ranges > 0) {
+        ranges--;
+        int lo = rangeLo[ranges], hi = rangeHi[ranges], depth = rangeDepth[ranges];
+        while (hi > lo) {
+            const int size = hi - lo + 1;
+            if (size == 2) { swapIfGreater(lo, hi); break; }
+            if (size == 3) { swapIfGreater(lo, hi - 1); swapIfGreater(lo, hi); swapIfGreater(hi - 1, hi); break; }
+            if (size <= 16) { insertionSort(lo, hi); break; }
+            if (depth == 0) { heapSort(lo, hi); break; }
+            depth--;
+            const int mid = lo + (hi - lo) / 2;
+            swapIfGreater(lo, mid); swapIfGreater(lo, hi); swapIfGreater(mid, hi);
+            const float pivot = get(mid).t;
+            swapHits(mid, hi - 1);
+            int left = lo, right = hi - 1;
+            while (left < right) {
+                while (pivot > get(++left).t) {}
+                while (pivot < get(--right).t) {}
+                if (left >= right) break;
+                swapHits(left, right);
+            }
+            swapHits(left, hi - 1);
+            rangeLo[ranges] = left + 1; rangeHi[ranges] = hi; rangeDepth[ranges] = depth; ranges++;
+            hi = left - 1;
+        }
+    }
+}
+
+// [hit-list sorts: end]
 // ------------------------------------------------------------------------------------------------------------
 // scene access: LDS image first, HBM/L2 for whatever did not fit
 // ------------------------------------------------------------------------------------------------------------
@@ -797,11 +920,10 @@ enum : int {
 // ------------------------------------------------------------------------------------------------------------
 template <bool ALL_LDS, int KIND>
 __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs& sc, const SceneLayout& L, V3 ro, V3 rd, float rtime, unsigned short* stack,
-                                                                       uint32_t* overflowFlag)
+                                                                       uint32_t* overflowFlag, HitSpill spill)
 {
-    constexpr int kMaxList = 24;
-    float hitT[kMaxList], hitDummy[kMaxList];
-    unsigned hitCode[kMaxList];
+    float hitT[kLocalHits], hitDummy[kLocalHits];
+    unsigned hitCode[kLocalHits];
     int n = 0;
     V3 inv = v3(RTOW_RCP(rd.x), RTOW_RCP(rd.y), RTOW_RCP(rd.z));                     // startRay's rayInvDirection
     if (inv.x != inv.x) inv.x = __builtin_inff();
@@ -837,8 +959,8 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
                 ok = sphere_hit(sub(ro, c), rd, a, r, t);
             }
             if (!ok) continue;
-            if (n < kMaxList) { hitT[n] = t; hitDummy[n] = 0.0f; hitCode[n] = (unsigned)i; n++; }
-            else *overflowFlag = 1u;                                                                       // RTOW_ERROR_CAPACITY on the host side
+            if ((unsigned)n < (unsigned)kLocalHits + spill.entries) { hit_set(hitT, hitDummy, hitCode, spill, n, HitRec{t, 0.0f, (unsigned)i}); n++; }
+            else *overflowFlag = 1u;                                                                       // more hits than the context's hitListCapacity: RTOW_ERROR_CAPACITY on the host side
         }
         const bool in0 = hit0 && c0 >= 0, in1 = hit1 && c1 >= 0;
         if (in0 && in1) { stack[sp * kBlockThreads] = (unsigned short)c1; sp++; cur = c0; }
@@ -847,7 +969,9 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
         else cur = -1;
     }
     if (n == 0) return -1;
-    if (n > 1) sort_hit_list(hitT, hitDummy, hitCode, n, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
+    const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
+    if (n > kLocalHits) sort_hit_list_spilled(hitT, hitDummy, hitCode, spill, n, rank);
+    else if (n > 1) sort_hit_list(hitT, hitDummy, hitCode, n, rank);
     return (int)(hitCode[0] & 0xffffu);
 }
 
@@ -958,7 +1082,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
     // is inside of (currentProbabilisticVolumeMaterial, :180) and RandomEvents left pending by ProbabilisticHit (RT/Material.cs:54)
     // TEXTURED only: what the fold needs of every hit of the current path (the 16-bit history code only names a material)
     float texHist[TEXTURED ? HW * 2 * 6 : 1];
-    constexpr int kMaxHits = VOLUMES ? 24 : 1;
+    constexpr int kMaxHits = VOLUMES ? kLocalHits : 1;   // entries of the ray's hit list the lane holds itself; the rest spills (HitSpill)
     float hitT[kMaxHits], hitTmin0[kMaxHits];
     unsigned hitCode[kMaxHits];      // primitive | dot(normal, dir) < 0 -> bit 30 | dot > 0 -> bit 31
     bool tieAtBest = false;          // scenes without volumes: a second surface at exactly the nearest distance was seen (resolve_nearest_tie)
@@ -1417,11 +1541,15 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             float t; V3 nl; float4 rq;
                             if (!general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, tmin, t, nl, rq)) break;
                             const float dn = dot(normalize(rotate(rq, nl)), rd);
+                            const unsigned code = (unsigned)i | (dn < 0 ? 0x40000000u : 0u) | (dn > 0 ? 0x80000000u : 0u);
                             if (nHits < kMaxHits) {
-                                hitT[nHits] = t; hitTmin0[nHits] = tmin; hitCode[nHits] = (unsigned)i | (dn < 0 ? 0x40000000u : 0u) | (dn > 0 ? 0x80000000u : 0u);
+                                hitT[nHits] = t; hitTmin0[nHits] = tmin; hitCode[nHits] = code;
+                                nHits++;
+                            } else if ((unsigned)(nHits - kMaxHits) < A.hitSpillEntries && A.hitSpill) {
+                                hit_set(hitT, hitTmin0, hitCode, hit_spill_of(A), nHits, HitRec{t, tmin, code});      // the list grows into the lane's spill column
                                 nHits++;
                             } else {
-                                hitOverflow = true;                                      // more surfaces than the list holds: reported, not ignored
+                                hitOverflow = true;                                      // more surfaces than the context's hitListCapacity: reported, not ignored
                             }
                             if (((mw >> 16) & 3u) != MAT_CLASS_VOLUME || !(type == RTOW_ENTITY_BOX || type == RTOW_ENTITY_SPHERE)) break;
                             tmin = t + 0.001f;
@@ -1462,7 +1590,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 if (EXACT_TIES && !VOLUMES && tieAtBest) {
                     // two surfaces at exactly this distance: let the reference's own procedure pick (rare; see resolve_nearest_tie)
                     tieAtBest = false;
-                    const int winner = resolve_nearest_tie<ALL_LDS, BASE>(sc, L, ro, rd, rtime, stack, A.overflowFlag);
+                    const int winner = resolve_nearest_tie<ALL_LDS, BASE>(sc, L, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
                     if (winner >= 0 && winner != prim) {
                         prim = winner;
                         if (KEEP_NORMAL) {
@@ -1776,8 +1904,11 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     else if (chosen >= 0 && chosen < nHits) { best = distAt(chosen); hitTmin = tminAt(chosen); prim = (int)(codeAt(chosen) & 0xffffu); st = ST_HIT; }
                     else st = ST_SKY;
                 };
-                if (nHits > 1) sort_hit_list(hitT, hitTmin0, hitCode, nHits, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
-                volumeLogic([&](int i) { return hitT[i]; }, [&](int i) { return hitCode[i]; }, [&](int i) { return hitTmin0[i]; });
+                const HitSpill spill = hit_spill_of(A);
+                if (nHits > kMaxHits) sort_hit_list_spilled(hitT, hitTmin0, hitCode, spill, nHits, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
+                else if (nHits > 1) sort_hit_list(hitT, hitTmin0, hitCode, nHits, reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset)));
+                volumeLogic([&](int i) { return hit_get(hitT, hitTmin0, hitCode, spill, i).t; }, [&](int i) { return hit_get(hitT, hitTmin0, hitCode, spill, i).code; },
+                            [&](int i) { return hit_get(hitT, hitTmin0, hitCode, spill, i).tmin0; });
             }
         }
         if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : need(4))) {

@@ -65,8 +65,9 @@ class DeviceBuffer:
 class Context:
     """RtowContext: one per GPU (one process per GPU in multi-GPU runs)."""
 
-    def __init__(self, device_ordinal=0, log=None, log_level=0, flags=0, lds_scene_budget=0, scheduler_tune=None):
-        """flags: abi.CONTEXT_* (RtowContextFlags); lds_scene_budget / scheduler_tune: the development knobs of RtowContextOptions."""
+    def __init__(self, device_ordinal=0, log=None, log_level=0, flags=0, lds_scene_budget=0, scheduler_tune=None, hit_list_capacity=0):
+        """flags: abi.CONTEXT_* (RtowContextFlags); lds_scene_budget / scheduler_tune: the development knobs of RtowContextOptions;
+        hit_list_capacity: most surfaces one ray may meet where the whole hit list is kept (0 = 1024)."""
         self._cb = abi.LogCallback(log) if log else abi.LogCallback()
         opts = abi.ContextOptions(device_ordinal, self._cb, None, log_level, flags, lds_scene_budget)
         if scheduler_tune is not None:
@@ -74,6 +75,7 @@ class Context:
                 raise ValueError("scheduler_tune takes 8 stage thresholds + the box-walk slice")
             for i, v in enumerate(scheduler_tune):
                 opts.schedulerTune[i] = int(v)
+        opts.hitListCapacity = int(hit_list_capacity)
         self.handle = C.c_void_p()
         check(load().rtowCreateContext(C.byref(opts), C.byref(self.handle)), "rtowCreateContext")
         self._scene_keepalive = None

@@ -473,18 +473,22 @@ def volume_tie_scene():
     return s
 
 
-def volume_stack_scene(slabs=10):
+def volume_stack_scene(slabs=10, thickness=0.5):
     """Ten thin fog slabs stacked face to face along the view axis, in front of a wall lying in the last slab's back face: a camera ray
     collects 21 hits (more than the 16 up to which the reference's sort is an insertion sort) of which ten pairs are at bit-identical
-    distances (camera and faces on dyadic coordinates), so the result depends on the partition steps of the unstable introsort."""
+    distances (camera and faces on dyadic coordinates), so the result depends on the partition steps of the unstable introsort.
+    More and thinner slabs (48 x 0.125) make hit lists of ~100 entries: the reference's list grows on the heap, the library's spills."""
     s = Scene("volume_stack")
     white = lambertian((0.8, 0.8, 0.8))
     up90 = quat_axis_angle((1, 0, 0), -90)
     s.add_rect((0, -1.5, 0), (12, 12), white, rotation=up90)
     s.add_rect((0, 0, -2.5), (3, 3), standard((0.0, 0.0, 0.0), 0.0, 0.0, emission=(3.0, 2.5, 2.0)))     # wall in the z = -2.5 face of the last slab
     fogs = [volume((0.9, 0.5, 0.3), 0.12), volume((0.3, 0.6, 0.9), 0.2), volume((0.5, 0.9, 0.4), 0.08)]
-    for k in [k for k in (3, 7, 0, 9, 12, 4, 1, 10, 8, 5, 11, 2, 6) if k < slabs]:          # not in depth order
-        s.add_box((0.0, 0.0, -2.25 + 0.5 * k), (3, 3, 0.5), fogs[k % 3])
+    order = [k for k in (3, 7, 0, 9, 12, 4, 1, 10, 8, 5, 11, 2, 6) if k < slabs]          # not in depth order
+    if slabs > 13:
+        order += [int(k) for k in np.random.default_rng(11).permutation(np.arange(13, slabs))]
+    for k in order:
+        s.add_box((0.0, 0.0, -2.5 + thickness * (k + 0.5)), (3, 3, thickness), fogs[k % 3])
     s.add_sphere((0.5, -0.25, 0.25), 0.5, dielectric(1.5))                                 # something solid inside the stack
     s.camera = {"position": [0.25, 0.5, 6.0], "target": [0.0, 0.0, -2.0], "up": [0.0, 1.0, 0.0], "vfov": 35.0, "aperture": 0.0}
     s.sky_bottom, s.sky_top = (0.4, 0.4, 0.4), (0.3, 0.4, 0.7)
@@ -530,6 +534,22 @@ def twin_spheres_scene(moving=False):
                 s.add_sphere(pos, r, mats[(k * 5 + c * (1 + k % 4)) % len(mats)], **mv)
             k += 1
     s.camera = {"position": [0.5, 3.0, 7.0], "target": [0.0, 0.2, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": 0.05 if moving else 0.0}
+    return s
+
+
+def twin_row_scene(count=30, moving=False):
+    """A row of `count` coinciding sphere pairs along the view axis: rays near the axis pass through every one of them (up to 2 x count
+    hits) and the nearest hit is always a tie, so the exact-tie procedure sorts hit lists far longer than a lane's own 24 entries."""
+    s = Scene("twin_row_moving" if moving else "twin_row")
+    s.add_sphere((0, -100.5, 0), 100, lambertian((0.6, 0.6, 0.6)))
+    mats = [lambertian((0.8, 0.2, 0.2)), metal((0.9, 0.9, 0.9), 0.0), dielectric(1.5), standard((0.1, 0.1, 0.1), 0.0, 0.0, emission=(2.0, 1.5, 1.0)),
+            lambertian((0.1, 0.7, 0.2)), metal((0.8, 0.6, 0.2), 0.4)]
+    order = [int(k) for k in np.random.default_rng(23).permutation(count)]                 # not in depth order
+    for k in order:
+        mv = dict(moving=True, dest_offset=(0.0, 0.25, 0.0), time_range=(0.0, 1.0)) if (moving and k % 3 == 0) else {}
+        for c in range(2):
+            s.add_sphere((0.0, 0.25, 4.0 - 0.75 * k), 0.375, mats[(k * 5 + c * (1 + k % 4)) % len(mats)], **mv)
+    s.camera = {"position": [0.0, 0.25, 8.0], "target": [0.0, 0.25, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 12.0, "aperture": 0.0}
     return s
 
 

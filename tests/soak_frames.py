@@ -30,9 +30,12 @@ def main():
         ("mixed", S.mixed_scene, 1920, 1080, 16, 8, {}),
         ("volumes", S.volume_scene, 1280, 720, 24, 10, {"focus": 6.5}),
         ("volume stack", S.volume_stack_scene, 640, 640, 16, 10, {}),
+        ("volume stack 48", lambda: S.volume_stack_scene(48, 0.125), 640, 640, 8, 10, {}),      # ~100 hits per camera ray: spilled hit lists
         ("textured", S.textured_scene, 1280, 720, 24, 8, {}),
         ("twin spheres", S.twin_spheres_scene, 1280, 720, 16, 8, {}),
         ("twin spheres moving", lambda: S.twin_spheres_scene(True), 1280, 720, 8, 8, {}),
+        ("twin row", lambda: S.twin_row_scene(30), 640, 640, 8, 8, {}),                           # exact-tie procedure on lists of up to 60 hits
+        ("twin row moving", lambda: S.twin_row_scene(30, True), 640, 640, 8, 8, {}),
         ("coplanar", S.coplanar_scene, 1280, 720, 12, 8, {"focus": 6.0}),
         ("cover per-sample", S.cover_scene, 1920, 1080, 48, 8, {"rng_policy": abi.RNG_PER_SAMPLE}),
         ("cover blue noise", S.cover_scene, 1920, 1080, 12, 8, {"noise_color": abi.NOISE_BLUE}),

@@ -103,11 +103,21 @@ def test_combine_interlace_lookaround_and_debug_colours(rt, oracle, gpu_context)
             assert np.array_equal(o.download(np.float32, (n, 3)).view(np.uint32), wv.view(np.uint32))
 
 
-def test_hit_list_overflow_is_reported(rt, gpu_context):
-    """The reference's hit list grows without bound; the kernel's holds 24 hits per ray (volume scenes).  A ray that meets more must not
-    pass silently: the batch reports RTOW_ERROR_CAPACITY, once, and the context stays usable."""
+def test_hit_list_overflow_is_reported(rt):
+    """The reference's hit list grows without bound; the kernel's grows up to RtowContextOptions.hitListCapacity (24 = what a lane holds
+    itself, no spill area).  A ray that meets more must not pass silently: the batch reports RTOW_ERROR_CAPACITY, once, and the context
+    stays usable."""
+    with rt.Context(0, hit_list_capacity=24) as ctx:
+        _hit_list_overflow_is_reported(rt, ctx)
+    with rt.Context(0, hit_list_capacity=26) as ctx:                    # two spilled entries: still one short of the 27 hits
+        ctx.upload_scene(rt.scenes.volume_stack_scene(slabs=13).desc())
+        with pytest.raises(rt.lib.RtowError) as e:
+            rt.sample_batch_host(ctx, rt.scenes.make_params(rt.scenes.volume_stack_scene(slabs=13), 32, 32, spp=1, trace_depth=4))
+        assert e.value.code == rt.abi.RTOW_ERROR_CAPACITY
+
+
+def _hit_list_overflow_is_reported(rt, ctx):
     a = rt.abi
-    ctx = gpu_context
     deep = rt.scenes.volume_stack_scene(slabs=13)                       # 13 hulls x (entry + exit) + the wall = 27 hits per camera ray
     ctx.upload_scene(deep.desc())
     p = rt.scenes.make_params(deep, 32, 32, spp=1, trace_depth=4)

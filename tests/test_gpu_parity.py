@@ -167,6 +167,25 @@ def test_volume_hit_lists_longer_than_sixteen_with_ties(rt, oracle, gpu_context)
     assert gpu["color"][:, 3].sum() > 0
 
 
+@pytest.mark.parametrize("slabs,thickness", [(13, 0.5), (48, 0.125)])
+def test_volume_hit_lists_longer_than_a_lane_holds(rt, oracle, gpu_context, slabs, thickness):
+    """27 and 99 hits per camera ray: the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71); the kernel keeps
+    24 hits per lane and the rest of the list in its spill column in HBM, sorted by the same introsort (with its depth limit and heap sort)."""
+    scene = rt.scenes.volume_stack_scene(slabs, thickness)
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 64, 64, 4, 12, diagnostics_stride=16)
+    _compare(gpu, ref)
+    assert gpu["color"][:, 3].sum() > 0
+
+
+@pytest.mark.parametrize("moving", [False, True])
+def test_exact_tie_procedure_with_long_hit_lists(rt, oracle, gpu_context, moving):
+    """A row of 30 coinciding sphere pairs seen end-on: every nearest hit is a tie and rays near the axis have up to 60 hits, so the
+    reference's sort of the whole list (partitions above 16 elements) decides which twin is shaded - and the list does not fit a lane."""
+    scene = rt.scenes.twin_row_scene(30, moving)
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 96, 96, 4, 8, diagnostics_stride=16)
+    _compare(gpu, ref)
+
+
 def test_nearest_hit_ties_between_coplanar_entities(rt, oracle, gpu_context):
     """Decals in a wall's plane, boxes sharing a face, one sphere twice: the nearest hit is shared by two or three entities and the
     one that comes first in the reference tree's leaf order wins (JOBS/SampleBatchJob.cs:450-475, csrc/rtow_reforder.h)."""

@@ -93,6 +93,24 @@ def test_product_index_sort_adversarial_sequence(shim):
     assert np.all(np.diff(keys[idx]) >= 0)
 
 
+def test_product_index_sort_heap_sort_fallback(shim):
+    """Inputs built by the quicksort adversary against this very introsort (oracle_kat_unity_sort_killer): sorting them reaches the
+    2 * floor(log2(n)) depth limit - the oracle counts its HeapSort calls - and the product's host sort still leaves the same permutation."""
+    lib = ob.load()
+    for n in (40, 100, 1000, 4096):
+        keys = np.zeros(n, dtype=np.float32)
+        lib.oracle_kat_unity_sort_killer(n, keys.ctypes.data_as(C.POINTER(C.c_float)))
+        assert sorted(keys.tolist()) == list(range(n))
+        for k in (keys, np.floor(keys / 3).astype(np.float32)):
+            lib.oracle_kat_unity_sort_heapsorts()
+            _, ids = oracle_sort(k)
+            if k is keys:
+                assert lib.oracle_kat_unity_sort_heapsorts() >= 1
+            idx = np.arange(n, dtype=np.uint32)
+            shim.shim_index_sort(idx.ctypes.data_as(C.POINTER(C.c_uint32)), n, np.ascontiguousarray(k).ctypes.data_as(C.POINTER(C.c_float)))
+            assert idx.tolist() == ids.tolist(), n
+
+
 def _boxes(desc_holder):
     lib = ob.load()
     d = desc_holder
