@@ -200,3 +200,14 @@ def test_host_buffer_chain_equals_host_batches_one_after_the_other(rt, gpu_conte
         rows = (np.arange(n) // w) % kw.get("slice_divider", 1) == kw.get("slice_offset", 0)
         for i, (x, y) in enumerate(zip(got["diag"], diags)):
             assert np.array_equal(x[rows].view(np.uint32), y[rows].view(np.uint32)), (kw, "diagnostics of batch", i)
+
+
+def test_chain_after_the_frame_grows(rt):
+    """A context's first chain on a small frame, the next on a larger one: the per-chunk hand-off counters are reallocated, the table
+    of per-batch seeds must survive that (it was once freed with them and written again: a use after free that a fresh context never shows)."""
+    scene = rt.scenes.cover_scene()
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene.desc())
+        for w, h in ((64, 36), (320, 180), (96, 54), (640, 360)):
+            plist = _params(rt, scene, w, h, 3, 8, (5, 6, 7))
+            _same(_chained(rt, ctx, plist, w * h, 4), _sequential(rt, ctx, plist, w * h, 4), "%dx%d" % (w, h))
