@@ -793,20 +793,30 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 
 // Development-only wave-level statistics (make stats -> librtow_hip_stats.so): how often each stage runs and with how
 // many lanes.  Compiled out of the product build.
+// Wave priority per stage (s_setprio at every stage entry; two bits per stage number: REGEN TRAV TEST HIT SKY VOL - scheduler).  The exact
+// tests run with a third of the lanes through dependent sqrt / division chains; letting a wave in that stage issue ahead of its three
+// SIMD neighbours gets it back to the walk sooner: +2 ... +3.5 % on the headline workload, same box, alternating runs (DESIGN.md 4.1,
+// profiles/r02_runs/run_r04m.sh).  Scheduling only - no effect on results.
+#ifndef RTOW_STAGE_PRIO
+#define RTOW_STAGE_PRIO (1 << (2 * 2))   // exact tests at priority 1, everything else 0
+#endif
+// (The first build with these instructions exposed a miscompiled tie update in the general-entity kernels - see the TEST stage - which
+// is how that one was found; with the update written as selects every variant equals the oracle with and without them.)
+#define STAGE_PRIO(k) do { if ((RTOW_STAGE_PRIO) != 0) __builtin_amdgcn_s_setprio((short)(((RTOW_STAGE_PRIO) >> (2 * (k))) & 3)); } while (0)
 #ifdef RTOW_STATS
 #define STAT_DECL unsigned long long stat[16] = {0}
 #define STAT_ADD(i, v) stat[i] += (unsigned long long)(v)
 #define STAT_LANES(i) stat[i] += 1ull
 // wall time (100 MHz ticks) per stage, wave level: the time since the previous mark belongs to the stage marked then (7 = scheduler)
 #define STAGE_DECL unsigned long long stageT[8] = {0}; unsigned long long stLast = wall_clock64(); int stCur = 7
-#define STAGE_MARK(k) do { const unsigned long long n_ = wall_clock64(); stageT[stCur] += n_ - stLast; stLast = n_; stCur = (k); } while (0)
+#define STAGE_MARK(k) do { const unsigned long long n_ = wall_clock64(); stageT[stCur] += n_ - stLast; stLast = n_; stCur = (k); STAGE_PRIO(k); } while (0)
 // per-segment trace of one pixel: {smp, depth, kind, prim, t bits, curVol, nHits, rng}
 #define DBG_TRACE(kind, primv, tv) do { if (A.stats && pix == A.debugPixel) { const unsigned long long k_ = atomicAdd(&A.stats[20], 1ull); if (k_ < 500) { unsigned long long* d_ = A.stats + 5000 + k_ * 8; d_[0] = smp; d_[1] = (unsigned)depth; d_[2] = (kind); d_[3] = (unsigned)(primv); d_[4] = __float_as_uint(tv); d_[5] = (unsigned)curVol; d_[6] = (unsigned)nHits; d_[7] = rng.trace_value(); } } } while (0)
 #else
 #define DBG_TRACE(kind, primv, tv)
 #define STAT_DECL
 #define STAGE_DECL
-#define STAGE_MARK(k)
+#define STAGE_MARK(k) STAGE_PRIO(k)
 #define STAT_ADD(i, v)
 #define STAT_LANES(i)
 #endif
@@ -1561,8 +1571,17 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             // two surfaces at the bit-identical distance: the reference's sorted hit list starts with the one that
                             // comes first in its tree's leaf order (rtow_reforder.h)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
-                            if (EXACT_TIES) { if (t == best && prim >= 0) tieAtBest = true; else if (t < best) tieAtBest = false; }
-                            if (t < best || (t == best && prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; if (KEEP_NORMAL) keptNormal = nl; }
+                            // Straight-line selects on purpose.  Written as `if (t < best || (t == best && ...)) { best = t; prim = i; keptNormal = nl; }`
+                            // one build of this kernel (hipcc 7.2, found when s_setprio instructions shifted its code generation) merged the nested
+                            // conditions so that a lane winning BY THE TIE RULE took nl.x but kept the old normal's y and z: 1 pixel of the 1080p mesh
+                            // frame with a 1-ulp wrong normal AOV, 4 097 pixels of the coplanar frame shaded off the wrong twin.
+                            const bool tie = t == best && prim >= 0;
+                            const unsigned rankHeld = tie ? rank[prim] : 0u;
+                            const bool take = t < best || (tie && rank[i] < rankHeld);
+                            if (EXACT_TIES) tieAtBest = tie ? true : (t < best ? false : tieAtBest);
+                            best = take ? t : best;
+                            prim = take ? i : prim;
+                            if (KEEP_NORMAL) { keptNormal.x = take ? nl.x : keptNormal.x; keptNormal.y = take ? nl.y : keptNormal.y; keptNormal.z = take ? nl.z : keptNormal.z; }
                         }
                     } else {
                         V3 c; float r, t;

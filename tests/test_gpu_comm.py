@@ -95,6 +95,12 @@ ctx.close()
 def test_two_ranks_gather_the_single_gpu_frame(rt, gpu_context):
     """Two processes, SliceDivider = 2: after rtowGatherRowsDevice the root holds, bit for bit, the frame one process renders alone."""
     world = 2
+    count = C.c_int(0)
+    C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(count))
+    if count.value < world:
+        # RCCL 2.27 refuses a communicator with two ranks on one device ("duplicate GPU") - and on some boxes the attempt does not return at
+        # all (one 240 s hang in round 2) - so a one-GPU box does not try; the 8-GPU node runs this path through bench.py --gpus N
+        pytest.skip("the gather needs one GPU per rank: %d device(s) here" % count.value)
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "rank.py")
         open(script, "w").write(RANK_SCRIPT)
