@@ -116,6 +116,14 @@ def test_hit_list_overflow_is_reported(rt):
         assert e.value.code == rt.abi.RTOW_ERROR_CAPACITY
 
 
+def test_context_options_are_validated(rt):
+    a = rt.abi
+    for kw in (dict(hit_list_capacity=-1), dict(flags=a.CONTEXT_EXACT_TIES_ALWAYS | a.CONTEXT_EXACT_TIES_NEVER), dict(device_ordinal=-1), dict(device_ordinal=4096)):
+        with pytest.raises(rt.lib.RtowError) as e:
+            rt.Context(**kw)
+        assert e.value.code == a.RTOW_ERROR_INVALID_VALUE, kw
+
+
 def _hit_list_overflow_is_reported(rt, ctx):
     a = rt.abi
     deep = rt.scenes.volume_stack_scene(slabs=13)                       # 13 hulls x (entry + exit) + the wall = 27 hits per camera ray
