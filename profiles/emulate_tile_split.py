@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--rng", choices=["reference", "per-sample"], default="reference")
     ap.add_argument("--spp", type=int, default=None, help="override the config's samples per pixel")
     ap.add_argument("--slices", default="1,2,4,8")
+    ap.add_argument("--tune", default=None, help="RtowContextOptions.schedulerTune: 8 stage thresholds + the box-walk slice, comma separated")
     args = ap.parse_args()
     name, w, h, spp, depth = CONFIGS[args.config]
     if args.spp:
@@ -35,7 +36,9 @@ def main():
     scene = {"cover": rt.scenes.cover_scene, "stress": rt.scenes.stress_scene, "moving": rt.scenes.moving_scene}[name]()
     n = w * h
     out = {"config": args.config, "scene": name, "width": w, "height": h, "spp": spp, "depth": depth, "rng": args.rng, "slices": {}}
-    with rt.Context(0) as ctx:
+    tune = [int(x) for x in args.tune.split(",")] if args.tune else None
+    out["tune"] = tune
+    with rt.Context(0, scheduler_tune=tune) as ctx:
         ctx.upload_scene(scene.desc())
         bufs = [rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)]
         outs = [rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)]
