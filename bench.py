@@ -203,12 +203,28 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     # the C-ABI communicator of the tile partition: rank 0 makes the id, torch.distributed is only the host channel that carries its 128 bytes
+    # (if the communicator cannot be made on some rank - every rank learns it - the same rows travel through torch.distributed instead and the
+    # line says so in config.gather)
     have_comm = False
     if world > 1 and not shared_gpu:
-        box = [rt.Context.comm_unique_id() if rank == 0 else None]
+        mine_ok = 0
+        try:
+            box = [rt.Context.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                                  # noqa: BLE001 - reported, then the fallback
+            box = [None]
+            print("[bench] rank 0: rtowCommGetUniqueId failed: %s" % e, file=sys.stderr, flush=True)
         dist.broadcast_object_list(box, src=0)
-        ctx.comm_init(box[0], rank, world)
-        have_comm = True
+        if box[0] is not None:
+            try:
+                ctx.comm_init(box[0], rank, world)
+                mine_ok = 1
+            except Exception as e:                              # noqa: BLE001
+                print("[bench] rank %d: rtowCommInit failed: %s" % (rank, e), file=sys.stderr, flush=True)
+        agreed = torch.tensor([mine_ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        have_comm = bool(int(agreed.item()))
+        if mine_ok and not have_comm:
+            ctx.comm_destroy()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -396,6 +412,7 @@ def main():
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
                               "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
                               if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),
+                "gather": None if world == 1 else ("rtowGatherRowsDevice (RCCL behind the C ABI)" if have_comm else "torch.distributed (debug: ranks share one GPU)" if shared_gpu else "torch.distributed (the C-ABI communicator was not available)"),
                 "batches_per_launch": args.chain if not batches else 1,
                 "launches": m["launches"],
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds),
