@@ -285,8 +285,10 @@ typedef void (*RtowLogCallback)(int32_t level, const char* tag, const char* mess
  * parameter block except where stated; nothing is read from the environment. */
 typedef enum RtowContextFlags {
     RTOW_CONTEXT_EXACT_TIES_ALWAYS = 1u << 0,      /* settle every nearest-hit tie with the reference's whole procedure (walk again unpruned, sort the hit
-                                                    * list like NativeSortExtension.Sort, take [0]) in every scene without volumes; default: only in scenes
-                                                    * that hold the same primitive twice.  Closes the one documented deviation; slower */
+                                                    * list like NativeSortExtension.Sort, take [0]) in every scene without volumes; default: in scenes
+                                                    * that hold the same primitive twice and in scenes of more than 16 entities that are not all
+                                                    * unrotated spheres - what is left are sphere-only scenes, where two different
+                                                    * spheres at bit-identical distance AND more than 16 hits on that ray would be needed.  Slower */
     RTOW_CONTEXT_EXACT_TIES_NEVER = 1u << 1,       /* never (the rank rule everywhere) */
     RTOW_CONTEXT_REFERENCE_DIAGNOSTICS = 1u << 2,  /* FULL_DIAGNOSTICS records (diagnosticsStride 16): BoundsHitCount / CandidateCount count the REFERENCE's tree -
                                                     * node boxes a ray passes and entities of the leaves it reaches in the tree RebuildBvh would build
@@ -310,7 +312,7 @@ typedef struct RtowContextOptions {
                                      * the exact-tie procedure): the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71);
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per
                                      * entry, sized at rtowUploadScene to min(this, the most the scene can produce: 2 per entity with volumes, else 1).
-                                     * 0 = 1024.  A ray beyond it makes the batch report RTOW_ERROR_CAPACITY */
+                                     * 0 = 1024 in scenes with volumes, 128 elsewhere.  A ray beyond it makes the batch report RTOW_ERROR_CAPACITY */
 } RtowContextOptions;
 
 RTOW_API int rtowGetApiVersion(void);

@@ -754,7 +754,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         // without volumes, so that bound - capped by RtowContextOptions.hitListCapacity - is all a scene can need.
         const bool volumes = compiled.layout.sceneKind == SCENE_KIND_VOLUMES || compiled.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
         uint64_t most = (volumes || compiled.layout.exactTies) ? (uint64_t)compiled.entityCount * (volumes ? 2u : 1u) : 0u;
-        const uint64_t cap = ctx->hitListCapacity ? ctx->hitListCapacity : kDefaultHitListCapacity;
+        const uint64_t cap = ctx->hitListCapacity ? ctx->hitListCapacity : (volumes ? kDefaultHitListCapacity : kDefaultTieListCapacity);
         if (most > cap) most = cap;
         const uint32_t entries = most > (uint64_t)kLocalHitEntries ? (uint32_t)(most - kLocalHitEntries) : 0u;
         if (entries > ctx->hitSpillCapacity) {

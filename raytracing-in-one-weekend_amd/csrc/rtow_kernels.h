@@ -25,7 +25,8 @@ constexpr unsigned kSampleGroup = 16;   // RTOW_RNG_PER_SAMPLE: samples per work
 constexpr int kQueueBytes = 256;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B)
 constexpr int kMaxChain = 16;      // successive batches one launch can run (rtowSampleBatchChainDevice)
 constexpr int kLocalHitEntries = 24;                // entries of a ray's hit list a lane holds itself; longer lists continue in SampleKernelArgs.hitSpill
-constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0
+constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0, scenes with volumes (long lists are their normal case)
+constexpr uint32_t kDefaultTieListCapacity = 128;   // ... scenes without: only the exact-tie procedure keeps a whole list, and only for the ray that ties
 
 // Per-batch fields of a chained launch (rtowSampleBatchChainDevice): everything else is shared by the chain's batches.
 struct ChainBatch {

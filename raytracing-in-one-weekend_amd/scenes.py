@@ -537,6 +537,27 @@ def twin_spheres_scene(moving=False):
     return s
 
 
+def decal_stack_scene(layers=20):
+    """No volumes, no duplicate primitives: a wall with decals IN its plane (ties between different surfaces) in front of `layers` more panes
+    along the view axis, so that rays through the decals have more than 16 hits - the case in which the order the reference's unstable sort
+    leaves the tied nearest hits in is no longer the leaf order and only the whole procedure reproduces it."""
+    s = Scene("decal_stack")
+    mats = [lambertian((0.8, 0.2, 0.2)), lambertian((0.2, 0.8, 0.2)), metal((0.9, 0.9, 0.9), 0.1), standard((0.1, 0.1, 0.1), 0.0, 0.0, emission=(2.0, 1.5, 1.0)),
+            lambertian((0.2, 0.3, 0.9)), dielectric(1.5)]
+    order = [int(k) for k in np.random.default_rng(31).permutation(layers)]
+    for k in order[: layers // 2]:
+        s.add_rect((0.0, 0.0, -0.25 * (k + 1)), (6.0 - 0.125 * k, 6.0 - 0.125 * k), mats[k % len(mats)])
+    s.add_rect((0.0, 0.0, 0.0), (4.0, 4.0), mats[0])                                   # the wall ...
+    s.add_rect((-1.0, 0.5, 0.0), (1.5, 1.5), mats[2])                                  # ... a mirror decal in its plane
+    s.add_rect((1.0, -0.5, 0.0), (1.5, 1.0), mats[3])                                  # ... a light panel in its plane
+    s.add_rect((1.0, -0.5, 0.0), (0.5, 0.5), mats[1])                                  # ... and a decal on the panel
+    s.add_box((-1.0, -1.25, 0.25), (1.0, 1.0, 0.5), mats[4])                           # a box standing on the wall: its back face lies in the plane too
+    for k in order[layers // 2:]:
+        s.add_rect((0.0, 0.0, -0.25 * (k + 1)), (6.0 - 0.125 * k, 6.0 - 0.125 * k), mats[k % len(mats)])
+    s.camera = {"position": [0.25, 0.5, 7.0], "target": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": 0.0}
+    return s
+
+
 def twin_row_scene(count=30, moving=False):
     """A row of `count` coinciding sphere pairs along the view axis: rays near the axis pass through every one of them (up to 2 x count
     hits) and the nearest hit is always a tie, so the exact-tie procedure sorts hit lists far longer than a lane's own 24 entries."""

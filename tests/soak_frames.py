@@ -36,6 +36,7 @@ def main():
         ("twin spheres moving", lambda: S.twin_spheres_scene(True), 1280, 720, 8, 8, {}),
         ("twin row", lambda: S.twin_row_scene(30), 640, 640, 8, 8, {}),                           # exact-tie procedure on lists of up to 60 hits
         ("twin row moving", lambda: S.twin_row_scene(30, True), 640, 640, 8, 8, {}),
+        ("decal stack", lambda: S.decal_stack_scene(20), 640, 640, 8, 8, {}),                      # ties between different surfaces, > 16 hits per ray
         ("coplanar", S.coplanar_scene, 1280, 720, 12, 8, {"focus": 6.0}),
         ("cover per-sample", S.cover_scene, 1920, 1080, 48, 8, {"rng_policy": abi.RNG_PER_SAMPLE}),
         ("cover blue noise", S.cover_scene, 1920, 1080, 12, 8, {"noise_color": abi.NOISE_BLUE}),

@@ -177,6 +177,19 @@ def test_volume_hit_lists_longer_than_a_lane_holds(rt, oracle, gpu_context, slab
     assert gpu["color"][:, 3].sum() > 0
 
 
+def test_ties_between_different_surfaces_on_rays_with_more_than_sixteen_hits(rt, oracle, gpu_context):
+    """Decals in a wall's plane in front of 20 more panes: no duplicate primitive, but more than 16 entities of general geometry - the scene
+    compiler picks the exact-tie kernels by itself, and the frame equals the reference's where the leaf-order rule alone would not have to."""
+    scene = rt.scenes.decal_stack_scene(20)
+    gpu, ref = _run_both(rt, oracle, gpu_context, scene, 128, 128, 4, 8, diagnostics_stride=16)
+    _compare(gpu, ref)
+    # ... and the rule alone does not: the same frame from a context that was told never to use the exact-tie kernels
+    with rt.Context(0, flags=rt.abi.CONTEXT_EXACT_TIES_NEVER) as ctx:
+        ctx.upload_scene(scene.desc(max_bvh_depth=32))
+        rule = rt.sample_batch_host(ctx, rt.scenes.make_params(scene, 128, 128, spp=4, trace_depth=8, diagnostics_stride=16))
+    assert np.any(rule["color"].view(np.uint32) != ref["color"].view(np.uint32), axis=1).sum() > 100
+
+
 @pytest.mark.parametrize("moving", [False, True])
 def test_exact_tie_procedure_with_long_hit_lists(rt, oracle, gpu_context, moving):
     """A row of 30 coinciding sphere pairs seen end-on: every nearest hit is a tie and rays near the axis have up to 60 hits, so the
