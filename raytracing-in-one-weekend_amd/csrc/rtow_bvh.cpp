@@ -473,7 +473,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         for (int i = 1; i < n; i++) if (keys[i] == keys[i - 1]) { L.exactTies = 1u; break; }
         // Rects, boxes and triangles do tie without being duplicates (faces in one plane, shared mesh edges), and the leaf-order rule is the
         // reference's answer only while a ray has at most 16 hits: with more than 16 such entities in the scene a ray can have more, so those
-        // scenes get the exact-tie kernels too (7-8 % slower; RTOW_CONTEXT_EXACT_TIES_NEVER keeps the rank rule).  Sphere-only scenes do not:
+        // scenes get the exact-tie kernels too (20 % slower on a mesh, far more where every ray ties; RTOW_CONTEXT_EXACT_TIES_NEVER keeps the rank rule).  Sphere-only scenes do not:
         // two different spheres meeting a ray at bit-identical distance is not a situation geometry produces.
         if ((general || hasImageTextures) && n > 16) L.exactTies = 1u;
     }
