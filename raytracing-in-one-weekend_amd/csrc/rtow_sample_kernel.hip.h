@@ -874,17 +874,22 @@ __device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic
 // builtin for a wider one).  A write-through store is its own memory transaction: dword by dword a pixel's 44 bytes became eleven 32-byte
 // writes (rocprofv3 WRITE_SIZE: 789 MB per batch against 99 MB algorithmic), as four wide stores they are four.  The loads wait for their
 // own data and coherent_flush() for the stores: the compiler's wait-count bookkeeping does not see into inline assembly.
+// Each store is followed by `s_nop 1`: a VMEM store of more than 8 bytes reads its data registers for a cycle or two after it issues, and
+// a VALU write to one of them in that window lands in memory instead (gfx9 "12-dword store" hazard; two wait states on gfx940+).  The
+// compiler inserts that wait for the stores IT emits and cannot for one inside inline assembly: the exact-tie general-entity kernel under
+// a chain wrote garbage into the x and y of ~1 200 albedo records of the decal-stack frame (z, colour and normal intact) until the nop was
+// there - found by tests/test_gpu_chain.py when the tie-heavy scenes were added to it.
 typedef float fvec4 __attribute__((ext_vector_type(4)));
 typedef float fvec3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ void coherent_store4(float* p, float x, float y, float z, float w)
 {
     const fvec4 v = {x, y, z, w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void coherent_store3(float* p, V3 a)
 {
     const fvec3 v = {a.x, a.y, a.z};
-    asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void coherent_flush() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 __device__ __forceinline__ float4 coherent_load4(const float* p)

@@ -44,6 +44,10 @@ def main():
              ("stress 10000 (tree in HBM)", S.stress_scene, 1920, 1080, 24, 8, 12, {}),
              ("mixed", S.mixed_scene, 1920, 1080, 16, 8, 10, {}),
              ("volumes", S.volume_scene, 1280, 720, 12, 10, 8, {"focus": 6.5}),
+             ("volume stack 48 (spilled hit lists)", lambda: S.volume_stack_scene(48, 0.125), 480, 480, 4, 10, 6, {}),
+             ("mesh (exact-tie kernels)", S.mesh_scene, 1280, 720, 8, 8, 8, {}),
+             ("decal stack (a tie on most rays)", lambda: S.decal_stack_scene(20), 640, 640, 6, 8, 8, {}),
+             ("twin spheres moving", lambda: S.twin_spheres_scene(True), 1280, 720, 6, 8, 8, {}),
              ("cover, adaptive counts", S.cover_scene, 1280, 720, 4, 8, 16, {"spp_max": 40, "extrema": (0.2, 1.4)}),
              ("cover, tiny frame", S.cover_scene, 160, 90, 64, 8, 16, {})]
     ctx = rt.Context(0)

@@ -67,11 +67,12 @@ def _same(a, b, what):
 
 @pytest.mark.parametrize("name,w,h,spp,depth,count", [("cover", 1920, 1080, 4, 8, 3), ("cover", 96, 54, 6, 8, 16), ("moving", 640, 360, 5, 8, 4),
                                                        ("mixed", 320, 200, 4, 6, 5), ("volumes", 256, 144, 3, 10, 4), ("textured", 256, 144, 3, 6, 3),
-                                                       ("stress", 960, 540, 3, 8, 3)])
+                                                       ("stress", 960, 540, 3, 8, 3), ("twins", 320, 180, 4, 8, 3), ("mesh", 320, 200, 3, 6, 3), ("decals", 256, 256, 3, 6, 3)])
 def test_chain_equals_the_batches_one_after_the_other(rt, gpu_context, name, w, h, spp, depth, count):
     S = rt.scenes
     scene = {"cover": S.cover_scene, "moving": S.moving_scene, "mixed": S.mixed_scene, "volumes": S.volume_scene, "textured": S.textured_scene,
-             "stress": lambda: S.stress_scene(count=6000, max_tentatives=30000)}[name]()
+             "stress": lambda: S.stress_scene(count=6000, max_tentatives=30000),
+             "twins": S.twin_spheres_scene, "mesh": S.mesh_scene, "decals": lambda: S.decal_stack_scene(20)}[name]()       # the last three: exact-tie kernels
     ctx = gpu_context
     ctx.upload_scene(scene.desc())
     n = w * h
