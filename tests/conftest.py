@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # no test of this suite runs for minutes: one that does (a kernel that never ends, a library load on a sick box) fails after 10 minutes with
+    # every thread's stack instead of holding the GPU box until the caller's own limit (pytest-timeout, where installed)
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 def _has_gpu():
     try:
         ctx = rtow.Context(0)
