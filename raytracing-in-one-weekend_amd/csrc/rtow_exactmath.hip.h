@@ -7,7 +7,11 @@
 // the range; everything else (zero, subnormal, huge, infinite, NaN, negative for sqrt) takes the compiler's expansion, so the function is
 // the IEEE operation for all 2^32 inputs.  That is not argued, it is checked: tests/native/exactmath_parity.hip evaluates every one of
 // the 2^32 operands on the device against `1.0f / x` and `__builtin_sqrtf(x)` (tests/test_gpu_detmath.py, every -m gpu run).
-// Binary division (a / b) stays the compiler's: its operand space cannot be enumerated.
+// Binary division: the operand space (2^64) cannot be enumerated, but the question "is one residual step on the correctly rounded
+// reciprocal the IEEE quotient?" does not depend on the exponents while no intermediate leaves the normal range (every step scales exactly
+// by powers of two), so it is enumerated over MANTISSAS: all 2^23 x 2^23 pairs, 34 s of an MI355X, no mismatch
+// (tests/native/exactdiv_parity.hip).  exact_div3 uses it where three numerators share one divisor (a sphere's normal, RT/HitTests.cs:56);
+// a single division gains nothing once the range guard is paid for and stays the compiler's.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,6 +56,36 @@ __device__ __forceinline__ float exact_sqrt(float x)
         return __builtin_fmaf(r, h, s);
     }
     return __builtin_sqrtf(x);
+}
+
+// RN(a / b) given y = RN(1 / b): q = RN(a y), r = a - b q (exact, fused), RN(q + r y).  Valid while a, b, the quotient and the residual
+// are normal; exact_div3 guards that.  This very function is what tests/native/exactdiv_parity.hip enumerates.
+__device__ __forceinline__ float exact_div_step(float a, float b, float y)
+{
+    const float q = a * y;
+    const float r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+// (ax / b, ay / b, az / b), each correctly rounded.  Fast path: the numerators' biased exponents are in [64, 191] (magnitudes in
+// [2^-63, 2^65)) and the divisor's in [96, 159] ([2^-31, 2^33)): then every quotient has an exponent in [-96, 96], the reciprocal one in
+// [-33, 31] and the residuals are at least 2^-110 - all normal, which is what the enumeration over mantissas needs to carry over.
+// Anything else (a zero component, infinities, NaNs, tiny or huge values) takes three IEEE divisions.  The numerators' range test:
+// (bits << 1) + 0x40000000 has its top bit set exactly when the biased exponent is in [64, 191].
+__device__ __forceinline__ void exact_div3(float ax, float ay, float az, float b, float& qx, float& qy, float& qz)
+{
+    const unsigned g = ((__float_as_uint(ax) << 1) + 0x40000000u) & ((__float_as_uint(ay) << 1) + 0x40000000u) & ((__float_as_uint(az) << 1) + 0x40000000u);
+    const bool bOk = ((__float_as_uint(b) & 0x7f800000u) - 0x30000000u) < 0x20000000u;
+    if (__builtin_expect((int)g < 0 && bOk, 1)) {
+        const float y0 = __builtin_amdgcn_rcpf(b);                 // exact_rcp's fast path: b is well inside its range
+        const float e = __builtin_fmaf(-b, y0, 1.0f);
+        const float y = __builtin_fmaf(e, y0, y0);
+        qx = exact_div_step(ax, b, y);
+        qy = exact_div_step(ay, b, y);
+        qz = exact_div_step(az, b, y);
+    } else {
+        qx = ax / b; qy = ay / b; qz = az / b;
+    }
 }
 
 } // namespace rtow

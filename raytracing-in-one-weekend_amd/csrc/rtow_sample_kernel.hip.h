@@ -46,10 +46,14 @@
 #define RTOW_RCP(x) rtow::exact_rcp(x)
 #define RTOW_RCP_NAN_TO_INF(x) rtow::exact_rcp_nan_to_inf(x)
 #define RTOW_SQRT(x) rtow::exact_sqrt(x)
+#ifndef RTOW_EXACT_DIV3
+#define RTOW_EXACT_DIV3 1
+#endif
 #else
 #define RTOW_RCP(x) (1.0f / (x))
 #define RTOW_RCP_NAN_TO_INF(x) ([](float r_) { return r_ != r_ ? __builtin_inff() : r_; }(1.0f / (x)))
 #define RTOW_SQRT(x) __builtin_sqrtf(x)
+#define RTOW_EXACT_DIV3 0
 #endif
 
 namespace rtow {
@@ -636,6 +640,18 @@ __device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout
     }
 }
 
+// (p.x / d, p.y / d, p.z / d): three IEEE divisions by one divisor (a sphere's outward normal, r.GetPoint(t) / radius, RT/HitTests.cs:56)
+__device__ __forceinline__ V3 div3(V3 p, float d)
+{
+#if RTOW_EXACT_DIV3
+    V3 q;
+    rtow::exact_div3(p.x, p.y, p.z, d, q.x, q.y, q.z);
+    return q;
+#else
+    return v3(p.x / d, p.y / d, p.z / d);
+#endif
+}
+
 // HitTests.Hit(Sphere) (RT/HitTests.cs:23-60) in entity space (oc = origin - centre), tMin = 0, tMax = +inf
 __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, float& tOut)
 {
@@ -747,7 +763,7 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
     if (type == RTOW_ENTITY_SPHERE) {
         float t;
         if (!sphere_hit_tmin(oL, dL, dot(dL, dL), q5.x, tMin, t)) return false;
-        nLocal = v3((oL.x + t * dL.x) / q5.x, (oL.y + t * dL.y) / q5.x, (oL.z + t * dL.z) / q5.x);
+        nLocal = div3(v3(oL.x + t * dL.x, oL.y + t * dL.y, oL.z + t * dL.z), q5.x);
         tOut = t;
         return true;
     }
@@ -1658,7 +1674,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     V3 c; float radius;
                     sphere_at<ALL_LDS, HAS_MOTION>(sc, L, prim, rtime, c, radius);
                     const V3 oc = sub(ro, c);
-                    const V3 nLocal = v3((oc.x + t * rd.x) / radius, (oc.y + t * rd.y) / radius, (oc.z + t * rd.z) / radius); // r.GetPoint(t) / radius
+                    const V3 nLocal = div3(v3(oc.x + t * rd.x, oc.y + t * rd.y, oc.z + t * rd.z), radius);                   // r.GetPoint(t) / radius
                     N = normalize(nLocal);                                                    // RT/Entity.cs:65
                 }
                 const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + matIdx * 64u;

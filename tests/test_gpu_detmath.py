@@ -37,3 +37,22 @@ def test_exact_rcp_and_sqrt_equal_ieee_for_every_operand():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rcp 0 mismatches" in r.stdout and "sqrt 0 " in r.stdout and "rcp(sqrt) 0 " in r.stdout and "NaN -> inf 0 " in r.stdout, r.stdout
+
+
+def test_exact_div3_equals_ieee_division():
+    """rtow::exact_div3 (csrc/rtow_exactmath.hip.h): three quotients by one divisor from one correctly rounded reciprocal and one fused
+    residual step each.  Binary division cannot be enumerated over operands, but whether that step gives the IEEE quotient depends on the
+    mantissas only (inside the guarded exponent ranges everything scales by powers of two): all 2^23 x 2^23 mantissa pairs are checked on
+    the device against `a / b`, then the function itself - guard and fallback included - on 2^32 arbitrary and 2^32 edge-exponent quadruples."""
+    src = os.path.join(ROOT, "tests", "native", "exactdiv_parity.hip")
+    hdr = os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc", "rtow_exactmath.hip.h")
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "exactdiv_parity")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-x", "hip", src, "-o", exe],
+                       check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=590)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mantissa pairs 70368744177664: 0 mismatches" in r.stdout and "random quadruples 4294967296: 0 mismatches" in r.stdout \
+        and "edge-exponent quadruples 4294967296: 0 mismatches" in r.stdout, r.stdout
