@@ -130,7 +130,7 @@ def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0, scene_name="cov
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2,
                     help="BASELINE.json config to time (1-based like SURVEY.md 8: 2 = configs[1], the headline; 3 = 4K/1024 spp/16 bounces; 4 = 10k spheres; 5 = moving + defocus)")
