@@ -7,7 +7,7 @@ BASELINE.json configs[1]) with the accumulators already resident in HBM; success
 ping-pong buffers with a fresh seed, exactly like the reference's successive batches
 (Assets/Scripts/Unity/Raytracer.cs:656-661,798-802).
 
-  python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus 1 --steps 8 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
