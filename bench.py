@@ -28,7 +28,13 @@ and the line also carries, measured in the same run (`partitions`):
            (the reference's batch accumulation, Raytracer.cs:656-661,798-802, run concurrently; raytracing-in-one-weekend_amd/multigpu.py);
   tiles under --rng per-sample (RTOW_RNG_PER_SAMPLE, NOT the reference's random stream: a pixel's samples become independent units).
 
-Rank 0 prints ONE JSON line (see the task contract) that also carries `roofline` and `cpu_baseline`.
+Rank 0 prints ONE JSON line (see the task contract) that also carries `roofline`, `cpu_baseline` (the C2 sample), `cpu_baseline_c1`
+(BASELINE.json configs[0] in full: 400x225, 8 spp), `plain_batches` (one launch per batch), `chain2` (two batches per launch: the queue depth of
+the unmodified reference host, UNITY/Raytracer.cs:586-593) and `post_passes` (CombineJob / FinalizeTexturesJob / ReduceMetricsJob / accumulator
+add on the device: achieved GB/s against the HBM roofline, the kernels of this repository that ARE bandwidth bound).
+
+RTOW_BENCH_DEBUG_SHARED_GPU=1 (development, one-GPU box): every rank uses cuda:0, torch.distributed runs over gloo and the C-ABI communicator
+over the tests' stand-in transport (tests/native/fake_rccl.cpp) - the N > 1 code path end to end, never a measurement (the line says so).
 """
 import argparse
 import importlib
@@ -127,6 +133,78 @@ def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0, scene_name="cov
     }
 
 
+def cpu_baseline_c1(rt):
+    """BASELINE.json configs[0] in full - cover scene 400x225, 8 spp, 8 bounces - on the CPU restatement ("timed in the same bench
+    run on C1 (full)"; the reference's call site is UNITY/Raytracer.cs:730).  0.72 M samples: best of 5 runs of about 50 ms each."""
+    from oracle import binding as ob  # checker / baseline only - never on the product path
+
+    scene = rt.scenes.cover_scene()
+    osc = ob.OracleScene(scene.desc(), kind="fast")
+    cores = usable_cores()
+    w, h, spp, depth = 400, 225, 8, 8
+    p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth)
+    best, rays = None, 0
+    for _ in range(5):
+        t = time.perf_counter()
+        _, counters = osc.sample_batch(p, nthreads=cores, want_counters=True)
+        dt = time.perf_counter() - t
+        rays = counters.rays
+        best = dt if best is None else min(best, dt)
+    osc.close()
+    return {"value": round(w * h * spp / best / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "BASELINE.json configs[0] in full: cover scene 400x225, 8 spp, 8 bounces, 1 batch, best of 5; C++ restatement of the reference Burst path, "
+                      "-O3 -ffast-math, 1 task/pixel dynamic", "mrays_per_s": round(rays / best / 1e6, 3), "seconds": round(best, 4)}
+
+
+def post_passes(rt, ctx, lib, torch, dev, stream, sizes=((1920, 1080), (3840, 2160)), iters=20):
+    """Achieved HBM GB/s of the post passes next to the sample kernel (JOBS/CombineJob.cs:29-71, JOBS/FinalizeTexturesJob.cs:23-55,
+    JOBS/ReduceMetricsJob.cs:22-45, rtowAddAccumDevice), timed with HIP events on the stream they are launched on.  Bytes per pixel are the
+    algorithmic ones: combine 44 read + 36 written, finalize 36 + 12, metrics 24 read, add 88 read + 44 written.
+    Peak 8 TB/s (spec), ~6.3 TB/s is what a float4 copy reaches on this part (MI355X_MICROARCH.md).  A 1080p working set (91-166 MB) partly
+    lives in the 256 MB Infinity Cache between iterations - the 4K figures (365-663 MB) are the HBM ones."""
+    import ctypes as C
+
+    abi = rt.abi
+    out = {"peak_GBps": HBM_PEAK_GBS, "achievable_GBps": 6300.0, "iterations": iters}
+    for w, h in sizes:
+        n = w * h
+        color4 = torch.rand(n, 4, device=dev)
+        color4[:, 3] = 8.0
+        normal, albedo = torch.rand(n, 3, device=dev), torch.rand(n, 3, device=dev)
+        o3 = [torch.empty(n, 3, device=dev) for _ in range(3)]
+        rgba = [torch.empty(n, 4, device=dev, dtype=torch.uint8) for _ in range(3)]
+        diag, scw = torch.rand(n, device=dev), torch.rand(n, device=dev)
+        acc2 = [torch.zeros(n, c, device=dev) for c in (4, 3, 3)] + [torch.zeros(n, device=dev)]
+        cp = abi.CombineParams(w, h, 0, 1)
+        metrics = abi.Metrics()
+        sp = stream.cuda_stream
+        dst = abi.AccumBuffers(*[t.data_ptr() for t in acc2])
+        src = abi.AccumBuffers(color4.data_ptr(), normal.data_ptr(), albedo.data_ptr(), scw.data_ptr())
+        passes = {
+            "combine": (80, lambda: lib.rtowCombineDevice(ctx.handle, C.byref(cp), color4.data_ptr(), normal.data_ptr(), albedo.data_ptr(), o3[0].data_ptr(), o3[1].data_ptr(), o3[2].data_ptr(), sp)),
+            "finalize": (48, lambda: lib.rtowFinalizeDevice(ctx.handle, n, o3[0].data_ptr(), o3[1].data_ptr(), o3[2].data_ptr(), rgba[0].data_ptr(), rgba[1].data_ptr(), rgba[2].data_ptr(), sp)),
+            "reduce_metrics": (24, lambda: lib.rtowReduceMetricsDevice(ctx.handle, n, diag.data_ptr(), 4, color4.data_ptr(), scw.data_ptr(), sp, C.byref(metrics))),
+            "add_accum": (132, lambda: lib.rtowAddAccumDevice(ctx.handle, n, C.byref(dst), C.byref(src), sp)),
+        }
+        res = {}
+        for name, (bytes_per_px, fn) in passes.items():
+            for _ in range(2):
+                rt.lib.check(fn(), name)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(iters):
+                rt.lib.check(fn(), name)
+            e1.record(stream)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            gbs = n * bytes_per_px / (ms * 1e-3) / 1e9
+            res[name] = {"ms": round(ms, 4), "bytes_per_pixel": bytes_per_px, "GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        res["reduce_metrics"]["note"] = "includes the 8 KB copy of the per-block partials to the host that ends the call"
+        out["%dx%d" % (w, h)] = res
+        del color4, normal, albedo, o3, rgba, diag, scw, acc2
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +284,12 @@ def main():
     # (if the communicator cannot be made on some rank - every rank learns it - the same rows travel through torch.distributed instead and the
     # line says so in config.gather)
     have_comm = False
-    if world > 1 and not shared_gpu:
+    if world > 1:
+        if shared_gpu:
+            fake = os.path.join(ROOT, "tests", "build", "libfake_rccl.so")
+            if not os.path.exists(fake):
+                raise SystemExit("RTOW_BENCH_DEBUG_SHARED_GPU=1 needs %s (python __graft_entry__.py builds it)" % fake)
+            rt.Context.comm_set_library_path(fake)
         mine_ok = 0
         try:
             box = [rt.Context.comm_unique_id() if rank == 0 else None]
@@ -220,7 +303,7 @@ def main():
                 mine_ok = 1
             except Exception as e:                              # noqa: BLE001
                 print("[bench] rank %d: rtowCommInit failed: %s" % (rank, e), file=sys.stderr, flush=True)
-        agreed = torch.tensor([mine_ok], device=dev, dtype=torch.int32)
+        agreed = torch.tensor([mine_ok], device=dev if not shared_gpu else "cpu", dtype=torch.int32)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         have_comm = bool(int(agreed.item()))
         if mine_ok and not have_comm:
@@ -298,7 +381,7 @@ def main():
                         launch([p], mg.accum_views(zero_flat, n), state["pong"])
                         return state["pong_flat"]
 
-                    mg.render_batches(render_full, acc_slice, n, rank, world, add_flat, exchange=exchange, frame=state["ping_flat"])   # ping = this batch's frame (rank 0)
+                    mg.render_batches(render_full, acc_slice, n, rank, world, add_flat, exchange=exchange, frame=state["ping_flat"], via_host=shared_gpu)   # ping = this batch's frame (rank 0)
                 else:
                     launch([params_for(i + 1 + k) for k in range(c)], state["ping"], state["pong"])
                     if world > 1:
@@ -338,7 +421,13 @@ def main():
     if not args.no_extras:
         if world == 1:
             if args.chain > 1:
-                extras["plain_batches"] = dict(summary(measure("tiles", args.rng, 1, args.steps, 1)), note="the same steps as one launch per batch (rtowSampleBatchDevice)")
+                extras["plain_batches"] = dict(summary(measure("tiles", args.rng, 1, args.steps, 1)), batches_per_launch=1, note="the same steps as one launch per batch (rtowSampleBatchDevice): like for like with round 1's `value`")
+            if args.chain != 2:
+                steps2 = args.steps + (args.steps & 1)
+                m2 = measure("tiles", args.rng, 2, steps2, 2)
+                extras["chain2"] = {"value": round(float(n) * spp * steps2 / m2["elapsed"] / 1e6, 2), "ms_per_step": round(m2["elapsed"] / steps2 * 1e3, 3), "kernel_ms_per_step": round(m2["kernel_ms_per_step"], 3),
+                                    "batches_per_launch": 2, "steps": steps2,
+                                    "note": "two batches per launch (rtowSampleBatchChainDevice, count = 2): what a host with the reference's queue depth of two gets (UNITY/Raytracer.cs:586-593); INTEGRATION.md 3 shows the edit that queues more"}
             # the drop-in form of INTEGRATION.md: rtowSampleBatch on the host's own (pinned, registered) accumulation arrays
             import numpy as np
             pool = [np.zeros((n, c), np.float32) for c in (4, 3, 3)] + [np.zeros(n, np.float32)]
@@ -390,7 +479,12 @@ def main():
         launch_ms = avg_kernel_ms * steps_per_launch
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         traffic, traffic_src, secondary = measured_hbm_traffic() if world == 1 else (None, None, {})
+        profiled_bpl = None
         if traffic is not None:
+            try:
+                profiled_bpl = int(json.load(open(os.path.join(ROOT, "profiles", traffic_src))).get("bench_line_under_profiler", {}).get("config", {}).get("batches_per_launch", 0)) or None
+            except (OSError, ValueError):
+                profiled_bpl = None
             traffic = round(traffic * steps_per_launch)      # per launch, like `achieved`: the committed profile's per-batch traffic x this run's batches per launch
         out = {
             "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce" if (args.config == 2 and not overridden) else
@@ -401,6 +495,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
+            "batches_per_launch": args.chain if not batches else 1,   # `value` is measured with this many successive batches fused into one launch (1 = plain batches)
+            "launches": m["launches"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -412,7 +508,7 @@ def main():
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
                               "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
                               if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),
-                "gather": None if world == 1 else ("rtowGatherRowsDevice (RCCL behind the C ABI)" if have_comm else "torch.distributed (debug: ranks share one GPU)" if shared_gpu else "torch.distributed (the C-ABI communicator was not available)"),
+                "gather": None if world == 1 else ("rtowGatherRowsDevice (DEBUG: the tests' stand-in transport instead of RCCL, ranks share one GPU)" if (have_comm and shared_gpu) else "rtowGatherRowsDevice (RCCL behind the C ABI)" if have_comm else "torch.distributed (debug: ranks share one GPU)" if shared_gpu else "torch.distributed (the C-ABI communicator was not available)"),
                 "batches_per_launch": args.chain if not batches else 1,
                 "launches": m["launches"],
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds),
@@ -431,6 +527,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 8),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_batches_per_launch_profiled": profiled_bpl,
+                "traffic_basis": None if traffic is None else ("measured: PMC passes of this command at this chain length" if profiled_bpl == args.chain else
+                                                                "extrapolated: per-batch PMC traffic of a %s-batch launch x this run's %d batches per launch" % (profiled_bpl, args.chain)),
                 "kernel": "sample_batch_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "secondary": secondary,   # what actually limits the kernel: from the same committed PMC summary as `traffic`
@@ -443,8 +542,11 @@ def main():
             out["host_buffer_ms_per_step"] = host_ms
             out["host_buffer_note"] = ("rtowSampleBatch on pinned host arrays registered with rtowRegisterHostBuffer: inputs by one DMA, outputs stored by the kernel straight into "
                                        "host memory (best of 3 after 1 warm-up); host_buffer_chain_ms_per_step: rtowSampleBatchChain on the same arrays, batches_per_launch batches per call")
+        if world == 1 and not args.no_extras:
+            out["post_passes"] = post_passes(rt, ctx, lib, torch, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, W, H, depth, scene_name=args.scene, full_spp=spp)
+            out["cpu_baseline_c1"] = cpu_baseline_c1(rt)
         print(json.dumps(out), flush=True)
 
     if have_comm:

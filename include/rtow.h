@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 6
+#define RTOW_API_VERSION 7
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -180,6 +180,11 @@ typedef struct RtowSceneInfo {
     int32_t ldsBytesScene;          /* bytes of scene data staged into LDS per workgroup */
     int32_t sceneInLds;             /* 1 if the whole scene is LDS resident, 0 if only the top levels */
     uint64_t sceneBytesDevice;      /* bytes of scene data resident in HBM */
+    uint64_t hitSpillBytes;         /* bytes of HBM this scene reserves for hit lists beyond the 24 entries a lane holds itself (scenes with
+                                       ProbabilisticVolume materials, exact-tie kernels): 16 B x 1024 lanes x CUs x (list capacity - 24) entries,
+                                       0 where no ray can need it.  Grow-only per context; RtowContextOptions.hitListCapacity sizes it */
+    int32_t hitListCapacity;        /* most surfaces one ray may meet in this scene before the batch reports RTOW_ERROR_CAPACITY (0: only the nearest hit is kept) */
+    int32_t wideCodes;              /* 1: more than 65 535 entities or tree nodes - the kernels that keep 32-bit candidate / stack codes run (tree read from HBM) */
 } RtowSceneInfo;
 
 /* ---- the operator's parameter block: SampleBatchJob's public fields (JOBS/SampleBatchJob.cs:23-51) ---- */
@@ -446,6 +451,11 @@ typedef enum RtowMemcpyKind {       /* CudaMemcpyKind, OptixApi.cs:33-40 */
  * receives every rank's rows in place (full-frame buffers; may be the same buffers as `mine`); on other ranks `frame` is ignored.
  * `what` selects the buffers (RtowGatherMask); rows are packed, sent and unpacked on `stream` (NULL = the context's own), asynchronously. */
 typedef struct RtowCommId { char bytes[128]; } RtowCommId;        /* ncclUniqueId */
+/* Which RCCL build rtowComm* loads.  NULL (the default): the copy this process already holds, else librccl.so.1 / librccl.so on the loader
+ * path, else /opt/rocm/lib.  A host that ships its own ROCm names the file here - before the first rtowComm* call of the process (afterwards:
+ * RTOW_ERROR_INVALID_VALUE; the library is loaded once).  tests/ point it at a stand-in transport (tests/native/fake_rccl.cpp: the same eight
+ * nccl* entry points over shared memory) so that the multi-rank gather runs on a box with one GPU, which RCCL itself refuses. */
+RTOW_API int rtowCommSetLibraryPath(const char* path);
 typedef enum RtowGatherMask { RTOW_GATHER_COLOR = 1, RTOW_GATHER_NORMAL = 2, RTOW_GATHER_ALBEDO = 4, RTOW_GATHER_SAMPLE_COUNT_WEIGHT = 8, RTOW_GATHER_ALL = 15 } RtowGatherMask;
 RTOW_API int rtowCommGetUniqueId(RtowCommId* outId);
 RTOW_API int rtowCommInit(RtowContext context, const RtowCommId* id, int32_t rank, int32_t worldSize);

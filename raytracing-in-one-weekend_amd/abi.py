@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 6
+RTOW_API_VERSION = 7
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -87,7 +87,7 @@ class SceneDesc(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("entityCount", C.c_int32), ("materialCount", C.c_int32), ("bvhNodeCount", C.c_int32),
                 ("bvhDepth", C.c_int32), ("ldsBytesScene", C.c_int32), ("sceneInLds", C.c_int32),
-                ("sceneBytesDevice", C.c_uint64)]
+                ("sceneBytesDevice", C.c_uint64), ("hitSpillBytes", C.c_uint64), ("hitListCapacity", C.c_int32), ("wideCodes", C.c_int32)]
 
 
 class View(C.Structure):
@@ -164,5 +164,5 @@ EXPORTED_SYMBOLS = [
     "rtowUploadSkyCubemap", "rtowUploadBlueNoise", "rtowUploadStbNoise", "rtowGetSceneInfo", "rtowSampleBatch", "rtowSampleBatchDevice", "rtowGetLastSampleKernelMs",
     "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize", "rtowGetBatchStatus", "rtowRegisterHostBuffer", "rtowUnregisterHostBuffer",
-    "rtowSampleBatchChainDevice", "rtowSampleBatchChain", "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
+    "rtowSampleBatchChainDevice", "rtowSampleBatchChain", "rtowCommSetLibraryPath", "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
 ]

@@ -115,6 +115,8 @@ struct RtowContext_t {
     int commRank = 0, commWorld = 1;
     float *dGatherSend = nullptr, *dGatherRecv = nullptr;
     size_t gatherSendFloats = 0, gatherRecvFloats = 0;
+    hipEvent_t evGatherDone = nullptr;    // end of the last gather: the staging blocks are per context, gathers may come on different streams
+    bool haveGatherDone = false;
 
     std::mutex mu;
 };
@@ -442,7 +444,8 @@ int takeOverflow(RtowContext ctx)
 {
     if (ctx->hCancel[1] == 0u) return RTOW_SUCCESS;
     ctx->hCancel[1] = 0u;
-    logf(ctx, 2, "rtow", "a ray hit more than 24 surfaces (hit-list capacity of volume scenes): results of this batch are invalid");
+    logf(ctx, 2, "rtow", "a ray met more surfaces than the hit-list capacity of this scene (%u; RtowContextOptions.hitListCapacity): results of this batch are invalid",
+         ctx->hitSpillEntries + (uint32_t)kLocalHitEntries);
     return RTOW_ERROR_CAPACITY;
 }
 
@@ -522,17 +525,29 @@ struct RcclApi {
 };
 constexpr int kRcclFloat32 = 7;
 
+std::mutex gRcclMu;
+std::string gRcclPath;        // rtowCommSetLibraryPath: the file to load instead of the default search
+std::string gRcclLoadError;   // why the last load attempt failed (dlerror() is per thread and may be null by the time it is logged)
+bool gRcclLoaded = false;
+
 RcclApi* rccl()
 {
-    static std::mutex mu;
     static RcclApi api;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(gRcclMu);
     if (api.ok()) return &api;
     static const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;     // a copy this process already holds
-    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) return nullptr;
+    if (!gRcclPath.empty()) {
+        h = dlopen(gRcclPath.c_str(), RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;     // a copy this process already holds
+        if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    }
+    if (!h) {
+        const char* e = dlerror();
+        gRcclLoadError = e ? e : "dlopen failed";
+        return nullptr;
+    }
     api.handle = h;
     api.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (int (*)(void**, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
@@ -542,7 +557,9 @@ RcclApi* rccl()
     api.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
     api.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
     api.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    return api.ok() ? &api : nullptr;
+    if (!api.ok()) { gRcclLoadError = "the library does not export the nccl* entry points the row gather needs"; return nullptr; }
+    gRcclLoaded = true;
+    return &api;
 }
 
 #define RCCL_TRY(ctx, api, expr)                                                                       \
@@ -573,6 +590,13 @@ int enqueueChain(RtowContext ctx, int count, const RtowSampleParams* params, con
     }
     const uint64_t paddedPixels = ((uint64_t)ownedRows(&params[0]) * (uint64_t)(int)params[0].size.x + 63u) & ~63ull;
     if (paddedPixels >= (1ull << 27)) fusable = false;
+    // one launch is one kernel variant, and the variant follows the record format (launchByDiag: 16-byte FULL_DIAGNOSTICS records need the
+    // counters compiled in): a chain in which only SOME batches carry a diagnostics buffer runs batch by batch, each with its own variant
+    if (diagnostics) {
+        int withDiag = 0;
+        for (int b = 0; b < count; b++) withDiag += diagnostics[b] != nullptr ? 1 : 0;
+        if (withDiag != 0 && withDiag != count) fusable = false;
+    }
     int rc = RTOW_SUCCESS;
     for (int first = 0; first < count && rc == RTOW_SUCCESS;) {
         const int n = fusable ? std::min(count - first, (int)kMaxChain) : 1;
@@ -644,6 +668,7 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->evStart) == hipSuccess && hipEventCreate(&ctx->evStop) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->evBatchDone, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->evGatherDone, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dWorkCounter, sizeof(unsigned int)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dPartials, sizeof(MetricsPartial) * kMetricsBlocks) == hipSuccess;
     void* pinned = nullptr;
@@ -687,6 +712,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     if (ctx->evBatchDone) (void)hipEventDestroy(ctx->evBatchDone);
+    if (ctx->evGatherDone) (void)hipEventDestroy(ctx->evGatherDone);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RTOW_SUCCESS;
@@ -881,6 +907,10 @@ RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
     info->ldsBytesScene = (int32_t)ctx->ldsSceneBytes;
     info->sceneInLds = ctx->ldsSceneBytes == ctx->scene.layout.totalBytes ? 1 : 0;
     info->sceneBytesDevice = ctx->scene.layout.totalBytes;
+    info->hitSpillBytes = (uint64_t)ctx->hitSpillEntries * (uint64_t)ctx->cuCount * (uint64_t)kBlockThreads * sizeof(uint4);
+    const bool keepsLists = ctx->scene.layout.exactTies || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
+    info->hitListCapacity = keepsLists ? (int32_t)(ctx->hitSpillEntries + (uint32_t)kLocalHitEntries) : 0;
+    info->wideCodes = 0;
     return RTOW_SUCCESS;
 }
 
@@ -1149,6 +1179,14 @@ RTOW_API int rtowAddAccumDevice(RtowContext ctx, int32_t pixelCount, const RtowA
     return RTOW_SUCCESS;
 }
 
+RTOW_API int rtowCommSetLibraryPath(const char* path)
+{
+    std::lock_guard<std::mutex> lock(gRcclMu);
+    if (gRcclLoaded) return RTOW_ERROR_INVALID_VALUE;              // loaded once per process: the choice comes before the first rtowComm* call
+    gRcclPath = path ? path : "";
+    return RTOW_SUCCESS;
+}
+
 RTOW_API int rtowCommGetUniqueId(RtowCommId* outId)
 {
     if (!outId) return RTOW_ERROR_INVALID_VALUE;
@@ -1167,7 +1205,11 @@ RTOW_API int rtowCommInit(RtowContext ctx, const RtowCommId* id, int32_t rank, i
     if (ctx->comm) return RTOW_ERROR_INVALID_VALUE;                // one communicator per context; rtowCommDestroy first
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     RcclApi* api = rccl();
-    if (!api) { logf(ctx, 2, "rccl", "librccl.so could not be loaded: %s", dlerror()); return RTOW_ERROR_UNSUPPORTED; }
+    if (!api) {
+        std::lock_guard<std::mutex> l2(gRcclMu);
+        logf(ctx, 2, "rccl", "the RCCL library could not be loaded: %s", gRcclLoadError.c_str());
+        return RTOW_ERROR_UNSUPPORTED;
+    }
     RcclUniqueId uid;
     memcpy(uid.internal, id->bytes, sizeof(uid.internal));
     void* comm = nullptr;
@@ -1231,11 +1273,20 @@ RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height
     }
     RcclApi* api = rccl();
     if (!api) return RTOW_ERROR_UNSUPPORTED;
+    // the packed-row staging is one block per context: a gather repacks it only after the previous gather's send / scatter is over,
+    // whatever stream that one was given
+    if (ctx->haveGatherDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evGatherDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+    auto gatherEnds = [&]() -> int {
+        HIP_TRY(ctx, hipEventRecord(ctx->evGatherDone, s), RTOW_ERROR_LAUNCH_FAILURE);
+        ctx->haveGatherDone = true;
+        return RTOW_SUCCESS;
+    };
 
     if (rank != root) {
         // pack this rank's rows of the selected buffers back to back, one send to the root over this GPU's own xGMI link to it
         const size_t need = packedFloats(rank);
         if (need > ctx->gatherSendFloats) {
+            HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);          // the old block may still be travelling
             if (ctx->dGatherSend) (void)hipFree(ctx->dGatherSend);
             ctx->dGatherSend = nullptr; ctx->gatherSendFloats = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->dGatherSend, need * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
@@ -1249,7 +1300,7 @@ RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height
                 at += (size_t)rows * width * kComponents[b];
             }
         if (need) RCCL_TRY(ctx, api, api->Send(ctx->dGatherSend, need, kRcclFloat32, root, ctx->comm, s));
-        return RTOW_SUCCESS;
+        return gatherEnds();
     }
 
     // root: one receive per peer into its own region of the staging block (posted as one group: all seven links run at once), then scatter
@@ -1257,15 +1308,21 @@ RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height
     std::vector<size_t> offset((size_t)world, 0);
     for (int r = 0; r < world; r++) { offset[(size_t)r] = total; if (r != root) total += packedFloats(r); }
     if (total > ctx->gatherRecvFloats) {
+        HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
         if (ctx->dGatherRecv) (void)hipFree(ctx->dGatherRecv);
         ctx->dGatherRecv = nullptr; ctx->gatherRecvFloats = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->dGatherRecv, total * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
         ctx->gatherRecvFloats = total;
     }
     RCCL_TRY(ctx, api, api->GroupStart());
-    for (int r = 0; r < world; r++)
-        if (r != root && packedFloats(r)) RCCL_TRY(ctx, api, api->Recv(ctx->dGatherRecv + offset[(size_t)r], packedFloats(r), kRcclFloat32, r, ctx->comm, s));
-    RCCL_TRY(ctx, api, api->GroupEnd());
+    int posted = 0;                                       // a failed ncclRecv must not leave the communicator's group open: it is closed on every path
+    for (int r = 0; r < world && posted == 0; r++)
+        if (r != root && packedFloats(r)) posted = api->Recv(ctx->dGatherRecv + offset[(size_t)r], packedFloats(r), kRcclFloat32, r, ctx->comm, s);
+    const int closed = api->GroupEnd();
+    if (posted != 0 || closed != 0) {
+        logf(ctx, 2, "rccl", "gather on the root failed: ncclRecv %s, ncclGroupEnd %s", api->GetErrorString(posted), api->GetErrorString(closed));
+        return RTOW_ERROR_LAUNCH_FAILURE;
+    }
     for (int r = 0; r < world; r++) {
         if (r == root) continue;
         size_t at = offset[(size_t)r];
@@ -1276,7 +1333,7 @@ RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height
                 at += (size_t)rows * width * kComponents[b];
             }
     }
-    return RTOW_SUCCESS;
+    return gatherEnds();
 }
 
 RTOW_API int rtowDeviceAlloc(RtowContext ctx, size_t sizeInBytes, void** outPointer)

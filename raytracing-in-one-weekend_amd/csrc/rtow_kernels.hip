@@ -7,6 +7,13 @@ namespace rtow {
 
 namespace {
 
+// The float3 streams of the post passes (normal, albedo, combined colour: 12 B per pixel, tightly packed) move as ONE 12-byte access per lane
+// (global_load_dwordx3 / global_store_dwordx3: lane stride 12 B, a wave's instruction covers 768 contiguous bytes) instead of three 4-byte
+// accesses with a 12-byte lane stride, which cost three times the address / tag work for the same bytes (rocprofv3, profiles/r03_post_passes.json).
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+__device__ __forceinline__ V3 load3(const float* p, size_t index) { const F3 v = reinterpret_cast<const F3*>(p)[index]; return v3(v.x, v.y, v.z); }
+__device__ __forceinline__ void store3(float* p, size_t index, V3 v) { F3 o; o.x = v.x; o.y = v.y; o.z = v.z; reinterpret_cast<F3*>(p)[index] = o; }
+
 // Launch order of the 64-pixel ticket chunks: most expensive first (longest-processing-time-first), from the per-chunk ray
 // counts of the previous launch.  Counting sort on a 1024-bucket quantisation of the cost; the order inside a bucket is
 // arbitrary - it only changes which lane renders which pixel, never a result.
@@ -39,8 +46,8 @@ __global__ void __launch_bounds__(256) fold_unit_records_kernel(SampleKernelArgs
     const size_t pix = (size_t)cy * (size_t)A.width + (size_t)cx;
     const float4 last = reinterpret_cast<const float4*>(A.inColor)[pix];
     V3 color = v3(last.x, last.y, last.z);
-    V3 normal = v3(A.inNormal[3 * pix], A.inNormal[3 * pix + 1], A.inNormal[3 * pix + 2]);
-    V3 albedo = v3(A.inAlbedo[3 * pix], A.inAlbedo[3 * pix + 1], A.inAlbedo[3 * pix + 2]);
+    V3 normal = load3(A.inNormal, pix);
+    V3 albedo = load3(A.inAlbedo, pix);
     float scw = A.inScw[pix];
     int count = (int)last.w;
     const float weight = scw / (float)count;                              // Diagnostics.SampleCountWeight (:128-130)
@@ -65,8 +72,8 @@ __global__ void __launch_bounds__(256) fold_unit_records_kernel(SampleKernelArgs
     }
     reinterpret_cast<float4*>(A.outColor)[pix] = make_float4(color.x, color.y, color.z, (float)count);
     const V3 on = count == 0 ? fbNormal : normal, oa = count == 0 ? fbAlbedo : albedo;
-    A.outNormal[3 * pix] = on.x; A.outNormal[3 * pix + 1] = on.y; A.outNormal[3 * pix + 2] = on.z;
-    A.outAlbedo[3 * pix] = oa.x; A.outAlbedo[3 * pix + 1] = oa.y; A.outAlbedo[3 * pix + 2] = oa.z;
+    store3(A.outNormal, pix, on);
+    store3(A.outAlbedo, pix, oa);
     A.outScw[pix] = scw;
     if (A.diagnostics) {
         if (A.diagnosticsStride >= 16) *reinterpret_cast<float4*>(A.diagnostics + pix * 16u) = make_float4(rays, bounds, cands, weight);
@@ -259,6 +266,7 @@ __global__ void __launch_bounds__(256) combine_kernel(RtowCombineParams p, const
     const int n = p.width * p.height;
     for (int index = (int)(blockIdx.x * blockDim.x + threadIdx.x); index < n; index += (int)(gridDim.x * blockDim.x)) {
         float4 c = inColor[index];
+        const V3 nIn = load3(inNormal, (size_t)index), aIn = load3(inAlbedo, (size_t)index);
         int count = (int)c.w;
         if (!p.debugMode && count == 0) {
             int tentative = index;
@@ -274,15 +282,15 @@ __global__ void __launch_bounds__(256) combine_kernel(RtowCombineParams p, const
         else finalColor = v3(c.x / (float)count, c.y / (float)count, c.z / (float)count);
 
         const float denom = (float)(count > 1 ? count : 1);
-        V3 alb = v3(inAlbedo[3 * (size_t)index] / denom, inAlbedo[3 * (size_t)index + 1] / denom, inAlbedo[3 * (size_t)index + 2] / denom);
+        V3 alb = v3(aIn.x / denom, aIn.y / denom, aIn.z / denom);
         if (p.ldrAlbedo) alb = v3(um_min(alb.x, 1.0f), um_min(alb.y, 1.0f), um_min(alb.z, 1.0f));
-        const V3 nv = v3(inNormal[3 * (size_t)index] / denom, inNormal[3 * (size_t)index + 1] / denom, inNormal[3 * (size_t)index + 2] / denom);
+        const V3 nv = v3(nIn.x / denom, nIn.y / denom, nIn.z / denom);
         const float len = dot(nv, nv);
         V3 nn = v3(0, 0, 0);
         if (len > 1.175494351e-38f) { const float r = 1.0f / __builtin_sqrtf(len); nn = v3(nv.x * r, nv.y * r, nv.z * r); } // normalizesafe
-        outColor[3 * (size_t)index] = finalColor.x; outColor[3 * (size_t)index + 1] = finalColor.y; outColor[3 * (size_t)index + 2] = finalColor.z;
-        outNormal[3 * (size_t)index] = nn.x; outNormal[3 * (size_t)index + 1] = nn.y; outNormal[3 * (size_t)index + 2] = nn.z;
-        outAlbedo[3 * (size_t)index] = alb.x; outAlbedo[3 * (size_t)index + 1] = alb.y; outAlbedo[3 * (size_t)index + 2] = alb.z;
+        store3(outColor, (size_t)index, finalColor);
+        store3(outNormal, (size_t)index, nn);
+        store3(outAlbedo, (size_t)index, alb);
     }
 }
 
@@ -314,11 +322,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(int n, const float* __res
                                                        uchar4* __restrict__ outAlbedo)
 {
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
-        const size_t b = 3 * (size_t)i;
-        outColor[i] = make_uchar4((unsigned char)to_byte(inColor[b]), (unsigned char)to_byte(inColor[b + 1]), (unsigned char)to_byte(inColor[b + 2]), 255);
-        outNormal[i] = make_uchar4((unsigned char)to_byte(inNormal[b] * 0.5f + 0.5f), (unsigned char)to_byte(inNormal[b + 1] * 0.5f + 0.5f),
-                                   (unsigned char)to_byte(inNormal[b + 2] * 0.5f + 0.5f), 255);
-        outAlbedo[i] = make_uchar4((unsigned char)to_byte(inAlbedo[b]), (unsigned char)to_byte(inAlbedo[b + 1]), (unsigned char)to_byte(inAlbedo[b + 2]), 255);
+        const V3 c = load3(inColor, (size_t)i), nm = load3(inNormal, (size_t)i), al = load3(inAlbedo, (size_t)i);
+        outColor[i] = make_uchar4((unsigned char)to_byte(c.x), (unsigned char)to_byte(c.y), (unsigned char)to_byte(c.z), 255);
+        outNormal[i] = make_uchar4((unsigned char)to_byte(nm.x * 0.5f + 0.5f), (unsigned char)to_byte(nm.y * 0.5f + 0.5f), (unsigned char)to_byte(nm.z * 0.5f + 0.5f), 255);
+        outAlbedo[i] = make_uchar4((unsigned char)to_byte(al.x), (unsigned char)to_byte(al.y), (unsigned char)to_byte(al.z), 255);
     }
 }
 
@@ -377,23 +384,30 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
 // rtowGatherRowsDevice: rows first, first + step, ... of a full-frame buffer <-> one contiguous block (what travels over xGMI).
 // HBM bound, 4 B read + 4 B written per float; at most 11 floats per owned pixel per batch.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) copy_rows_kernel(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, int toFrame)
+template <typename T>
+__global__ void __launch_bounds__(256) copy_rows_kernel(T* frame, T* packed, unsigned rowUnits, unsigned rows, unsigned first, unsigned step, int toFrame)
 {
-    const size_t total = (size_t)rows * rowFloats;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t k = i / rowFloats, j = i - k * rowFloats;
-        const size_t f = ((size_t)first + k * step) * rowFloats + j;
-        if (toFrame) frame[f] = packed[i];
-        else packed[i] = frame[f];
+    // one row per blockIdx.y slice, grid-stride inside the row: no division per element
+    for (unsigned k = blockIdx.y; k < rows; k += gridDim.y) {
+        T* f = frame + ((size_t)first + (size_t)k * step) * rowUnits;
+        T* q = packed + (size_t)k * rowUnits;
+        for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < rowUnits; j += gridDim.x * blockDim.x) {
+            if (toFrame) f[j] = q[j];
+            else q[j] = f[j];
+        }
     }
 }
 
 hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, bool toFrame, hipStream_t stream)
 {
-    const size_t total = (size_t)rows * rowFloats;
-    if (total == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)(total < (size_t)256 * 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, stream, frame, packed, rowFloats, rows, first, step, toFrame ? 1 : 0);
+    if ((size_t)rows * rowFloats == 0) return hipSuccess;
+    // rows travel as 16-byte units when every row starts on a 16-byte boundary in both buffers
+    const bool wide = (rowFloats & 3u) == 0u && ((reinterpret_cast<uintptr_t>(frame) | reinterpret_cast<uintptr_t>(packed)) & 15u) == 0u;
+    const unsigned units = wide ? rowFloats / 4u : rowFloats;
+    const unsigned bx = units < 256u * 8u ? (units + 255u) / 256u : 8u;
+    const unsigned by = rows < 4096u ? rows : 4096u;
+    if (wide) hipLaunchKernelGGL(copy_rows_kernel<float4>, dim3(bx, by), dim3(256), 0, stream, reinterpret_cast<float4*>(frame), reinterpret_cast<float4*>(packed), units, rows, first, step, toFrame ? 1 : 0);
+    else hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(bx, by), dim3(256), 0, stream, frame, packed, units, rows, first, step, toFrame ? 1 : 0);
     return hipGetLastError();
 }
 

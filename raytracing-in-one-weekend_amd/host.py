@@ -99,6 +99,11 @@ class Context:
 
     # ---- multi-GPU: one process per GPU, rows gathered over RCCL behind the C ABI ----
     @staticmethod
+    def comm_set_library_path(path):
+        """rtowCommSetLibraryPath: which RCCL build rtowComm* loads (None = the default search); before the first rtowComm* call of the process."""
+        check(load().rtowCommSetLibraryPath(path.encode() if path else None), "rtowCommSetLibraryPath")
+
+    @staticmethod
     def comm_unique_id():
         cid = abi.CommId()
         check(load().rtowCommGetUniqueId(C.byref(cid)), "rtowCommGetUniqueId")
@@ -119,8 +124,8 @@ class Context:
 
     def close(self):
         if self.handle:
-            self._registered = []          # rtowDestroyContext drops the registrations
-            load().rtowDestroyContext(self.handle)
+            load().rtowDestroyContext(self.handle)   # drops the registrations (hipHostUnregister) while the arrays are still alive ...
+            self._registered = []                    # ... and only then may they go
             self.handle = C.c_void_p()
 
     def __enter__(self):

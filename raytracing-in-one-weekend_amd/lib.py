@@ -68,6 +68,7 @@ def load():
     lib.rtowGetBatchStatus.argtypes = [vp]
     lib.rtowRegisterHostBuffer.argtypes = [vp, vp, C.c_size_t]
     lib.rtowUnregisterHostBuffer.argtypes = [vp, vp]
+    lib.rtowCommSetLibraryPath.argtypes = [C.c_char_p]
     lib.rtowCommGetUniqueId.argtypes = [C.POINTER(abi.CommId)]
     lib.rtowCommInit.argtypes = [vp, C.POINTER(abi.CommId), C.c_int32, C.c_int32]
     lib.rtowCommDestroy.argtypes = [vp]

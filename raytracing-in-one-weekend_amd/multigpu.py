@@ -118,7 +118,7 @@ def fold_partials(acc_flat, partials, add_flat):
     return acc_flat
 
 
-def render_batches(render_full, acc_slice, n, rank, world, add_flat, group=None, dst=0, exchange=None, frame=None):
+def render_batches(render_full, acc_slice, n, rank, world, add_flat, group=None, dst=0, exchange=None, frame=None, via_host=False):
     """One sample batch, batch-parallel, with the fold spread over the ranks.
 
     `render_full()` returns this rank's partial accumulators (from ZERO inputs, its own seed and sample share) as one flat
@@ -129,19 +129,29 @@ def render_batches(render_full, acc_slice, n, rank, world, add_flat, group=None,
       2. acc_slice += partial_0[r], += partial_1[r], ...  in rank order - element for element the same float adds, in the same
          order, as folding whole partials on one rank, so the frame is bit-identical to that;
       3. gather of the accumulated slices on `dst`: the frame of this batch (1/world of the frame per peer).
-    Returns the flat frame [padded_floats] on `dst`, None elsewhere.  `exchange` / `frame` are optional preallocated buffers."""
+    Returns the flat frame [padded_floats] on `dst`, None elsewhere.  `exchange` / `frame` are optional preallocated buffers.
+    `via_host`: development only (ranks sharing one GPU over gloo, which has no device all-to-all): the two collectives run on host copies."""
     part = render_full()
     m = slice_floats(n, world)
     if world == 1:
         return fold_partials(acc_slice, [part], add_flat)
     if exchange is None:
         exchange = torch.empty_like(part)
-    dist.all_to_all_single(exchange, part, group=group)
+    if via_host:
+        host_out = torch.empty(part.shape, dtype=part.dtype)
+        dist.all_to_all_single(host_out, part.cpu(), group=group)
+        exchange.copy_(host_out)
+    else:
+        dist.all_to_all_single(exchange, part, group=group)
     fold_partials(acc_slice, [exchange[j * m:(j + 1) * m] for j in range(world)], add_flat)
-    gather_list = None
-    if rank == dst:
-        if frame is None:
-            frame = torch.empty_like(part)
-        gather_list = list(frame.view(world, m).unbind(0))
+    if rank == dst and frame is None:
+        frame = torch.empty_like(part)
+    if via_host:
+        host_list = [torch.empty(m, dtype=part.dtype) for _ in range(world)] if rank == dst else None
+        dist.gather(acc_slice.cpu(), host_list, dst=dst, group=group)
+        if rank == dst:
+            frame.view(world, m).copy_(torch.stack(host_list))
+        return frame if rank == dst else None
+    gather_list = list(frame.view(world, m).unbind(0)) if rank == dst else None
     dist.gather(acc_slice, gather_list, dst=dst, group=group)
     return frame if rank == dst else None

@@ -84,3 +84,29 @@ def test_missing_library_raises(rt, monkeypatch, tmp_path):
     monkeypatch.setattr(rt.lib, "LIB_PATH", str(tmp_path / "librtow_hip.so"))
     with pytest.raises(FileNotFoundError):
         rt.lib.load()
+
+
+def test_comm_library_path_selects_the_rccl_build_once_per_process():
+    """rtowCommSetLibraryPath (include/rtow.h): the host names the RCCL build rtowComm* loads, before the first rtowComm* call; afterwards the choice is
+    over.  Checked without a GPU through the tests' stand-in transport, whose ncclGetUniqueId needs no device (a fresh process: the library is
+    loaded once)."""
+    import subprocess
+    import sys
+    fake = os.path.join(ROOT, "tests", "build", "libfake_rccl.so")
+    assert os.path.exists(fake), "python __graft_entry__.py builds tests/build/libfake_rccl.so"
+    code = r'''
+import importlib, sys
+sys.path.insert(0, sys.argv[1])
+rt = importlib.import_module("raytracing-in-one-weekend_amd")
+lib = rt.lib.load()
+a = rt.abi
+assert lib.rtowCommSetLibraryPath(b"/nonexistent/librccl.so") == 0
+assert lib.rtowCommGetUniqueId(a.CommId()) == a.RTOW_ERROR_UNSUPPORTED          # cannot be loaded: reported, not fatal, and not yet final
+assert lib.rtowCommSetLibraryPath(sys.argv[2].encode()) == 0
+uid = rt.Context.comm_unique_id()
+assert uid.startswith(b"fake_rccl_") and len(uid) == 128
+assert lib.rtowCommSetLibraryPath(None) == a.RTOW_ERROR_INVALID_VALUE             # loaded: the choice is over for this process
+print("ok")
+'''
+    proc = subprocess.run([sys.executable, "-c", code, ROOT, fake], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0 and proc.stdout.strip() == "ok", proc.stdout + proc.stderr

@@ -212,3 +212,35 @@ def test_chain_after_the_frame_grows(rt):
         for w, h in ((64, 36), (320, 180), (96, 54), (640, 360)):
             plist = _params(rt, scene, w, h, 3, 8, (5, 6, 7))
             _same(_chained(rt, ctx, plist, w * h, 4), _sequential(rt, ctx, plist, w * h, 4), "%dx%d" % (w, h))
+
+
+@pytest.mark.parametrize("stride", [4, 16])
+@pytest.mark.parametrize("pattern", [(False, True, True), (True, False, True), (False, False, True)])
+def test_chain_with_diagnostics_for_some_batches_only(rt, gpu_context, stride, pattern):
+    """Per-batch diagnostics pointers may be NULL (include/rtow.h).  One launch is one kernel variant and the variant follows the record
+    format, so a chain whose FIRST batch has no buffer while a later one wants 16-byte FULL_DIAGNOSTICS records must not run the short-record
+    variant over all of them (4-byte RayCount records at pix * 4 inside a buffer read as 16-byte records, BoundsHitCount /
+    CandidateCount never written): every batch that has a buffer gets exactly the records it gets when run on its own."""
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h, spp, depth = 160, 90, 3, 8
+    n = w * h
+    plist = _params(rt, scene, w, h, spp, depth, [41, 42, 43], diagnostics_stride=stride)
+    seq = _sequential(rt, ctx, plist, n, stride)
+    outs = _zero_bufs(rt, ctx, n)
+    diags = [rt.DeviceBuffer(ctx, n * stride).zero() if want else None for want in pattern]
+    assert rt.sample_batch_chain_device(ctx, plist, outs, outs, diags) == 0
+    ctx.synchronize()
+    got = _download(outs, n)
+    for k, _ in KEYS:
+        assert np.array_equal(got[k].view(np.uint32), seq[k].view(np.uint32)), k
+    for i, d in enumerate(diags):
+        if d is None:
+            continue
+        rec = d.download(np.float32, (n, stride // 4))
+        assert np.array_equal(rec.view(np.uint32), seq["diag"][i].view(np.uint32)), ("diagnostics of batch", i)
+        if stride == 16:
+            assert rec[:, 1].max() > 0 and rec[:, 2].max() > 0        # BoundsHitCount / CandidateCount were really counted
+    for b in outs + [d for d in diags if d is not None]:
+        b.free()

@@ -1,9 +1,10 @@
 """GPU: the multi-GPU boundary behind the C ABI (rtowComm*, rtowGatherRowsDevice, include/rtow.h).
 
 One process per GPU, the frame row-interleaved with the reference's slice contract (JOBS/SampleBatchJob.cs:69-70), one gather of the owned
-rows to the root per batch.  The box these tests run on has ONE GPU: the two-rank test puts both ranks on it (two processes, two contexts,
-one RCCL communicator) - which RCCL 2.27 refuses, so there the test skips with that reason; on a box with two or more GPUs each rank takes
-its own and the test runs.  The collective, the packing and the assembly are the same code an 8-GPU node runs."""
+rows to the root per batch.  The box these tests run on has ONE GPU and RCCL refuses two ranks on one device, so the multi-rank tests point
+the product at a stand-in transport (rtowCommSetLibraryPath -> tests/native/fake_rccl.cpp: the same nccl* entry points over /dev/shm) and
+run 2, 3 and 8 PROCESSES on that GPU: packing, ncclSend | grouped ncclRecv, scatter and assembly are the product's own code, the one an
+8-GPU node runs over xGMI.  Where the box has a GPU per rank the same test also runs over the real RCCL."""
 import ctypes as C
 import importlib
 import os
@@ -43,89 +44,183 @@ def test_gather_rows_single_rank_copies_owned_rows(rt, gpu_context):
         b.free()
 
 
-RANK_SCRIPT = r'''
-import importlib, os, sys, time
+FAKE_RCCL = os.path.join(ROOT, "tests", "build", "libfake_rccl.so")
+
+
+def _build_fake_rccl():
+    src = os.path.join(ROOT, "tests", "native", "fake_rccl.cpp")
+    if not os.path.exists(FAKE_RCCL) or os.path.getmtime(FAKE_RCCL) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(FAKE_RCCL), exist_ok=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-fPIC", "-shared", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", FAKE_RCCL,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-pthread"], check=True)
+    return FAKE_RCCL
+
+
+RANK_SCRIPT = r"""
+import ctypes, importlib, json, os, sys, time
 import numpy as np
 sys.path.insert(0, sys.argv[1])
-rank, world, idfile, outfile = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+rank, world, idfile, outdir, transport = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+cases = json.load(open(os.path.join(outdir, "cases.json")))
 rt = importlib.import_module("raytracing-in-one-weekend_amd")
 a = rt.abi
-import ctypes
+lib = rt.lib.load()
 count = ctypes.c_int(0)
 ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(count))
-device = rank if count.value > rank else 0           # one GPU per rank where the box has them; else every rank on the one GPU
-ctx = rt.Context(device, log=lambda lvl, tag, msg, ud: print("[rank %d] %s: %s" % (rank, tag.decode(), msg.decode()), flush=True), log_level=4)
+device = 0
+if transport != "rccl":
+    rt.Context.comm_set_library_path(transport)          # the stand-in transport: every rank on the one GPU
+else:
+    device = rank                                         # the real thing: one GPU per rank
+log = []
+ctx = rt.Context(device, log=lambda lvl, tag, msg, ud: log.append("[rank %d] %s: %s" % (rank, tag.decode(), msg.decode())), log_level=4)
 if rank == 0:
     uid = rt.Context.comm_unique_id()
     open(idfile + ".tmp", "wb").write(uid)
-    os.rename(idfile + ".tmp", idfile)                # the host's own channel for the 128 bytes: here a file
+    os.rename(idfile + ".tmp", idfile)                    # the host's own channel for the 128 bytes: here a file
 else:
-    for _ in range(600):
+    for _ in range(2400):
         if os.path.exists(idfile):
             break
         time.sleep(0.05)
     uid = open(idfile, "rb").read()
-try:
-    ctx.comm_init(uid, rank, world)
-except rt.lib.RtowError as e:
-    print("[rank %d] comm_init failed: %s" % (rank, e), flush=True)
-    sys.exit(3)
+ctx.comm_init(uid, rank, world)
+assert lib.rtowCommSetLibraryPath(None) == a.RTOW_ERROR_INVALID_VALUE      # the library is loaded: the choice is over
 scene = rt.scenes.cover_scene()
 ctx.upload_scene(scene.desc())
-w, h, spp = 96, 54, 4
-n = w * h
-p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=6, seed=9, slice_offset=rank, slice_divider=world)
-bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
-acc = a.AccumBuffers(*[b.ptr for b in bufs])
-for batch in range(2):                                # two batches: accumulate in place, gather after each like a frame loop would
-    p.seed = 9 + batch
-    job = rt.SampleBatchJob(ctx, p)
-    job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = bufs
-    job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = bufs
-    rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
-    ctx.gather_rows(w, h, world, acc, acc if rank == 0 else None, what=a.GATHER_ALL, root=0)
-ctx.synchronize()
-if rank == 0:
-    np.savez(outfile, **{k: b.download(np.float32, (n, c)) for k, b, c in zip(("color", "normal", "albedo", "scw"), bufs, (4, 3, 3, 1))})
+fake = ctypes.CDLL(transport) if transport != "rccl" else None
+for ci, case in enumerate(cases):
+    w, h, spp, what, root, separate = case["w"], case["h"], case["spp"], case["what"], case["root"], case["separate"]
+    n = w * h
+    p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=6, seed=9, slice_offset=rank, slice_divider=world)
+    bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+    frame = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)] if (separate and rank == root) else bufs
+    acc = a.AccumBuffers(*[b.ptr for b in bufs])
+    fr = a.AccumBuffers(*[b.ptr for b in frame])
+    for batch in range(case["batches"]):                  # accumulate in place, gather after each batch like a frame loop would
+        p.seed = 9 + batch
+        job = rt.SampleBatchJob(ctx, p)
+        job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = bufs
+        job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = bufs
+        rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
+        if case.get("fail_first_recv") and rank == root and batch == 0:
+            # the first ncclRecv of this process fails (FAKE_RCCL_FAIL_RECV=1): the call reports it, the communicator's group is closed again ...
+            rc = lib.rtowGatherRowsDevice(ctx.handle, w, h, world, ctypes.byref(acc), ctypes.byref(fr), what, root, None)
+            assert rc == a.RTOW_ERROR_LAUNCH_FAILURE, rc
+            assert fake.fakeRcclGroupDepth() == 0 and fake.fakeRcclOpenGroups() == 0, "the gather left ncclGroupStart open on its error path"
+            assert any("gather on the root failed" in l for l in log), log
+            # ... and the very next gather of the same communicator delivers the rows the peers sent
+        ctx.gather_rows(w, h, world, acc, fr if rank == root else None, what=what, root=root)
+    ctx.synchronize()
+    if rank == root:
+        np.savez(os.path.join(outdir, "case%d.npz" % ci), **{k: b.download(np.float32, (n, c)) for k, b, c in zip(("color", "normal", "albedo", "scw"), frame, (4, 3, 3, 1))})
+    for b in set(bufs + frame):
+        b.free()
 ctx.comm_destroy()
 ctx.close()
-'''
+"""
+
+KEYS = (("color", 4, 1), ("normal", 3, 2), ("albedo", 3, 4), ("scw", 1, 8))
 
 
-def test_two_ranks_gather_the_single_gpu_frame(rt, gpu_context):
-    """Two processes, SliceDivider = 2: after rtowGatherRowsDevice the root holds, bit for bit, the frame one process renders alone."""
-    world = 2
-    count = C.c_int(0)
-    C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(count))
-    if count.value < world:
-        # RCCL 2.27 refuses a communicator with two ranks on one device ("duplicate GPU") - and on some boxes the attempt does not return at
-        # all (one 240 s hang in round 2) - so a one-GPU box does not try; the 8-GPU node runs this path through bench.py --gpus N
-        pytest.skip("the gather needs one GPU per rank: %d device(s) here" % count.value)
+def _run_ranks(rt, gpu_context, world, cases, transport, env_extra=None, root_env=None):
+    """`world` processes render their slices of every case and gather them; returns nothing - asserts that each gathered frame equals, bit for
+    bit, the frame ONE process renders alone (buffers outside the `what` mask: only the root's own rows, in place)."""
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "rank.py")
         open(script, "w").write(RANK_SCRIPT)
-        idfile, outfile = os.path.join(tmp, "uid"), os.path.join(tmp, "frame.npz")
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
-        procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), idfile, outfile if r == 0 else os.path.join(tmp, "r%d.txt" % r)],
-                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        import json
+        json.dump(cases, open(os.path.join(tmp, "cases.json"), "w"))
+        idfile = os.path.join(tmp, "uid")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"), **(env_extra or {}))
+        procs = []
+        for r in range(world):
+            e = dict(env, **(root_env or {})) if (root_env and r == cases[0]["root"]) else env
+            procs.append(subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), idfile, tmp, transport], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         outs = []
         for pr in procs:
             try:
-                outs.append(pr.communicate(timeout=240)[0])
+                outs.append(pr.communicate(timeout=420)[0])
             except subprocess.TimeoutExpired:
                 for q in procs:
                     q.kill()
                 pytest.fail("rank processes hung: " + "\n".join(outs))
-        if any(pr.returncode == 3 for pr in procs) and any("uplicate GPU" in o or "invalid usage" in o for o in outs):
-            pytest.skip("this RCCL build refuses two ranks on one device; the gather needs one GPU per rank: " + outs[0][-300:])
         assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
-        got = np.load(outfile)
         scene = rt.scenes.cover_scene()
         gpu_context.upload_scene(scene.desc())
-        w, h, spp = 96, 54, 4
-        acc = None
-        for batch in range(2):
-            p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=6, seed=9 + batch)
-            acc = rt.sample_batch_host(gpu_context, p, inputs=None if acc is None else {k: acc[k] for k in ("color", "normal", "albedo", "scw")})
-        for k in ("color", "normal", "albedo", "scw"):
-            assert np.array_equal(got[k].reshape(-1).view(np.uint32), acc[k].reshape(-1).view(np.uint32)), k
+        for ci, case in enumerate(cases):
+            w, h, spp = case["w"], case["h"], case["spp"]
+            got = np.load(os.path.join(tmp, "case%d.npz" % ci))
+            acc = None
+            for batch in range(case["batches"]):
+                p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=6, seed=9 + batch)
+                acc = rt.sample_batch_host(gpu_context, p, inputs=None if acc is None else {k: acc[k] for k, _, _ in KEYS})
+            rows = np.arange(w * h) // w
+            mine = rows % world == case["root"]
+            for k, c, bit in KEYS:
+                want = acc[k].reshape(w * h, c).copy()
+                if not (case["what"] & bit):
+                    want[~mine] = 0                                        # not gathered: the root holds its own rows only ...
+                    if case["separate"]:
+                        want[:] = 0                                        # ... and a separate frame buffer outside the mask is not touched at all
+                assert np.array_equal(got[k].reshape(w * h, c).view(np.uint32), want.view(np.uint32)), (world, ci, case, k)
+
+
+def _cases(world):
+    A = 15
+    if world == 2:
+        cases = [dict(w=96, h=54, spp=4, what=A, root=0, separate=False, batches=2), dict(w=97, h=53, spp=2, what=1, root=1, separate=False, batches=2),
+                 dict(w=64, h=33, spp=2, what=2 | 8, root=0, separate=True, batches=2)]
+        cases += [dict(w=32, h=9, spp=1, what=m, root=m & 1, separate=bool(m & 4), batches=1) for m in range(1, 16)]      # every `what` mask
+        return cases
+    if world == 3:
+        return [dict(w=96, h=55, spp=3, what=A, root=2, separate=False, batches=2), dict(w=50, h=7, spp=2, what=4, root=1, separate=True, batches=2),
+                dict(w=33, h=2, spp=2, what=A, root=0, separate=False, batches=1)]                                          # rank 2 owns no row
+    return [dict(w=96, h=54, spp=3, what=A, root=0, separate=False, batches=2), dict(w=40, h=5, spp=2, what=1 | 4, root=5, separate=False, batches=2),     # ranks 5..7 own no row - one of them is the root
+            dict(w=64, h=67, spp=2, what=1, root=3, separate=True, batches=1)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_ranks_gather_the_single_gpu_frame(rt, gpu_context, world):
+    """SliceDivider = world processes: after rtowGatherRowsDevice the root holds, bit for bit, the frame one process renders alone - even and odd
+    heights, fewer rows than ranks, root != 0, every `what` mask, frame == mine and frame != mine, two batches accumulated in place."""
+    _run_ranks(rt, gpu_context, world, _cases(world), _build_fake_rccl())
+    count = C.c_int(0)
+    C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(count))
+    if count.value >= world:                                                # a GPU per rank: the same over the real RCCL
+        _run_ranks(rt, gpu_context, world, _cases(world)[:3], "rccl")
+
+
+def test_gather_closes_the_rccl_group_on_a_failed_receive(rt, gpu_context):
+    """an ncclRecv that fails between ncclGroupStart and ncclGroupEnd must not leave the communicator's group open.  The root's first
+    receive is made to fail: rtowGatherRowsDevice reports RTOW_ERROR_LAUNCH_FAILURE, no group is left open, and the next gather on the same
+    communicator delivers the frame."""
+    _run_ranks(rt, gpu_context, 2, [dict(w=96, h=54, spp=2, what=15, root=0, separate=False, batches=2, fail_first_recv=True)], _build_fake_rccl(),
+               root_env={"FAKE_RCCL_FAIL_RECV": "1"})
+
+
+def test_bench_with_two_ranks_runs_end_to_end_through_the_c_abi_gather(rt):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on this one-GPU box in its debug mode: both ranks on
+    cuda:0, torch.distributed over gloo, the tile partition's gather through rtowCommInit / rtowGatherRowsDevice on the stand-in transport.  The
+    N > 1 JSON line - `value` from the tile partition, `partitions` beside it, `config.gather` naming the C-ABI path - prints and is consistent."""
+    import json
+    import socket
+    _build_fake_rccl()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RTOW_BENCH_DEBUG_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "181", "--spp", "8"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560, cwd=ROOT)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["config"]["gather"].startswith("rtowGatherRowsDevice"), out["config"]["gather"]
+    assert out["config"]["partition"].startswith("DEBUG")
+    parts = out["partitions"]
+    assert set(parts) >= {"tiles", "batches"} and all(v["value"] > 0 for v in parts.values())
+    assert abs(parts["tiles"]["value"] - out["value"]) < 1e-6 * max(out["value"], 1.0)
