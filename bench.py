@@ -91,6 +91,8 @@ SCENE_TEXT = {
     "cover": "cover scene (486 spheres, generated per Final Scene (Book 1).asset, seed 700)",
     "stress": "stress scene (10 000 spheres dart-thrown on 100x100, seed 10000; tree does not fit LDS)",
     "moving": "moving-spheres scene (Random With Movement (Book 2).asset: 80 % of the random spheres move, aperture 0.05)",
+    "mesh": "mesh-grid scene (14 x 14 icospheres of 1 280 smooth triangles + floor = 250 882 triangle entities, one per mesh triangle like the reference's live host, "
+            "materials blended across the grid like UNITY/GridGenerator.cs; 32-bit candidate codes, tree in HBM, exact-tie kernels)",
 }
 
 
@@ -106,12 +108,13 @@ def cpu_baseline(rt, scene, width, height, depth, budget_s=10.0, scene_name="cov
     osc = ob.OracleScene(scene.desc(), kind="fast")
     cores = usable_cores()
     # calibration on the workload itself (full frame, 8 spp, ~1 s): small frames under-report the rate (thread start-up, cold caches)
-    cal = rt.scenes.make_params(scene, width, height, spp=8, trace_depth=depth)
+    focus = scene.meta.get("focus")
+    cal = rt.scenes.make_params(scene, width, height, spp=8, trace_depth=depth, focus=focus)
     t = time.perf_counter()
     osc.sample_batch(cal, nthreads=cores)
     cal_rate = width * height * 8 / (time.perf_counter() - t)
     spp = int(max(8, min(128, round(budget_s * cal_rate / (width * height)))))
-    p = rt.scenes.make_params(scene, width, height, spp=spp, trace_depth=depth)
+    p = rt.scenes.make_params(scene, width, height, spp=spp, trace_depth=depth, focus=focus)
     best = None
     rays = 0
     for _ in range(2):
@@ -177,7 +180,11 @@ def post_passes(rt, ctx, lib, torch, dev, stream, sizes=((1920, 1080), (3840, 21
         acc2 = [torch.zeros(n, c, device=dev) for c in (4, 3, 3)] + [torch.zeros(n, device=dev)]
         cp = abi.CombineParams(w, h, 0, 1)
         metrics = abi.Metrics()
-        sp = stream.cuda_stream
+        # a stream of its own with a real handle: the C ABI maps a NULL stream to the CONTEXT's stream, which torch's events would not see
+        ps = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        sp = ps.cuda_stream
+        assert sp != 0
         dst = abi.AccumBuffers(*[t.data_ptr() for t in acc2])
         src = abi.AccumBuffers(color4.data_ptr(), normal.data_ptr(), albedo.data_ptr(), scw.data_ptr())
         passes = {
@@ -191,10 +198,11 @@ def post_passes(rt, ctx, lib, torch, dev, stream, sizes=((1920, 1080), (3840, 21
             for _ in range(2):
                 rt.lib.check(fn(), name)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
+            ps.synchronize()
+            e0.record(ps)
             for _ in range(iters):
                 rt.lib.check(fn(), name)
-            e1.record(stream)
+            e1.record(ps)
             e1.synchronize()
             ms = e0.elapsed_time(e1) / iters
             gbs = n * bytes_per_px / (ms * 1e-3) / 1e9
@@ -270,7 +278,8 @@ def main():
 
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
     n = W * H
-    scene = {"cover": rt.scenes.cover_scene, "stress": rt.scenes.stress_scene, "moving": rt.scenes.moving_scene}[args.scene]()
+    scene = {"cover": rt.scenes.cover_scene, "stress": rt.scenes.stress_scene, "moving": rt.scenes.moving_scene, "mesh": rt.scenes.mesh_grid_scene}[args.scene]()
+    focus = scene.meta.get("focus")                       # scenes without spheres carry their focus distance (the host's auto-focus probe, UNITY/Raytracer.cs:608-609)
     ctx = rt.Context(local_rank, flags=args.context_flags, scheduler_tune=[int(x) for x in args.tune.split(",")] if args.tune else None)
     ctx.upload_scene(scene.desc())
     info = ctx.scene_info()
@@ -338,9 +347,9 @@ def main():
         exchange = flat() if batches else None
         diags = [torch.zeros(n, device=dev) for _ in range(max(1, chain))]
         if batches:
-            base = rt.scenes.make_params(scene, W, H, spp=mg.batch_split(spp, rank, world), trace_depth=depth)
+            base = rt.scenes.make_params(scene, W, H, spp=mg.batch_split(spp, rank, world), trace_depth=depth, focus=focus)
         else:
-            base = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, slice_offset=rank, slice_divider=world)
+            base = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, slice_offset=rank, slice_divider=world, focus=focus)
         kernel_ms = []
 
         def params_for(seed):
@@ -511,7 +520,8 @@ def main():
                 "gather": None if world == 1 else ("rtowGatherRowsDevice (DEBUG: the tests' stand-in transport instead of RCCL, ranks share one GPU)" if (have_comm and shared_gpu) else "rtowGatherRowsDevice (RCCL behind the C ABI)" if have_comm else "torch.distributed (debug: ranks share one GPU)" if shared_gpu else "torch.distributed (the C-ABI communicator was not available)"),
                 "batches_per_launch": args.chain if not batches else 1,
                 "launches": m["launches"],
-                "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds),
+                "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds), "wide_codes": bool(info.wideCodes),
+                "entities": int(info.entityCount), "hit_spill_bytes": int(info.hitSpillBytes),
             },
             "kernel_ms_per_step": round(avg_kernel_ms, 3),
             "kernel_ms_per_launch": round(launch_ms, 3),

@@ -300,7 +300,9 @@ typedef enum RtowContextFlags {
                                                     * (UNITY/BvhNodeData.cs:122-213, JOBS/SampleBatchJob.cs:427-440, UNITY/Raytracer.cs:54-64) - instead of the
                                                     * library's own tree.  Costs a second, unpruned walk per ray in such batches */
     RTOW_CONTEXT_NO_CAMERA_RAY_LISTS = 1u << 3,    /* development: walk the tree for camera rays too */
-    RTOW_CONTEXT_NO_CHUNK_ORDER = 1u << 4          /* development: hand out pixel chunks in row order, not most-expensive-first */
+    RTOW_CONTEXT_NO_CHUNK_ORDER = 1u << 4,         /* development: hand out pixel chunks in row order, not most-expensive-first */
+    RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5        /* development: run every scene kind that has them through the kernels with 32-bit candidate / stack codes
+                                                    * (what scenes beyond 65 535 entities or tree nodes use; the tree is then read from HBM) */
 } RtowContextFlags;
 
 typedef struct RtowContextOptions {
@@ -318,6 +320,9 @@ typedef struct RtowContextOptions {
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per
                                      * entry, sized at rtowUploadScene to min(this, the most the scene can produce: 2 per entity with volumes, else 1).
                                      * 0 = 1024 in scenes with volumes, 128 elsewhere.  A ray beyond it makes the batch report RTOW_ERROR_CAPACITY */
+    int32_t sliceBlockThreads;      /* development: lanes per workgroup of the sample kernel.  0 = chosen per launch (1024; 512 or 256 for launches that own
+                                     * about one pixel per resident lane - a GPU's slice of a frame split over several - which end when their slowest
+                                     * pixel does); 256 / 512 / 1024 forces it where such a kernel exists.  Never changes a result */
 } RtowContextOptions;
 
 RTOW_API int rtowGetApiVersion(void);

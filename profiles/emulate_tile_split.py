@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override the config's samples per pixel")
     ap.add_argument("--slices", default="1,2,4,8")
     ap.add_argument("--tune", default=None, help="RtowContextOptions.schedulerTune: 8 stage thresholds + the box-walk slice, comma separated")
+    ap.add_argument("--block-threads", default="0", help="RtowContextOptions.sliceBlockThreads for the slices, comma separated list: 0 = the library's own choice per launch, "
+                    "256 / 512 / 1024 forced; the whole frame (G = 1) always runs the default geometry")
     args = ap.parse_args()
     name, w, h, spp, depth = CONFIGS[args.config]
     if args.spp:
@@ -38,13 +40,18 @@ def main():
     out = {"config": args.config, "scene": name, "width": w, "height": h, "spp": spp, "depth": depth, "rng": args.rng, "slices": {}}
     tune = [int(x) for x in args.tune.split(",")] if args.tune else None
     out["tune"] = tune
-    with rt.Context(0, scheduler_tune=tune) as ctx:
+    whole_ms = None
+    results = {}
+    for bt in [int(x) for x in args.block_threads.split(",")]:
+      with rt.Context(0, scheduler_tune=tune, slice_block_threads=bt) as ctx:
         ctx.upload_scene(scene.desc())
         bufs = [rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)]
         outs = [rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)]
         diag = rt.DeviceBuffer(ctx, n * 4).zero()
-        whole_ms = None
+        out["slices"] = {}
         for G in [int(x) for x in args.slices.split(",")]:
+            if G == 1 and whole_ms is not None:
+                continue
             times = []
             for g in range(G):
                 p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, slice_offset=g, slice_divider=G,
@@ -60,6 +67,8 @@ def main():
                     ms = ctx.last_sample_kernel_ms()
                 times.append(ms)
             if G == 1:
+                if bt not in (0, 1024):
+                    continue                       # the whole frame is the baseline: default geometry only
                 whole_ms = times[0]
             gather_ms = 0.0 if G == 1 else (n // G) * 16 / (XGMI_LINK_GBS * 1e9) * 1e3     # colour rows of one peer over its own link
             out["slices"][str(G)] = {
@@ -72,6 +81,9 @@ def main():
             }
         for b in bufs + outs + [diag]:
             b.free()
+        results[str(bt)] = out["slices"]
+    out["whole_frame_ms"] = whole_ms
+    out["slices"] = results if len(results) > 1 else next(iter(results.values()))
     print(json.dumps(out))
 
 

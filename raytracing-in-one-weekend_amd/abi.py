@@ -134,7 +134,7 @@ LogCallback = C.CFUNCTYPE(None, C.c_int32, C.c_char_p, C.c_char_p, C.c_void_p)
 
 
 # RtowContextFlags
-CONTEXT_EXACT_TIES_ALWAYS, CONTEXT_EXACT_TIES_NEVER, CONTEXT_REFERENCE_DIAGNOSTICS, CONTEXT_NO_CAMERA_RAY_LISTS, CONTEXT_NO_CHUNK_ORDER = 1, 2, 4, 8, 16
+CONTEXT_EXACT_TIES_ALWAYS, CONTEXT_EXACT_TIES_NEVER, CONTEXT_REFERENCE_DIAGNOSTICS, CONTEXT_NO_CAMERA_RAY_LISTS, CONTEXT_NO_CHUNK_ORDER, CONTEXT_FORCE_WIDE_CODES = 1, 2, 4, 8, 16, 32
 # RtowGatherMask
 GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_ALL = 1, 2, 4, 8, 15
 
@@ -142,7 +142,7 @@ GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_A
 class ContextOptions(C.Structure):
     _fields_ = [("deviceOrdinal", C.c_int32), ("logCallback", LogCallback), ("logCallbackData", C.c_void_p),
                 ("logCallbackLevel", C.c_int32), ("flags", C.c_uint32), ("ldsSceneBudgetBytes", C.c_int32), ("schedulerTune", C.c_int32 * 9),
-                ("hitListCapacity", C.c_int32)]
+                ("hitListCapacity", C.c_int32), ("sliceBlockThreads", C.c_int32)]
 
 
 class CommId(C.Structure):

@@ -22,6 +22,15 @@
 #include "rtow_bvh.h"
 #include "rtow_kernels.h"
 
+// Launches that own at most this many pixels per resident lane (CUs x 1024) run 256 / 512 lanes per workgroup instead of 1024 (launchSample).
+#ifndef RTOW_SLICE_256_PIXELS_PER_LANE
+#define RTOW_SLICE_256_PIXELS_PER_LANE 0.0
+#endif
+#ifndef RTOW_SLICE_512_PIXELS_PER_LANE
+#define RTOW_SLICE_512_PIXELS_PER_LANE 0.0
+#endif
+constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice512PixelsPerLane = RTOW_SLICE_512_PIXELS_PER_LANE;
+
 // minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: any
 // threshold above 1 loses (waiting lanes cost more than the skipped stage saves); slicing the walk at 16 wins ~5 %.
 #ifndef RTOW_DEFAULT_TUNE
@@ -102,6 +111,8 @@ struct RtowContext_t {
     MetricsPartial* dPartials = nullptr;
 
     // RtowContextOptions: behaviour switches and development knobs (nothing is read from the environment)
+    int sliceBlockThreads = 0;            // 0 = chosen per launch; 256 / 512 / 1024 forces (development)
+    bool wideCodes = false;               // current scene: more than 65 535 entities or tree nodes (32-bit candidate / stack codes, tree read from HBM)
     uint32_t flags = 0;
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
     int tune[9] = {RTOW_DEFAULT_TUNE};
@@ -273,7 +284,20 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         }
         a.unitRecords = ctx->dUnitRecords;
     }
-    int blocks = (int)((a.totalWork + kBlockThreads - 1) / kBlockThreads);
+    // ---- launch geometry.  One persistent workgroup per CU; how many lanes it has is a property of the launch.  1024 (four waves per SIMD) is the
+    // throughput shape.  A launch that owns only about one pixel per resident lane - one GPU's slice of a frame split over several - is not
+    // bound by throughput but by its slowest pixel: `spp` samples that can only run one after the other under the reference stream
+    // (JOBS/SampleBatchJob.cs:91,132-157), each a chain of trips of the stage loop, and a wave that shares its SIMD with fewer others gets
+    // through a trip sooner.  Such launches run 512 or 256 lanes per CU (two / one wave per SIMD); the thresholds are measured
+    // (profiles/emulate_tile_split.py).  Results do not depend on it: pixels are independent.
+    a.wideCodes = ctx->wideCodes ? 1 : 0;
+    a.blockThreads = kBlockThreads;
+    {
+        const double pixelsPerLane = (double)a.totalWork / ((double)ctx->cuCount * kBlockThreads);
+        int want = ctx->sliceBlockThreads ? ctx->sliceBlockThreads : (pixelsPerLane <= kSlice256PixelsPerLane ? 256 : pixelsPerLane <= kSlice512PixelsPerLane ? 512 : kBlockThreads);
+        if (want != kBlockThreads && sliceGeometryAvailable(a, want)) a.blockThreads = want;
+    }
+    int blocks = (int)((a.totalWork + (uint32_t)a.blockThreads - 1) / (uint32_t)a.blockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
     if (blocks < 1) blocks = 1;
 
@@ -288,7 +312,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
             ctx->dPixCand = nullptr;
             ctx->pixCandCapacity = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dPixCand, pixels * sizeof(uint2)), RTOW_ERROR_MEMORY_ALLOCATION);
+            HIP_TRY(ctx, hipMalloc(&ctx->dPixCand, pixels * sizeof(uint4)), RTOW_ERROR_MEMORY_ALLOCATION);   // uint2 records; uint4 with wide codes
             ctx->pixCandCapacity = pixels;
             ctx->pixCandValid = false;
         }
@@ -660,6 +684,8 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
         if ((ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) && (ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER)) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
         if (options->ldsSceneBudgetBytes > 0) ctx->ldsSceneBudget = (uint32_t)options->ldsSceneBudgetBytes;
         if (options->hitListCapacity < 0) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
+        if (options->sliceBlockThreads != 0 && options->sliceBlockThreads != 256 && options->sliceBlockThreads != 512 && options->sliceBlockThreads != 1024) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
+        ctx->sliceBlockThreads = options->sliceBlockThreads;
         ctx->hitListCapacity = (uint32_t)options->hitListCapacity;
         bool anyTune = false;
         for (int i = 0; i < 9; i++) anyTune = anyTune || options->schedulerTune[i] != 0;
@@ -793,10 +819,17 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         }
         ctx->hitSpillEntries = entries;
     }
+    const bool wide = compiled.entityCount > 65535 || compiled.layout.nodeCount > 65535u ||
+                      ((ctx->flags & RTOW_CONTEXT_FORCE_WIDE_CODES) && wideCodesAvailable(compiled.layout.sceneKind));
+    if (wide && !wideCodesAvailable(compiled.layout.sceneKind)) {
+        logf(ctx, 2, "scene", "scenes of more than 65535 entities are built for sphere, general and textured scenes, not for scenes with ProbabilisticVolume materials");
+        return RTOW_ERROR_CAPACITY;
+    }
+    ctx->wideCodes = wide;
     ctx->scene = std::move(compiled);
-    uint32_t budget = (uint32_t)(kLdsBytesMax - kStackBytes - kQueueBytes);
+    uint32_t budget = (uint32_t)(kLdsBytesMax - (wide ? kStackBytesWide : kStackBytes) - kQueueBytes);
     if (ctx->ldsSceneBudget >= sizeof(GpuNode) && ctx->ldsSceneBudget < budget) budget = ctx->ldsSceneBudget;   // development aid: small scenes through the tree-in-HBM kernels
-    if (ctx->scene.layout.totalBytes <= budget) {
+    if (ctx->scene.layout.totalBytes <= budget && !wide) {
         ctx->ldsSceneBytes = ctx->scene.layout.totalBytes;
         ctx->ldsNodeCount = ctx->scene.layout.nodeCount;
     } else {
@@ -910,7 +943,7 @@ RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
     info->hitSpillBytes = (uint64_t)ctx->hitSpillEntries * (uint64_t)ctx->cuCount * (uint64_t)kBlockThreads * sizeof(uint4);
     const bool keepsLists = ctx->scene.layout.exactTies || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
     info->hitListCapacity = keepsLists ? (int32_t)(ctx->hitSpillEntries + (uint32_t)kLocalHitEntries) : 0;
-    info->wideCodes = 0;
+    info->wideCodes = ctx->wideCodes ? 1 : 0;
     return RTOW_SUCCESS;
 }
 

@@ -36,6 +36,11 @@ struct TmpNode {
     int child[2]; // >= 0: TmpNode index, < 0: ~primitive
 };
 
+// Ranges above this many primitives are split with a binned SAH (32 bins per axis, O(n) per node) instead of the full sweep (three sorts per node):
+// a million-triangle mesh builds in seconds.  Below it the sweep stands, so every scene of up to 32 768 entities gets the tree it always got.
+constexpr int kBinnedAbove = 32768;
+constexpr int kBins = 32;
+
 struct Builder {
     std::vector<Box> primBox;
     std::vector<float> centroid[3];
@@ -54,6 +59,8 @@ struct Builder {
         }
         maxDepthSeen = std::max(maxDepthSeen, depth + 1);
         const long long cap = depthLeft - 1 >= 30 ? (1LL << 30) : (1LL << std::max(depthLeft - 1, 0));
+
+        if (n > kBinnedAbove) return buildBinned(idx, begin, end, depthLeft, depth, cap, outBox);
 
         double bestCost = DBL_MAX;
         int bestAxis = -1, bestSplit = -1;
@@ -87,6 +94,77 @@ struct Builder {
         Box b0, b1;
         const int c0 = build(idx, begin, begin + bestSplit, depthLeft - 1, depth + 1, &b0);
         const int c1 = build(idx, begin + bestSplit, end, depthLeft - 1, depth + 1, &b1);
+        nodes[self].box[0] = b0; nodes[self].box[1] = b1;
+        nodes[self].child[0] = c0; nodes[self].child[1] = c1;
+        *outBox = b0;
+        outBox->grow(b1);
+        return self;
+    }
+
+    // binned SAH step for a large range; partitions idx[begin, end) in place and recurses through build()
+    int buildBinned(std::vector<int>& idx, int begin, int end, int depthLeft, int depth, long long cap, Box* outBox)
+    {
+        const int n = end - begin;
+        float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = begin; i < end; i++)
+            for (int a = 0; a < 3; a++) { const float c = centroid[a][idx[i]]; clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c); }
+        double bestCost = DBL_MAX;
+        int bestAxis = -1, bestBin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            const float ext = chi[axis] - clo[axis];
+            if (!(ext > 0)) continue;
+            const float scale = (float)kBins / ext;
+            Box bb[kBins];
+            int cnt[kBins] = {0};
+            for (int b = 0; b < kBins; b++) bb[b].reset();
+            for (int i = begin; i < end; i++) {
+                int b = (int)((centroid[axis][idx[i]] - clo[axis]) * scale);
+                b = b < 0 ? 0 : b >= kBins ? kBins - 1 : b;
+                cnt[b]++;
+                bb[b].grow(primBox[idx[i]]);
+            }
+            double rArea[kBins];
+            int rCnt[kBins];
+            Box acc;
+            acc.reset();
+            int c = 0;
+            for (int b = kBins - 1; b >= 1; b--) { if (cnt[b]) acc.grow(bb[b]); c += cnt[b]; rArea[b] = c ? acc.area() : 0.0; rCnt[b] = c; }
+            acc.reset();
+            c = 0;
+            for (int b = 1; b < kBins; b++) {                       // split between bin b - 1 and bin b
+                if (cnt[b - 1]) acc.grow(bb[b - 1]);
+                c += cnt[b - 1];
+                if (c == 0 || rCnt[b] == 0 || c > cap || rCnt[b] > cap) continue;
+                const double cost = acc.area() * c + rArea[b] * rCnt[b];
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+            }
+        }
+        int mid;
+        if (bestAxis >= 0) {
+            const float scale = (float)kBins / (chi[bestAxis] - clo[bestAxis]);
+            const std::vector<float>& cc = centroid[bestAxis];
+            const float lo = clo[bestAxis];
+            const int bin = bestBin;
+            int* first = idx.data() + begin;
+            int* split = std::partition(first, idx.data() + end, [&](int p) {
+                int b = (int)((cc[p] - lo) * scale);
+                b = b < 0 ? 0 : b >= kBins ? kBins - 1 : b;
+                return b < bin;
+            });
+            mid = begin + (int)(split - first);
+        } else {
+            // all centroids coincide on every axis, or no bin boundary keeps both sides within the depth bound: median split along the widest axis
+            int axis = 0;
+            for (int a = 1; a < 3; a++) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+            const std::vector<float>& cc = centroid[axis];
+            mid = begin + n / 2;
+            std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end, [&cc](int a, int b) { return cc[a] < cc[b] || (cc[a] == cc[b] && a < b); });
+        }
+        const int self = (int)nodes.size();
+        nodes.push_back(TmpNode{});
+        Box b0, b1;
+        const int c0 = build(idx, begin, mid, depthLeft - 1, depth + 1, &b0);
+        const int c1 = build(idx, mid, end, depthLeft - 1, depth + 1, &b1);
         nodes[self].box[0] = b0; nodes[self].box[1] = b1;
         nodes[self].child[0] = c0; nodes[self].child[1] = c1;
         *outBox = b0;
@@ -144,8 +222,12 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         return RTOW_ERROR_INVALID_VALUE;
     }
     const int n = desc->entityCount;
-    if (n > 65535 || desc->materialCount > 32767) {
-        *err = "scene exceeds 65535 entities or 32767 materials (16-bit candidate and path-history codes)";
+    // Entities: candidate / stack codes are 16 bits wide up to 65 535 entities and tree nodes and 32 bits beyond (the kernels' wide-code variants,
+    // chosen at upload); hit codes keep 30 bits for the primitive, and the blob's section offsets are 32-bit.  Materials: the path history names
+    // a material in 15 bits.  The reference's live host makes one entity per mesh triangle (UNITY/Raytracer.cs:1193-1198,1290-1300) - hundreds of
+    // thousands for its own test scenes (UNITY/GridGenerator.cs:78-159) - and one material per renderer.
+    if (n > (1 << 23) || desc->materialCount > 32767) {
+        *err = "scene exceeds 8388608 entities or 32767 materials (30-bit hit codes / 32-bit blob offsets, 15-bit path-history codes)";
         return RTOW_ERROR_CAPACITY;
     }
     if (maxDepth <= 0) maxDepth = RTOW_DEFAULT_MAX_BVH_DEPTH;
@@ -418,9 +500,14 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
             gnodes[i] = g;
         }
     }
-    if (gnodes.size() > 65535) {
-        *err = "more than 65535 BVH nodes";
-        return RTOW_ERROR_CAPACITY;
+    {
+        // section offsets are 32-bit: the whole image must stay below 4 GiB
+        const uint64_t bytes = (uint64_t)gnodes.size() * sizeof(GpuNode) + (uint64_t)n * (sizeof(GpuSphere) + (hasMotion ? sizeof(GpuMotion) : 0) + (general ? sizeof(GpuPrim) : 0) + (hasVolumes ? 32u : 0u) + 8u) +
+                               (uint64_t)mats.size() * sizeof(GpuMaterial) + 256u;
+        if (bytes >= 0xfff00000ull) {
+            *err = "scene image exceeds 4 GiB";
+            return RTOW_ERROR_CAPACITY;
+        }
     }
 
     // ---- pack the blob ----
@@ -451,7 +538,8 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     // float programs to agree to the last bit (faces in one plane, shared mesh edges) and the leaf-order rule stands, exact up to 16 hits
     // per ray.  Volume scenes resolve every tie in their hit list anyway.
     L.exactTies = 0u;
-    if (!hasVolumes) {
+    if (!hasVolumes && (general || hasImageTextures) && n > 16) L.exactTies = 1u;      // see below; decided first so that a million-triangle mesh skips the duplicate scan
+    if (!hasVolumes && !L.exactTies) {
         std::vector<std::array<uint32_t, 38>> keys(n);
         for (int i = 0; i < n; i++) {
             const RtowEntity& e = desc->entities[i];

@@ -19,7 +19,8 @@ constexpr int kLdsBytesMax = 160 * 1024;
 #define RTOW_TRAV_SLICE 8   // box-walk node visits per scheduler trip
 #endif
 constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting their exact test (flushed when full)
-constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane]
+constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane] (the default geometry; rtow_sample_kernel.hip.h: geo_stack_bytes)
+constexpr int kStackBytesWide = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 4; // 32-bit entries: scenes beyond 65 535 entities / tree nodes
 constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: first slot empty, second not - "no list, walk the tree"
 constexpr unsigned kSampleGroup = 16;   // RTOW_RNG_PER_SAMPLE: samples per work unit (part of that policy's definition: partial sums are per group)
 constexpr int kQueueBytes = 256;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B)
@@ -60,7 +61,8 @@ struct SampleKernelArgs {
     const unsigned int* chunkOrder;       // chunk launch order (most expensive first), null = natural order
     unsigned short* pixelCost;            // [64 * chunkCount], ticket order: ray count of every pixel of THIS launch (input of the next launch's order); null = not recorded
     uint32_t chunkCount;
-    const uint2* pixelCandidates;         // [width * height]: camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray
+    const uint2* pixelCandidates;         // [width * height]: camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray;
+                                          // wideCodes: uint4 records (4 x 32-bit node indices) behind the same pointer
     int32_t probeOnly;                    // 1: cost probe - one sample per pixel, nothing stored but pixelCost
     const volatile uint32_t* cancelFlag;  // host-pinned, may be null
     uint32_t* overflowFlag;               // host-pinned: set when a ray's hit list (volume scenes) exceeds the per-lane capacity
@@ -117,6 +119,11 @@ struct SampleKernelArgs {
     const ChainBatch* chainBatches;       // [chainCount] what differs between the batches of the chain (device memory: indexed per lane)
     unsigned int* chunkDone;              // [chunkCount] pixels stored so far, all batches of this launch; zeroed before the launch
 
+    // launch geometry (rtow_sample_kernel.hip.h, GEO): lanes per workgroup of THIS launch (1024, or 512 / 256 for slices that own about one pixel
+    // per resident lane) and whether candidate / stack codes are 32 bits wide (scenes beyond 65 535 entities or tree nodes)
+    int32_t blockThreads;
+    int32_t wideCodes;
+
     // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice
     int32_t tune[8];
     int32_t travSlice;
@@ -132,17 +139,21 @@ struct KernelInfo {
 
 // launchers (defined in rtow_kernels.hip)
 // per scene kind, each defined in its own translation unit (rtow_sample_*.hip)
-hipError_t launchSampleSpheres(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleSpheresMotion(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleGeneral(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleGeneralTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleTexturedTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleSpheresTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleSpheresMotionTies(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleVolumes(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleTextured(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
-hipError_t launchSampleVolumesTextured(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds);
+hipError_t launchSampleSpheres(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleSpheresMotion(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleGeneral(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleGeneralTies(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleTexturedTies(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleSpheresTies(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleSpheresMotionTies(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleVolumes(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleTextured(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleVolumesTextured(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
+// can this batch run with `blockThreads` lanes per workgroup (512 / 256: the slice geometries exist for the sphere kinds, reference stream, short records, depth <= 16)?
+bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads);
+// do kernels with 32-bit candidate / stack codes exist for this scene kind (spheres, general, textured; not the volume kinds)?
+bool wideCodesAvailable(uint32_t sceneKind);
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
 hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream);
 hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream);

@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(256) primary_candidates_kernel(SampleKernelArg
         return !(tn > tf);                                                      // NaN (cannot happen with finite inv) would count as a hit
     };
 
-    unsigned list[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+    const unsigned none = A.wideCodes ? 0xffffffffu : 0xffffu;
+    unsigned list[4] = {none, none, none, none};
     int count = 0;
     int stack[RTOW_STACK_CAPACITY + 1];
     int sp = 0, cur = 0;
@@ -166,7 +167,8 @@ __global__ void __launch_bounds__(256) primary_candidates_kernel(SampleKernelArg
         }
         if (cur < 0 && sp > 0) cur = stack[--sp];
     }
-    out[pix] = ok ? make_uint2(list[0] | (list[1] << 16), list[2] | (list[3] << 16)) : make_uint2(kNoPrimaryList, 0u);
+    if (A.wideCodes) reinterpret_cast<uint4*>(out)[pix] = ok ? make_uint4(list[0], list[1], list[2], list[3]) : make_uint4(0xffffffffu, 0u, 0u, 0u);   // first slot empty, second not: no list
+    else out[pix] = ok ? make_uint2(list[0] | (list[1] << 16), list[2] | (list[3] << 16)) : make_uint2(kNoPrimaryList, 0u);
 }
 
 // pixelCost[64 * chunk .. +63] -> cost[chunk] = sum, cost[n + chunk] = max; one wave per chunk
@@ -368,17 +370,26 @@ __global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_
 
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
-    const size_t ldsBytes = (size_t)kStackBytes + kQueueBytes + args.ldsSceneBytes;
     const bool allLds = args.ldsSceneBytes == args.layout.totalBytes;
     switch (args.layout.sceneKind) {
-        case SCENE_KIND_SPHERES: return args.layout.exactTies ? launchSampleSpheresTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleSpheres(args, numBlocks, ldsBytes, stream, allLds);
-        case SCENE_KIND_SPHERES_MOTION: return args.layout.exactTies ? launchSampleSpheresMotionTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleSpheresMotion(args, numBlocks, ldsBytes, stream, allLds);
-        case SCENE_KIND_VOLUMES: return launchSampleVolumes(args, numBlocks, ldsBytes, stream, allLds);
-        case SCENE_KIND_TEXTURED: return args.layout.exactTies ? launchSampleTexturedTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleTextured(args, numBlocks, ldsBytes, stream, allLds);
-        case SCENE_KIND_VOLUMES_TEXTURED: return launchSampleVolumesTextured(args, numBlocks, ldsBytes, stream, allLds);
-        default: return args.layout.exactTies ? launchSampleGeneralTies(args, numBlocks, ldsBytes, stream, allLds) : launchSampleGeneral(args, numBlocks, ldsBytes, stream, allLds);
+        case SCENE_KIND_SPHERES: return args.layout.exactTies ? launchSampleSpheresTies(args, numBlocks, stream, allLds) : launchSampleSpheres(args, numBlocks, stream, allLds);
+        case SCENE_KIND_SPHERES_MOTION: return args.layout.exactTies ? launchSampleSpheresMotionTies(args, numBlocks, stream, allLds) : launchSampleSpheresMotion(args, numBlocks, stream, allLds);
+        case SCENE_KIND_VOLUMES: return launchSampleVolumes(args, numBlocks, stream, allLds);
+        case SCENE_KIND_TEXTURED: return args.layout.exactTies ? launchSampleTexturedTies(args, numBlocks, stream, allLds) : launchSampleTextured(args, numBlocks, stream, allLds);
+        case SCENE_KIND_VOLUMES_TEXTURED: return launchSampleVolumesTextured(args, numBlocks, stream, allLds);
+        default: return args.layout.exactTies ? launchSampleGeneralTies(args, numBlocks, stream, allLds) : launchSampleGeneral(args, numBlocks, stream, allLds);
     }
 }
+
+bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads)
+{
+    if (blockThreads == kBlockThreads) return true;
+    if (blockThreads != 512 && blockThreads != 256) return false;
+    const bool kind = (args.layout.sceneKind == SCENE_KIND_SPHERES || args.layout.sceneKind == SCENE_KIND_SPHERES_MOTION) && !args.layout.exactTies;
+    return kind && !args.wideCodes && args.noiseColor == RTOW_NOISE_WHITE && !args.unitRecords && !(args.diagnostics && args.diagnosticsStride >= 16) && args.traceDepth <= 16;
+}
+
+bool wideCodesAvailable(uint32_t sceneKind) { return sceneKind == SCENE_KIND_SPHERES || sceneKind == SCENE_KIND_SPHERES_MOTION || sceneKind == SCENE_KIND_GENERAL || sceneKind == SCENE_KIND_TEXTURED; }
 
 // ------------------------------------------------------------------------------------------------------------
 // rtowGatherRowsDevice: rows first, first + step, ... of a full-frame buffer <-> one contiguous block (what travels over xGMI).

@@ -414,9 +414,10 @@ __device__ __forceinline__ float texture_scalar(const SampleKernelArgs& A, const
 // A real call on purpose (the lists live in scratch anyway): it keeps this rarely run code and its temporaries out of the
 // register allocation of the stage loop.
 // ------------------------------------------------------------------------------------------------------------
+constexpr unsigned kHitPrimMask = 0x3fffffffu;   // hit code = primitive index | bit 30: dot(normal, dir) < 0 | bit 31: dot(normal, dir) > 0
 __device__ __noinline__ __attribute__((unused)) void sort_hit_list(float* hitT, float* hitTmin0, unsigned* hitCode, int nHits, const unsigned* rank)
 {
-    auto rankOf = [&](unsigned code) { return rank[code & 0xffffu]; };
+    auto rankOf = [&](unsigned code) { return rank[code & kHitPrimMask]; };
     auto swapHits = [&](int a, int b) {
         const float t = hitT[a], tm = hitTmin0[a]; const unsigned c = hitCode[a];
         hitT[a] = hitT[b]; hitTmin0[a] = hitTmin0[b]; hitCode[a] = hitCode[b];
@@ -521,7 +522,7 @@ __device__ __noinline__ __attribute__((unused)) void sort_hit_list_spilled(float
 {
     auto get = [&](int i) { return hit_get(hitT, hitTmin0, hitCode, sp, i); };
     auto set = [&](int i, HitRec r) { hit_set(hitT, hitTmin0, hitCode, sp, i, r); };
-    auto rankOf = [&](unsigned code) { return rank[code & 0xffffu]; };
+    auto rankOf = [&](unsigned code) { return rank[code & kHitPrimMask]; };
     auto swapHits = [&](int a, int b) { const HitRec x = get(a), y = get(b); set(a, y); set(b, x); };
     auto swapIfGreater = [&](int l, int r) { if (l != r && get(l).t > get(r).t) swapHits(l, r); };
     for (int i = 1; i < nHits; i++) {                                   // leaf order; an entity's exit hit was recorded after its entry
@@ -949,8 +950,8 @@ enum : int {
 // that one ray: every hit of the ray (the walk again, not pruned, same box tests), in leaf order, through the same sort; element 0 wins.
 // A real call: it is rare, and its list lives in scratch.
 // ------------------------------------------------------------------------------------------------------------
-template <bool ALL_LDS, int KIND>
-__device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs& sc, const SceneLayout& L, V3 ro, V3 rd, float rtime, unsigned short* stack,
+template <bool ALL_LDS, int KIND, typename Code, int BT>
+__device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs& sc, const SceneLayout& L, V3 ro, V3 rd, float rtime, Code* stack,
                                                                        uint32_t* overflowFlag, HitSpill spill)
 {
     float hitT[kLocalHits], hitDummy[kLocalHits];
@@ -994,16 +995,16 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
             else *overflowFlag = 1u;                                                                       // more hits than the context's hitListCapacity: RTOW_ERROR_CAPACITY on the host side
         }
         const bool in0 = hit0 && c0 >= 0, in1 = hit1 && c1 >= 0;
-        if (in0 && in1) { stack[sp * kBlockThreads] = (unsigned short)c1; sp++; cur = c0; }
+        if (in0 && in1) { stack[sp * BT] = (Code)c1; sp++; cur = c0; }
         else if (in0 || in1) cur = in0 ? c0 : c1;
-        else if (sp > 0) { sp--; cur = stack[sp * kBlockThreads]; }
+        else if (sp > 0) { sp--; cur = (int)stack[sp * BT]; }
         else cur = -1;
     }
     if (n == 0) return -1;
     const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
     if (n > kLocalHits) sort_hit_list_spilled(hitT, hitDummy, hitCode, spill, n, rank);
     else if (n > 1) sort_hit_list(hitT, hitDummy, hitCode, n, rank);
-    return (int)(hitCode[0] & 0xffffu);
+    return (int)(hitCode[0] & kHitPrimMask);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1040,26 +1041,39 @@ __device__ __noinline__ __attribute__((unused)) void reference_counts(const uint
     *candidates += cc;
 }
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
-__global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const SampleKernelArgs A)
+// Launch geometry of a variant (template parameter GEO): bits 0..1 = lanes per workgroup (one workgroup per CU: 1024 = four waves per SIMD, the
+// throughput shape; 512 / 256 = two / one wave per SIMD, for launches that own about one pixel per resident lane - a slice of a frame split over
+// GPUs - where the launch ends when its slowest pixel's sequential samples do and a wave that shares its SIMD with fewer others gets there sooner);
+// bit 2 = 32-bit traversal-stack / candidate codes (scenes of more than 65 535 entities or tree nodes; the tree is then read from HBM).
+constexpr int kGeoWide = 4;
+constexpr int geo_block_threads(int geo) { return (geo & 3) == 0 ? 1024 : (geo & 3) == 1 ? 512 : 256; }
+constexpr size_t geo_stack_bytes(int geo) { return (size_t)(RTOW_STACK_CAPACITY + kCandCapacity) * (size_t)geo_block_threads(geo) * ((geo & kGeoWide) ? 4u : 2u); }
+
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
+__global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(const SampleKernelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = (int)threadIdx.x;
+    constexpr int BT = geo_block_threads(GEO);
+    constexpr bool WIDE = (GEO & kGeoWide) != 0;
+    using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
+    constexpr int kStackBytesT = (int)geo_stack_bytes(GEO);
 
     // ---- stage the scene image into LDS: coalesced 16 B per lane ----
     // [level][lane] uint16 arrays; within a wave lane l sits at 2*(l&31) + (l>>5), so the 32 lanes the LDS services together
     // touch 32 different dwords (= banks) whatever level each of them is at
-    unsigned short* const stack = reinterpret_cast<unsigned short*>(smem) + (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
-    unsigned short* const cand = stack + RTOW_STACK_CAPACITY * kBlockThreads;                // [slot][lane] leaf candidates
+    // (32-bit codes: one dword per lane, the natural order already is conflict free)
+    Code* const stack = reinterpret_cast<Code*>(smem) + (WIDE ? tid : (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1));
+    Code* const cand = stack + RTOW_STACK_CAPACITY * BT;                                       // [slot][lane] leaf candidates
     // {next, end} ticket chunk of this wave; chains: {.., needDone, chunk} = the chunk may only be handed out once chunkDone[chunk] >= needDone
-    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytes) + (tid >> 6) * 4;
-    uint8_t* const ldsScene = smem + kStackBytes + kQueueBytes;
+    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytesT) + (tid >> 6) * 4;
+    uint8_t* const ldsScene = smem + kStackBytesT + kQueueBytes;
     if ((tid & 63) == 0) { waveQueue[0] = 0; waveQueue[1] = 0; waveQueue[2] = 0; waveQueue[3] = 0; }
     {
         const uint4* src = reinterpret_cast<const uint4*>(A.sceneBlob);
         uint4* dst = reinterpret_cast<uint4*>(ldsScene);
         const uint32_t n16 = A.ldsSceneBytes >> 4;
-        for (uint32_t i = (uint32_t)tid; i < n16; i += kBlockThreads) dst[i] = src[i];
+        for (uint32_t i = (uint32_t)tid; i < n16; i += BT) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -1191,7 +1205,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         st = prim < 0 ? ST_SKY : ST_HIT;
     };
 
-    uint2 pcand = make_uint2(kNoPrimaryList, 0u);   // this pixel's camera-ray candidate list (4 x 16 bit), or kNoPrimaryList in .x
+    // this pixel's camera-ray candidate list: leaf-parent node indices, 4 x 16 bit in .x / .y (kNoPrimaryList in .x: none) - with wide codes
+    // 4 x 32 bit (0xffffffff = empty slot; first slot empty, second not: no list)
+    uint4 pcand = make_uint4(WIDE ? 0xffffffffu : kNoPrimaryList, 0u, 0u, 0u);
     int force = -1;
     unsigned trip = 0;          // chained batches only: paces the polls of parked lanes
     STAT_DECL;
@@ -1238,7 +1254,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
 #ifdef RTOW_STATS
                     if (pix >= 0 && C.stats) {
                         // last pixel this wave finished: {end, start, rays, tick} (100 MHz ticks since the wave started); later stores overwrite earlier ones
-                        unsigned long long* rec = C.stats + 9000 + (size_t)(blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)) * 4;
+                        unsigned long long* rec = C.stats + 9000 + (size_t)(blockIdx.x * (BT / 64) + (threadIdx.x >> 6)) * 4;
                         rec[0] = wall_clock64() - statT0; rec[1] = pixT0 - statT0; rec[2] = (unsigned long long)rayCount; rec[3] = tick;
                     }
 #endif
@@ -1416,7 +1432,8 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     }
                     rayCount = 0; boundsHits = 0; candidates = 0;
                     // the pixel's camera-ray candidates (primary_candidates_kernel): up to 4 primitive indices, 0xFFFF = none
-                    pcand = C.pixelCandidates ? C.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u);
+                    if (WIDE) pcand = C.pixelCandidates ? reinterpret_cast<const uint4*>(C.pixelCandidates)[pix] : make_uint4(0xffffffffu, 0u, 0u, 0u);
+                    else { const uint2 pc = C.pixelCandidates ? C.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u); pcand = make_uint4(pc.x, pc.y, 0u, 0u); }
                 }
                 if (st == ST_REGEN) {
                     // ---- camera ray (:134-135, RT/View.cs:38-48) ----
@@ -1454,7 +1471,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     curVol = -1;
                     pendRE = 0;
                     startRay();
-                    if (pcand.x != kNoPrimaryList) {
+                    if (WIDE ? !(pcand.x == 0xffffffffu && pcand.y != 0xffffffffu) : pcand.x != kNoPrimaryList) {
                         // Every camera ray of this pixel can only hit primitives under the (at most four) leaf-parent nodes of the pixel's
                         // list: instead of walking the tree, visit just those nodes - with the walk's own slab test of this very ray against
                         // their leaf boxes (same expressions, so the same candidates the walk would find: a ray that misses a leaf's box must
@@ -1463,8 +1480,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
                         cur = -1;
                         for (int k = 0; k < 4; k++) {
-                            const unsigned node = (k < 2 ? pcand.x >> (16 * k) : pcand.y >> (16 * (k - 2))) & 0xffffu;
-                            if (node == 0xffffu) break;
+                            const unsigned node = WIDE ? (k == 0 ? pcand.x : k == 1 ? pcand.y : k == 2 ? pcand.z : pcand.w)
+                                                       : ((k < 2 ? pcand.x >> (16 * k) : pcand.y >> (16 * (k - 2))) & 0xffffu);
+                            if (node == (WIDE ? 0xffffffffu : 0xffffu)) break;
                             float4 q0, q1, q2;
                             int c0, c1;
                             load_node<ALL_LDS>(sc, L, (int)node, q0, q1, q2, c0, c1);
@@ -1478,9 +1496,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                             const bool leaf0 = c0 < 0 && tmin0 < tfar0;                        // AxisAlignedBoundingBox.Hit on the entity's own box
                             const bool leaf1 = c1 < 0 && tmin1 < tfar1 && twoChildren;
                             if (FULL_DIAG && !refDiag) boundsHits += (leaf0 ? 1.0f : 0.0f) + (leaf1 ? 1.0f : 0.0f);
-                            cand[nc * kBlockThreads] = (unsigned short)~c0;
+                            cand[nc * BT] = (Code)~c0;
                             nc += leaf0 ? 1 : 0;
-                            cand[nc * kBlockThreads] = (unsigned short)~c1;
+                            cand[nc * BT] = (Code)~c1;
                             nc += leaf1 ? 1 : 0;
                         }
                         if (nc == 0) classify(); else st = ST_TEST;
@@ -1515,7 +1533,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     int c0, c1;
                     load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
                     const int spm1 = sp > 0 ? sp - 1 : 0;
-                    const int popped = stack[spm1 * kBlockThreads];
+                    const int popped = (int)stack[spm1 * BT];
                     // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
                     const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
                     const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
@@ -1531,15 +1549,15 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     const bool hit1 = tmin1 <= vmin(tfar1, bestPrune) && twoChildren;
                     const bool leaf0 = c0 < 0 && hit0 && tmin0 < tfar0, leaf1 = c1 < 0 && hit1 && tmin1 < tfar1;
                     if (FULL_DIAG && !refDiag) boundsHits += ((c0 < 0 ? leaf0 : hit0) ? 1.0f : 0.0f) + ((c1 < 0 ? leaf1 : hit1) ? 1.0f : 0.0f);
-                    cand[nc * kBlockThreads] = (unsigned short)~c0;
+                    cand[nc * BT] = (Code)~c0;
                     nc += leaf0 ? 1 : 0;
-                    cand[nc * kBlockThreads] = (unsigned short)~c1;
+                    cand[nc * BT] = (Code)~c1;
                     nc += leaf1 ? 1 : 0;
                     const bool in0 = hit0 && c0 >= 0;
                     const bool in1 = hit1 && c1 >= 0;
                     const bool both = in0 && in1;
                     const bool swap = tmin1 < tmin0;                         // near child first
-                    stack[sp * kBlockThreads] = (unsigned short)(swap ? c0 : c1);
+                    stack[sp * BT] = (Code)(swap ? c0 : c1);
                     const int next = both ? (swap ? c1 : c0) : (in0 ? c0 : c1);
                     const bool any = in0 || in1;
                     cur = any ? next : (sp > 0 ? popped : -1);
@@ -1562,7 +1580,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                     STAT_ADD(5, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0);
                     STAT_LANES(6);
                     nc--;
-                    const int i = cand[nc * kBlockThreads];
+                    const int i = (int)cand[nc * BT];
                     if (VOLUMES) {
                         // FindHits keeps EVERY hit (:457-460) and injects an exit hit for volume hulls (Box / Sphere, :463-469)
                         const unsigned mw = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u);
@@ -1630,7 +1648,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                 if (EXACT_TIES && !VOLUMES && tieAtBest) {
                     // two surfaces at exactly this distance: let the reference's own procedure pick (rare; see resolve_nearest_tie)
                     tieAtBest = false;
-                    const int winner = resolve_nearest_tie<ALL_LDS, BASE>(sc, L, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
+                    const int winner = resolve_nearest_tie<ALL_LDS, BASE, Code, BT>(sc, L, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
                     if (winner >= 0 && winner != prim) {
                         prim = winner;
                         if (KEEP_NORMAL) {
@@ -1833,7 +1851,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
             ran = true;
             STAGE_MARK(5);
             if (st == ST_VOL) {
-                auto matOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (code & 0xffffu) * 4u); };
+                auto matOf = [&](unsigned code) { return *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (code & kHitPrimMask) * 4u); };
                 auto isVolume = [&](unsigned code) { return ((matOf(code) >> 16) & 3u) == MAT_CLASS_VOLUME; };
                 // ---- hitBuffer.Sort(DistanceComparer) (:473-474) comes first (below); the rest of the stage reads the list through accessors ----
                 auto volumeLogic = [&](auto distAt, auto codeAt, auto tminAt) {
@@ -1883,9 +1901,9 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                                     if (general_hit<ALL_LDS>(sc, L, ~cc, mw >> kPrimTypeShift, ro, bd, rtime, 0.0f, t, nl, rq) && dot(normalize(rotate(rq, nl)), bd) > 0) insideVolume = true;
                                 }
                                 const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
-                                if (in0 && in1) { stack[bsp * kBlockThreads] = (unsigned short)c1; bsp++; bcur = c0; }
+                                if (in0 && in1) { stack[bsp * BT] = (Code)c1; bsp++; bcur = c0; }
                                 else if (in0 || in1) bcur = in0 ? c0 : c1;
-                                else if (bsp > 0) { bsp--; bcur = stack[bsp * kBlockThreads]; }
+                                else if (bsp > 0) { bsp--; bcur = (int)stack[bsp * BT]; }
                                 else bcur = -1;
                             }
                             if (insideVolume) { curVol = (int)(matOf(c) & 0xffffu); break; }
@@ -1941,7 +1959,7 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
                         break;
                     }
                     if (insideHit) { prim = -1; st = ST_HIT; }
-                    else if (chosen >= 0 && chosen < nHits) { best = distAt(chosen); hitTmin = tminAt(chosen); prim = (int)(codeAt(chosen) & 0xffffu); st = ST_HIT; }
+                    else if (chosen >= 0 && chosen < nHits) { best = distAt(chosen); hitTmin = tminAt(chosen); prim = (int)(codeAt(chosen) & kHitPrimMask); st = ST_HIT; }
                     else st = ST_SKY;
                 };
                 const HitSpill spill = hit_spill_of(A);
@@ -2022,18 +2040,19 @@ __global__ void __launch_bounds__(kBlockThreads) sample_batch_kernel(const Sampl
         atomicAdd(&A.stats[16], dt);
         atomicMax(&A.stats[17], dt);
         atomicAdd(&A.stats[18], 1ull);
-        A.stats[32 + blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)] = dt;   // per-wave residency
+        A.stats[32 + blockIdx.x * (BT / 64) + (threadIdx.x >> 6)] = dt;   // per-wave residency
     }
 #endif
 }
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE>
-hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
+template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
+hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
-    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE, PER_SAMPLE>;
+    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE, PER_SAMPLE, GEO>;
+    const size_t ldsBytes = geo_stack_bytes(GEO) + (size_t)kQueueBytes + args.ldsSceneBytes;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(numBlocks), dim3(kBlockThreads), ldsBytes, stream, args);
+    hipLaunchKernelGGL(k, dim3(numBlocks), dim3(geo_block_threads(GEO)), ldsBytes, stream, args);
     return hipGetLastError();
 }
 
@@ -2042,31 +2061,67 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, size_t lds
 // elsewhere: ONE variant with the full history (32 words) and the counters switched on serves every deeper path, every 16-byte
 // diagnostics record, the texture-driven noise sources and the per-sample policy beyond depth 8 (the counters cost ~2 % there; the record
 // format is chosen at run time from diagnosticsStride).  Scenes that need the exact-tie resolver (kExactTiesBit) are rare: depth <= 16 shares
-// the 8-word variant.  144 instantiations instead of 320 (tests/test_gpu_variants.py runs every one of them on every build).
-template <bool ALL_LDS, int KIND>
-hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream)
+// the 8-word variant.  On top of these 144 (tests/test_gpu_variants.py runs every variant on every build):
+//   * slice geometries (args.blockThreads 512 / 256, chosen per launch by the host side): the two sphere kinds, reference stream, short records,
+//     depth <= 8 and <= 16 - the launches of a tile split; everything else runs 1024 lanes per workgroup;
+//   * wide codes (args.wideCodes, scenes beyond 65 535 entities / nodes; the tree is read from HBM, so ALL_LDS = false only): the scene kinds a host
+//     that ingests triangle meshes produces - spheres (static / moving), general entities, textured, each with and without the exact-tie resolver - as the
+//     specialised reference-stream variant (4 words, or 8 with the resolver) plus the generic one per noise source / RNG policy.
+template <bool ALL_LDS, int KIND, int GEO>
+hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
     constexpr bool TIES = (KIND & kExactTiesBit) != 0;
+    constexpr bool WIDE = (GEO & kGeoWide) != 0;
     const bool fullDiag = args.diagnostics && args.diagnosticsStride >= 16;
-    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_BLUE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false>(args, numBlocks, ldsBytes, stream);
+    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_BLUE, false, GEO>(args, numBlocks, stream);
+    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false, GEO>(args, numBlocks, stream);
     if (args.unitRecords) {      // RTOW_RNG_PER_SAMPLE
-        if constexpr (!TIES) if (!fullDiag && args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
-        return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, true>(args, numBlocks, ldsBytes, stream);
+        if constexpr (!TIES && !WIDE) if (!fullDiag && args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
+        return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
     }
-    if (fullDiag) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-    if constexpr (!TIES) if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-    if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
-    return launchVariant<ALL_LDS, KIND, 32, false, RTOW_NOISE_WHITE, false>(args, numBlocks, ldsBytes, stream);
+    if constexpr (WIDE) {
+        if constexpr (!TIES) { if (!fullDiag && args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
+        else { if (!fullDiag && args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
+        return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+    } else {
+        if (fullDiag) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+        if constexpr (!TIES) if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+        if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+        return launchVariant<ALL_LDS, KIND, 32, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+    }
+}
+
+// does a slice geometry (512 / 256 lanes per workgroup) exist for this batch?  (rtow_api.hip asks before it sizes the grid)
+template <int KIND>
+constexpr bool kind_has_slice_geometry() { return KIND == SCENE_KIND_SPHERES || KIND == SCENE_KIND_SPHERES_MOTION; }
+template <int KIND>
+constexpr bool kind_has_wide_codes() { return (KIND & 7) == SCENE_KIND_SPHERES || (KIND & 7) == SCENE_KIND_SPHERES_MOTION || (KIND & 7) == SCENE_KIND_GENERAL || (KIND & 7) == SCENE_KIND_TEXTURED; }
+
+template <bool ALL_LDS, int KIND>
+hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
+{
+    if constexpr (!ALL_LDS && kind_has_wide_codes<KIND>()) {
+        if (args.wideCodes) return launchByDiagGeo<false, KIND, kGeoWide>(args, numBlocks, stream);
+    }
+    if (args.wideCodes) return hipErrorInvalidValue;                                    // refused at upload (rtow_api.hip): never reached
+    if constexpr (kind_has_slice_geometry<KIND>()) {
+        const bool sliceable = args.noiseColor == RTOW_NOISE_WHITE && !args.unitRecords && !(args.diagnostics && args.diagnosticsStride >= 16) && args.traceDepth <= 16;
+        if (sliceable && args.blockThreads == 512) return args.traceDepth <= 8 ? launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, 1>(args, numBlocks, stream)
+                                                                                : launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, 1>(args, numBlocks, stream);
+        if (sliceable && args.blockThreads == 256) return args.traceDepth <= 8 ? launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, 2>(args, numBlocks, stream)
+                                                                                : launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, 2>(args, numBlocks, stream);
+    }
+    if (args.blockThreads != kBlockThreads) return hipErrorInvalidValue;                // the host side only asks for a geometry that exists (sliceGeometryAvailable)
+    return launchByDiagGeo<ALL_LDS, KIND, 0>(args, numBlocks, stream);
 }
 
 } // namespace
 
 // One launcher per scene kind, each in its own translation unit (rtow_sample_kind*.hip).
 #define RTOW_DEFINE_KIND_LAUNCHER(NAME, KIND)                                                                                         \
-    hipError_t NAME(const SampleKernelArgs& args, int numBlocks, size_t ldsBytes, hipStream_t stream, bool allLds)                   \
+    hipError_t NAME(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds)                                    \
     {                                                                                                                                 \
-        return allLds ? launchByDiag<true, KIND>(args, numBlocks, ldsBytes, stream) : launchByDiag<false, KIND>(args, numBlocks, ldsBytes, stream); \
+        return allLds ? launchByDiag<true, KIND>(args, numBlocks, stream) : launchByDiag<false, KIND>(args, numBlocks, stream);     \
     }
 
 } // namespace rtow

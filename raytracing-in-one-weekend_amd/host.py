@@ -65,7 +65,7 @@ class DeviceBuffer:
 class Context:
     """RtowContext: one per GPU (one process per GPU in multi-GPU runs)."""
 
-    def __init__(self, device_ordinal=0, log=None, log_level=0, flags=0, lds_scene_budget=0, scheduler_tune=None, hit_list_capacity=0):
+    def __init__(self, device_ordinal=0, log=None, log_level=0, flags=0, lds_scene_budget=0, scheduler_tune=None, hit_list_capacity=0, slice_block_threads=0):
         """flags: abi.CONTEXT_* (RtowContextFlags); lds_scene_budget / scheduler_tune: the development knobs of RtowContextOptions;
         hit_list_capacity: most surfaces one ray may meet where the whole hit list is kept (0 = 1024)."""
         self._cb = abi.LogCallback(log) if log else abi.LogCallback()
@@ -76,6 +76,7 @@ class Context:
             for i, v in enumerate(scheduler_tune):
                 opts.schedulerTune[i] = int(v)
         opts.hitListCapacity = int(hit_list_capacity)
+        opts.sliceBlockThreads = int(slice_block_threads)      # development: 0 = per launch; 256 / 512 / 1024 forces the sample kernel's lanes per workgroup
         self.handle = C.c_void_p()
         check(load().rtowCreateContext(C.byref(opts), C.byref(self.handle)), "rtowCreateContext")
         self._scene_keepalive = None

@@ -20,6 +20,8 @@ Frozen build decisions:
 """
 import math
 
+import ctypes as C
+
 import numpy as np
 
 from . import abi
@@ -664,6 +666,116 @@ def mesh_scene(subdivisions=3):
             s.add_triangle(c + radius * verts[a], c + radius * verts[b], c + radius * verts[cc], mi, normals=(verts[a], verts[b], verts[cc]))
     _quad(s, (-30, 0, -30), (30, 0, -30), (30, 0, 30), (-30, 0, 30), lambertian((0.5, 0.5, 0.5)))
     s.camera = {"position": [0.0, 2.2, 7.5], "target": [0.0, 0.9, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 35.0, "aperture": 0.0}
+    return s
+
+
+def _icosphere(subdivisions):
+    """Unit icosphere: vertices [V, 3] float64 and faces [F, 3] int (F = 20 * 4^subdivisions)."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    verts = [np.array(v, dtype=np.float64) / np.linalg.norm(v) for v in verts]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+             (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(subdivisions):
+        cache, out = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            out += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = out
+    return np.asarray(verts), np.asarray(faces, dtype=np.int64)
+
+
+_ENTITY_DTYPE = np.dtype([("type", "<i4"), ("moving", "<i4"), ("rotation", "<f4", 4), ("position", "<f4", 3), ("destinationOffset", "<f4", 3), ("timeRange", "<f4", 2),
+                          ("materialIndex", "<i4"), ("size", "<f4", 3), ("contentIndex", "<i4")])
+
+
+class BulkScene(Scene):
+    """A scene whose entities are kept as packed arrays (one RtowEntity / RtowTriangle record each) instead of per-entity Python lists: what a host
+    that turns every mesh triangle into an entity hands over (UNITY/Raytracer.cs:1193-1198,1290-1300) - hundreds of thousands of records."""
+
+    def __init__(self, name, entities, triangles, materials):
+        super().__init__(name)
+        assert entities.dtype == _ENTITY_DTYPE and _ENTITY_DTYPE.itemsize == C.sizeof(abi.Entity)
+        assert triangles.dtype == np.float32 and triangles.ndim == 2 and triangles.shape[1] * 4 == C.sizeof(abi.Triangle)
+        self.entities = np.ascontiguousarray(entities)
+        self.triangle_records = np.ascontiguousarray(triangles)
+        self.materials = list(materials)
+
+    @property
+    def entity_count(self):
+        return len(self.entities)
+
+    def desc(self, max_bvh_depth=32):
+        n = len(self.entities)
+        ents = (abi.Entity * n).from_buffer(self.entities)
+        tris = (abi.Triangle * len(self.triangle_records)).from_buffer(self.triangle_records)
+        mats = (abi.Material * len(self.materials))(*self.materials)
+        d = abi.SceneDesc(ents, n, mats, len(self.materials), max_bvh_depth, tris, len(self.triangle_records), None, 0)
+        self._keepalive = (ents, mats, tris)
+        return d
+
+
+def mesh_grid_scene(grid=(14, 14), subdivisions=3, spacing=2.4, radius=1.0):
+    """The reference's own kind of test scene (UNITY/GridGenerator.cs:78-159): a grid of sphere MESHES whose material parameters blend across the
+    grid - here icospheres of 20 * 4^subdivisions smooth-shaded triangles, metallic growing along one axis and glossiness along the other, on a
+    two-triangle floor.  Every triangle is an entity (UNITY/Raytracer.cs:1193-1198): 14 x 14 x 1280 + 2 = 250 882 of them by default, far beyond
+    the 65 535 that 16-bit candidate codes can name."""
+    verts, faces = _icosphere(subdivisions)
+    gx, gy = grid
+    per = len(faces)
+    total = gx * gy * per + 2
+    tri = np.zeros((total, 24), np.float32)
+    ent = np.zeros(total, _ENTITY_DTYPE)
+    ent["type"] = abi.ENTITY_TRIANGLE
+    ent["contentIndex"] = np.arange(total)
+    materials = []
+    v = verts.astype(np.float32)
+    k = 0
+    for j in range(gy):
+        for i in range(gx):
+            hs = 0.0 if gx == 1 else i / (gx - 1)
+            vs = 0.0 if gy == 1 else j / (gy - 1)
+            centre = np.array([(i - (gx - 1) / 2) * spacing, radius, -(j * spacing)], np.float32)
+            materials.append(standard((0.9 - 0.5 * vs, 0.35 + 0.4 * hs, 0.3 + 0.5 * vs), float(f32(hs)), float(f32(0.15 + 0.85 * vs))))
+            p = (centre[None, :] + f32(radius) * v).astype(np.float32)                    # world-space vertices of this sphere
+            a, b, c = p[faces[:, 0]], p[faces[:, 1]], p[faces[:, 2]]
+            block = tri[k:k + per]
+            block[:, 0:3] = c - a                                                            # Data: v2 - v0, v1 - v0, v0 (RT/EntityTypes/Triangle.cs:15-30)
+            block[:, 3:6] = b - a
+            block[:, 6:9] = a
+            for q, col in enumerate((0, 1, 2)):                                              # smooth normals = the unit sphere's directions, normalised like the ctor does
+                nn = v[faces[:, col]]
+                d = (nn[:, 0] * nn[:, 0] + nn[:, 1] * nn[:, 1]).astype(np.float32) + (nn[:, 2] * nn[:, 2]).astype(np.float32)
+                block[:, 9 + 3 * q:12 + 3 * q] = ((np.float32(1.0) / np.sqrt(d, dtype=np.float32))[:, None] * nn).astype(np.float32)
+            block[:, 18:24] = np.array([0, 0, 1, 0, 0, 1], np.float32)
+            ent["materialIndex"][k:k + per] = len(materials) - 1
+            k += per
+    # floor: two triangles with face normals
+    materials.append(lambertian((0.5, 0.5, 0.5)))
+    ext = max(gx, gy) * spacing + 20.0
+    quad = [np.array(q, np.float32) for q in ((-ext, 0, ext), (ext, 0, ext), (ext, 0, -ext - gy * spacing), (-ext, 0, -ext - gy * spacing))]
+    for (a, b, c) in ((quad[0], quad[1], quad[2]), (quad[0], quad[2], quad[3])):
+        d0, d1 = (c - a).astype(np.float32), (b - a).astype(np.float32)
+        fn = _normalize(_cross(d1, d0))
+        tri[k, 0:3], tri[k, 3:6], tri[k, 6:9] = d0, d1, a
+        tri[k, 9:12] = tri[k, 12:15] = tri[k, 15:18] = fn
+        tri[k, 18:24] = np.array([0, 0, 1, 0, 0, 1], np.float32)
+        ent["materialIndex"][k] = len(materials) - 1
+        k += 1
+    assert k == total
+    s = BulkScene("mesh_grid", ent, tri, materials)
+    depth = gy * spacing
+    s.camera = {"position": [0.0, 0.35 * depth + 3.0, 0.45 * depth + 6.0], "target": [0.0, 0.5, -0.45 * depth], "up": [0.0, 1.0, 0.0], "vfov": 42.0, "aperture": 0.0}
+    s.meta = {"triangles": int(total), "grid": [gx, gy], "subdivisions": subdivisions, "focus": float(np.linalg.norm(np.array(s.camera["position"]) - np.array(s.camera["target"])))}
     return s
 
 

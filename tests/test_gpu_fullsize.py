@@ -29,11 +29,11 @@ def _device_render(rt, ctx, p, n, stride):
     return res
 
 
-def _check_sparse(rt, oracle, ctx, scene, w, h, spp, depth, count, seed=1, stride=4, nthreads=0):
+def _check_sparse(rt, oracle, ctx, scene, w, h, spp, depth, count, seed=1, stride=4, nthreads=0, focus=None, **params):
     desc = scene.desc()
     ctx.upload_scene(desc)
     n = w * h
-    p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=seed, diagnostics_stride=stride)
+    p = rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=seed, diagnostics_stride=stride, focus=focus, **params)
     gpu = _device_render(rt, ctx, p, n, stride)
     # size-independent properties over the WHOLE frame
     assert not np.isnan(gpu["color"]).any() and not np.isnan(gpu["scw"]).any(), "a pixel was not written"
@@ -97,6 +97,26 @@ def test_config4_stress_10k_spheres(rt, oracle, gpu_context):
 def test_config5_moving_defocus_1080p(rt, oracle, gpu_context):
     """BASELINE.json configs[4]: moving spheres + aperture 0.05 at 1920x1080, 512 spp."""
     _check_sparse(rt, oracle, gpu_context, rt.scenes.moving_scene(), 1920, 1080, 512, 8, count=400, seed=7, stride=16)
+
+
+def test_mesh_grid_of_250k_triangles(rt, oracle, gpu_context):
+    """Beyond 65 535 entities: the reference's live host turns every mesh triangle into an entity (UNITY/Raytracer.cs:1193-1198,1290-1300) and its own
+    test scenes are grids of sphere meshes (UNITY/GridGenerator.cs:78-159).  14 x 14 icospheres of 1 280 triangles + floor = 250 882 entities,
+    501 761 tree nodes: the kernels with 32-bit candidate / stack codes and 4 x 32-bit camera-ray lists, the tree read from HBM, the exact-tie
+    resolver on (general entities).  1080p; sparse pixels bit for bit against the oracle, under the reference stream, the per-sample policy and
+    with 16-byte records."""
+    scene = rt.scenes.mesh_grid_scene()
+    assert scene.entity_count == 250882
+    _check_sparse(rt, oracle, gpu_context, scene, 1920, 1080, 8, 8, count=500, seed=9, focus=scene.meta["focus"])
+    info = gpu_context.scene_info()
+    assert info.wideCodes == 1 and info.sceneInLds == 0 and info.bvhNodeCount == 250881 and info.entityCount == 250882
+    assert info.hitListCapacity == 128 and info.hitSpillBytes > 0 and info.hitSpillBytes % ((128 - 24) * 16 * 1024) == 0      # 104 spill entries x 16 B x 1024 lanes x CUs
+    _check_sparse(rt, oracle, gpu_context, scene, 1920, 1080, 20, 12, count=300, seed=10, stride=16, focus=scene.meta["focus"], rng_policy=rt.abi.RNG_PER_SAMPLE)
+    # the rank rule instead of the resolver (RTOW_CONTEXT_EXACT_TIES_NEVER): the other wide kernel family; a smooth closed mesh ties only on shared edges,
+    # where both triangles give the same answer up to the leaf order the rank reproduces
+    with rt.Context(0, flags=rt.abi.CONTEXT_EXACT_TIES_NEVER) as ctx:
+        _check_sparse(rt, oracle, ctx, scene, 1280, 720, 6, 8, count=300, seed=11, focus=scene.meta["focus"])
+        assert ctx.scene_info().wideCodes == 1 and ctx.scene_info().hitSpillBytes == 0
 
 
 @pytest.mark.parametrize("name", ["cover", "moving", "stress", "mixed"])

@@ -82,3 +82,67 @@ def test_every_kernel_variant(rt, oracle, kind, in_lds):
                     assert np.array_equal(gpu["diag"][:, 3].view(np.uint32), ref["diag"][:, 3].view(np.uint32)), (where, "sample count weight")
     finally:
         osc.close()
+
+
+def _compare_modes(rt, oracle, ctx, scene, desc, modes, where):
+    abi = rt.abi
+    noise = rt.scenes.NoiseTextures(row_stride=8, count=2, seed=3)
+    ctx.upload_blue_noise(noise.blue_desc())
+    ctx.upload_stb_noise(noise.stb_desc())
+    osc = oracle.OracleScene(desc)
+    osc.set_blue_noise(noise.blue_desc())
+    osc.set_stb_noise(noise.stb_desc())
+    w, h = 40, 24
+    rng = np.random.default_rng(11)
+    ins = {"color": rng.random((w * h, 4)).astype(np.float32), "normal": rng.normal(size=(w * h, 3)).astype(np.float32),
+           "albedo": rng.random((w * h, 3)).astype(np.float32), "scw": rng.random(w * h).astype(np.float32)}
+    ins["color"][:, 3] = rng.integers(0, 4, w * h)
+    try:
+        for depth, noise_color, policy, stride in modes:
+            p = rt.scenes.make_params(scene, w, h, spp=3, trace_depth=depth, seed=77, diagnostics_stride=stride, noise_color=noise_color, noise_texture_index=1, rng_policy=policy)
+            gpu = rt.sample_batch_host(ctx, p, ins)
+            ref = osc.sample_batch(p, ins)
+            for k in ("color", "normal", "albedo", "scw"):
+                assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (where, depth, noise_color, policy, stride, k)
+            assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0]), (where, depth, noise_color, policy, stride, "ray count")
+    finally:
+        osc.close()
+
+
+@pytest.mark.parametrize("in_lds", [True, False], ids=["lds", "hbm"])
+@pytest.mark.parametrize("block_threads", [512, 256])
+@pytest.mark.parametrize("kind", ["spheres", "spheres_motion"])
+def test_slice_geometry_variants(rt, oracle, kind, block_threads, in_lds):
+    """The 16 kernels with 512 / 256 lanes per workgroup (RtowContextOptions.sliceBlockThreads forces the geometry a tile-split launch picks by
+    itself): sphere kinds, reference stream, short records, history width 4 and 8.  Same image, bit for bit."""
+    abi = rt.abi
+    scene = _scene(rt, kind)
+    desc = scene.desc()
+    with rt.Context(0, lds_scene_budget=0 if in_lds else 1024, slice_block_threads=block_threads) as ctx:
+        ctx.upload_scene(desc)
+        assert bool(ctx.scene_info().sceneInLds) == in_lds
+        _compare_modes(rt, oracle, ctx, scene, desc, [(5, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4), (12, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4),
+                                                      (20, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4), (5, abi.NOISE_WHITE, abi.RNG_REFERENCE, 16)],      # the last two: no such geometry - 1024 lanes, same image
+                       (kind, block_threads, in_lds))
+
+
+@pytest.mark.parametrize("kind", ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "textured", "textured_ties"])
+def test_wide_code_variants(rt, oracle, kind):
+    """The kernels with 32-bit candidate / stack codes and 4 x 32-bit camera-ray lists (scenes beyond 65 535 entities or tree nodes), forced onto
+    small scenes with RTOW_CONTEXT_FORCE_WIDE_CODES: five per scene kind - the specialised reference-stream variant and the generic one per
+    noise source / RNG policy."""
+    abi = rt.abi
+    scene = _scene(rt, kind)
+    desc = scene.desc()
+    with rt.Context(0, flags=abi.CONTEXT_FORCE_WIDE_CODES) as ctx:
+        ctx.upload_scene(desc)
+        info = ctx.scene_info()
+        assert info.wideCodes == 1 and not info.sceneInLds
+        modes = [(5, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4), (12, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4), (20, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4), (5, abi.NOISE_WHITE, abi.RNG_REFERENCE, 16),
+                 (5, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE, 4), (12, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE_XOROSHIRO, 16), (6, abi.NOISE_BLUE, abi.RNG_REFERENCE, 4),
+                 (6, abi.NOISE_SPATIOTEMPORAL_BLUE, abi.RNG_REFERENCE, 16)]
+        _compare_modes(rt, oracle, ctx, scene, desc, modes, (kind, "wide"))
+    # volume scenes have no such kernels: the flag is ignored there, a scene that NEEDS them is refused at upload (tests/test_gpu_api.py)
+    with rt.Context(0, flags=abi.CONTEXT_FORCE_WIDE_CODES) as ctx:
+        ctx.upload_scene(rt.scenes.volume_tie_scene().desc())
+        assert ctx.scene_info().wideCodes == 0

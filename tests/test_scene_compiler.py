@@ -28,8 +28,8 @@ def shim():
     return C.CDLL(so)
 
 
-def compile_scene(shim, desc, max_depth=STACK_CAPACITY):
-    buf = (C.c_uint8 * (96 << 20))()
+def compile_scene(shim, desc, max_depth=STACK_CAPACITY, capacity_mb=96):
+    buf = (C.c_uint8 * (capacity_mb << 20))()
     lay = (C.c_uint32 * 32)()
     rc = shim.shim_compile_scene(C.byref(desc), max_depth, buf, len(buf), lay)
     assert rc == 0, rc
@@ -117,6 +117,66 @@ def test_largest_scene_builds_in_seconds(shim):
     L, _ = compile_scene(shim, d)
     assert L["nodeCount"] == 65534 and L["bvhDepth"] <= STACK_CAPACITY
     assert time.time() - t < 20.0
+
+
+def _check_tree(L, blob, n):
+    """Every primitive is exactly one leaf, children come after their parent (breadth-first), depth within the stack."""
+    lo, hi, child = nodes_of(L, blob)
+    assert L["sphereCount"] == n and L["nodeCount"] == n - 1 and 1 <= L["bvhDepth"] <= STACK_CAPACITY
+    leaves = ~child[child < 0]
+    assert len(leaves) == n and np.array_equal(np.sort(leaves), np.arange(n))
+    inner = child[child >= 0]
+    assert len(inner) == n - 2 and np.array_equal(np.sort(inner), np.arange(1, n - 1))
+    rows = np.repeat(np.arange(len(child)), 2).reshape(-1, 2)
+    assert np.all(child[child >= 0] > rows[child >= 0])
+    # depth by one breadth-first pass (parents precede children)
+    depth = np.zeros(len(child), np.int32)
+    depth[0] = 1
+    for i in range(len(child)):
+        for c in child[i]:
+            if c >= 0:
+                depth[c] = depth[i] + 1
+    assert depth.max() == L["bvhDepth"]
+
+
+def test_mesh_scene_beyond_65535_entities_compiles(shim):
+    """The reference's live host makes one entity per mesh triangle (UNITY/Raytracer.cs:1193-1198); its own test scenes are grids of sphere
+    meshes (UNITY/GridGenerator.cs:78-159).  250 882 triangles: beyond 16-bit candidate codes (the kernels' wide-code variants take over,
+    chosen at upload), built with the binned SAH above 32 768 primitives per node and the full sweep below."""
+    scene = S.mesh_grid_scene()
+    n = scene.entity_count
+    assert n == 14 * 14 * 1280 + 2
+    t = time.time()
+    L, blob = compile_scene(shim, scene.desc(), capacity_mb=160)
+    took = time.time() - t
+    assert L["sceneKind"] == 2 and L["exactTies"] == 1               # general entities, more than 16 of them: exact-tie kernels (DESIGN.md 5.1)
+    _check_tree(L, blob, n)
+    assert took < 30.0, took
+
+
+def test_a_million_triangles_build_in_seconds(shim):
+    """VERDICT r02 next #3: SAH build time at 10^6 triangles (28 x 28 icospheres of 1 280 triangles + floor)."""
+    scene = S.mesh_grid_scene(grid=(28, 28))
+    n = scene.entity_count
+    assert n > 1000000
+    t = time.time()
+    L, blob = compile_scene(shim, scene.desc(), capacity_mb=512)
+    took = time.time() - t
+    assert L["nodeCount"] == n - 1 and L["bvhDepth"] <= STACK_CAPACITY
+    assert took < 90.0, took
+    print("1M-triangle scene: %.1f s, depth %d" % (took, L["bvhDepth"]))
+
+
+def test_entity_cap_is_reported(shim):
+    """Beyond 2^23 entities (30-bit hit codes, 32-bit blob offsets): RTOW_ERROR_CAPACITY, not a crash."""
+    ent = np.zeros((1 << 23) + 1, S._ENTITY_DTYPE)
+    ent["type"] = 1
+    ent["rotation"][:, 3] = 1.0
+    ent["size"][:, 0] = 1.0
+    scene = S.BulkScene("too many", ent, np.zeros((1, 24), np.float32), [S.lambertian((0.5, 0.5, 0.5))])
+    buf = (C.c_uint8 * 16)()
+    lay = (C.c_uint32 * 32)()
+    assert shim.shim_compile_scene(C.byref(scene.desc()), 24, buf, len(buf), lay) == 8
 
 
 @pytest.mark.parametrize("name,max_depth", [("cover", 32), ("cover", 5), ("moving", 32), ("mixed", 32), ("mixed", 2), ("volumes", 32), ("mesh", 32), ("mesh", 7)])
