@@ -1,0 +1,130 @@
+"""CPU: properties of the COMPILED hot kernels, checked in the build container (hipcc cross-compiles gfx950 without a GPU).
+
+The sample kernel lives at the edge of the register file (DESIGN.md 4.1 "Registers", 5.3): the headline variants are spill-free at 121-126
+VGPRs, and the chained path's wide stores are inline assembly that the compiler's hazard recogniser cannot see into.  A ROCm bump, or an edit
+that moves the allocation, can silently undo either - and the next GPU run would only show "slower" or, worse, a wrong albedo record in one
+kernel under a chain.  So every CPU-suite run recompiles the two sphere translation units (~20 s each, in parallel) and asserts:
+
+  * resource usage (-Rpass-analysis=kernel-resource-usage) of the reference-stream variants at trace depth <= 8 / <= 16, tree in LDS and in
+    HBM, all three launch geometries: no VGPR spill, at most 128 VGPRs at four waves per SIMD, no scratch at all for the static-sphere kernels
+    with the scene in LDS (the headline), at most the known 36 / 68 bytes elsewhere;
+  * ISA (-save-temps): inside those kernels no scratch_ instruction at all; in EVERY kernel of the unit each `global_store_dwordx3/x4 ... sc1`
+    is followed by its `s_nop 1` (a VMEM store of more than 8 bytes still reads its data registers for up to two wait states after issue on
+    gfx940+; LLVM pads the stores it emits itself - GCNHazardRecognizer::checkVALUHazardsHelper, VALUWaitStates = 2 - and cannot pad an asm
+    statement), and each wide `sc1` load waits for its own data (`s_waitcnt vmcnt(0)`).
+"""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc")
+FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "-x", "hip"]   # csrc/Makefile's
+
+
+def _compile(unit, out_dir):
+    src = os.path.join(CSRC, unit + ".hip")
+    proc = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [src, "-c", "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(out_dir, unit + ".o")],
+                          capture_output=True, text=True, cwd=CSRC)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    asm = [f for f in os.listdir(out_dir) if f.startswith(unit) and f.endswith(".s") and "amdgcn" in f]
+    assert len(asm) == 1, os.listdir(out_dir)
+    return proc.stderr, open(os.path.join(out_dir, asm[0])).read()
+
+
+def _usage(remarks):
+    """mangled kernel name -> {field: int} from the kernel-resource-usage remarks"""
+    out = {}
+    for block in re.split(r"remark: (?:[^\n]*?: )?Function Name: ", remarks)[1:]:      # "remark: Function Name:" or "remark: file:line:col: Function Name:" (-save-temps)
+        name = block.split(" [")[0].strip()
+        fields = {}
+        for key, tag in (("vgprs", r"\bVGPRs"), ("agprs", "AGPRs"), ("scratch", r"ScratchSize \[bytes/lane\]"), ("occupancy", r"Occupancy \[waves/SIMD\]"),
+                         ("sgpr_spill", "SGPRs Spill"), ("vgpr_spill", "VGPRs Spill")):
+            m = re.search(tag + r": (\d+)", block)
+            assert m, (name, key)
+            fields[key] = int(m.group(1))
+        out[name] = fields
+    return out
+
+
+def _bodies(asm):
+    """mangled kernel name -> list of instruction lines (comments and directives dropped)"""
+    out = {}
+    for m in re.finditer(r"^(_ZN4rtow[^\n:]*sample_batch_kernel[^\n:]*):[^\n]*\n(.*?)^\.Lfunc_end", asm, re.S | re.M):
+        lines = []
+        for line in m.group(2).splitlines():
+            line = line.split(";")[0].strip()
+            if line and not line.startswith(".") and not line.endswith(":"):
+                lines.append(line)
+        out[m.group(1)] = lines
+    return out
+
+
+def _variant(name):
+    """template arguments of sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE, PER_SAMPLE, GEO> out of the mangled name"""
+    m = re.search(r"sample_batch_kernelILb([01])ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])ELi(\d+)EE", name)
+    assert m, name
+    return tuple(int(x) for x in m.groups())
+
+
+@pytest.fixture(scope="module")
+def compiled():
+    with tempfile.TemporaryDirectory() as tmp:
+        dirs = {u: os.path.join(tmp, u) for u in ("rtow_sample_spheres", "rtow_sample_spheres_motion")}
+        for d in dirs.values():
+            os.makedirs(d)
+        with ThreadPoolExecutor(2) as pool:
+            res = list(pool.map(lambda u: _compile(u, dirs[u]), dirs))
+    return {u: r for u, r in zip(dirs, res)}
+
+
+@pytest.mark.parametrize("unit,kind", [("rtow_sample_spheres", 0), ("rtow_sample_spheres_motion", 1)])
+def test_hot_variants_stay_spill_free(compiled, unit, kind):
+    remarks, asm = compiled[unit]
+    usage = _usage(remarks)
+    bodies = _bodies(asm)
+    hot = 0
+    for name, u in usage.items():
+        if "sample_batch_kernel" not in name:
+            continue
+        all_lds, k, hw, full_diag, noise, per_sample, geo = _variant(name)
+        assert k == kind
+        waves = {0: 4, 1: 2, 2: 1}[geo & 3]                                                 # waves per SIMD of one workgroup per CU: 1024 / 512 / 256 lanes
+        assert u["vgprs"] <= 512 // waves and u["agprs"] == 0 and u["occupancy"] >= waves, (name, u)      # the workgroup must fit the CU in EVERY variant (128 VGPRs at 1024 lanes)
+        if hw in (4, 8) and not full_diag and noise == 0 and not per_sample and not (geo & 4):
+            # the reference stream at depth <= 8 / <= 16: the benchmark's kernels and their slice geometries
+            hot += 1
+            assert u["vgpr_spill"] == 0 and u["sgpr_spill"] <= 14, (name, u)
+            if all_lds and kind == 0:
+                # the benchmark's kernels (cover scene: static spheres, scene in LDS): nothing in scratch, not one scratch instruction
+                assert u["scratch"] == 0, (name, u)
+                assert not [l for l in bodies[name] if l.startswith("scratch_")], name
+            else:
+                # moving spheres (36 B since round 2: SGPRs saved to memory around the motion record's loads) and trees in HBM (the node fetch's
+                # 64-bit pointers): a known, bounded amount - growth means the allocator went over the edge
+                assert u["scratch"] <= (36 if all_lds else 68), (name, u)
+    assert hot == 12, hot                                    # 2 history widths x (LDS | HBM) x 3 geometries
+    headline = [u for n, u in usage.items() if "sample_batch_kernel" in n and _variant(n) == (1, kind, 4, 0, 0, 0, 0)]
+    assert len(headline) == 1 and headline[0]["vgprs"] <= 126, headline
+
+
+@pytest.mark.parametrize("unit", ["rtow_sample_spheres", "rtow_sample_spheres_motion"])
+def test_every_wide_coherent_store_carries_its_wait_states(compiled, unit):
+    _, asm = compiled[unit]
+    bodies = _bodies(asm)
+    assert len(bodies) >= 20
+    stores = loads = 0
+    for name, lines in bodies.items():
+        for i, line in enumerate(lines):
+            if re.match(r"global_store_dwordx[34]\b.*\bsc1\b", line):
+                stores += 1
+                assert lines[i + 1].startswith("s_nop 1"), (name, line, lines[i + 1])
+            if re.match(r"global_load_dwordx[34]\b.*\bsc1\b", line):
+                loads += 1
+                assert re.match(r"s_waitcnt vmcnt\(0\)", lines[i + 1]), (name, line, lines[i + 1])
+    # every reference-stream variant has the chained path: colour (x4) + two normal / albedo pairs (x3) stored, three wide loads
+    assert stores >= 5 * 12 and loads >= 3 * 12, (stores, loads)
