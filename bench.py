@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default: on one GPU the steps split into equal chains of at most 16, on several 1 (one gather per batch)")
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
     ap.add_argument("--context-flags", type=int, default=0, help="development: RtowContextOptions.flags (e.g. 1 = exact-tie kernels always)")
+    ap.add_argument("--post-only", default=None, metavar="WxH", help="profiling aid: run only the post-pass measurement at this frame size and print its block (profiles/collect.sh)")
     ap.add_argument("--partition", choices=("tiles", "batches"), default="tiles", help="which N > 1 partition `value` reports (the other is reported beside it)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -284,6 +285,11 @@ def main():
     ctx.upload_scene(scene.desc())
     info = ctx.scene_info()
     mg = importlib.import_module("raytracing-in-one-weekend_amd.multigpu")
+    if args.post_only:
+        pw, ph = (int(x) for x in args.post_only.lower().split("x"))
+        print(json.dumps({"post_passes": post_passes(rt, ctx, rt.lib.load(), torch, dev, torch.cuda.current_stream(dev), sizes=((pw, ph),))}), flush=True)
+        ctx.close()
+        return
 
     import ctypes as C
     lib = rt.lib.load()

@@ -94,6 +94,44 @@ def main():
         summary["bench_line_under_profiler"] = json.loads(open(bl).read())
     json.dump(summary, open(os.path.join(ROOT, "profiles", TAG + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(summary["derived"], indent=1))
+    post_passes()
+
+
+# algorithmic bytes per pixel of the post passes: combine 44 read + 36 written; finalize 36 + 12; reduce_metrics 24 read;
+# add_kernel runs once per accumulation buffer (4 / 3 / 3 / 1 floats per pixel, 8 B read + 4 B written per float): 132 B per pixel over its four launches
+POST = {"combine_kernel": 80, "finalize_kernel": 48, "reduce_metrics_kernel": 24, "add_kernel": 132}
+
+
+def post_passes():
+    """profiles/<tag>_post_passes.json: rocprofv3 kernel-trace time of the post-pass kernels at 1080p and 4K -> achieved GB/s against the HBM roofline
+    (8 TB/s spec, ~6.3 TB/s achievable), next to what bench.py measured with HIP events in the same process."""
+    out = {"peak_GBps": 8000.0, "achievable_GBps": 6300.0}
+    for size in ("1920x1080", "3840x2160"):
+        stats = find("post_%s/**/*kernel_stats.csv" % size)
+        if not stats:
+            continue
+        shutil.copy(stats, os.path.join(ROOT, "profiles", "%s_post_%s_kernel_stats.csv" % (TAG, size)))
+        w, h = (int(x) for x in size.split("x"))
+        res = {}
+        for row in csv.DictReader(open(stats)):
+            for kernel, bytes_per_px in POST.items():
+                if kernel in row["Name"]:
+                    calls, total_ns = int(row["Calls"]), float(row["TotalDurationNs"])
+                    per_pass_ns = total_ns / calls * (4 if kernel == "add_kernel" else 1)      # one rtowAddAccumDevice = four add_kernel launches
+                    gbs = w * h * bytes_per_px / per_pass_ns
+                    e = res.setdefault(kernel, {"calls": 0, "GBps": 0.0})
+                    if calls > e["calls"]:                                                      # (copy_rows_kernel<float4> / <float>: take the row with the most calls)
+                        res[kernel] = {"calls": calls, "avg_ns_per_launch": round(total_ns / calls, 1), "ns_per_pass": round(per_pass_ns, 1), "bytes_per_pixel": bytes_per_px,
+                                       "GBps": round(gbs, 1), "frac_of_peak": round(gbs / 8000.0, 4), "frac_of_achievable": round(gbs / 6300.0, 4)}
+        log = os.path.join(SRC, "post_%s.log" % size)
+        if os.path.exists(log):
+            lines = [l for l in open(log) if l.startswith("{")]
+            if lines:
+                res["bench_hip_events_same_run"] = json.loads(lines[-1])["post_passes"].get(size)
+        out[size] = res
+    if len(out) > 2:
+        json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_post_passes.json"), "w"), indent=1, sort_keys=True)
+        print(json.dumps({k: {kk: vv.get("GBps") for kk, vv in v.items() if isinstance(vv, dict) and "GBps" in vv} for k, v in out.items() if isinstance(v, dict)}, indent=1))
 
 
 if __name__ == "__main__":

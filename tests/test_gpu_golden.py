@@ -86,22 +86,49 @@ class _ContextAsOracleScene:
 
 
 def test_feature_renders_equal_the_committed_digests(rt, gpu_context, golden):
+    """One render per feature - round 1's (primitives, volumes, ties, textures, sky, noise, adaptive counts) and round 2 / 3's: exact ties by
+    size (decal stack), hit lists of 27 and 99 entries (spilled to HBM), the long tie lists of the twin row, both per-sample RNG policies, the
+    reference's own FULL_DIAGNOSTICS columns (also with leaves forced at MaxBvhDepth), three batches as one chained launch (whole frame and an
+    interlaced slice), and sparse pixels of the 250 882-triangle mesh (32-bit candidate codes) - against digests committed by
+    tests/golden/make_golden.py, no oracle in the loop."""
     fc = _feature_module()
     cases = fc.feature_cases(rt)
     assert sorted(cases) == sorted(golden["features"])
-    ctx = gpu_context
-    try:
-        for name, (scene, kw, setup) in cases.items():
-            ctx.upload_scene(scene.desc())
+    keys = ("color", "normal", "albedo", "scw")
+    for name, case in cases.items():
+        scene, kw, setup, opts = fc.unpack(case)
+        own = "context_flags" in opts
+        ctx = rt.Context(0, flags=opts["context_flags"]) if own else gpu_context
+        try:
+            ctx.upload_scene(scene.desc(max_bvh_depth=opts["max_bvh_depth"]) if "max_bvh_depth" in opts else scene.desc())
             if setup:
                 setup(_ContextAsOracleScene(ctx))
-            got = rt.sample_batch_host(ctx, rt.scenes.make_params(scene, **kw))
+            p = rt.scenes.make_params(scene, **kw)
+            batch_raycounts = None
+            if "chain_seeds" in opts:
+                plist = []
+                for seed in opts["chain_seeds"]:
+                    q = rt.abi.SampleParams.from_buffer_copy(p)
+                    q.seed = seed
+                    plist.append(q)
+                got = rt.sample_batch_chain_host(ctx, plist)
+                batch_raycounts = [d[:, 0].copy() for d in got["diag"]]
+                got["diag"] = got["diag"][-1]
+            else:
+                got = rt.sample_batch_host(ctx, p)
+            if "sparse" in opts:
+                idx = fc.sparse_indices(kw, opts)
+                got = {k: got[k][idx] for k in keys + ("diag",)}
+                assert ctx.scene_info().wideCodes == 1
             want = golden["features"][name]
-            d = _digests(fc, got)
+            d = fc.digests_of(got, opts, batch_raycounts)
+            assert sorted(d) == sorted(want), name
             for k in d:
                 assert d[k] == want[k], (name, k)
-            assert float(got["color"][:, 3].sum()) == want["successful_samples"], name
-    finally:
-        ctx.upload_blue_noise(None)
-        ctx.upload_stb_noise(None)
-        ctx.upload_sky_cubemap(None)
+        finally:
+            if own:
+                ctx.close()
+            else:
+                ctx.upload_blue_noise(None)
+                ctx.upload_stb_noise(None)
+                ctx.upload_sky_cubemap(None)
