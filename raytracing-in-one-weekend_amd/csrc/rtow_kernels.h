@@ -173,7 +173,7 @@ struct MetricsPartial {
     long long rays, samples;
     float minW, maxW, minS, maxS;
 };
-constexpr int kMetricsBlocks = 256;
+constexpr int kMetricsBlocks = 2048;   // 8 workgroups of 256 lanes per CU: 256 blocks (one per CU) left the reduction at 3.5 TB/s, latency bound (profiles/r03a_post_passes.json)
 hipError_t launchReduceMetrics(int pixelCount, const uint8_t* diagnostics, int stride, const float* color, const float* scw,
                                MetricsPartial* partials, hipStream_t stream);
 

@@ -1376,6 +1376,12 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
 #ifdef RTOW_STATS
                     pixT0 = wall_clock64();
 #endif
+#ifdef RTOW_EXPERIMENT_COHERENT_WAVES
+                    // TIMING EXPERIMENT ONLY (wrong image): all 64 lanes of a chunk trace the chunk's FIRST pixel - same seed, same paths, so every lane of a
+                    // wave is in the same stage on every trip and every loop runs with all 64 lanes.  Rays per second of this build is the ceiling of ANY
+                    // regrouping of rays between lanes (walk, exact tests and shading at once; DESIGN.md 4.1 "Regrouping").
+                    ticket &= ~63u;
+#endif
                     const int ownedRow = (int)(ticket / (unsigned)C.width);
                     cx = (int)(ticket - (unsigned)ownedRow * (unsigned)C.width);
                     cy = C.sliceOffset + ownedRow * C.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
@@ -1545,6 +1551,22 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     // inner child (padded box): conservative, pruned by the nearest hit so far.  Leaf child (the reference's own entity box):
                     // AxisAlignedBoundingBox.Hit itself, tMin < tMax (RT/HitTests.cs:15-20) - pruning by `best` on top (<=, so that a tie at
                     // exactly `best` is still tested) cannot change which hit is nearest.
+#ifdef RTOW_EXPERIMENT_DOUBLE_WALK
+                    // TIMING EXPERIMENT ONLY (same image): the slab arithmetic of the visit a second time on laundered operands (see RTOW_EXPERIMENT_DOUBLE_TEST)
+                    {
+                        f2 ix = invx, iy = invy, iz = invz;
+                        asm volatile("" : "+v"(ix), "+v"(iy), "+v"(iz));
+                        const f2 ulx = (f2{q0.x, q0.y} - ox) * ix, uhx = (f2{q1.z, q1.w} - ox) * ix;
+                        const f2 uly = (f2{q0.z, q0.w} - oy) * iy, uhy = (f2{q2.x, q2.y} - oy) * iy;
+                        const f2 ulz = (f2{q1.x, q1.y} - oz) * iz, uhz = (f2{q2.z, q2.w} - oz) * iz;
+                        const float um0 = vmax3(vmin(ulx.x, uhx.x), vmin(uly.x, uhy.x), vmax(vmin(ulz.x, uhz.x), 0.0f));
+                        const float uf0 = vmin3(vmax(ulx.x, uhx.x), vmax(uly.x, uhy.x), vmax(ulz.x, uhz.x));
+                        const float um1 = vmax3(vmin(ulx.y, uhx.y), vmin(uly.y, uhy.y), vmax(vmin(ulz.y, uhz.y), 0.0f));
+                        const float uf1 = vmin3(vmax(ulx.y, uhx.y), vmax(uly.y, uhy.y), vmax(ulz.y, uhz.y));
+                        const bool g0 = um0 <= vmin(uf0, bestPrune), g1 = um1 <= vmin(uf1, bestPrune);
+                        asm volatile("" : : "v"((int)g0), "v"((int)g1), "v"(um0 < uf0 ? 1.0f : 0.0f), "v"(um1 < uf1 ? 1.0f : 0.0f));
+                    }
+#endif
                     const bool hit0 = tmin0 <= vmin(tfar0, bestPrune);
                     const bool hit1 = tmin1 <= vmin(tfar1, bestPrune) && twoChildren;
                     const bool leaf0 = c0 < 0 && hit0 && tmin0 < tfar0, leaf1 = c1 < 0 && hit1 && tmin1 < tfar1;
@@ -1625,6 +1647,16 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     } else {
                         V3 c; float r, t;
                         sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
+#ifdef RTOW_EXPERIMENT_DOUBLE_TEST
+                        // TIMING EXPERIMENT ONLY (same image): the exact test runs twice on laundered operands.  What this build loses against the product
+                        // is what the TEST stage's arithmetic costs in wall time; times (1 - lane utilisation of the stage) = the ceiling of running it dense.
+                        {
+                            float r2 = r, a2 = a, t2 = 0;
+                            asm volatile("" : "+v"(r2), "+v"(a2));
+                            const bool h2 = sphere_hit(sub(ro, c), rd, a2, r2, t2);
+                            asm volatile("" : : "v"(t2), "v"((int)h2));
+                        }
+#endif
                         if (sphere_hit(sub(ro, c), rd, a, r, t) && t <= best) {
                             // same tie rule as above (duplicate or exactly tangent spheres)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
