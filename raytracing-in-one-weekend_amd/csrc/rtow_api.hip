@@ -116,6 +116,7 @@ struct RtowContext_t {
     uint32_t flags = 0;
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
     int tune[9] = {RTOW_DEFAULT_TUNE};
+    bool userTune = false;                // RtowContextOptions.schedulerTune was given: no per-scene adjustment
 
     // rtowRegisterHostBuffer: pinned + device-mapped ranges of caller memory
     struct HostRange { uint8_t* base; size_t size; uint8_t* device; };
@@ -690,6 +691,7 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
         bool anyTune = false;
         for (int i = 0; i < 9; i++) anyTune = anyTune || options->schedulerTune[i] != 0;
         if (anyTune) for (int i = 0; i < 9; i++) ctx->tune[i] = options->schedulerTune[i] < 1 ? 1 : options->schedulerTune[i];
+        ctx->userTune = anyTune;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->evStart) == hipSuccess && hipEventCreate(&ctx->evStop) == hipSuccess;
@@ -826,6 +828,14 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         return RTOW_ERROR_CAPACITY;
     }
     ctx->wideCodes = wide;
+    if (!ctx->userTune) {
+        // Box-walk slice (node visits per trip).  16 is the measured optimum for trees whose nodes come from LDS or L2 (cover 12 / 16 / 20 visits:
+        // 7.93 / 8.23 / 8.01 Gsamples/s; 10 000 spheres 16 / 24 / 32: 6.77 / 6.54 / 6.18).  A tree of hundreds of thousands of nodes is read from
+        // HBM at several times the latency per visit, and a ray visits twice as many nodes: longer slices amortise the trip around them
+        // (250 882-triangle mesh, 16 / 24 / 32 / 48 / 64 visits: 1.28 / 1.39 / 1.46 / 1.44 / 1.41 Gsamples/s; profiles/r03_runs/run_r03h.sh).
+        static const int kDefault[9] = {RTOW_DEFAULT_TUNE};
+        ctx->tune[8] = compiled.layout.nodeCount > 65535u ? 32 : kDefault[8];
+    }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - (wide ? kStackBytesWide : kStackBytes) - kQueueBytes);
     if (ctx->ldsSceneBudget >= sizeof(GpuNode) && ctx->ldsSceneBudget < budget) budget = ctx->ldsSceneBudget;   // development aid: small scenes through the tree-in-HBM kernels

@@ -472,17 +472,35 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         b.nodes.reserve(n);
         const int root = b.build(idx, 0, n, maxDepth, 0, &rootBox);
         depthSeen = b.maxDepthSeen;
+        // Numbering.  The first kBreadthFirstNodes nodes are numbered breadth-first - "the first K nodes" must be the top levels, because a scene
+        // that does not fit LDS stages a prefix of the node array (at most (160 KB - 64 KB) / 64 B = 1 535 nodes) - and every subtree hanging
+        // below that front is numbered depth-first (pre-order): a ray that has descended into a subtree keeps reading nodes that lie next to
+        // each other in memory, instead of one 64-byte line per level spread over a 16-32 MB array (a 250 000-triangle mesh: 500 000 nodes; each
+        // XCD's L2 holds 4 MB).  Children still come after their parent.  Scenes of up to kBreadthFirstNodes nodes get the order they always got.
+        constexpr size_t kBreadthFirstNodes = 2048;
         std::vector<int> newIndex(b.nodes.size(), -1);
         std::vector<int> bfs;
         bfs.reserve(b.nodes.size());
         std::queue<int> q;
         q.push(root);
-        while (!q.empty()) {
+        while (!q.empty() && bfs.size() < kBreadthFirstNodes) {
             const int t = q.front();
             q.pop();
             newIndex[t] = (int)bfs.size();
             bfs.push_back(t);
             for (int c = 0; c < 2; c++) if (b.nodes[t].child[c] >= 0) q.push(b.nodes[t].child[c]);
+        }
+        std::vector<int> dfs;
+        while (!q.empty()) {                                  // the front: one depth-first run per subtree, in breadth-first order of their roots
+            dfs.push_back(q.front());
+            q.pop();
+            while (!dfs.empty()) {
+                const int t = dfs.back();
+                dfs.pop_back();
+                newIndex[t] = (int)bfs.size();
+                bfs.push_back(t);
+                for (int c = 1; c >= 0; c--) if (b.nodes[t].child[c] >= 0) dfs.push_back(b.nodes[t].child[c]);   // child 0 next
+            }
         }
         gnodes.resize(bfs.size());
         for (size_t i = 0; i < bfs.size(); i++) {

@@ -70,7 +70,20 @@ def test_tree_shape_and_boxes(shim, name):
             if child[i, s] >= 0:
                 assert child[i, s] > i
                 parent_of[child[i, s]] = i
-    assert np.all(np.diff(inner) > 0), "children are numbered in breadth-first order"
+    # numbering: breadth-first for the first 2048 nodes (any prefix of them is "the top of the tree": what gets staged into LDS when the image does
+    # not fit, at most 1 535 nodes), depth-first pre-order inside every subtree below that front (memory locality of deep walks)
+    top = min(L["nodeCount"], 2048)
+    listed = child[:top][child[:top] >= 0]
+    assert np.all(np.diff(listed[listed < top]) > 0), "the top of the tree is numbered breadth-first"
+    depth_of = np.zeros(L["nodeCount"], np.int64)
+    for i in range(L["nodeCount"]):
+        for sd in range(2):
+            if child[i, sd] >= 0:
+                depth_of[child[i, sd]] = depth_of[i] + 1
+    assert np.all(np.diff(depth_of[:top]) >= 0), "no node of the staged prefix is deeper than a node that follows it in the prefix"
+    for i in range(top, L["nodeCount"]):
+        if child[i, 0] >= 0:
+            assert child[i, 0] == i + 1, "below the front a node's first inner child follows it directly (pre-order)"
     # a child's box encloses the boxes of both of ITS children (inner boxes are unions; padded or not)
     depth = np.zeros(L["nodeCount"], np.int64)
     for i in range(L["nodeCount"]):
