@@ -49,12 +49,20 @@ def main():
              ("decal stack (a tie on most rays)", lambda: S.decal_stack_scene(20), 640, 640, 6, 8, 8, {}),
              ("twin spheres moving", lambda: S.twin_spheres_scene(True), 1280, 720, 6, 8, 8, {}),
              ("cover, adaptive counts", S.cover_scene, 1280, 720, 4, 8, 16, {"spp_max": 40, "extrema": (0.2, 1.4)}),
-             ("cover, tiny frame", S.cover_scene, 160, 90, 64, 8, 16, {})]
-    ctx = rt.Context(0)
+             ("cover, tiny frame", S.cover_scene, 160, 90, 64, 8, 16, {}),
+             # round 3: chains through the wide-code kernels (tree in HBM, 32-bit codes) and the mesh that needs them
+             ("cover, wide codes", S.cover_scene, 1920, 1080, 16, 8, 8, {"_context": dict(flags=rt.abi.CONTEXT_FORCE_WIDE_CODES)}),
+             ("mesh grid 250k", S.mesh_grid_scene, 1280, 720, 2, 8, 4, {"_focus_from_meta": True})]
+    main_ctx = rt.Context(0)
     bad_total = 0
     for name, make, w, h, spp, depth, count, kw in cases:
+        kw = dict(kw)
         spp = max(1, int(round(spp * scale)))
         scene = make()
+        own = kw.pop("_context", None)
+        if kw.pop("_focus_from_meta", False):
+            kw["focus"] = scene.meta["focus"]
+        ctx = rt.Context(0, **own) if own else main_ctx
         ctx.upload_scene(scene.desc())
         n = w * h
         plist = [S.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=1000 + 13 * k, **kw) for k in range(count)]
@@ -64,6 +72,8 @@ def main():
             got = run(ctx, plist, n, True)
             bad += sum(int(np.any(a.reshape(n, -1) != b.reshape(n, -1), axis=1).sum()) for a, b in zip(got, seq))
         bad_total += bad
+        if own:
+            ctx.close()
         print("%-30s %4dx%-4d %3d spp x %2d batches  differing pixel-buffers: %d" % (name, w, h, spp, count, bad), flush=True)
     print("total differing: %d" % bad_total)
     return 1 if bad_total else 0

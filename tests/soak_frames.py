@@ -42,21 +42,35 @@ def main():
         ("cover blue noise", S.cover_scene, 1920, 1080, 12, 8, {"noise_color": abi.NOISE_BLUE}),
         ("cover stbn", S.cover_scene, 1920, 1080, 12, 8, {"noise_color": abi.NOISE_SPATIOTEMPORAL_BLUE}),
         ("cover cubemap", S.cover_scene, 1920, 1080, 16, 8, {"sky_type": abi.SKY_CUBEMAP}),
+        # round 3: 32-bit candidate codes (forced onto small scenes, and the 250 882-triangle mesh that needs them), slice geometries
+        ("cover wide codes", S.cover_scene, 1920, 1080, 16, 8, {"_context": dict(flags=abi.CONTEXT_FORCE_WIDE_CODES)}),
+        ("mixed wide codes", S.mixed_scene, 1280, 720, 8, 8, {"_context": dict(flags=abi.CONTEXT_FORCE_WIDE_CODES)}),
+        ("moving wide codes", S.moving_scene, 1280, 720, 8, 8, {"_context": dict(flags=abi.CONTEXT_FORCE_WIDE_CODES)}),
+        ("mesh grid 250k", S.mesh_grid_scene, 1280, 720, 3, 8, {"_focus_from_meta": True}),
+        ("cover 512 lanes", S.cover_scene, 1920, 1080, 12, 8, {"_context": dict(slice_block_threads=512)}),
+        ("moving 256 lanes", S.moving_scene, 1280, 720, 8, 8, {"_context": dict(slice_block_threads=256)}),
     ]
-    ctx = rt.Context(0)
-    ctx.upload_blue_noise(noise.blue_desc())
-    ctx.upload_stb_noise(noise.stb_desc())
-    ctx.upload_sky_cubemap(sky.desc())
+    main_ctx = rt.Context(0)
+    main_ctx.upload_blue_noise(noise.blue_desc())
+    main_ctx.upload_stb_noise(noise.stb_desc())
+    main_ctx.upload_sky_cubemap(sky.desc())
     total_rays, bad_total = 0.0, 0
     for name, make, w, h, spp, depth, kw in cases:
+        kw = dict(kw)
         spp = max(1, int(round(spp * scale)))
         scene = make()
         desc = scene.desc()
+        own = kw.pop("_context", None)
+        if kw.pop("_focus_from_meta", False):
+            kw["focus"] = scene.meta["focus"]
+        ctx = rt.Context(0, **own) if own else main_ctx
         ctx.upload_scene(desc)
         p = S.make_params(scene, w, h, spp=spp, trace_depth=depth, **kw)
         t0 = time.time()
         gpu = rt.sample_batch_host(ctx, p)
         t1 = time.time()
+        if own:
+            ctx.close()
         osc = oracle.OracleScene(desc)
         osc.set_blue_noise(noise.blue_desc())
         osc.set_stb_noise(noise.stb_desc())
