@@ -42,6 +42,10 @@
 #ifndef RTOW_EXACT_MATH
 #define RTOW_EXACT_MATH 1
 #endif
+// ballot / prefix-sum compaction of the exact tests (TEST stage, sphere kinds): see the stage.  0 = every lane loops over its own candidates
+#ifndef RTOW_COMPACT_TESTS
+#define RTOW_COMPACT_TESTS 0
+#endif
 #if RTOW_EXACT_MATH
 #define RTOW_RCP(x) rtow::exact_rcp(x)
 #define RTOW_RCP_NAN_TO_INF(x) rtow::exact_rcp_nan_to_inf(x)
@@ -1595,6 +1599,94 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
             ran = true;
             STAGE_MARK(2);
             // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
+#if RTOW_COMPACT_TESTS
+            // ---- ballot / prefix-sum compaction of the candidate tests (sphere kinds without the exact-tie resolver, 16-bit codes) ----
+            // The loop below runs max(nc) iterations with a third of the lanes.  Here the wave's candidates - (owner lane, list slot) pairs - are
+            // numbered with a prefix sum over the lanes' counts (bit-sliced ballots), written as a dense list into two unused rows of the traversal
+            // stack, and tested 64 at a time: lane j of a round takes item 64 r + j, pulls the owner's ray through ds_bpermute, runs the same
+            // sphere_at / sphere_hit on it and hands (t, rank, primitive) back as one 64-bit key; the owner takes the minimum of its items' keys
+            // and its own (best, rank[prim], prim): the lexicographic minimum over (t, rank) is exactly what the sequential
+            // `t <= best && (t < best || rank[i] < rank[prim])` update leaves, whatever the order (ranks are unique).  Same float program per test,
+            // same result; only which lane evaluates it changes.
+            constexpr bool kCompactTests = !GENERAL && !VOLUMES && !EXACT_TIES && !WIDE;
+            if (kCompactTests && L.bvhDepth <= RTOW_STACK_CAPACITY - 3) {
+                const int lane = tid & 63;
+                const unsigned cnt = st == ST_TEST ? (unsigned)nc : 0u;
+                // exclusive prefix sum of cnt (0..8) over the wave, total in an SGPR
+                unsigned start = 0, total = 0;
+                for (int bit = 0; bit < 4; bit++) {
+                    const unsigned long long m = __ballot((cnt >> bit) & 1u);
+                    start += (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << bit;
+                    total += (unsigned)__popcll(m) << bit;
+                }
+                if (FULL_DIAG && !refDiag) candidates += (float)cnt;
+                // the dense list: byte g = owner lane of item g, in rows 22 and 23 of this wave's slice of the stack (never reached: depth <= 21)
+                unsigned char* const itemList = reinterpret_cast<unsigned char*>(reinterpret_cast<Code*>(smem) + (RTOW_STACK_CAPACITY - 2) * BT) + (tid >> 6) * 256;
+                const unsigned long long ownerKey = st == ST_TEST && prim >= 0
+                    ? ((unsigned long long)__float_as_uint(best) << 32) | (reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset))[prim] << 16) | (unsigned)prim
+                    : ((unsigned long long)__float_as_uint(best) << 32) | 0xffffffffull;
+                unsigned long long bestKey = ownerKey;
+                const float a = dot(rd, rd);
+                const unsigned kmax = (unsigned)(32 - __builtin_clz(((__ballot(cnt & 8u) ? 8u : 0u) | (__ballot(cnt & 4u) ? 4u : 0u) | (__ballot(cnt & 2u) ? 2u : 0u) | (__ballot(cnt & 1u) ? 1u : 0u)) | 1u)) ;
+                (void)kmax;
+                for (unsigned base = 0; base < total; base += 256u) {                       // a pass holds at most 256 items (the list's size)
+                    for (unsigned k = 0; k < 8u; k++) {
+                        if (__ballot(k < cnt) == 0ull) break;
+                        const unsigned g = start + k;
+                        if (k < cnt && g >= base && g < base + 256u) itemList[g - base] = (unsigned char)lane;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned passItems = total - base < 256u ? total - base : 256u;
+                    for (unsigned r = 0; r < passItems; r += 64u) {
+                        const unsigned g = base + r + (unsigned)lane;
+                        const bool have = r + (unsigned)lane < passItems;
+                        const unsigned owner = have ? (unsigned)itemList[r + lane] : (unsigned)lane;
+                        const int oaddr = (int)(owner << 2);
+                        const unsigned ostart = (unsigned)__builtin_amdgcn_ds_bpermute(oaddr, (int)start);
+                        const unsigned k = have ? g - ostart : 0u;
+                        // the owner's candidate list entry [k]: same [slot][lane] layout, the owner's column
+                        const int otid = (tid & ~63) | (int)owner;
+                        const Code* ocand = reinterpret_cast<const Code*>(smem) + (otid & ~63) + ((otid & 31) << 1) + ((otid >> 5) & 1) + (RTOW_STACK_CAPACITY + k) * BT;
+                        const int i = have ? (int)*ocand : 0;
+                        V3 oro, ord_;
+                        oro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.x)));
+                        oro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.y)));
+                        oro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.z)));
+                        ord_.x = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rd.x)));
+                        ord_.y = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rd.y)));
+                        ord_.z = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rd.z)));
+                        const float oa = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(a)));
+                        const float otime = HAS_MOTION ? __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rtime))) : 0.0f;
+                        unsigned long long key = ~0ull;
+                        if (have) {
+                            V3 c; float rr, t;
+                            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, otime, c, rr);
+                            if (sphere_hit(sub(oro, c), ord_, oa, rr, t))
+                                key = ((unsigned long long)__float_as_uint(t) << 32) | (reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset))[i] << 16) | (unsigned)i;
+                        }
+                        // back to the owners: item start + k of this lane sits in lane (start + k - base - r) of this round
+                        for (unsigned kk = 0; kk < 8u; kk++) {
+                            if (__ballot(kk < cnt) == 0ull) break;
+                            const unsigned src = start + kk - base - r;                     // wraps for items of other rounds
+                            const int saddr = (int)((src & 63u) << 2);
+                            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(saddr, (int)(unsigned)key);
+                            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(saddr, (int)(unsigned)(key >> 32));
+                            const unsigned long long got = ((unsigned long long)hi << 32) | lo;
+                            const bool mine = kk < cnt && src < 64u && src < passItems - r;
+                            bestKey = (mine && got < bestKey) ? got : bestKey;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (st == ST_TEST) {
+                    if (bestKey != ownerKey) { best = __uint_as_float((unsigned)(bestKey >> 32)); prim = (int)(bestKey & 0xffffu); }
+                    nc = 0;
+                    if (cur >= 0) st = ST_TRAV;
+                    else classify();
+                }
+            } else
+#endif
             if (st == ST_TEST) {
                 const float a = dot(rd, rd);
                 if (FULL_DIAG && !refDiag) candidates += (float)nc;
