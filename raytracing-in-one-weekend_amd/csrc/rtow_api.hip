@@ -63,6 +63,7 @@ struct RtowContext_t {
     unsigned int* dWorkCounter = nullptr;
     // chunk cost map -> launch order (longest chunks first); valid for one (width, height, slice, scene) configuration
     unsigned int* dChunkDone = nullptr;   // chained batches: pixels stored per chunk
+    uint8_t* dXcdState = nullptr;         // chained batches: XcdState + kMaxXcds lists of chunkDoneCapacity entries (which XCD owns which chunk)
     ChainBatch* dChainBatches = nullptr;  // chained batches: per-batch seed / diagnostics table of the launch being enqueued
     uint32_t chunkDoneCapacity = 0;
     unsigned int *dChunkCost = nullptr, *dChunkOrder = nullptr;
@@ -387,13 +388,20 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         // per-chunk hand-off counters of the chain: pixels stored so far (all batches); batch b of a chunk waits for b x its pixels
         if (a.chunkCount > ctx->chunkDoneCapacity) {
             if (ctx->dChunkDone) (void)hipFree(ctx->dChunkDone);
+            if (ctx->dXcdState) (void)hipFree(ctx->dXcdState);
             ctx->dChunkDone = nullptr;
+            ctx->dXcdState = nullptr;
             ctx->chunkDoneCapacity = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkDone, (size_t)a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            HIP_TRY(ctx, hipMalloc(&ctx->dXcdState, sizeof(XcdState) + (size_t)kMaxXcds * a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             ctx->chunkDoneCapacity = a.chunkCount;
         }
         HIP_TRY(ctx, hipMemsetAsync(ctx->dChunkDone, 0, (size_t)a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
         a.chunkDone = ctx->dChunkDone;
+        // chunk ownership per XCD: counters zero, list entries "not written yet" (the kernel indexes the lists with THIS launch's chunkCount)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dXcdState, 0, sizeof(XcdState), stream), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dXcdState + sizeof(XcdState), 0xff, (size_t)kMaxXcds * a.chunkCount * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+        a.xcdState = reinterpret_cast<XcdState*>(ctx->dXcdState);
         // what differs between the chain's batches, indexed per lane by the kernel: a small table in device memory, written in stream order
         // (the previous chain's kernel may still be reading its own table: this copy is enqueued behind it)
         if (!ctx->dChainBatches) HIP_TRY(ctx, hipMalloc(&ctx->dChainBatches, sizeof(ChainBatch) * kMaxChain), RTOW_ERROR_MEMORY_ALLOCATION);
@@ -719,6 +727,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
     if (ctx->dChunkDone) (void)hipFree(ctx->dChunkDone);
+    if (ctx->dXcdState) (void)hipFree(ctx->dXcdState);
     if (ctx->dChainBatches) (void)hipFree(ctx->dChainBatches);
     if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
     if (ctx->dCubemap) (void)hipFree(ctx->dCubemap);

@@ -29,6 +29,17 @@ constexpr int kLocalHitEntries = 24;                // entries of a ray's hit li
 constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0, scenes with volumes (long lists are their normal case)
 constexpr uint32_t kDefaultTieListCapacity = 128;   // ... scenes without: only the exact-tie procedure keeps a whole list, and only for the ray that ties
 
+// Chained launches keep all batches of a pixel chunk on one XCD (rtow_sample_kernel.hip.h, "Chained batches"): per XCD, how many chunks it took for
+// batch 0 and the ticket counter of its later batches; kMaxXcds lists of chunk numbers (chunkCount entries each, 0xffffffff = not written yet) follow
+// the struct in the same allocation.  Zeroed (lists: 0xff) before every chained launch.
+constexpr unsigned kMaxXcds = 16;        // XCC_ID is four bits wide; MI355X has eight
+struct XcdState {
+    unsigned owned[kMaxXcds];     // chunks this XCD took for batch 0
+    unsigned ticket[kMaxXcds];    // tickets handed out for its later batches
+    unsigned listed;              // batch-0 chunks whose list entry is written (all XCDs): the later batches start at chunkCount
+    unsigned pad[15];
+};
+
 // Per-batch fields of a chained launch (rtowSampleBatchChainDevice): everything else is shared by the chain's batches.
 struct ChainBatch {
     uint8_t* diagnostics;   // of this batch, may be null
@@ -118,6 +129,7 @@ struct SampleKernelArgs {
     uint32_t chainCount;                  // >= 1; 1 = a plain batch
     const ChainBatch* chainBatches;       // [chainCount] what differs between the batches of the chain (device memory: indexed per lane)
     unsigned int* chunkDone;              // [chunkCount] pixels stored so far, all batches of this launch; zeroed before the launch
+    XcdState* xcdState;                   // chunk ownership per XCD + the lists behind it (chained launches only)
 
     // launch geometry (rtow_sample_kernel.hip.h, GEO): lanes per workgroup of THIS launch (1024, or 512 / 256 for slices that own about one pixel
     // per resident lane) and whether candidate / stack codes are 32 bits wide (scenes beyond 65 535 entities or tree nodes)

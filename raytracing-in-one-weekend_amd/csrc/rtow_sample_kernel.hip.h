@@ -882,36 +882,23 @@ template <> struct Hist<8> {
 };
 
 // ------------------------------------------------------------------------------------------------------------
-// Chained batches: accumulators handed from one batch to the next INSIDE a running kernel, possibly between workgroups on different XCDs
-// (eight L2s).  Measured on the part (profiles/calib/coherence_probe.hip): plain accesses read stale lines every time; a release /
-// acquire fence pair at agent scope is correct but writes the whole L2 back (4 us per release); relaxed agent-scope atomic accesses
-// (sc1: each one coherent at the device's coherence point) ordered by s_waitcnt are correct and cost what a plain access costs.
-// So under a chain every accumulator / diagnostics access is one of these, and a chunk is published by: stores (sc1) -> workgroup-scope
-// release (s_waitcnt vmcnt(0), keeps the compiler from reordering) -> relaxed agent-scope add on the chunk's counter.
+// Chained batches: accumulators handed from one batch to the next INSIDE a running kernel.  gfx950 has eight XCDs with one L2 each, and the L2s
+// are not coherent with each other for ordinary device memory.  Measured on the part (profiles/calib/coherence_probe.hip, xcd_affinity_probe.hip):
+//   * between workgroups on DIFFERENT XCDs plain accesses read stale lines every time; release / acquire fences at agent scope are correct but write
+//     the whole L2 back (4 us per release); write-through stores + L2-bypassing loads (sc1 on both sides) are correct and cheap, but a write-through
+//     store that leaves lane by lane is its own 32-byte memory write (round 2 shipped this: 3.7 x the algorithmic write traffic);
+//   * between workgroups on the SAME XCD plain (write-back) stores followed by s_waitcnt vmcnt(0), and sc1 loads on the reading side - which miss
+//     the CU's L1 and are served by the XCD's L2 from its own dirty lines - are correct: 0 stale dwords of 655 M (plain and sc0 loads read the
+//     reader's stale L1 copy every time).
+// So a chain keeps all batches of a pixel chunk on ONE XCD - whichever XCD takes a chunk for batch 0 owns it for the rest of the launch (XcdState
+// below) - and its accumulator traffic is ordinary: plain stores that merge in L2 like a single launch's, loads that bypass L1.  A chunk is
+// published by: stores -> s_waitcnt vmcnt(0) (coherent_flush) -> relaxed agent-scope add on the chunk's counter.
+// The loads are inline assembly (there is no builtin for a 16- / 12-byte agent-scope load) and wait for their own data: the compiler's
+// wait-count bookkeeping does not see into an asm statement.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// The same accesses 16 and 12 bytes wide (what the compiler emits for an agent-scope atomic is `sc1` on a one-dword access; there is no
-// builtin for a wider one).  A write-through store is its own memory transaction: dword by dword a pixel's 44 bytes became eleven 32-byte
-// writes (rocprofv3 WRITE_SIZE: 789 MB per batch against 99 MB algorithmic), as four wide stores they are four.  The loads wait for their
-// own data and coherent_flush() for the stores: the compiler's wait-count bookkeeping does not see into inline assembly.
-// Each store is followed by `s_nop 1`: a VMEM store of more than 8 bytes reads its data registers for a cycle or two after it issues, and
-// a VALU write to one of them in that window lands in memory instead (gfx9 "12-dword store" hazard; two wait states on gfx940+).  The
-// compiler inserts that wait for the stores IT emits and cannot for one inside inline assembly: the exact-tie general-entity kernel under
-// a chain wrote garbage into the x and y of ~1 200 albedo records of the decal-stack frame (z, colour and normal intact) until the nop was
-// there - found by tests/test_gpu_chain.py when the tie-heavy scenes were added to it.
 typedef float fvec4 __attribute__((ext_vector_type(4)));
 typedef float fvec3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void coherent_store4(float* p, float x, float y, float z, float w)
-{
-    const fvec4 v = {x, y, z, w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void coherent_store3(float* p, V3 a)
-{
-    const fvec3 v = {a.x, a.y, a.z};
-    asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
+__device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coherent_flush() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 __device__ __forceinline__ float4 coherent_load4(const float* p)
 {
@@ -924,6 +911,13 @@ __device__ __forceinline__ V3 coherent_load3(const float* p)
     fvec3 v;
     asm volatile("global_load_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v3(v.x, v.y, v.z);
+}
+// which XCD this wave runs on (gfx940+: XCC_ID, bits 3..0)
+__device__ __forceinline__ unsigned xcc_id()
+{
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & (kMaxXcds - 1u);
 }
 constexpr unsigned kChainShift = 27;                       // ticket = batch << 27 | owned-pixel number (chains need fewer than 2^27 padded pixels)
 constexpr unsigned kChainTicketMask = (1u << kChainShift) - 1u;
@@ -1179,13 +1173,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         } else if (smp == 0 && !A.probeOnly) {
             // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
             // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
-            if (chained) {
-                coherent_store3(A.outNormal + 3 * (size_t)pix, sampleNormal);
-                coherent_store3(A.outAlbedo + 3 * (size_t)pix, sampleAlbedo);
-            } else {
-                A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
-                A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
-            }
+            A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
+            A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
         }
         smp++;
         st = ST_REGEN;
@@ -1281,13 +1270,14 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         pix = -1;
                     }
                     if (pix >= 0 && chained) {
-                        // ---- pixel done, chained batches: the same stores (:159-163) as device-coherent accesses, then publish the pixel ----
-                        coherent_store4(C.outColor + 4 * (size_t)pix, colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
+                        // ---- pixel done, chained batches: the same stores (:159-163), then publish the pixel ----
+                        reinterpret_cast<float4*>(C.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
                         if (sampleCount != 0 || nsamp == 0) {
-                            coherent_store3(C.outNormal + 3 * (size_t)pix, sampleCount != 0 ? normalAcc : v3(0, 0, 0));
-                            coherent_store3(C.outAlbedo + 3 * (size_t)pix, sampleCount != 0 ? albedoAcc : v3(0, 0, 0));
+                            const V3 nrm = sampleCount != 0 ? normalAcc : v3(0, 0, 0), alb = sampleCount != 0 ? albedoAcc : v3(0, 0, 0);
+                            C.outNormal[3 * (size_t)pix + 0] = nrm.x; C.outNormal[3 * (size_t)pix + 1] = nrm.y; C.outNormal[3 * (size_t)pix + 2] = nrm.z;
+                            C.outAlbedo[3 * (size_t)pix + 0] = alb.x; C.outAlbedo[3 * (size_t)pix + 1] = alb.y; C.outAlbedo[3 * (size_t)pix + 2] = alb.z;
                         }
-                        coherent_store(C.outScw + pix, scwAcc);
+                        C.outScw[pix] = scwAcc;
                         uint8_t* dg = C.chainBatches[batch].diagnostics;
                         if (dg) {
                             if (FULL_DIAG && C.diagnosticsStride >= 16)
@@ -1295,8 +1285,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             else
                                 *reinterpret_cast<float*>(dg + (size_t)pix * 4u) = rayCount;
                         }
-                        // every store above has reached the coherence point before the chunk's counter moves (release at workgroup scope =
-                        // s_waitcnt vmcnt(0) + no compiler reordering; the stores themselves are device-coherent)
+                        // every store above has reached this XCD's L2 (s_waitcnt vmcnt(0); the workgroup-scope release keeps the compiler from reordering)
+                        // before the chunk's counter moves; the chunk's next batch runs on this XCD too and reads through that L2
                         coherent_flush();
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __hip_atomic_fetch_add(C.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1337,18 +1327,49 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         const unsigned next = waveQueue[0], end = waveQueue[1];      // wave-private: same value in every lane
                         if (next == 0xffffffffu) break;                               // queue exhausted (or cancelled)
                         if (next == end) {
+                            if (chained && waveQueue[2] == 0xffffffffu) {
+                                // the leader found the chain's hand-over from batch 0 to the per-XCD lists not complete yet (below): everybody asks again later
+                                if (lane == leader) waveQueue[2] = 0u;
+                                parked = true;
+                                break;
+                            }
                             if (lane == leader) {
                                 bool cancelled = false;
                                 if (C.cancelFlag) cancelled = *C.cancelFlag != 0u;
-                                const unsigned slot = cancelled ? 0xffffffffu : atomicAdd(C.workCounter, 1u);
-                                if (slot >= C.chunkCount * C.chainCount) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
+                                // most expensive chunks first (cost map of the previous launch, or of a 1-spp probe), so that the
+                                // chunks handed out last - the ones that decide when a wave can retire - are the cheap ones
+                                unsigned slot = cancelled ? 0xffffffffu : atomicAdd(C.workCounter, 1u);
+                                unsigned b = 0u, chunk = 0u;
+                                bool exhausted = slot >= C.chunkCount, notReady = false;
+                                if (!exhausted) chunk = C.chunkOrder ? C.chunkOrder[slot] : slot;
+                                if (chained && !cancelled) {
+                                    // Batch 0 of every chunk comes from the one device-wide queue above; the XCD whose wave takes it owns the chunk for
+                                    // the rest of the chain (its accumulator lines then live in that XCD's L2: see the note on chained batches).
+                                    // Batches 1 .. chainCount - 1 are handed out per XCD, batch after batch over the XCD's own list in the order it
+                                    // was filled (still most expensive first), once every chunk has an owner.
+                                    XcdState* const xs = C.xcdState;
+                                    unsigned* const list = reinterpret_cast<unsigned*>(xs + 1) + (size_t)xcc_id() * C.chunkCount;
+                                    unsigned* const owned = &xs->owned[xcc_id()];
+                                    if (!exhausted) {
+                                        const unsigned k = __hip_atomic_fetch_add(owned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        __hip_atomic_store(list + k, chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        coherent_flush();                            // the entry is written before it is counted as listed
+                                        __hip_atomic_fetch_add(&xs->listed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    } else if (__hip_atomic_load(&xs->listed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < C.chunkCount) {
+                                        notReady = true;                             // a wave holds a batch-0 slot it has not listed yet (nanoseconds)
+                                    } else {
+                                        const unsigned mine = __hip_atomic_load(owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        const unsigned t = mine ? __hip_atomic_fetch_add(&xs->ticket[xcc_id()], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                                        if (mine != 0u && t < mine * (C.chainCount - 1u)) {
+                                            b = 1u + t / mine;
+                                            chunk = __hip_atomic_load(list + (t - (b - 1u) * mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                            exhausted = false;
+                                        }
+                                    }
+                                }
+                                if (notReady) { waveQueue[2] = 0xffffffffu; }
+                                else if (exhausted) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
                                 else {
-                                    // chains: slots run batch after batch, each batch in the same chunk order
-                                    unsigned b = 0u, within = slot;
-                                    if (chained) { b = slot / C.chunkCount; within = slot - b * C.chunkCount; }
-                                    // most expensive chunks first (cost map of the previous launch, or of a 1-spp probe), so that the
-                                    // chunks handed out last - the ones that decide when a wave can retire - are the cheap ones
-                                    const unsigned chunk = C.chunkOrder ? C.chunkOrder[within] : within;
                                     const unsigned base = chunk * 64u;
                                     const unsigned last = (C.totalWork - base < 64u) ? C.totalWork : base + 64u;
                                     waveQueue[2] = b * (last - base);                // pixels of this chunk that must be stored before batch b may read them
