@@ -1,5 +1,6 @@
 """GPU: seeded random scenes - random mixes of every entity type, transform, material class, texture kind, camera (also inside geometry),
-lens, noise colour, RNG policy, slice and trace depth - rendered small and compared with the oracle bit for bit.  Catches the
+lens, noise colour, RNG policy, slice and trace depth, and (round 3) kernel family: forced 32-bit candidate codes, 512- / 256-lane launch geometries,
+a chain of two batches - rendered small and compared with the oracle bit for bit.  Catches the
 combinations nobody thought of writing a scene for."""
 import os
 
@@ -87,12 +88,26 @@ def _random_scene(rt, seed):
     return s, rng
 
 
+@pytest.fixture(scope="module")
+def geometry_contexts(rt):
+    """Contexts that force the kernels a small scene would not pick by itself: 32-bit candidate codes (what scenes beyond 65 535 entities use) and
+    the 512- / 256-lane launch geometries (what a tile-split launch may pick)."""
+    ctxs = {"wide": rt.Context(0, flags=rt.abi.CONTEXT_FORCE_WIDE_CODES), "lanes512": rt.Context(0, slice_block_threads=512), "lanes256": rt.Context(0, slice_block_threads=256)}
+    yield ctxs
+    for c in ctxs.values():
+        c.close()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("RTOW_FUZZ_SEEDS", "24")))))   # RTOW_FUZZ_SEEDS=1000 for a soak run
-def test_random_scene(rt, oracle, gpu_context, seed):
+def test_random_scene(rt, oracle, gpu_context, geometry_contexts, seed):
     abi = rt.abi
     scene, rng = _random_scene(rt, 1000 + seed)
     desc = scene.desc(max_bvh_depth=int(rng.choice([32, 32, 3])))
-    ctx = gpu_context
+    # (drawn from a generator of its own so that every seed keeps the scene and parameters it always had)
+    extra = np.random.default_rng(77000 + seed)
+    which = str(extra.choice(["default", "default", "default", "wide", "lanes512", "lanes256"]))
+    chain = bool(extra.random() < 0.25)
+    ctx = gpu_context if which == "default" else geometry_contexts[which]
     ctx.upload_scene(desc)
     noise_color = int(rng.choice([abi.NOISE_WHITE, abi.NOISE_WHITE, abi.NOISE_BLUE, abi.NOISE_SPATIOTEMPORAL_BLUE]))
     policy = int(rng.choice([abi.RNG_REFERENCE, abi.RNG_REFERENCE, abi.RNG_PER_SAMPLE, abi.RNG_PER_SAMPLE_XOROSHIRO])) if noise_color == abi.NOISE_WHITE else abi.RNG_REFERENCE
@@ -113,8 +128,14 @@ def test_random_scene(rt, oracle, gpu_context, seed):
         ins = {"color": rng.random((n, 4)).astype(np.float32), "normal": rng.normal(size=(n, 3)).astype(np.float32),
                "albedo": rng.random((n, 3)).astype(np.float32), "scw": rng.random(n).astype(np.float32)}
         ins["color"][:, 3] = rng.integers(0, 5, n)
+        p2 = abi.SampleParams.from_buffer_copy(p)
+        p2.seed = (p.seed * 7 + 1) & 0x3fffffff
         try:
-            gpu = rt.sample_batch_host(ctx, p, ins)
+            if chain:                                    # two successive batches as one rtowSampleBatchChain call: defined as the batches in sequence
+                gpu = rt.sample_batch_chain_host(ctx, [p, p2], ins)
+                gpu["diag"] = gpu["diag"][-1]
+            else:
+                gpu = rt.sample_batch_host(ctx, p, ins)
         except rt.lib.RtowError as e:
             # the one legitimate refusal: a ray whose whole hit list is needed (volume scenes; nearest-hit ties in scenes with duplicate
             # primitives) met more surfaces than the context's hitListCapacity (default 1024; lists beyond 24 entries spill to HBM) - the
@@ -124,9 +145,11 @@ def test_random_scene(rt, oracle, gpu_context, seed):
             assert counters.maxHits > 1024, (seed, counters.maxHits)
             return
         ref = osc.sample_batch(p, ins)
+        if chain:
+            ref = osc.sample_batch(p2, {k: ref[k] for k in ("color", "normal", "albedo", "scw")})
         for k in ("color", "normal", "albedo", "scw"):
-            assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (seed, k)
-        assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0]), seed
+            assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (seed, which, chain, k)
+        assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0]), (seed, which, chain)
     finally:
         ctx.upload_blue_noise(None); ctx.upload_stb_noise(None); ctx.upload_sky_cubemap(None)
         osc.close()
