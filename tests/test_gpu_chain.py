@@ -244,3 +244,32 @@ def test_chain_with_diagnostics_for_some_batches_only(rt, gpu_context, stride, p
             assert rec[:, 1].max() > 0 and rec[:, 2].max() > 0        # BoundsHitCount / CandidateCount were really counted
     for b in outs + [d for d in diags if d is not None]:
         b.free()
+
+
+def test_cancelled_chain_returns_promptly_and_leaves_the_context_usable(rt, gpu_context):
+    """The cancellation token inside ONE chained launch (JOBS/SampleBatchJob.cs:61-62): waves stop taking chunks at the next refill - in the device-wide
+    queue of batch 0 and in the per-XCD queues of the later batches alike - lanes parked behind a chunk's previous batch are released when that batch's
+    pixels (already handed out) finish, and the call returns RTOW_ERROR_CANCELLED well before the chain would have ended.  The next chain on the same
+    context equals its batches in sequence."""
+    import ctypes as C
+    import threading
+    import time
+    ctx = gpu_context
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    w, h = 1920, 1080
+    n = w * h
+    plist = _params(rt, scene, w, h, 256, 8, [1, 2, 3, 4, 5, 6, 7, 8])          # ~0.5 s of GPU work if not cancelled
+    bufs = _zero_bufs(rt, ctx, n)
+    for delay in (0.03, 0.2):                                                      # during batch 0; in the middle of the chain
+        token = C.c_uint8(0)
+        threading.Timer(delay, lambda t=token: setattr(t, "value", 1)).start()
+        t0 = time.perf_counter()
+        rc = rt.sample_batch_chain_device(ctx, plist, bufs, bufs, None, cancel=C.addressof(token))
+        dt = time.perf_counter() - t0
+        assert rc == rt.abi.RTOW_ERROR_CANCELLED, rc
+        assert dt < delay + 0.25, "a cancelled chain took %.3f s" % dt
+    for b in bufs:
+        b.free()
+    small = _params(rt, scene, 160, 90, 3, 8, [11, 12, 13])
+    _same(_chained(rt, ctx, small, 160 * 90, 4), _sequential(rt, ctx, small, 160 * 90, 4), "after the cancelled chains")
