@@ -549,7 +549,10 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         if (same && !first) { L.commonTimeRange = 1u; memcpy(&L.commonT0, &t0, 4); memcpy(&L.commonT1, &t1, 4); }
     }
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
-    L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? SCENE_KIND_TEXTURED : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
+    bool allTriangles = general;
+    for (int i = 0; i < n && allTriangles; i++) allTriangles = desc->entities[i].type == RTOW_ENTITY_TRIANGLE;
+    L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? SCENE_KIND_TEXTURED : allTriangles ? SCENE_KIND_TRIANGLES
+                  : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     // Does the scene hold the same primitive twice (same geometry, any material)?  Two such surfaces coincide everywhere - the same float
     // program produces both distances - and tie at the nearest hit of whole image regions; then the kernel variant that settles nearest-hit
     // ties through the reference's whole hit list is used (kExactTiesBit).  Without duplicates a tie needs two different

@@ -721,13 +721,13 @@ __device__ __forceinline__ float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.
 // Entity.HitInternal + HitContent for primitive `i` (RT/Entity.cs:74-122) with tMax = +inf (tMin = 0 except for the exit-hit
 // probe of volume hulls, JOBS/SampleBatchJob.cs:465).
 // Returns the distance, the entity-space normal and the rotation that takes it to world space.
-template <bool ALL_LDS>
+template <bool ALL_LDS, bool TRIANGLES_ONLY = false>
 __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time, float tMin,
                                             float& tOut, V3& nLocal, float4& rot, float2* texCoord = nullptr)
 {
     const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)i * 128u);
     if (texCoord) *texCoord = make_float2(0, 0);       // only triangles have texture coordinates (RT/Entity.cs:108, RT/HitTests.cs:123)
-    if (type == RTOW_ENTITY_TRIANGLE) {
+    if (TRIANGLES_ONLY || type == RTOW_ENTITY_TRIANGLE) {       // TRIANGLES_ONLY (SCENE_KIND_TRIANGLES): the other primitives' code is not compiled in
         // HitTests.Hit(Triangle) (RT/HitTests.cs:115-150); triangles are tested in world space (RT/Entity.cs:91-93)
         const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
         rot = p[6];
@@ -980,9 +980,10 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
             float t;
             bool ok;
             if (KIND >= SCENE_KIND_GENERAL) {
-                const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
+                constexpr bool TRI = KIND == SCENE_KIND_TRIANGLES;
+                const unsigned type = TRI ? (unsigned)RTOW_ENTITY_TRIANGLE : *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
                 V3 nl; float4 rq;
-                ok = general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq);
+                ok = general_hit<ALL_LDS, TRI>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq);
             } else {
                 V3 c; float r;
                 sphere_at<ALL_LDS, KIND == SCENE_KIND_SPHERES_MOTION>(sc, L, i, rtime, c, r);
@@ -1135,7 +1136,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     float pendRE = 0;
     bool insideHit = false;          // the chosen "hit" is a scattering event inside the volume
     float hitTmin = 0;               // tMin of the test that produced the chosen hit (exit hits use entry + 0.001)
-    constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
+    constexpr bool TRIANGLES_ONLY = BASE == SCENE_KIND_TRIANGLES;   // every entity is a triangle: no type dispatch, no transform code
+    constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL || TRIANGLES_ONLY;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
     V3 keptNormal = v3(0, 0, 0);
 
     // per-ray traversal state (resumable across trips)
@@ -1739,9 +1741,9 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             tmin = t + 0.001f;
                         }
                     } else if (GENERAL) {
-                        const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
+                        const unsigned type = TRIANGLES_ONLY ? (unsigned)RTOW_ENTITY_TRIANGLE : *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
                         float t; V3 nl; float4 rq;
-                        if (general_hit<ALL_LDS>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq)) {
+                        if (general_hit<ALL_LDS, TRIANGLES_ONLY>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq)) {
                             // two surfaces at the bit-identical distance: the reference's sorted hit list starts with the one that
                             // comes first in its tree's leaf order (rtow_reforder.h)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
@@ -1797,9 +1799,9 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     if (winner >= 0 && winner != prim) {
                         prim = winner;
                         if (KEEP_NORMAL) {
-                            const unsigned type = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u) >> kPrimTypeShift;
+                            const unsigned type = TRIANGLES_ONLY ? (unsigned)RTOW_ENTITY_TRIANGLE : *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u) >> kPrimTypeShift;
                             float t2; float4 rq;
-                            (void)general_hit<ALL_LDS>(sc, L, prim, type, ro, rd, rtime, 0.0f, t2, keptNormal, rq);
+                            (void)general_hit<ALL_LDS, TRIANGLES_ONLY>(sc, L, prim, type, ro, rd, rtime, 0.0f, t2, keptNormal, rq);
                         }
                     }
                 }
@@ -1826,7 +1828,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     if (KEEP_NORMAL) {
                         // TEST kept the entity-space normal of this very hit; only the rotation is fetched again (GpuPrim: [6] for triangles, else [0])
                         const float4* pp = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)prim * 128u);
-                        const float4 rq = pp[(mi >> kPrimTypeShift) == RTOW_ENTITY_TRIANGLE ? 6 : 0];
+                        const float4 rq = pp[(TRIANGLES_ONLY || (mi >> kPrimTypeShift) == RTOW_ENTITY_TRIANGLE) ? 6 : 0];
                         N = normalize(rotate(rq, keptNormal));
                     } else {
                         float t2; V3 nLocal; float4 rq;
@@ -2240,7 +2242,7 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
 template <int KIND>
 constexpr bool kind_has_slice_geometry() { return KIND == SCENE_KIND_SPHERES || KIND == SCENE_KIND_SPHERES_MOTION; }
 template <int KIND>
-constexpr bool kind_has_wide_codes() { return (KIND & 7) == SCENE_KIND_SPHERES || (KIND & 7) == SCENE_KIND_SPHERES_MOTION || (KIND & 7) == SCENE_KIND_GENERAL || (KIND & 7) == SCENE_KIND_TEXTURED; }
+constexpr bool kind_has_wide_codes() { return (KIND & 7) == SCENE_KIND_SPHERES || (KIND & 7) == SCENE_KIND_SPHERES_MOTION || (KIND & 7) == SCENE_KIND_GENERAL || (KIND & 7) == SCENE_KIND_TEXTURED || (KIND & 7) == SCENE_KIND_TRIANGLES; }
 
 template <bool ALL_LDS, int KIND>
 hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)

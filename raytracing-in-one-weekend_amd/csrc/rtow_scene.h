@@ -114,6 +114,9 @@ enum : uint32_t {
     SCENE_KIND_VOLUMES = 3,        // GENERAL + at least one ProbabilisticVolume material: all hits of a ray are collected and sorted
     SCENE_KIND_TEXTURED = 4,       // GENERAL + at least one Image texture: materials are evaluated per hit at the hit's texture coordinates
     SCENE_KIND_VOLUMES_TEXTURED = 5, // both
+    SCENE_KIND_TRIANGLES = 6,      // GENERAL whose entities are ALL triangles (what the reference's live host produces: one entity per mesh triangle,
+                                   // UNITY/Raytracer.cs:1193-1198): the same GpuPrim records and float program, without the type dispatch and the
+                                   // transform code of the other primitives in the kernel (+11 % on a 250 000-triangle mesh)
 };
 // template flag OR-ed to the kind of the sample kernel: settle nearest-hit ties with the reference's whole procedure (SceneLayout::exactTies)
 constexpr int kExactTiesBit = 8;

@@ -6,6 +6,7 @@ short diagnostics) was once MISCOMPILED by hipcc (ROCm 7.2): a VGPR spill store 
 block, so the lanes that had skipped the region kept a stale spill slot and later reloaded it - their ray-count diagnostic came out 0
 while the colours were right.  Any source change reshuffles the register allocation of all of them, so every build
 renders a small, divergent frame through each of them and compares every output with the oracle, bit for bit."""
+import math
 import os
 
 import numpy as np
@@ -13,7 +14,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "volumes", "textured", "textured_ties", "volumes_textured"]
+KINDS = ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "volumes", "textured", "textured_ties", "volumes_textured",
+         "triangles", "triangles_ties"]
 
 
 def _scene(rt, kind):
@@ -25,7 +27,26 @@ def _scene(rt, kind):
         s.add_sphere((0.4, 0.6, 0.3), 0.35, S.metal((0.9, 0.9, 0.9), 0.1))
         return s
 
-    return {"spheres": lambda: S.cover_scene(60, 600), "spheres_ties": S.twin_spheres_scene, "spheres_motion": S.tiny_scene,
+    def few_triangles():
+        # 14 triangles (a tetrahedron-ish fan, a slanted pane of two, a floor of two, glass and metal among them): all-triangle scene of at most 16
+        # entities -> SCENE_KIND_TRIANGLES without the exact-tie resolver
+        s = S.Scene("few triangles")
+        mats = [S.lambertian((0.7, 0.3, 0.3)), S.metal((0.8, 0.8, 0.9), 0.1), S.dielectric(1.5), S.standard((0.4, 0.7, 0.3), 0.3, 0.7, emission=(0.3, 0.2, 0.1))]
+        apex = (0.0, 1.6, 0.0)
+        ring = [(math.cos(a) * 1.1, 0.2, math.sin(a) * 1.1) for a in (0.0, 1.3, 2.5, 3.8, 5.0)]
+        for k in range(5):
+            s.add_triangle(apex, ring[k], ring[(k + 1) % 5], mats[k % 4])
+        for k in range(3):
+            s.add_triangle((0.0, 0.2, 0.0), ring[(k + 1) % 5], ring[k], mats[(k + 1) % 4])
+        S._quad(s, (-1.8, 0.1, -1.5), (-0.9, 0.1, -1.9), (-0.9, 1.7, -1.9), (-1.8, 1.7, -1.5), mats[1])
+        S._quad(s, (1.0, 0.3, 1.2), (1.9, 0.3, 0.6), (1.9, 1.4, 0.6), (1.0, 1.4, 1.2), mats[2])
+        S._quad(s, (-20, 0, -20), (20, 0, -20), (20, 0, 20), (-20, 0, 20), S.lambertian((0.5, 0.5, 0.5)))
+        assert s.entity_count == 14
+        s.camera = {"position": [0.4, 1.9, 5.5], "target": [0.0, 0.7, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": 0.05}
+        return s
+
+    return {"triangles": few_triangles, "triangles_ties": lambda: S.mesh_scene(1),
+            "spheres": lambda: S.cover_scene(60, 600), "spheres_ties": S.twin_spheres_scene, "spheres_motion": S.tiny_scene,
             "spheres_motion_ties": lambda: S.twin_spheres_scene(True), "general": S.mixed_scene, "general_ties": S.coplanar_scene,
             "volumes": S.volume_tie_scene, "textured": S.textured_scene, "textured_ties": textured_with_twins,
             "volumes_textured": S.textured_volume_scene}[kind]()
@@ -126,7 +147,7 @@ def test_slice_geometry_variants(rt, oracle, kind, block_threads, in_lds):
                        (kind, block_threads, in_lds))
 
 
-@pytest.mark.parametrize("kind", ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "textured", "textured_ties"])
+@pytest.mark.parametrize("kind", ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "textured", "textured_ties", "triangles", "triangles_ties"])
 def test_wide_code_variants(rt, oracle, kind):
     """The kernels with 32-bit candidate / stack codes and 4 x 32-bit camera-ray lists (scenes beyond 65 535 entities or tree nodes), forced onto
     small scenes with RTOW_CONTEXT_FORCE_WIDE_CODES: five per scene kind - the specialised reference-stream variant and the generic one per

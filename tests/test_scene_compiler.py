@@ -162,7 +162,7 @@ def test_mesh_scene_beyond_65535_entities_compiles(shim):
     t = time.time()
     L, blob = compile_scene(shim, scene.desc(), capacity_mb=160)
     took = time.time() - t
-    assert L["sceneKind"] == 2 and L["exactTies"] == 1               # general entities, more than 16 of them: exact-tie kernels
+    assert L["sceneKind"] == 6 and L["exactTies"] == 1               # all triangles (SCENE_KIND_TRIANGLES), more than 16 of them: exact-tie kernels
     _check_tree(L, blob, n)
     assert took < 30.0, took
 
