@@ -31,10 +31,12 @@
 #endif
 constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice512PixelsPerLane = RTOW_SLICE_512_PIXELS_PER_LANE;
 
-// minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: any
+// minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: on TEST and HIT any
 // threshold above 1 loses (waiting lanes cost more than the skipped stage saves); slicing the walk at 16 wins ~5 %.
 #ifndef RTOW_DEFAULT_TUNE
-#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 1, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4 of the live lanes; TEST, HIT, SKY, VOL at once; 16 node visits per walk slice */
+#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 32, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4, SKY from 1/2 of the live lanes; TEST, HIT, VOL at once; 16 node visits per walk slice.
+                                                           * SKY at 1/2 (round 3, gpurun_out/r03t / r03u, alternating runs): cover 8 357 against 8 242 Msamples/s, C3 8 533 against 8 381,
+                                                           * C4 / C5 unchanged; 40/64 and above lose */
 #endif
 
 using namespace rtow;
