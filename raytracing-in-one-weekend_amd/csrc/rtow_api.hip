@@ -846,6 +846,9 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         // (250 882-triangle mesh, 16 / 24 / 32 / 48 / 64 visits: 1.28 / 1.39 / 1.46 / 1.44 / 1.41 Gsamples/s; profiles/r03_runs/run_r03h.sh).
         static const int kDefault[9] = {RTOW_DEFAULT_TUNE};
         ctx->tune[8] = compiled.layout.nodeCount > 65535u ? 32 : kDefault[8];
+        // SKY + fold from half of the live lanes pays on the sphere kinds (cover +1.4 %, C3 +1.8 %, C4 / C5 neutral) and loses on the mesh
+        // (1 520 against 1 574 Msamples/s): the general-entity kinds keep "at once"
+        ctx->tune[4] = compiled.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? kDefault[4] : 1;
     }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - (wide ? kStackBytesWide : kStackBytes) - kQueueBytes);
