@@ -43,7 +43,7 @@
 #define RTOW_EXACT_MATH 1
 #endif
 // ballot / prefix-sum compaction of the exact tests (TEST stage, sphere kinds): see the stage.  0 = every lane loops over its own candidates
-// the exact-tie kernels of the all-triangle kind also exist with the 4-word path history (trace depth <= 8): +3.8 % on the 250 882-triangle mesh
+// the exact-tie kernels also exist with the 4-word path history (trace depth <= 8): +3.8 % on the 250 882-triangle mesh
 #ifndef RTOW_TIES_SHORT_HISTORY
 #define RTOW_TIES_SHORT_HISTORY 1
 #endif
@@ -2218,9 +2218,10 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_
 //   * wide codes (args.wideCodes, scenes beyond 65 535 entities / nodes; the tree is read from HBM, so ALL_LDS = false only): the scene kinds a host
 //     that ingests triangle meshes produces - spheres (static / moving), general entities, textured, each with and without the exact-tie resolver - as the
 //     specialised reference-stream variant (4 words, or 8 with the resolver) plus the generic one per noise source / RNG policy.
-// exact-tie kinds that also get the 4-word history variant (depth <= 8); the others share the 8-word one up to depth 16
+// the exact-tie kinds get the 4-word history variant (depth <= 8) too (round 2 let them share the 8-word one up to depth 16; on the kinds whose
+// kernels spill - general, textured, triangles - the four registers are worth 3-4 %)
 template <int KIND>
-constexpr bool kTiesWithShortHistory = RTOW_TIES_SHORT_HISTORY && (KIND & 7) == SCENE_KIND_TRIANGLES;
+constexpr bool kTiesWithShortHistory = RTOW_TIES_SHORT_HISTORY != 0;
 
 template <bool ALL_LDS, int KIND, int GEO>
 hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
