@@ -733,8 +733,9 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
     if (texCoord) *texCoord = make_float2(0, 0);       // only triangles have texture coordinates (RT/Entity.cs:108, RT/HitTests.cs:123)
     if (TRIANGLES_ONLY || type == RTOW_ENTITY_TRIANGLE) {       // TRIANGLES_ONLY (SCENE_KIND_TRIANGLES): the other primitives' code is not compiled in
         // HitTests.Hit(Triangle) (RT/HitTests.cs:115-150); triangles are tested in world space (RT/Entity.cs:91-93)
-        const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
-        rot = p[6];
+        // the first three quads (edges, v0, first normal) decide the test; the rest of the record - its second cache line when it is read from HBM -
+        // is only fetched for a hit
+        const float4 a0 = p[0], a1 = p[1], a2 = p[2];
         const V3 e0 = v3(a0.x, a0.y, a0.z), e1 = v3(a0.w, a1.x, a1.y), v0 = v3(a1.z, a1.w, a2.x);
         const V3 pvec = cross(rd, e0);
         const float det = dot(e1, pvec);
@@ -749,6 +750,8 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
         const float dist = dot(e0, qvec) * invDet;
         if (dist < tMin || dist > __builtin_inff()) return false;
         const float b0 = 1 - u - v;
+        const float4 a3 = p[3], a4 = p[4];
+        rot = p[6];
         const V3 n0 = v3(a2.y, a2.z, a2.w), n1 = v3(a3.x, a3.y, a3.z), n2 = v3(a3.w, a4.x, a4.y);
         nLocal = v3(n0.x * b0 + n1.x * u + n2.x * v, n0.y * b0 + n1.y * u + n2.y * v, n0.z * b0 + n1.z * u + n2.z * v);
         if (texCoord) {                                  // mul(tri.TextureCoordinates, barycentricCoords) (:148): float2x3 columns t0 t1 t2
