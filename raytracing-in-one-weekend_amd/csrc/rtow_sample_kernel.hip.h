@@ -956,9 +956,13 @@ enum : int {
 // A real call: it is rare, and its list lives in scratch.
 // ------------------------------------------------------------------------------------------------------------
 template <bool ALL_LDS, int KIND, typename Code, int BT>
-__device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs& sc, const SceneLayout& L, V3 ro, V3 rd, float rtime, Code* stack,
+__device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs sc, const SceneLayout* layoutInKernarg, V3 ro, V3 rd, float rtime, Code* stack,
                                                                        uint32_t* overflowFlag, HitSpill spill)
 {
+    // The scene layout is read through a pointer into the kernarg segment, the scene references travel by value: taking the address of the kernel's
+    // own copies for a by-reference parameter forced those copies - 25 dwords every stage reads - into scratch for the whole kernel (the exact-tie
+    // variants ran 7 - 17 % behind their rank-rule twins "whether the call is taken or not": most of it was this).
+    const SceneLayout& L = *layoutInKernarg;
     float hitT[kLocalHits], hitDummy[kLocalHits];
     unsigned hitCode[kLocalHits];
     int n = 0;
@@ -1020,7 +1024,8 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
 // reference's tree (rtow_reforder.h: RefTreeNode, from HBM through L2) is walked a second time, unpruned, only to count.
 // AxisAlignedBoundingBox.Hit as in the reference (RT/HitTests.cs:9-21).  A real call: only batches that asked for it pay.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __noinline__ __attribute__((unused)) void reference_counts(const uint8_t* tree, V3 ro, V3 rd, float* boundsHits, float* candidates)
+// (returns {boundsHits, candidates} by value: out-parameters would pin the caller's two counters to scratch for the whole kernel)
+__device__ __noinline__ __attribute__((unused)) float2 reference_counts(const uint8_t* tree, V3 ro, V3 rd)
 {
     V3 inv = v3(RTOW_RCP(rd.x), RTOW_RCP(rd.y), RTOW_RCP(rd.z));                     // rcp(ray.Direction), NaN -> +INF (:406-412)
     if (inv.x != inv.x) inv.x = __builtin_inff();
@@ -1043,8 +1048,7 @@ __device__ __noinline__ __attribute__((unused)) void reference_counts(const uint
         if (left < 0) cc += (float)(~left);                                  // diagnostics.CandidateCount += entityCount
         else if (sp <= 62) { stack[sp++] = left; stack[sp++] = __float_as_int(b.w); }     // Push(Left); Push(Right)
     }
-    *boundsHits += bh;
-    *candidates += cc;
+    return make_float2(bh, cc);
 }
 
 // Launch geometry of a variant (template parameter GEO): bits 0..1 = lanes per workgroup (one workgroup per CU: 1024 = four waves per SIMD, the
@@ -1198,7 +1202,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         tieAtBest = false;
         nHits = 0;
         st = ST_TRAV;
-        if (FULL_DIAG) { if (refDiag) reference_counts(A.refTree, ro, rd, &boundsHits, &candidates); }   // FindHitCandidates(ray, ...) of this segment (:186)
+        if (FULL_DIAG) { if (refDiag) { const float2 rc = reference_counts(A.refTree, ro, rd); boundsHits += rc.x; candidates += rc.y; } }   // FindHitCandidates(ray, ...) of this segment (:186)
     };
     // traversal finished: classify the result
     auto classify = [&]() {
@@ -1802,7 +1806,12 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 if (EXACT_TIES && !VOLUMES && tieAtBest) {
                     // two surfaces at exactly this distance: let the reference's own procedure pick (rare; see resolve_nearest_tie)
                     tieAtBest = false;
-                    const int winner = resolve_nearest_tie<ALL_LDS, BASE, Code, BT>(sc, L, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const SampleKernelArgs* argsInKernarg = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+                    const SampleKernelArgs* argsInKernarg = &A;                                                           // host pass of the HIP compiler: never executed
+#endif
+                    const int winner = resolve_nearest_tie<ALL_LDS, BASE, Code, BT>(sc, &argsInKernarg->layout, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
                     if (winner >= 0 && winner != prim) {
                         prim = winner;
                         if (KEEP_NORMAL) {
@@ -2017,7 +2026,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             if (c & 0x40000000u) break;                                   // entry hit, early out
                             // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
                             const V3 bd = neg(rd);
-                            if (FULL_DIAG) { if (refDiag) reference_counts(A.refTree, ro, bd, &boundsHits, &candidates); }   // FindHitCandidates(backwardsRay, ...) counts too (:495)
+                            if (FULL_DIAG) { if (refDiag) { const float2 rc = reference_counts(A.refTree, ro, bd); boundsHits += rc.x; candidates += rc.y; } }   // FindHitCandidates(backwardsRay, ...) counts too (:495)
                             V3 einv = v3(RTOW_RCP(bd.x), RTOW_RCP(bd.y), RTOW_RCP(bd.z));                    // math.rcp + "convert NaN to INFINITY" (:409-412)
                             if (einv.x != einv.x) einv.x = __builtin_inff();
                             if (einv.y != einv.y) einv.y = __builtin_inff();
