@@ -34,9 +34,9 @@ constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice
 // minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: on TEST and HIT any
 // threshold above 1 loses (waiting lanes cost more than the skipped stage saves); slicing the walk at 16 wins ~5 %.
 #ifndef RTOW_DEFAULT_TUNE
-#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 32, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4, SKY from 1/2 of the live lanes; TEST, HIT, VOL at once; 16 node visits per walk slice.
+#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 28, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4, SKY from 7/16 of the live lanes; TEST, HIT, VOL at once; 16 node visits per walk slice.
                                                            * SKY at 1/2 (round 3, gpurun_out/r03t / r03u, alternating runs): cover 8 357 against 8 242 Msamples/s, C3 8 533 against 8 381,
-                                                           * C4 / C5 unchanged; 40/64 and above lose */
+                                                           * C4 / C5 unchanged; 28 against 32: +0.5 % (r03aa); 36/64 and above lose 2 - 5 % */
 #endif
 
 using namespace rtow;
