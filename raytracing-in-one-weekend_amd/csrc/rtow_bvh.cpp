@@ -551,7 +551,7 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
     bool allTriangles = general;
     for (int i = 0; i < n && allTriangles; i++) allTriangles = desc->entities[i].type == RTOW_ENTITY_TRIANGLE;
-    L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? SCENE_KIND_TEXTURED : allTriangles ? SCENE_KIND_TRIANGLES
+    L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? (allTriangles ? SCENE_KIND_TRIANGLES_TEXTURED : SCENE_KIND_TEXTURED) : allTriangles ? SCENE_KIND_TRIANGLES
                   : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     // Does the scene hold the same primitive twice (same geometry, any material)?  Two such surfaces coincide everywhere - the same float
     // program produces both distances - and tie at the nearest hit of whole image regions; then the kernel variant that settles nearest-hit

@@ -163,6 +163,8 @@ hipError_t launchSampleTextured(const SampleKernelArgs& args, int numBlocks, hip
 hipError_t launchSampleVolumesTextured(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
 hipError_t launchSampleTriangles(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
 hipError_t launchSampleTrianglesTies(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleTrianglesTextured(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
+hipError_t launchSampleTrianglesTexturedTies(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
 // can this batch run with `blockThreads` lanes per workgroup (512 / 256: the slice geometries exist for the sphere kinds, reference stream, short records, depth <= 16)?
 bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads);

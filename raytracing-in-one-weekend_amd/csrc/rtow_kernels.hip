@@ -377,6 +377,7 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
         case SCENE_KIND_VOLUMES: return launchSampleVolumes(args, numBlocks, stream, allLds);
         case SCENE_KIND_TEXTURED: return args.layout.exactTies ? launchSampleTexturedTies(args, numBlocks, stream, allLds) : launchSampleTextured(args, numBlocks, stream, allLds);
         case SCENE_KIND_VOLUMES_TEXTURED: return launchSampleVolumesTextured(args, numBlocks, stream, allLds);
+        case SCENE_KIND_TRIANGLES_TEXTURED: return args.layout.exactTies ? launchSampleTrianglesTexturedTies(args, numBlocks, stream, allLds) : launchSampleTrianglesTextured(args, numBlocks, stream, allLds);
         case SCENE_KIND_TRIANGLES: return args.layout.exactTies ? launchSampleTrianglesTies(args, numBlocks, stream, allLds) : launchSampleTriangles(args, numBlocks, stream, allLds);
         default: return args.layout.exactTies ? launchSampleGeneralTies(args, numBlocks, stream, allLds) : launchSampleGeneral(args, numBlocks, stream, allLds);
     }
@@ -390,7 +391,7 @@ bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads)
     return kind && !args.wideCodes && args.noiseColor == RTOW_NOISE_WHITE && !args.unitRecords && !(args.diagnostics && args.diagnosticsStride >= 16) && args.traceDepth <= 16;
 }
 
-bool wideCodesAvailable(uint32_t sceneKind) { return sceneKind == SCENE_KIND_SPHERES || sceneKind == SCENE_KIND_SPHERES_MOTION || sceneKind == SCENE_KIND_GENERAL || sceneKind == SCENE_KIND_TEXTURED || sceneKind == SCENE_KIND_TRIANGLES; }
+bool wideCodesAvailable(uint32_t sceneKind) { return sceneKind == SCENE_KIND_SPHERES || sceneKind == SCENE_KIND_SPHERES_MOTION || sceneKind == SCENE_KIND_GENERAL || sceneKind == SCENE_KIND_TEXTURED || sceneKind == SCENE_KIND_TRIANGLES || sceneKind == SCENE_KIND_TRIANGLES_TEXTURED; }
 
 // ------------------------------------------------------------------------------------------------------------
 // rtowGatherRowsDevice: rows first, first + step, ... of a full-frame buffer <-> one contiguous block (what travels over xGMI).

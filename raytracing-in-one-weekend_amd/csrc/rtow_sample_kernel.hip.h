@@ -991,7 +991,7 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
             float t;
             bool ok;
             if (KIND >= SCENE_KIND_GENERAL) {
-                constexpr bool TRI = KIND == SCENE_KIND_TRIANGLES;
+                constexpr bool TRI = KIND == SCENE_KIND_TRIANGLES || KIND == SCENE_KIND_TRIANGLES_TEXTURED;
                 const unsigned type = TRI ? (unsigned)RTOW_ENTITY_TRIANGLE : *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
                 V3 nl; float4 rq;
                 ok = general_hit<ALL_LDS, TRI>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq);
@@ -1105,7 +1105,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool HAS_MOTION = BASE == SCENE_KIND_SPHERES_MOTION;
     constexpr bool GENERAL = BASE >= SCENE_KIND_GENERAL;
     constexpr bool VOLUMES = BASE == SCENE_KIND_VOLUMES || BASE == SCENE_KIND_VOLUMES_TEXTURED;   // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
-    constexpr bool TEXTURED = BASE == SCENE_KIND_TEXTURED || BASE == SCENE_KIND_VOLUMES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
+    constexpr bool TEXTURED = BASE == SCENE_KIND_TEXTURED || BASE == SCENE_KIND_VOLUMES_TEXTURED || BASE == SCENE_KIND_TRIANGLES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
 
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
@@ -1147,8 +1147,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     float pendRE = 0;
     bool insideHit = false;          // the chosen "hit" is a scattering event inside the volume
     float hitTmin = 0;               // tMin of the test that produced the chosen hit (exit hits use entry + 0.001)
-    constexpr bool TRIANGLES_ONLY = BASE == SCENE_KIND_TRIANGLES;   // every entity is a triangle: no type dispatch, no transform code
-    constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL || TRIANGLES_ONLY;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
+    constexpr bool TRIANGLES_ONLY = BASE == SCENE_KIND_TRIANGLES || BASE == SCENE_KIND_TRIANGLES_TEXTURED;   // every entity is a triangle: no type dispatch, no transform code
+    constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL || BASE == SCENE_KIND_TRIANGLES;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
     V3 keptNormal = v3(0, 0, 0);
 
     // per-ray traversal state (resumable across trips)
@@ -1848,7 +1848,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         N = normalize(rotate(rq, keptNormal));
                     } else {
                         float t2; V3 nLocal; float4 rq;
-                        (void)general_hit<ALL_LDS>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq, TEXTURED ? &hitUv : nullptr);
+                        (void)general_hit<ALL_LDS, TRIANGLES_ONLY>(sc, L, prim, mi >> kPrimTypeShift, ro, rd, rtime, hitTmin, t2, nLocal, rq, TEXTURED ? &hitUv : nullptr);
                         N = normalize(rotate(rq, nLocal));
                     }
                 } else {
@@ -2263,7 +2263,7 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
 template <int KIND>
 constexpr bool kind_has_slice_geometry() { return KIND == SCENE_KIND_SPHERES || KIND == SCENE_KIND_SPHERES_MOTION; }
 template <int KIND>
-constexpr bool kind_has_wide_codes() { return (KIND & 7) == SCENE_KIND_SPHERES || (KIND & 7) == SCENE_KIND_SPHERES_MOTION || (KIND & 7) == SCENE_KIND_GENERAL || (KIND & 7) == SCENE_KIND_TEXTURED || (KIND & 7) == SCENE_KIND_TRIANGLES; }
+constexpr bool kind_has_wide_codes() { return (KIND & 7) == SCENE_KIND_SPHERES || (KIND & 7) == SCENE_KIND_SPHERES_MOTION || (KIND & 7) == SCENE_KIND_GENERAL || (KIND & 7) == SCENE_KIND_TEXTURED || (KIND & 7) == SCENE_KIND_TRIANGLES || (KIND & 7) == SCENE_KIND_TRIANGLES_TEXTURED; }
 
 template <bool ALL_LDS, int KIND>
 hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)

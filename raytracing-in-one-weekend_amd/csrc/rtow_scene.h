@@ -117,6 +117,7 @@ enum : uint32_t {
     SCENE_KIND_TRIANGLES = 6,      // GENERAL whose entities are ALL triangles (what the reference's live host produces: one entity per mesh triangle,
                                    // UNITY/Raytracer.cs:1193-1198): the same GpuPrim records and float program, without the type dispatch and the
                                    // transform code of the other primitives in the kernel (+11 % on a 250 000-triangle mesh)
+    SCENE_KIND_TRIANGLES_TEXTURED = 7, // TEXTURED whose entities are all triangles: the same specialisation for meshes with image textures
 };
 // template flag OR-ed to the kind of the sample kernel: settle nearest-hit ties with the reference's whole procedure (SceneLayout::exactTies)
 constexpr int kExactTiesBit = 8;

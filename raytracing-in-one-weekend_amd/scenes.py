@@ -583,7 +583,7 @@ def _quad(s, p00, p10, p11, p01, material, uv0=(0.0, 0.0), uv1=(1.0, 1.0)):
     s.add_triangle(p00, p11, p01, material, uvs=((u0, v0), (u1, v1), (u0, v1)))
 
 
-def textured_scene():
+def textured_scene(triangles_only=False):
     """Triangle meshes with Image textures on every texture slot (albedo, emission, glossiness, metallic; Standard and Dielectric),
     a constant-scalar texture, a null image pointer, and image-textured spheres / rects (whose texture coordinates are always 0).
     The reference's texture assets are not in the mount: the images are procedural."""
@@ -610,11 +610,36 @@ def textured_scene():
     _quad(s, (0.2, 0.3, 0.5), (1.8, 0.3, 0.5), (1.8, 1.9, 0.2), (0.2, 1.9, 0.2), frosted, uv0=(0.1, 0.2), uv1=(0.9, 0.8))   # glass pane
     _quad(s, (-2.2, 0.01, 0.5), (-1.0, 0.01, 0.5), (-1.0, 0.01, 1.7), (-2.2, 0.01, 1.7), missing)
     _quad(s, (-1.5, 3.99, -1.5), (1.5, 3.99, -1.5), (1.5, 3.99, 1.5), (-1.5, 3.99, 1.5), standard((0, 0, 0), 0.0, 0.0, emission=(5.0, 5.0, 5.0)))
-    s.add_sphere((-1.2, 0.6, -0.8), 0.6, ball)                                                                # texture coordinates (0, 0): one texel
-    s.add_rect((2.99, 1.5, 0.0), (2.0, 2.0), wall, rotation=quat_axis_angle((0, 1, 0), -90))
-    s.add_sphere((0.9, 0.45, 1.6), 0.45, plain)
+    if triangles_only:                                  # 14 triangles and nothing else: the all-triangle textured kind, without the exact-tie resolver
+        _quad(s, (2.99, 0.5, -1.0), (2.99, 0.5, 1.0), (2.99, 2.5, 1.0), (2.99, 2.5, -1.0), ball, uv0=(0.2, 0.1), uv1=(0.7, 0.9))
+    else:
+        s.add_sphere((-1.2, 0.6, -0.8), 0.6, ball)                                                            # texture coordinates (0, 0): one texel
+        s.add_rect((2.99, 1.5, 0.0), (2.0, 2.0), wall, rotation=quat_axis_angle((0, 1, 0), -90))
+        s.add_sphere((0.9, 0.45, 1.6), 0.45, plain)
     s.camera = {"position": [0.3, 1.8, 6.5], "target": [0.0, 1.3, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 48.0, "aperture": 0.0}
     s.sky_bottom, s.sky_top = (0.05, 0.05, 0.08), (0.1, 0.15, 0.3)
+    return s
+
+
+def textured_mesh_scene(subdivisions=1):
+    """mesh_scene with image textures on its materials (albedo map on the first icosphere and the floor, a gloss / metal map on the third): an
+    all-triangle textured scene of more than 16 entities (the exact-tie kernels of the all-triangle textured kind).  Icosphere vertices carry
+    spherical texture coordinates."""
+    s = mesh_scene(subdivisions)
+    s.name = "textured mesh"
+    yy, xx = np.mgrid[0:16, 0:24]
+    albedo = np.stack([np.where(((xx // 3) + (yy // 2)) % 2 == 0, 220, 60), (xx * 9) % 256, (yy * 13) % 256], axis=-1).astype(np.uint8)
+    params = np.random.default_rng(5).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    s.images = [albedo, params]
+    s.materials[0] = abi.Material(abi.MATERIAL_STANDARD, image_tex(0, (0.9, 0.9, 0.9)), _const_tex(0.0), _none_tex(), _const_tex(0.0), 0.0)
+    s.materials[2] = abi.Material(abi.MATERIAL_STANDARD, _const_tex((0.8, 0.8, 0.9)), image_tex(1, (1.0, 1.0, 1.0), channel=1), _none_tex(), image_tex(1, (1.0, 1.0, 1.0), channel=2), 0.0)
+    s.materials[3] = abi.Material(abi.MATERIAL_STANDARD, image_tex(0, (0.6, 0.6, 0.6)), _const_tex(0.0), _none_tex(), _const_tex(0.0), 0.0)
+    for t in s.triangles:                                # texture coordinates from the vertex normals (spherical map); the floor keeps its quad coordinates
+        if abs(t.normals[0].y) > 0.999 and abs(t.normals[1].y) > 0.999 and abs(t.normals[2].y) > 0.999:
+            continue
+        for k in range(3):
+            nx, ny, nz = t.normals[k].x, t.normals[k].y, t.normals[k].z
+            t.textureCoordinates[k] = abi.Float2(float(f32(0.5 + math.atan2(nz, nx) / (2 * math.pi))), float(f32(0.5 + 0.5 * ny)))
     return s
 
 

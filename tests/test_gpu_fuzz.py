@@ -10,7 +10,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _random_scene(rt, seed):
+def _random_scene(rt, seed, only_triangles=False):
+    """only_triangles: every entity becomes a triangle and there is no ground sphere (the all-triangle scene kinds); the random stream is consumed
+    exactly as without it, so every other seed keeps its scene."""
     S, abi = rt.scenes, rt.abi
     rng = np.random.default_rng(seed)
     s = S.Scene("fuzz%d" % seed)
@@ -59,6 +61,8 @@ def _random_scene(rt, seed):
         moving = rng.random() < 0.25
         kw = dict(moving=moving, dest_offset=tuple(rng.uniform(-0.6, 0.6, 3)) if moving else (0, 0, 0), time_range=(0.0, 1.0) if moving else (0, 0))
         t = rng.random()
+        if only_triangles:
+            t = 0.9
         copies = 2 if rng.random() < 0.06 else 1            # now and then the same primitive twice (other material): nearest-hit ties everywhere on it
         if t < 0.4:
             r = float(rng.uniform(0.2, 1.1)) * (-1 if rng.random() < 0.1 else 1)
@@ -77,7 +81,7 @@ def _random_scene(rt, seed):
             uvs = tuple(tuple(rng.uniform(-0.2, 1.3, 2)) for _ in range(3))
             for _c in range(copies):
                 s.add_triangle(v[0], v[1], v[2], material(), uvs=uvs)
-    if rng.random() < 0.6:
+    if rng.random() < 0.6 and not only_triangles:
         s.add_sphere((0, -101.5, 0), 100.0, S.lambertian((0.5, 0.5, 0.5)))
     cam = rng.uniform(-4, 4, 3)
     if rng.random() < 0.2 and n > 0:
@@ -101,10 +105,11 @@ def geometry_contexts(rt):
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("RTOW_FUZZ_SEEDS", "24")))))   # RTOW_FUZZ_SEEDS=1000 for a soak run
 def test_random_scene(rt, oracle, gpu_context, geometry_contexts, seed):
     abi = rt.abi
-    scene, rng = _random_scene(rt, 1000 + seed)
-    desc = scene.desc(max_bvh_depth=int(rng.choice([32, 32, 3])))
     # (drawn from a generator of its own so that every seed keeps the scene and parameters it always had)
     extra = np.random.default_rng(77000 + seed)
+    only_triangles = bool(extra.random() < 0.12)
+    scene, rng = _random_scene(rt, 1000 + seed, only_triangles)
+    desc = scene.desc(max_bvh_depth=int(rng.choice([32, 32, 3])))
     which = str(extra.choice(["default", "default", "default", "wide", "lanes512", "lanes256"]))
     chain = bool(extra.random() < 0.25)
     ctx = gpu_context if which == "default" else geometry_contexts[which]

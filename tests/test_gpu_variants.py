@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 KINDS = ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "volumes", "textured", "textured_ties", "volumes_textured",
-         "triangles", "triangles_ties"]
+         "triangles", "triangles_ties", "triangles_textured", "triangles_textured_ties"]
 
 
 def _scene(rt, kind):
@@ -46,6 +46,7 @@ def _scene(rt, kind):
         return s
 
     return {"triangles": few_triangles, "triangles_ties": lambda: S.mesh_scene(1),
+            "triangles_textured": lambda: S.textured_scene(triangles_only=True), "triangles_textured_ties": S.textured_mesh_scene,
             "spheres": lambda: S.cover_scene(60, 600), "spheres_ties": S.twin_spheres_scene, "spheres_motion": S.tiny_scene,
             "spheres_motion_ties": lambda: S.twin_spheres_scene(True), "general": S.mixed_scene, "general_ties": S.coplanar_scene,
             "volumes": S.volume_tie_scene, "textured": S.textured_scene, "textured_ties": textured_with_twins,
@@ -147,7 +148,7 @@ def test_slice_geometry_variants(rt, oracle, kind, block_threads, in_lds):
                        (kind, block_threads, in_lds))
 
 
-@pytest.mark.parametrize("kind", ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "textured", "textured_ties", "triangles", "triangles_ties"])
+@pytest.mark.parametrize("kind", ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "textured", "textured_ties", "triangles", "triangles_ties", "triangles_textured", "triangles_textured_ties"])
 def test_wide_code_variants(rt, oracle, kind):
     """The kernels with 32-bit candidate / stack codes and 4 x 32-bit camera-ray lists (scenes beyond 65 535 entities or tree nodes), forced onto
     small scenes with RTOW_CONTEXT_FORCE_WIDE_CODES: five per scene kind - the specialised reference-stream variant and the generic one per
