@@ -130,6 +130,7 @@ struct RtowContext_t {
     int commRank = 0, commWorld = 1;
     float *dGatherSend = nullptr, *dGatherRecv = nullptr;
     size_t gatherSendFloats = 0, gatherRecvFloats = 0;
+    float* dByteThresholds = nullptr;     // FinalizeTexturesJob's float -> byte step table (rtow_finalize.hip.h), built when the context is created
     hipEvent_t evGatherDone = nullptr;    // end of the last gather: the staging blocks are per context, gathers may come on different streams
     bool haveGatherDone = false;
 
@@ -709,6 +710,9 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     ok = ok && hipEventCreateWithFlags(&ctx->evGatherDone, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dWorkCounter, sizeof(unsigned int)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dPartials, sizeof(MetricsPartial) * kMetricsBlocks) == hipSuccess;
+    // the finalize pass may be given any stream later: the table is complete before the context exists for the caller
+    ok = ok && hipMalloc(&ctx->dByteThresholds, kByteThresholdTableBytes) == hipSuccess;
+    ok = ok && launchBuildByteThresholds(ctx->dByteThresholds, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
     void* pinned = nullptr;
     ok = ok && hipHostMalloc(&pinned, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (!ok) { rtowDestroyContext(ctx); return RTOW_ERROR_MEMORY_ALLOCATION; }
@@ -740,6 +744,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dHitSpill) (void)hipFree(ctx->dHitSpill);
     if (ctx->dUnitRecords) (void)hipFree(ctx->dUnitRecords);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
+    if (ctx->dByteThresholds) (void)hipFree(ctx->dByteThresholds);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
     if (ctx->dDiag) (void)hipFree(ctx->dDiag);
@@ -1216,7 +1221,7 @@ RTOW_API int rtowFinalizeDevice(RtowContext ctx, int32_t pixelCount, const float
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    HIP_TRY(ctx, launchFinalize(pixelCount, inColor, inNormal, inAlbedo, outColor, outNormal, outAlbedo, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchFinalize(pixelCount, inColor, inNormal, inAlbedo, outColor, outNormal, outAlbedo, ctx->dByteThresholds, s), RTOW_ERROR_LAUNCH_FAILURE);
     return RTOW_SUCCESS;
 }
 

@@ -177,8 +177,11 @@ hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream);  // inverse transforms of general entities, on device
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
                          float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream);
+// thresholds: the 261-float step table of the float -> byte conversion (rtow_finalize.hip.h), built once per context by launchBuildByteThresholds
+constexpr size_t kByteThresholdTableBytes = 261 * sizeof(float);
+hipError_t launchBuildByteThresholds(float* thresholds, hipStream_t stream);
 hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
-                          uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, hipStream_t stream);
+                          uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream);
 
 hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t stream); // dst += src
 // rows first, first + step, ... (`rows` of them, `rowFloats` floats each) of a full-frame buffer -> / <- one contiguous block

@@ -2,6 +2,7 @@
 // node lists, chunk ordering, scene preparation and the post passes (CombineJob, FinalizeTexturesJob, ReduceMetricsJob), and the host
 // launchers of all of them.
 #include "rtow_sample_kernel.hip.h"
+#include "rtow_finalize.hip.h"
 
 namespace rtow {
 
@@ -310,24 +311,21 @@ __global__ void __launch_bounds__(256) add_kernel(size_t n4, float4* __restrict_
     for (size_t i = tailStart + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dstS[i] += srcS[i];
 }
 
-// LinearToGamma (UTIL/MathExtensions.cs:17-21) -> saturate -> * 255 -> (byte)
-__device__ __forceinline__ unsigned to_byte(float v)
-{
-    v = um_max(v, 0.0f);
-    const float g = um_max(1.055f * det_pow(v, 0.416666667f) - 0.055f, 0.0f);
-    return (unsigned)(um_saturate(g) * 255);
-}
-
-// FinalizeTexturesJob.Execute (JOBS/FinalizeTexturesJob.cs:23-55)
+// FinalizeTexturesJob.Execute (JOBS/FinalizeTexturesJob.cs:23-55).  The nine float -> byte conversions per pixel go through the step table
+// (rtow_finalize.hip.h: same byte as the deterministic-pow form for every float operand, a fifth of its instructions), staged in LDS.
 __global__ void __launch_bounds__(256) finalize_kernel(int n, const float* __restrict__ inColor, const float* __restrict__ inNormal,
                                                        const float* __restrict__ inAlbedo, uchar4* __restrict__ outColor, uchar4* __restrict__ outNormal,
-                                                       uchar4* __restrict__ outAlbedo)
+                                                       uchar4* __restrict__ outAlbedo, const float* __restrict__ thresholds)
 {
+    __shared__ float T[kByteThresholdFloats];
+    for (int i = (int)threadIdx.x; i < kByteThresholdFloats; i += (int)blockDim.x) T[i] = thresholds[i];
+    __syncthreads();
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
         const V3 c = load3(inColor, (size_t)i), nm = load3(inNormal, (size_t)i), al = load3(inAlbedo, (size_t)i);
-        outColor[i] = make_uchar4((unsigned char)to_byte(c.x), (unsigned char)to_byte(c.y), (unsigned char)to_byte(c.z), 255);
-        outNormal[i] = make_uchar4((unsigned char)to_byte(nm.x * 0.5f + 0.5f), (unsigned char)to_byte(nm.y * 0.5f + 0.5f), (unsigned char)to_byte(nm.z * 0.5f + 0.5f), 255);
-        outAlbedo[i] = make_uchar4((unsigned char)to_byte(al.x), (unsigned char)to_byte(al.y), (unsigned char)to_byte(al.z), 255);
+        outColor[i] = make_uchar4((unsigned char)to_byte_table(c.x, T), (unsigned char)to_byte_table(c.y, T), (unsigned char)to_byte_table(c.z, T), 255);
+        outNormal[i] = make_uchar4((unsigned char)to_byte_table(nm.x * 0.5f + 0.5f, T), (unsigned char)to_byte_table(nm.y * 0.5f + 0.5f, T),
+                                   (unsigned char)to_byte_table(nm.z * 0.5f + 0.5f, T), 255);
+        outAlbedo[i] = make_uchar4((unsigned char)to_byte_table(al.x, T), (unsigned char)to_byte_table(al.y, T), (unsigned char)to_byte_table(al.z, T), 255);
     }
 }
 
@@ -469,12 +467,20 @@ hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const
     return hipGetLastError();
 }
 
+static_assert(kByteThresholdTableBytes == kByteThresholdFloats * sizeof(float), "rtow_kernels.h and rtow_finalize.hip.h disagree on the table");
+
+hipError_t launchBuildByteThresholds(float* thresholds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(build_byte_thresholds_kernel, dim3(1), dim3(256), 0, stream, thresholds);
+    return hipGetLastError();
+}
+
 hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
-                          uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, hipStream_t stream)
+                          uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream)
 {
     const int blocks = pixelCount < 256 * 2048 ? (pixelCount + 255) / 256 : 2048;
     hipLaunchKernelGGL(finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, pixelCount, inColor, inNormal, inAlbedo,
-                       reinterpret_cast<uchar4*>(outColor), reinterpret_cast<uchar4*>(outNormal), reinterpret_cast<uchar4*>(outAlbedo));
+                       reinterpret_cast<uchar4*>(outColor), reinterpret_cast<uchar4*>(outNormal), reinterpret_cast<uchar4*>(outAlbedo), thresholds);
     return hipGetLastError();
 }
 

@@ -1,0 +1,48 @@
+// Test-only program: rtow::to_byte_table (raytracing-in-one-weekend_amd/csrc/rtow_finalize.hip.h: hardware estimate + two comparisons against
+// the 255 step thresholds) against rtow::to_byte_exact (the specification: deterministic pow) for EVERY one of the 2^32 float operands, on the
+// device, with the table built by the product's own kernel.  Also counts the places where the exact conversion steps DOWN between two
+// neighbouring non-negative floats (reported, not a failure: the table's mixed zones exist for them).
+// Built by tests/test_gpu_post.py with the product's own flags.  Prints the counts; exit code 1 on any mismatch.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../raytracing-in-one-weekend_amd/csrc/rtow_finalize.hip.h"
+
+__global__ void sweep(const float* __restrict__ table, unsigned long long* bad, unsigned* firstBad)
+{
+    __shared__ float T[rtow::kByteThresholdFloats];
+    for (int i = threadIdx.x; i < rtow::kByteThresholdFloats; i += blockDim.x) T[i] = table[i];
+    __syncthreads();
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned b0 = 0, b1 = 0;
+    for (unsigned k = 0; k < (unsigned)((1ull << 32) / stride); k++, i += stride) {     // the grid size (2^20 threads) divides 2^32
+        const float x = __uint_as_float(i);
+        const unsigned e = rtow::to_byte_exact(x);
+        if (e != rtow::to_byte_table(x, T)) { if (!b0) atomicCAS(&firstBad[0], 0u, i); b0++; }
+        if (i < 0x7f800000u && rtow::to_byte_exact(__uint_as_float(i + 1u)) < e) { if (!b1) atomicCAS(&firstBad[1], 0u, i); b1++; }
+    }
+    if (b0) atomicAdd(&bad[0], (unsigned long long)b0);
+    if (b1) atomicAdd(&bad[1], (unsigned long long)b1);
+}
+
+int main()
+{
+    unsigned long long* bad; unsigned* first; float* table;
+    (void)hipMalloc(&bad, 16); (void)hipMalloc(&first, 8); (void)hipMalloc(&table, rtow::kByteThresholdFloats * sizeof(float));
+    (void)hipMemset(bad, 0, 16); (void)hipMemset(first, 0, 8);
+    hipLaunchKernelGGL(rtow::build_byte_thresholds_kernel, dim3(1), dim3(256), 0, 0, table);
+    hipLaunchKernelGGL(sweep, dim3(4096), dim3(256), 0, 0, table, bad, first);
+    unsigned long long h[2]; unsigned f[2]; float T[rtow::kByteThresholdFloats];
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
+    (void)hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost); (void)hipMemcpy(f, first, sizeof(f), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(T, table, sizeof(T), hipMemcpyDeviceToHost);
+    printf("finalize parity over 2^32 operands: table vs exact %llu mismatches (first 0x%08x), downward steps of the exact form %llu (first 0x%08x); T[1] %.9g T[128] %.9g T[255] %.9g\n",
+           h[0], f[0], h[1], f[1], T[1], T[128], T[255]);
+    printf("mixed zones:");
+    for (int z = 0; z < rtow::kByteZones; z++) { unsigned a, b; memcpy(&a, &T[257 + 2 * z], 4); memcpy(&b, &T[258 + 2 * z], 4); printf(" [0x%08x, 0x%08x)", a, b); }
+    printf("\n");
+    return h[0] ? 1 : 0;
+}

@@ -56,3 +56,22 @@ def test_exact_div3_equals_ieee_division():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mantissa pairs 70368744177664: 0 mismatches" in r.stdout and "random quadruples 4294967296: 0 mismatches" in r.stdout \
         and "edge-exponent quadruples 4294967296: 0 mismatches" in r.stdout, r.stdout
+
+
+def test_finalize_byte_table_equals_the_pow_form_for_every_operand():
+    """FinalizeTexturesJob's float -> byte conversion runs from a 255-step table (csrc/rtow_finalize.hip.h: hardware log2 / exp2 estimate, two
+    comparisons) instead of nine deterministic pows per pixel.  Same byte for all 2^32 float operands - enumerated on the device against
+    to_byte_exact, with the table built by the product's own kernel (the one stretch of floats where the polynomial pow is not monotone
+    included: the table marks it and the kernel takes the exact form there)."""
+    src = os.path.join(ROOT, "tests", "native", "finalize_parity.hip")
+    csrc = os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc")
+    newest = max(os.path.getmtime(p) for p in (src, os.path.join(csrc, "rtow_finalize.hip.h"), os.path.join(csrc, "rtow_detmath.hip.h")))
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "finalize_parity")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
+        subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-x", "hip", src, "-o", exe],
+                       check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "table vs exact 0 mismatches" in r.stdout, r.stdout
