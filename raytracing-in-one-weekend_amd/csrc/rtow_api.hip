@@ -837,12 +837,8 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         }
         ctx->hitSpillEntries = entries;
     }
-    const bool wide = compiled.entityCount > 65535 || compiled.layout.nodeCount > 65535u ||
-                      ((ctx->flags & RTOW_CONTEXT_FORCE_WIDE_CODES) && wideCodesAvailable(compiled.layout.sceneKind));
-    if (wide && !wideCodesAvailable(compiled.layout.sceneKind)) {
-        logf(ctx, 2, "scene", "scenes of more than 65535 entities are built for sphere, general and textured scenes, not for scenes with ProbabilisticVolume materials");
-        return RTOW_ERROR_CAPACITY;
-    }
+    // every scene kind has kernels with 32-bit codes (volume kinds included: a triangle-mesh scene with one fog volume among the meshes)
+    const bool wide = compiled.entityCount > 65535 || compiled.layout.nodeCount > 65535u || (ctx->flags & RTOW_CONTEXT_FORCE_WIDE_CODES) != 0;
     ctx->wideCodes = wide;
     if (!ctx->userTune) {
         // Box-walk slice (node visits per trip).  16 is the measured optimum for trees whose nodes come from LDS or L2 (cover 12 / 16 / 20 visits:

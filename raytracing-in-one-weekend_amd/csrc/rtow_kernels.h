@@ -168,8 +168,6 @@ hipError_t launchSampleTrianglesTexturedTies(const SampleKernelArgs& args, int n
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
 // can this batch run with `blockThreads` lanes per workgroup (512 / 256: the slice geometries exist for the sphere kinds, reference stream, short records, depth <= 16)?
 bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads);
-// do kernels with 32-bit candidate / stack codes exist for this scene kind (spheres, general, textured; not the volume kinds)?
-bool wideCodesAvailable(uint32_t sceneKind);
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
 hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream);
 hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream);
@@ -178,7 +176,7 @@ hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipSt
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
                          float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream);
 // thresholds: the 261-float step table of the float -> byte conversion (rtow_finalize.hip.h), built once per context by launchBuildByteThresholds
-constexpr size_t kByteThresholdTableBytes = 261 * sizeof(float);
+constexpr size_t kByteThresholdTableBytes = 259 * sizeof(float);
 hipError_t launchBuildByteThresholds(float* thresholds, hipStream_t stream);
 hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
                           uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream);

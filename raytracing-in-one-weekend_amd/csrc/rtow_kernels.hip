@@ -313,19 +313,32 @@ __global__ void __launch_bounds__(256) add_kernel(size_t n4, float4* __restrict_
 
 // FinalizeTexturesJob.Execute (JOBS/FinalizeTexturesJob.cs:23-55).  The nine float -> byte conversions per pixel go through the step table
 // (rtow_finalize.hip.h: same byte as the deterministic-pow form for every float operand, a fifth of its instructions), staged in LDS.
-__global__ void __launch_bounds__(256) finalize_kernel(int n, const float* __restrict__ inColor, const float* __restrict__ inNormal,
+__global__ void __launch_bounds__(256, 8) finalize_kernel(int n, const float* __restrict__ inColor, const float* __restrict__ inNormal,
                                                        const float* __restrict__ inAlbedo, uchar4* __restrict__ outColor, uchar4* __restrict__ outNormal,
                                                        uchar4* __restrict__ outAlbedo, const float* __restrict__ thresholds)
 {
     __shared__ float T[kByteThresholdFloats];
     for (int i = (int)threadIdx.x; i < kByteThresholdFloats; i += (int)blockDim.x) T[i] = thresholds[i];
     __syncthreads();
-    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
-        const V3 c = load3(inColor, (size_t)i), nm = load3(inNormal, (size_t)i), al = load3(inAlbedo, (size_t)i);
-        outColor[i] = make_uchar4((unsigned char)to_byte_table(c.x, T), (unsigned char)to_byte_table(c.y, T), (unsigned char)to_byte_table(c.z, T), 255);
-        outNormal[i] = make_uchar4((unsigned char)to_byte_table(nm.x * 0.5f + 0.5f, T), (unsigned char)to_byte_table(nm.y * 0.5f + 0.5f, T),
-                                   (unsigned char)to_byte_table(nm.z * 0.5f + 0.5f, T), 255);
-        outAlbedo[i] = make_uchar4((unsigned char)to_byte_table(al.x, T), (unsigned char)to_byte_table(al.y, T), (unsigned char)to_byte_table(al.z, T), 255);
+    const ByteZones Z = load_byte_zones(T);
+    // software pipelined: the next pixel's three 12-byte loads are issued before this pixel's conversions, so a wave always has a pixel in flight
+    const int stride = (int)(gridDim.x * blockDim.x);
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    V3 c = v3(0, 0, 0), nm = v3(0, 0, 0), al = v3(0, 0, 0);
+    if (i < n) { c = load3(inColor, (size_t)i); nm = load3(inNormal, (size_t)i); al = load3(inAlbedo, (size_t)i); }
+    while (i < n) {
+        const int j = i + stride;
+        V3 c2 = v3(0, 0, 0), nm2 = v3(0, 0, 0), al2 = v3(0, 0, 0);
+        if (j < n) { c2 = load3(inColor, (size_t)j); nm2 = load3(inNormal, (size_t)j); al2 = load3(inAlbedo, (size_t)j); }
+        // nine independent conversions (rtow_finalize.hip.h): their LDS reads are in flight together
+        const float v[9] = {c.x, c.y, c.z, nm.x * 0.5f + 0.5f, nm.y * 0.5f + 0.5f, nm.z * 0.5f + 0.5f, al.x, al.y, al.z};
+        unsigned b[9];
+        to_bytes_table<9>(v, b, T, Z);
+        outColor[i] = make_uchar4((unsigned char)b[0], (unsigned char)b[1], (unsigned char)b[2], 255);
+        outNormal[i] = make_uchar4((unsigned char)b[3], (unsigned char)b[4], (unsigned char)b[5], 255);
+        outAlbedo[i] = make_uchar4((unsigned char)b[6], (unsigned char)b[7], (unsigned char)b[8], 255);
+        c = c2; nm = nm2; al = al2;
+        i = j;
     }
 }
 
@@ -389,7 +402,6 @@ bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads)
     return kind && !args.wideCodes && args.noiseColor == RTOW_NOISE_WHITE && !args.unitRecords && !(args.diagnostics && args.diagnosticsStride >= 16) && args.traceDepth <= 16;
 }
 
-bool wideCodesAvailable(uint32_t sceneKind) { return sceneKind == SCENE_KIND_SPHERES || sceneKind == SCENE_KIND_SPHERES_MOTION || sceneKind == SCENE_KIND_GENERAL || sceneKind == SCENE_KIND_TEXTURED || sceneKind == SCENE_KIND_TRIANGLES || sceneKind == SCENE_KIND_TRIANGLES_TEXTURED; }
 
 // ------------------------------------------------------------------------------------------------------------
 // rtowGatherRowsDevice: rows first, first + step, ... of a full-frame buffer <-> one contiguous block (what travels over xGMI).

@@ -2227,9 +2227,10 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_
 // the 8-word variant.  On top of these 144 (tests/test_gpu_variants.py runs every variant on every build):
 //   * slice geometries (args.blockThreads 512 / 256, chosen per launch by the host side): the two sphere kinds, reference stream, short records,
 //     depth <= 8 and <= 16 - the launches of a tile split; everything else runs 1024 lanes per workgroup;
-//   * wide codes (args.wideCodes, scenes beyond 65 535 entities / nodes; the tree is read from HBM, so ALL_LDS = false only): the scene kinds a host
-//     that ingests triangle meshes produces - spheres (static / moving), general entities, textured, each with and without the exact-tie resolver - as the
-//     specialised reference-stream variant (4 words, or 8 with the resolver) plus the generic one per noise source / RNG policy.
+//   * wide codes (args.wideCodes, scenes beyond 65 535 entities / nodes; the tree is read from HBM, so ALL_LDS = false only): every scene kind
+//     (a host that ingests triangle meshes produces spheres, general entities, triangles, textured ones - and a volume scene as soon as one fog
+//     volume stands among the meshes), each with and without the exact-tie resolver where the kind has one - as the specialised
+//     reference-stream variant (4 words, or 8 with the resolver) plus the generic one per noise source / RNG policy.
 // the exact-tie kinds get the 4-word history variant (depth <= 8) too (round 2 let them share the 8-word one up to depth 16; on the kinds whose
 // kernels spill - general, textured, triangles - the four registers are worth 3-4 %)
 template <int KIND>
@@ -2263,7 +2264,7 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
 template <int KIND>
 constexpr bool kind_has_slice_geometry() { return KIND == SCENE_KIND_SPHERES || KIND == SCENE_KIND_SPHERES_MOTION; }
 template <int KIND>
-constexpr bool kind_has_wide_codes() { return (KIND & 7) == SCENE_KIND_SPHERES || (KIND & 7) == SCENE_KIND_SPHERES_MOTION || (KIND & 7) == SCENE_KIND_GENERAL || (KIND & 7) == SCENE_KIND_TEXTURED || (KIND & 7) == SCENE_KIND_TRIANGLES || (KIND & 7) == SCENE_KIND_TRIANGLES_TEXTURED; }
+constexpr bool kind_has_wide_codes() { return true; }   // every scene kind (volume kinds since round 3: a triangle-mesh scene with one fog volume is a volume scene)
 
 template <bool ALL_LDS, int KIND>
 hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)

@@ -804,6 +804,28 @@ def mesh_grid_scene(grid=(14, 14), subdivisions=3, spacing=2.4, radius=1.0):
     return s
 
 
+def mesh_grid_fog_scene(grid=(8, 8), subdivisions=3):
+    """A grid of sphere meshes (mesh_grid_scene) with ProbabilisticVolume hulls standing among them: a fog ball around one mesh, a haze box across a
+    row, a thin haze sphere around the camera (the containment probe runs for every camera ray).  One fog volume makes a triangle-mesh scene a
+    VOLUME scene - every hit of a ray is kept and sorted - and 8 x 8 x 1280 + 2 + 3 = 81 925 entities put it beyond 16-bit candidate codes."""
+    s = mesh_grid_scene(grid, subdivisions)
+    gx, gy = grid
+    spacing, radius = 2.4, 1.0
+    extra = np.zeros(3, _ENTITY_DTYPE)
+    extra["rotation"] = (0.0, 0.0, 0.0, 1.0)
+    base = len(s.materials)
+    s.materials += [volume((0.3, 0.5, 0.9), 1.2), volume((0.9, 0.9, 0.9), 0.25), volume((1.0, 1.0, 1.0), 0.02)]
+    cx = ((gx // 2) - (gx - 1) / 2) * spacing
+    extra[0]["type"], extra[0]["position"], extra[0]["size"], extra[0]["materialIndex"] = abi.ENTITY_SPHERE, (cx, radius, -(1 * spacing)), (1.6, 0, 0), base
+    extra[1]["type"], extra[1]["position"], extra[1]["size"], extra[1]["materialIndex"] = abi.ENTITY_BOX, (0.0, 1.25, -(3 * spacing)), (gx * spacing, 2.5, 2.2), base + 1
+    cam = np.array(s.camera["position"], np.float32)
+    extra[2]["type"], extra[2]["position"], extra[2]["size"], extra[2]["materialIndex"] = abi.ENTITY_SPHERE, tuple(cam), (4.0, 0, 0), base + 2
+    s.entities = np.ascontiguousarray(np.concatenate([s.entities, extra]))
+    s.name = "mesh_grid_fog"
+    s.meta = dict(s.meta, entities=int(len(s.entities)))
+    return s
+
+
 def tiny_scene():
     """Five spheres, one of each material branch + a negative-radius hollow glass shell; for fast unit tests."""
     s = Scene("tiny")

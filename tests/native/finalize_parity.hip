@@ -1,5 +1,5 @@
-// Test-only program: rtow::to_byte_table (raytracing-in-one-weekend_amd/csrc/rtow_finalize.hip.h: hardware estimate + two comparisons against
-// the 255 step thresholds) against rtow::to_byte_exact (the specification: deterministic pow) for EVERY one of the 2^32 float operands, on the
+// Test-only program: rtow::to_byte_table and to_bytes_table<9> (raytracing-in-one-weekend_amd/csrc/rtow_finalize.hip.h: hardware estimate + two
+// comparisons against the 255 step thresholds; the second is the nine-at-once form the finalize kernel uses, checked in each of its positions) against rtow::to_byte_exact (the specification: deterministic pow) for EVERY one of the 2^32 float operands, on the
 // device, with the table built by the product's own kernel.  Also counts the places where the exact conversion steps DOWN between two
 // neighbouring non-negative floats (reported, not a failure: the table's mixed zones exist for them).
 // Built by tests/test_gpu_post.py with the product's own flags.  Prints the counts; exit code 1 on any mismatch.
@@ -15,6 +15,7 @@ __global__ void sweep(const float* __restrict__ table, unsigned long long* bad, 
     __shared__ float T[rtow::kByteThresholdFloats];
     for (int i = threadIdx.x; i < rtow::kByteThresholdFloats; i += blockDim.x) T[i] = table[i];
     __syncthreads();
+    const rtow::ByteZones Z = rtow::load_byte_zones(T);
     const unsigned stride = gridDim.x * blockDim.x;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned b0 = 0, b1 = 0;
@@ -22,6 +23,14 @@ __global__ void sweep(const float* __restrict__ table, unsigned long long* bad, 
         const float x = __uint_as_float(i);
         const unsigned e = rtow::to_byte_exact(x);
         if (e != rtow::to_byte_table(x, T)) { if (!b0) atomicCAS(&firstBad[0], 0u, i); b0++; }
+        // the form the finalize kernel instantiates: nine operands converted side by side (operand i + c in position c, so every operand
+        // passes through every one of the nine positions)
+        float v[9];
+        unsigned got[9];
+        for (int c = 0; c < 9; c++) v[c] = __uint_as_float(i + (unsigned)c);
+        rtow::to_bytes_table<9>(v, got, T, Z);
+        for (int c = 0; c < 9; c++)
+            if (got[c] != rtow::to_byte_exact(v[c])) { if (!b0) atomicCAS(&firstBad[0], 0u, i + (unsigned)c); b0++; }
         if (i < 0x7f800000u && rtow::to_byte_exact(__uint_as_float(i + 1u)) < e) { if (!b1) atomicCAS(&firstBad[1], 0u, i); b1++; }
     }
     if (b0) atomicAdd(&bad[0], (unsigned long long)b0);

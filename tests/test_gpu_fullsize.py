@@ -119,6 +119,20 @@ def test_mesh_grid_of_250k_triangles(rt, oracle, gpu_context):
         assert ctx.scene_info().wideCodes == 1 and ctx.scene_info().hitSpillBytes == 0
 
 
+def test_mesh_grid_with_fog_volumes_beyond_65535_entities(rt, oracle, gpu_context):
+    """One ProbabilisticVolume among the meshes makes a triangle-mesh scene a VOLUME scene (every hit of a ray kept, sorted, containment probe):
+    8 x 8 icospheres + floor + a fog ball around one mesh, a haze box across a row and a haze sphere around the camera = 81 925 entities, beyond
+    16-bit candidate codes - the volume kinds' kernels with 32-bit codes (tree in HBM, hit lists spilling to HBM).  Sparse pixels bit for bit
+    against the oracle under the reference stream (4- and 16-byte records) and the per-sample policy."""
+    scene = rt.scenes.mesh_grid_fog_scene()
+    assert scene.entity_count == 81925
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 8, 8, count=400, seed=21, focus=scene.meta["focus"])
+    info = gpu_context.scene_info()
+    assert info.wideCodes == 1 and info.sceneInLds == 0 and info.entityCount == 81925 and info.hitSpillBytes > 0
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 12, 12, count=250, seed=22, stride=16, focus=scene.meta["focus"])
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 20, 6, count=250, seed=23, focus=scene.meta["focus"], rng_policy=rt.abi.RNG_PER_SAMPLE)
+
+
 @pytest.mark.parametrize("name", ["cover", "moving", "stress", "mixed"])
 def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, name):
     """Results-neutral machinery at full size: camera-ray candidate lists on / off, longest-chunk-first ordering on / off (first launch =

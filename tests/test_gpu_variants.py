@@ -148,11 +148,11 @@ def test_slice_geometry_variants(rt, oracle, kind, block_threads, in_lds):
                        (kind, block_threads, in_lds))
 
 
-@pytest.mark.parametrize("kind", ["spheres", "spheres_ties", "spheres_motion", "spheres_motion_ties", "general", "general_ties", "textured", "textured_ties", "triangles", "triangles_ties", "triangles_textured", "triangles_textured_ties"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_wide_code_variants(rt, oracle, kind):
     """The kernels with 32-bit candidate / stack codes and 4 x 32-bit camera-ray lists (scenes beyond 65 535 entities or tree nodes), forced onto
-    small scenes with RTOW_CONTEXT_FORCE_WIDE_CODES: five per scene kind - the specialised reference-stream variant and the generic one per
-    noise source / RNG policy."""
+    small scenes with RTOW_CONTEXT_FORCE_WIDE_CODES: five per scene kind (the volume kinds included) - the specialised reference-stream variant and
+    the generic one per noise source / RNG policy."""
     abi = rt.abi
     scene = _scene(rt, kind)
     desc = scene.desc()
@@ -164,7 +164,3 @@ def test_wide_code_variants(rt, oracle, kind):
                  (5, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE, 4), (12, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE_XOROSHIRO, 16), (6, abi.NOISE_BLUE, abi.RNG_REFERENCE, 4),
                  (6, abi.NOISE_SPATIOTEMPORAL_BLUE, abi.RNG_REFERENCE, 16)]
         _compare_modes(rt, oracle, ctx, scene, desc, modes, (kind, "wide"))
-    # volume scenes have no such kernels: the flag is ignored there, a scene that NEEDS them is refused at upload (tests/test_gpu_api.py)
-    with rt.Context(0, flags=abi.CONTEXT_FORCE_WIDE_CODES) as ctx:
-        ctx.upload_scene(rt.scenes.volume_tie_scene().desc())
-        assert ctx.scene_info().wideCodes == 0
