@@ -301,7 +301,7 @@ typedef enum RtowContextFlags {
                                                     * library's own tree.  Costs a second, unpruned walk per ray in such batches */
     RTOW_CONTEXT_NO_CAMERA_RAY_LISTS = 1u << 3,    /* development: walk the tree for camera rays too */
     RTOW_CONTEXT_NO_CHUNK_ORDER = 1u << 4,         /* development: hand out pixel chunks in row order, not most-expensive-first */
-    RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5        /* development: run every scene kind that has them through the kernels with 32-bit candidate / stack codes
+    RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5        /* development: run the scene through the kernels with 32-bit candidate / stack codes (every scene kind has them)
                                                     * (what scenes beyond 65 535 entities or tree nodes use; the tree is then read from HBM) */
 } RtowContextFlags;
 

@@ -41,8 +41,8 @@ __global__ void __launch_bounds__(256) fold_unit_records_kernel(SampleKernelArgs
     // a cancelled batch leaves units that were never pulled with stale records: like the reference, whose cancelled Execute returns before
     // any write (JOBS/SampleBatchJob.cs:61-62), nothing is folded then (the flag stays set until the next batch is enqueued)
     if (A.cancelFlag && *A.cancelFlag != 0u) return;
-    const int ownedRow = (int)(ticket / (unsigned)A.width);
-    const int cx = (int)(ticket - (unsigned)ownedRow * (unsigned)A.width);
+    int cx, ownedRow;
+    owned_pixel_xy(ticket, (unsigned)A.width, A.tilesPerRow, A.tiledPixels, cx, ownedRow);      // the sample kernel's numbering of the owned pixels
     const int cy = A.sliceOffset + ownedRow * A.sliceDivider;
     const size_t pix = (size_t)cy * (size_t)A.width + (size_t)cx;
     const float4 last = reinterpret_cast<const float4*>(A.inColor)[pix];

@@ -1420,8 +1420,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     // regrouping of rays between lanes (walk, exact tests and shading at once; DESIGN.md 4.1 "Regrouping").
                     ticket &= ~63u;
 #endif
-                    const int ownedRow = (int)(ticket / (unsigned)C.width);
-                    cx = (int)(ticket - (unsigned)ownedRow * (unsigned)C.width);
+                    int ownedRow;
+                    owned_pixel_xy(ticket, (unsigned)C.width, C.tilesPerRow, C.tiledPixels, cx, ownedRow);   // a chunk's 64 tickets: an 8 x 8 tile of the owned pixels (rtow_kernels.h), or a strip
                     cy = C.sliceOffset + ownedRow * C.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
                     pix = cy * C.width + cx;
 

@@ -106,6 +106,47 @@ def test_slices_partition_the_frame(rt, oracle, gpu_context):
         assert np.array_equal(parts[k], full[k])
 
 
+@pytest.mark.parametrize("w,h", [(64, 24), (64, 27), (72, 13), (8, 64), (70, 16), (136, 5)])
+def test_ticket_numbering_in_tiles_reaches_every_owned_pixel(rt, oracle, gpu_context, w, h):
+    """The 64 tickets of a chunk are an 8 x 8 tile of the owned pixels where the width is a multiple of 8 (csrc/rtow_kernels.h: owned_pixel_xy;
+    rows behind the last whole tile row, and frames of any other width, are numbered row by row).  Whatever the frame's shape - whole tiles,
+    a partial tile row, fewer than 8 rows, a width that is no multiple of 8 - every owned pixel is rendered exactly once: whole frames and
+    3-way row slices (the owned rows of a slice form the tiles) against the oracle, under the reference stream, the per-sample policy (units
+    are numbered pixel by pixel through the same function, and the fold kernel maps them back) and as a chain of two batches."""
+    scene = rt.scenes.cover_scene(60, 600)
+    desc = scene.desc()
+    ctx = gpu_context
+    ctx.upload_scene(desc)
+    osc = oracle.OracleScene(desc)
+    try:
+        for policy in (rt.abi.RNG_REFERENCE, rt.abi.RNG_PER_SAMPLE):
+            for div in (1, 3):
+                got = {k: np.full((w * h, c), -7.0, np.float32) for k, c in (("color", 4), ("normal", 3), ("albedo", 3))}
+                got["scw"] = np.full(w * h, -7.0, np.float32)
+                want = {k: v.copy() for k, v in got.items()}
+                for g in range(div):
+                    p = rt.scenes.make_params(scene, w, h, spp=3, trace_depth=5, seed=5, slice_offset=g, slice_divider=div, rng_policy=policy)
+                    mask = np.repeat(np.arange(h) % div == g, w)
+                    gpu, ref = rt.sample_batch_host(ctx, p), osc.sample_batch(p)
+                    for k in got:
+                        got[k][mask], want[k][mask] = gpu[k][mask], ref[k][mask]
+                    assert np.array_equal(gpu["diag"][mask, 0], ref["diag"][mask, 0])
+                for k in got:
+                    assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (k, policy, div)
+                    assert not np.any(got[k] == -7.0)
+        # two chained batches in one launch (the per-chunk hand-off counts the pixels of a chunk: tiles and the row-major remainder alike)
+        plist = [rt.scenes.make_params(scene, w, h, spp=3, trace_depth=5, seed=s) for s in (8, 9)]
+        n = w * h
+        bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+        rt.lib.check(rt.sample_batch_chain_device(ctx, plist, bufs, bufs), "rtowSampleBatchChainDevice")
+        ctx.synchronize()
+        ref = osc.sample_batch(plist[1], {k: v for k, v in osc.sample_batch(plist[0]).items() if k != "diag"})
+        for k, b, c in zip(("color", "normal", "albedo", "scw"), bufs, (4, 3, 3, 1)):
+            assert np.array_equal(b.download(np.float32, (n, c)).reshape(ref[k].shape).view(np.uint32), ref[k].view(np.uint32)), ("chain", k)
+    finally:
+        osc.close()
+
+
 def test_mixed_primitives_rotated_and_moving(rt, oracle, gpu_context):
     """Rect / Box / Triangle / rotated + moving entities through the general Entity transform (RT/Entity.cs:58-127)."""
     scene = rt.scenes.mixed_scene()
