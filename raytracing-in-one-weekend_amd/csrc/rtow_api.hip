@@ -31,12 +31,18 @@
 #endif
 constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice512PixelsPerLane = RTOW_SLICE_512_PIXELS_PER_LANE;
 
-// minimum lane population per stage: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice.  Measured on MI355X: on TEST and HIT any
-// threshold above 1 loses (waiting lanes cost more than the skipped stage saves); slicing the walk at 16 wins ~5 %.
+// minimum lane population per stage, in 64ths of the wave's live lanes: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice (node visits per trip).
+// Sphere kinds: REGEN from 3/8, the walk and HIT from 1/2, SKY from 7/16, TEST at once.  Since a chunk's 64 tickets are an 8 x 8 tile of the image
+// (rtow_kernels.h) the lanes of a wave meet the same few materials, and a HIT stage that waits for half of them runs its class bodies a third as
+// often with three times the lanes; with 64 x 1 strips any threshold on HIT lost (rounds 1 / 2).  Same box, alternating runs, gpurun_out/r03am-r03ao:
+// cover 9 417 against 8 685 Msamples/s (+8.4 %), 10 000 spheres 7 513 against 7 042 (+6.7 %), moving + defocus 6 306 against 5 958 (+5.8 %),
+// 4K / 1024 spp / 16 bounces 9 464 against 8 851 (+6.9 %).  The general-entity kinds keep REGEN 1/4, walk 3/4, HIT and SKY at once (kGeneralTune):
+// on the 250 k-triangle mesh HIT from 1/2 loses 6 % (1 732 against 1 840), SKY from 1/2 3 %.
 #ifndef RTOW_DEFAULT_TUNE
-#define RTOW_DEFAULT_TUNE 16, 48, 1, 1, 28, 1, 1, 1, 16   /* REGEN from 1/4, TRAV from 3/4, SKY from 7/16 of the live lanes; TEST, HIT, VOL at once; 16 node visits per walk slice.
-                                                           * SKY at 1/2 (round 3, gpurun_out/r03t / r03u, alternating runs): cover 8 357 against 8 242 Msamples/s, C3 8 533 against 8 381,
-                                                           * C4 / C5 unchanged; 28 against 32: +0.5 % (r03aa); 36/64 and above lose 2 - 5 % */
+#define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 1, 1, 16
+#endif
+#ifndef RTOW_GENERAL_TUNE
+#define RTOW_GENERAL_TUNE 16, 48, 1, 1, 1, 1, 1, 1, 16
 #endif
 
 using namespace rtow;
@@ -847,11 +853,10 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         // 7.93 / 8.23 / 8.01 Gsamples/s; 10 000 spheres 16 / 24 / 32: 6.77 / 6.54 / 6.18).  A tree of hundreds of thousands of nodes is read from
         // HBM at several times the latency per visit, and a ray visits twice as many nodes: longer slices amortise the trip around them
         // (250 882-triangle mesh, 16 / 24 / 32 / 48 / 64 visits: 1.28 / 1.39 / 1.46 / 1.44 / 1.41 Gsamples/s; profiles/r03_runs/run_r03h.sh).
-        static const int kDefault[9] = {RTOW_DEFAULT_TUNE};
-        ctx->tune[8] = compiled.layout.nodeCount > 65535u ? 32 : kDefault[8];
-        // SKY + fold from half of the live lanes pays on the sphere kinds (cover +1.4 %, C3 +1.8 %, C4 / C5 neutral) and loses on the mesh
-        // (1 520 against 1 574 Msamples/s): the general-entity kinds keep "at once"
-        ctx->tune[4] = compiled.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? kDefault[4] : 1;
+        static const int kDefault[9] = {RTOW_DEFAULT_TUNE}, kGeneral[9] = {RTOW_GENERAL_TUNE};
+        const int* base = compiled.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? kDefault : kGeneral;      // measured per family: see RTOW_DEFAULT_TUNE
+        for (int k = 0; k < 9; k++) ctx->tune[k] = base[k];
+        if (compiled.layout.nodeCount > 65535u) ctx->tune[8] = 32;
     }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - (wide ? kStackBytesWide : kStackBytes) - kQueueBytes);
@@ -865,6 +870,9 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         if (nodes > ctx->scene.layout.nodeCount) nodes = ctx->scene.layout.nodeCount;
         ctx->ldsNodeCount = nodes;
         ctx->ldsSceneBytes = nodes * (uint32_t)sizeof(GpuNode);
+        // sphere scenes whose tree is only partly LDS resident: 20 visits per slice (10 000 spheres under the thresholds above, 12 / 16 / 20 / 24 visits:
+        // 6.78 / 7.08 / 7.48 / 7.26 Gsamples/s, gpurun_out/r03ap; the cover scene, all in LDS, keeps 16: 14 / 16 / 18 / 20 = 9.12 / 9.25 / 9.23 / 9.03)
+        if (!ctx->userTune && ctx->scene.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION && ctx->scene.layout.nodeCount <= 65535u) ctx->tune[8] = 20;
     }
     ctx->haveScene = true;
     ctx->sceneSerial++;
