@@ -211,6 +211,9 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.totalWork = (uint32_t)ownedRows(p) * (uint32_t)a.width;
     a.tilesPerRow = (RTOW_TICKET_TILES && a.width % (int)kTileW == 0) ? (uint32_t)a.width / kTileW : 0u;
     a.tiledPixels = a.tilesPerRow ? ((uint32_t)ownedRows(p) / kTileH) * kTileH * (uint32_t)a.width : 0u;
+#ifdef RTOW_EXPERIMENT_SCATTER_TICKETS
+    if (p->sliceDivider > 1) { a.tilesPerRow = 0u; a.tiledPixels = a.totalWork; }      // timing experiment: see owned_pixel_xy
+#endif
     a.sizeX = p->size.x; a.sizeY = p->size.y;
     a.sliceOffset = p->sliceOffset; a.sliceDivider = p->sliceDivider;
     a.seed = chain ? chain->seeds[0] : p->seed;
