@@ -93,6 +93,10 @@ SCENE_TEXT = {
     "moving": "moving-spheres scene (Random With Movement (Book 2).asset: 80 % of the random spheres move, aperture 0.05)",
     "mesh": "mesh-grid scene (14 x 14 icospheres of 1 280 smooth triangles + floor = 250 882 triangle entities, one per mesh triangle like the reference's live host, "
             "materials blended across the grid like UNITY/GridGenerator.cs; 32-bit candidate codes, tree in HBM, exact-tie kernels)",
+    "mixed": "mixed-primitive scene (spheres, rects, boxes, triangles, rotated and moving: the general-entity kernels, scene in LDS)",
+    "volumes": "Cornell-with-volumes scene (ProbabilisticVolume boxes and spheres: the volume kernels, every hit of a ray kept and sorted)",
+    "textured": "image-textured scene (per-hit albedo / emission / metallic / glossiness: the textured kernels)",
+    "meshfog": "mesh grid of 81 922 triangles with three fog volumes (volume kernels with 32-bit codes, tree in HBM, hit lists spilling to HBM)",
 }
 
 
@@ -279,7 +283,8 @@ def main():
 
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
     n = W * H
-    scene = {"cover": rt.scenes.cover_scene, "stress": rt.scenes.stress_scene, "moving": rt.scenes.moving_scene, "mesh": rt.scenes.mesh_grid_scene}[args.scene]()
+    scene = {"cover": rt.scenes.cover_scene, "stress": rt.scenes.stress_scene, "moving": rt.scenes.moving_scene, "mesh": rt.scenes.mesh_grid_scene,
+             "mixed": rt.scenes.mixed_scene, "volumes": rt.scenes.volume_scene, "textured": rt.scenes.textured_scene, "meshfog": rt.scenes.mesh_grid_fog_scene}[args.scene]()
     focus = scene.meta.get("focus")                       # scenes without spheres carry their focus distance (the host's auto-focus probe, UNITY/Raytracer.cs:608-609)
     ctx = rt.Context(local_rank, flags=args.context_flags, scheduler_tune=[int(x) for x in args.tune.split(",")] if args.tune else None)
     ctx.upload_scene(scene.desc())
@@ -501,6 +506,7 @@ def main():
             except (OSError, ValueError):
                 profiled_bpl = None
             traffic = round(traffic * steps_per_launch)      # per launch, like `achieved`: the committed profile's per-batch traffic x this run's batches per launch
+        tuned = ctx.scene_info()
         out = {
             "metric": "Msamples/s, 486-sphere cover scene 1920x1080 8-bounce" if (args.config == 2 and not overridden) else
                       "Msamples/s, %s scene %dx%d %d-bounce" % (args.scene, W, H, depth),
@@ -528,6 +534,8 @@ def main():
                 "launches": m["launches"],
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds), "wide_codes": bool(info.wideCodes),
                 "entities": int(info.entityCount), "hit_spill_bytes": int(info.hitSpillBytes),
+                # stage thresholds in use: -1 = the kernel kind's built-in ones, 0..3 = the set the first (warm-up) batch measured as fastest for this scene
+                "threshold_set": int(tuned.thresholdSet), "scheduler_tune": [int(x) for x in tuned.schedulerTune],
             },
             "kernel_ms_per_step": round(avg_kernel_ms, 3),
             "kernel_ms_per_launch": round(launch_ms, 3),

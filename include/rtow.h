@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 7
+#define RTOW_API_VERSION 8
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -185,6 +185,10 @@ typedef struct RtowSceneInfo {
                                        0 where no ray can need it.  Grow-only per context; RtowContextOptions.hitListCapacity sizes it */
     int32_t hitListCapacity;        /* most surfaces one ray may meet in this scene before the batch reports RTOW_ERROR_CAPACITY (0: only the nearest hit is kept) */
     int32_t wideCodes;              /* 1: more than 65 535 entities or tree nodes - the kernels that keep 32-bit candidate / stack codes run (tree read from HBM) */
+    int32_t thresholdSet;           /* stage thresholds in use for this scene: -1 the built-in ones of its kernel kind (nothing measured yet, tiny frames, tuning off, or
+                                       RtowContextOptions.schedulerTune given); 0 / 1 the sphere / general family as measured by the first batch, 2 / 3 the same with the
+                                       volume stage waiting too (RTOW_CONTEXT_NO_THRESHOLD_TUNING) */
+    int32_t schedulerTune[9];       /* the values themselves (REGEN TRAV TEST HIT SKY VOL - - | walk slice), as RtowContextOptions.schedulerTune would set them */
 } RtowSceneInfo;
 
 /* ---- the operator's parameter block: SampleBatchJob's public fields (JOBS/SampleBatchJob.cs:23-51) ---- */
@@ -301,8 +305,11 @@ typedef enum RtowContextFlags {
                                                     * library's own tree.  Costs a second, unpruned walk per ray in such batches */
     RTOW_CONTEXT_NO_CAMERA_RAY_LISTS = 1u << 3,    /* development: walk the tree for camera rays too */
     RTOW_CONTEXT_NO_CHUNK_ORDER = 1u << 4,         /* development: hand out pixel chunks in row order, not most-expensive-first */
-    RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5        /* development: run the scene through the kernels with 32-bit candidate / stack codes (every scene kind has them)
+    RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5,       /* development: run the scene through the kernels with 32-bit candidate / stack codes (every scene kind has them)
                                                     * (what scenes beyond 65 535 entities or tree nodes use; the tree is then read from HBM) */
+    RTOW_CONTEXT_NO_THRESHOLD_TUNING = 1u << 6     /* keep the built-in stage thresholds of the scene's kernel kind.  By default the first batch after rtowUploadScene measures
+                                                    * two (volume scenes: four) threshold sets with 4-sample probes of its own frame - a few milliseconds to ~0.1 s, waited for
+                                                    * inside that call, once per scene - and keeps the fastest; thresholds are pure scheduling and never change a result */
 } RtowContextFlags;
 
 typedef struct RtowContextOptions {

@@ -12,8 +12,10 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # bench.py with chains of $CHAIN batches per launch - the chain length of the driver's command, so that roofline.traffic in the driver's line is a
 # measurement at that very chain length and not an extrapolation; the counter passes profile ONE chain launch after the probe
-BENCH="python $REPO/bench.py --steps $((2 * CHAIN)) --warmup 0 --chain $CHAIN --no-cpu-baseline --no-extras"
-ONE="python $REPO/bench.py --steps $CHAIN --warmup 0 --chain $CHAIN --no-cpu-baseline --no-extras"
+# --context-flags 64 = RTOW_CONTEXT_NO_THRESHOLD_TUNING: the cover scene's measured thresholds ARE the sphere kinds' built-in ones, and without the four
+# tuning probes (launches of this same kernel, 1.3 ms each) the trace holds the batch launches and the one cost probe only
+BENCH="python $REPO/bench.py --steps $((2 * CHAIN)) --warmup 0 --chain $CHAIN --no-cpu-baseline --no-extras --context-flags 64"
+ONE="python $REPO/bench.py --steps $CHAIN --warmup 0 --chain $CHAIN --no-cpu-baseline --no-extras --context-flags 64"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $ONE > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $ONE > $OUT/pmc_write.log 2>&1

@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 7
+RTOW_API_VERSION = 8
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -87,7 +87,8 @@ class SceneDesc(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("entityCount", C.c_int32), ("materialCount", C.c_int32), ("bvhNodeCount", C.c_int32),
                 ("bvhDepth", C.c_int32), ("ldsBytesScene", C.c_int32), ("sceneInLds", C.c_int32),
-                ("sceneBytesDevice", C.c_uint64), ("hitSpillBytes", C.c_uint64), ("hitListCapacity", C.c_int32), ("wideCodes", C.c_int32)]
+                ("sceneBytesDevice", C.c_uint64), ("hitSpillBytes", C.c_uint64), ("hitListCapacity", C.c_int32), ("wideCodes", C.c_int32),
+                ("thresholdSet", C.c_int32), ("schedulerTune", C.c_int32 * 9)]
 
 
 class View(C.Structure):
@@ -134,7 +135,7 @@ LogCallback = C.CFUNCTYPE(None, C.c_int32, C.c_char_p, C.c_char_p, C.c_void_p)
 
 
 # RtowContextFlags
-CONTEXT_EXACT_TIES_ALWAYS, CONTEXT_EXACT_TIES_NEVER, CONTEXT_REFERENCE_DIAGNOSTICS, CONTEXT_NO_CAMERA_RAY_LISTS, CONTEXT_NO_CHUNK_ORDER, CONTEXT_FORCE_WIDE_CODES = 1, 2, 4, 8, 16, 32
+CONTEXT_EXACT_TIES_ALWAYS, CONTEXT_EXACT_TIES_NEVER, CONTEXT_REFERENCE_DIAGNOSTICS, CONTEXT_NO_CAMERA_RAY_LISTS, CONTEXT_NO_CHUNK_ORDER, CONTEXT_FORCE_WIDE_CODES, CONTEXT_NO_THRESHOLD_TUNING = 1, 2, 4, 8, 16, 32, 64
 # RtowGatherMask
 GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_ALL = 1, 2, 4, 8, 15
 

@@ -44,6 +44,15 @@ constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice
 #ifndef RTOW_GENERAL_TUNE
 #define RTOW_GENERAL_TUNE 16, 48, 1, 1, 1, 1, 1, 1, 16
 #endif
+// Which of the two families suits a scene is a property of the scene, not of its kernel kind: an image-textured scene of spheres runs 25 % faster
+// on the sphere kinds' thresholds (10 160 against 8 100 Msamples/s), a scene of rects, boxes and triangles 9 % slower (3 220 against 3 540), a mesh with
+// fog volumes 15 % faster when the volume stage too waits for half of the live lanes (460 against 399; gpurun_out/r03ax).  So the first batch after
+// rtowUploadScene MEASURES them: each candidate renders kTuneProbeSamples samples per pixel through the batch's own kernel (a probe: nothing is
+// stored), twice, timed with events on the batch's stream; the fastest one stays for the scene.  A probe of a few samples per pixel ranks the
+// candidates like the full workload does (cover, textured, mixed, volumes, 10 000 spheres at 2 / 4 / 8 / 64 samples per pixel: same order every
+// time, gpurun_out/r03ay).  Thresholds never change a result (tests/test_gpu_fullsize.py: frames under every schedule).  The call that tunes
+// waits for its probes (a few milliseconds to ~0.1 s, once per scene); RTOW_CONTEXT_NO_THRESHOLD_TUNING keeps the per-kind values above.
+constexpr int kTuneProbeSamples = 4, kTuneProbeRepeats = 2;
 
 using namespace rtow;
 
@@ -126,6 +135,8 @@ struct RtowContext_t {
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
     int tune[9] = {RTOW_DEFAULT_TUNE};
     bool userTune = false;                // RtowContextOptions.schedulerTune was given: no per-scene adjustment
+    uint64_t tunedScene = ~0ull;          // sceneSerial whose thresholds were measured (tuneThresholds)
+    int tunedCandidate = -1;              // which candidate won (rtowGetSceneInfo-independent; logged)
 
     // rtowRegisterHostBuffer: pinned + device-mapped ranges of caller memory
     struct HostRange { uint8_t* base; size_t size; uint8_t* device; };
@@ -396,6 +407,53 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider; ctx->orderGroups = a.groupsPerPixel;
         }
         a.chunkOrder = haveOrder ? ctx->dChunkOrder : nullptr;
+
+        // ---- stage thresholds: measured once per scene on this batch's own kernel, frame and view (see kTuneProbeSamples) ----
+        if (!ctx->userTune && !(ctx->flags & RTOW_CONTEXT_NO_THRESHOLD_TUNING) && ctx->tunedScene != ctx->sceneSerial && !a.unitRecords && haveOrder) {
+            static const int kSets[2][9] = {{RTOW_DEFAULT_TUNE}, {RTOW_GENERAL_TUNE}};     // (the ninth value, the walk slice, is set by rtowUploadScene)
+            const bool volumes = a.layout.sceneKind == SCENE_KIND_VOLUMES || a.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
+            const int candidates = volumes ? 4 : 2;                                          // volume kinds: each family also with the volume stage from half of the live lanes
+            const int launches = candidates * kTuneProbeRepeats;
+            std::vector<hipEvent_t> ev((size_t)launches + 1);
+            bool ok = true;
+            for (auto& e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+            SampleKernelArgs probe = a;
+            probe.probeOnly = kTuneProbeSamples;
+            probe.pixelCost = nullptr;                           // the cost map stays the cost probe's (or the previous batch's)
+            probe.cancelFlag = nullptr;
+            probe.chainCount = 1;
+            if (ok) ok = hipEventRecord(ev[0], stream) == hipSuccess;
+            for (int l = 0; ok && l < launches; l++) {
+                const int c = l % candidates;
+                for (int k = 0; k < 8; k++) probe.tune[k] = kSets[c & 1][k];
+                if (c >= 2) probe.tune[5] = 32;
+                ok = hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream) == hipSuccess && launchSampleBatch(probe, blocks, stream) == hipSuccess &&
+                     hipEventRecord(ev[(size_t)l + 1], stream) == hipSuccess;
+            }
+            if (ok) ok = hipEventSynchronize(ev[(size_t)launches]) == hipSuccess;
+            if (ok) {
+                float best = 0.0f;
+                int winner = -1;
+                for (int c = 0; c < candidates; c++) {
+                    float t = 0.0f;
+                    for (int r = 0; r < kTuneProbeRepeats; r++) {
+                        float ms = 0.0f;
+                        if (hipEventElapsedTime(&ms, ev[(size_t)(r * candidates + c)], ev[(size_t)(r * candidates + c) + 1]) != hipSuccess) ms = 1e30f;
+                        t = (r == 0 || ms < t) ? ms : t;
+                    }
+                    if (winner < 0 || t < best) { best = t; winner = c; }
+                }
+                for (int k = 0; k < 8; k++) ctx->tune[k] = kSets[winner & 1][k];
+                if (winner >= 2) ctx->tune[5] = 32;
+                for (int k = 0; k < 8; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
+                ctx->tunedCandidate = winner;
+                logf(ctx, 4, "tune", "stage thresholds measured on this scene: candidate %d of %d (%.3f ms per %d-sample probe)", winner, candidates, best, kTuneProbeSamples);
+            }
+            for (auto& e : ev) (void)hipEventDestroy(e);
+            if (!ok) ctx->tunedCandidate = -1;
+            ctx->tunedScene = ctx->sceneSerial;                 // measured (or not measurable): do not try again for this scene
+            if (!ok) { (void)hipGetLastError(); logf(ctx, 2, "tune", "threshold probes failed; the per-kind values stay"); }
+        }
     }
 
     if (a.chainCount > 1u) {
@@ -982,6 +1040,8 @@ RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
     const bool keepsLists = ctx->scene.layout.exactTies || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
     info->hitListCapacity = keepsLists ? (int32_t)(ctx->hitSpillEntries + (uint32_t)kLocalHitEntries) : 0;
     info->wideCodes = ctx->wideCodes ? 1 : 0;
+    info->thresholdSet = ctx->tunedScene == ctx->sceneSerial ? ctx->tunedCandidate : -1;
+    for (int k = 0; k < 9; k++) info->schedulerTune[k] = ctx->tune[k];
     return RTOW_SUCCESS;
 }
 

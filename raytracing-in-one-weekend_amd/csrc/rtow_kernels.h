@@ -106,7 +106,7 @@ struct SampleKernelArgs {
     uint32_t chunkCount;
     const uint2* pixelCandidates;         // [width * height]: camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray;
                                           // wideCodes: uint4 records (4 x 32-bit node indices) behind the same pointer
-    int32_t probeOnly;                    // 1: cost probe - one sample per pixel, nothing stored but pixelCost
+    int32_t probeOnly;                    // > 0: probe - this many samples per pixel, nothing stored but pixelCost (1: the cost probe; 4: the threshold-tuning probes)
     const volatile uint32_t* cancelFlag;  // host-pinned, may be null
     uint32_t* overflowFlag;               // host-pinned: set when a ray's hit list (volume scenes) exceeds the per-lane capacity
     uint32_t totalWork;                   // owned pixels = ownedRows * width

@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         const float lo = (float)C.sampleCountMin, hi = (float)C.sampleCountMax;
                         nsamp = (unsigned)__builtin_rintf(lo + nw * (hi - lo));
                     }
-                    if (C.probeOnly) nsamp = 1;
+                    if (C.probeOnly) nsamp = (unsigned)C.probeOnly;                                     // probes: 1 sample (cost map) or a few (threshold tuning), nothing stored
                     scw0 = w;
                     smp = 0;
                     if (PER_SAMPLE) {

@@ -157,6 +157,63 @@ def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, name):
             assert np.array_equal(base[k].view(np.uint32), r[k].view(np.uint32)), (name, what, k)
 
 
+@pytest.mark.parametrize("name", ["cover", "mixed", "volumes", "textured"])
+def test_stage_thresholds_are_measured_per_scene_and_change_nothing(rt, gpu_context, name):
+    """The first batch after an upload measures the candidate threshold sets with probes of its own frame and keeps the fastest
+    (csrc/rtow_api.hip: kTuneProbeSamples; RtowSceneInfo.thresholdSet / schedulerTune say which).  Probes store nothing and thresholds are
+    scheduling only: the frame equals the one of a context that keeps the built-in values (RTOW_CONTEXT_NO_THRESHOLD_TUNING), bit for bit, as
+    do the next batch on top of it and a chained launch.  Tiny frames are not worth a measurement; thresholds given by the caller are kept."""
+    a = rt.abi
+    S = rt.scenes
+    scene = {"cover": S.cover_scene, "mixed": S.mixed_scene, "volumes": S.volume_scene, "textured": S.textured_scene}[name]()
+    desc = scene.desc()
+    w, h = 1280, 720
+    n = w * h
+    focus = 6.5 if name == "volumes" else None
+    p = rt.scenes.make_params(scene, w, h, spp=4, trace_depth=8, focus=focus)
+    gpu_context.upload_scene(desc)
+    assert gpu_context.scene_info().thresholdSet == -1                      # nothing measured before the first batch
+    tuned = _device_render(rt, gpu_context, p, n, 4)
+    info = gpu_context.scene_info()
+    assert 0 <= info.thresholdSet < (4 if name == "volumes" else 2)
+    sets = {0: [24, 32, 1, 32, 28, 1], 1: [16, 48, 1, 1, 1, 1], 2: [24, 32, 1, 32, 28, 32], 3: [16, 48, 1, 1, 1, 32]}
+    assert list(info.schedulerTune)[:6] == sets[info.thresholdSet]
+    again = _device_render(rt, gpu_context, p, n, 4)                        # measured once per scene: the choice stays
+    assert gpu_context.scene_info().thresholdSet == info.thresholdSet
+    with rt.Context(0, flags=a.CONTEXT_NO_THRESHOLD_TUNING) as ctx:
+        ctx.upload_scene(desc)
+        plain = _device_render(rt, ctx, p, n, 4)
+        assert ctx.scene_info().thresholdSet == -1
+    for k in ("color", "normal", "albedo", "scw", "diag"):
+        assert np.array_equal(tuned[k].view(np.uint32), plain[k].view(np.uint32)), (name, k)
+        assert np.array_equal(again[k].view(np.uint32), plain[k].view(np.uint32)), (name, "second batch", k)
+    # a new upload is a new scene: measured again; a chained first launch measures too and equals the batches one after the other
+    gpu_context.upload_scene(desc)
+    assert gpu_context.scene_info().thresholdSet == -1
+    plist = [rt.scenes.make_params(scene, w, h, spp=3, trace_depth=8, seed=s, focus=focus) for s in (3, 4)]
+    bufs = [rt.DeviceBuffer(gpu_context, n * c * 4).zero() for c in (4, 3, 3, 1)]
+    rt.lib.check(rt.sample_batch_chain_device(gpu_context, plist, bufs, bufs), "rtowSampleBatchChainDevice")
+    gpu_context.synchronize()
+    assert gpu_context.scene_info().thresholdSet >= 0
+    chained = [b.download(np.uint32, (n, c)) for b, c in zip(bufs, (4, 3, 3, 1))]
+    with rt.Context(0, scheduler_tune=(16, 48, 1, 1, 28, 1, 1, 1, 16)) as ctx:
+        ctx.upload_scene(desc)
+        seq = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+        for q in plist:
+            job = rt.SampleBatchJob(ctx, q)
+            job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = seq
+            job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = seq
+            rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
+        ctx.synchronize()
+        assert ctx.scene_info().thresholdSet == -1 and list(ctx.scene_info().schedulerTune) == [16, 48, 1, 1, 28, 1, 1, 1, 16]      # the caller's values are kept
+        for got, b, c in zip(chained, seq, (4, 3, 3, 1)):
+            assert np.array_equal(got, b.download(np.uint32, (n, c))), (name, "chain")
+    # a frame too small to be worth a measurement keeps the built-in values
+    gpu_context.upload_scene(desc)
+    _device_render(rt, gpu_context, rt.scenes.make_params(scene, 64, 36, spp=2, trace_depth=4, focus=focus), 64 * 36, 4)
+    assert gpu_context.scene_info().thresholdSet == -1
+
+
 @pytest.mark.parametrize("name,spp", [("cover", 6), ("stress", 4), ("moving", 4)])
 def test_whole_1080p_frame_equals_the_oracle(rt, oracle, gpu_context, name, spp):
     """Every one of the 2 073 600 pixels of a full-size frame (at a sample count the CPU checker finishes in seconds), not a sparse sample:
