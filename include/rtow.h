@@ -188,7 +188,7 @@ typedef struct RtowSceneInfo {
     int32_t thresholdSet;           /* stage thresholds in use for this scene: -1 the built-in ones of its kernel kind (nothing measured yet, tiny frames, tuning off, or
                                        RtowContextOptions.schedulerTune given); 0 / 1 the sphere / general family as measured by the first batch, 2 / 3 the same with the
                                        volume stage waiting too (RTOW_CONTEXT_NO_THRESHOLD_TUNING) */
-    int32_t schedulerTune[9];       /* the values themselves (REGEN TRAV TEST HIT SKY VOL - - | walk slice), as RtowContextOptions.schedulerTune would set them */
+    int32_t schedulerTune[9];       /* the values themselves (REGEN TRAV TEST HIT SKY VOL | hand-over count | - | walk slice), as RtowContextOptions.schedulerTune would set them */
 } RtowSceneInfo;
 
 /* ---- the operator's parameter block: SampleBatchJob's public fields (JOBS/SampleBatchJob.cs:23-51) ---- */
@@ -320,8 +320,9 @@ typedef struct RtowContextOptions {
     uint32_t flags;                 /* RtowContextFlags, 0 = defaults */
     int32_t ldsSceneBudgetBytes;    /* development: cap on the bytes of scene image staged into LDS (0 = all that fits); smaller scenes then run
                                      * through the kernels that read the tree from HBM */
-    int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL - -) and the box-walk
-                                     * slice (node visits per trip); all zero = the built-in values */
+    int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL), the number of candidates at which
+                                     * a box walk hands over to the exact tests (1 .. 7), one unused value, and the box-walk slice (node visits per trip);
+                                     * all zero = the built-in values, measured per scene */
     int32_t hitListCapacity;        /* most surfaces one ray may meet where every hit of a ray is kept (scenes with ProbabilisticVolume materials, and
                                      * the exact-tie procedure): the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71);
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per

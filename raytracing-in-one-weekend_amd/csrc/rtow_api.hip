@@ -31,7 +31,7 @@
 #endif
 constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice512PixelsPerLane = RTOW_SLICE_512_PIXELS_PER_LANE;
 
-// minimum lane population per stage, in 64ths of the wave's live lanes: REGEN TRAV TEST HIT SKY (3 unused) | box-walk slice (node visits per trip).
+// minimum lane population per stage, in 64ths of the wave's live lanes: REGEN TRAV TEST HIT SKY VOL | candidates that end a walk (hand-over to TEST) | unused | box-walk slice (node visits per trip).
 // Sphere kinds: REGEN from 3/8, the walk and HIT from 1/2, SKY from 7/16, TEST at once.  Since a chunk's 64 tickets are an 8 x 8 tile of the image
 // (rtow_kernels.h) the lanes of a wave meet the same few materials, and a HIT stage that waits for half of them runs its class bodies a third as
 // often with three times the lanes; with 64 x 1 strips any threshold on HIT lost (rounds 1 / 2).  Same box, alternating runs, gpurun_out/r03am-r03ao:
@@ -39,10 +39,10 @@ constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice
 // 4K / 1024 spp / 16 bounces 9 464 against 8 851 (+6.9 %).  The general-entity kinds keep REGEN 1/4, walk 3/4, HIT and SKY at once (kGeneralTune):
 // on the 250 k-triangle mesh HIT from 1/2 loses 6 % (1 732 against 1 840), SKY from 1/2 3 %.
 #ifndef RTOW_DEFAULT_TUNE
-#define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 1, 1, 16
+#define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 3, 1, 16
 #endif
 #ifndef RTOW_GENERAL_TUNE
-#define RTOW_GENERAL_TUNE 16, 48, 1, 1, 1, 1, 1, 1, 16
+#define RTOW_GENERAL_TUNE 16, 48, 1, 1, 1, 1, 3, 1, 16
 #endif
 // Which of the two families suits a scene is a property of the scene, not of its kernel kind: an image-textured scene of spheres runs 25 % faster
 // on the sphere kinds' thresholds (10 160 against 8 100 Msamples/s), a scene of rects, boxes and triangles 9 % slower (3 220 against 3 540), a mesh with

@@ -100,7 +100,7 @@ def test_hot_variants_stay_spill_free(compiled, unit, kind):
         if hw in (4, 8) and not full_diag and noise == 0 and not per_sample and not (geo & 4):
             # the reference stream at depth <= 8 / <= 16: the benchmark's kernels and their slice geometries
             hot += 1
-            assert u["vgpr_spill"] == 0 and u["sgpr_spill"] <= 28, (name, u)      # SGPRs spill into VGPR lanes (22 - 28 since the per-XCD chain hand-out; same speed)
+            assert u["vgpr_spill"] == 0 and u["sgpr_spill"] <= 32, (name, u)      # SGPRs spill into VGPR lanes (22 - 28 since the per-XCD chain hand-out, 30 in the moving kind's 512-lane tree-in-HBM variant since the walk's hand-over count; same speed)
             if all_lds and kind == 0:
                 # the benchmark's kernels (cover scene: static spheres, scene in LDS): not one scratch instruction (a private segment of 36 B
                 # may be reserved - an object the optimiser removed the accesses of)
