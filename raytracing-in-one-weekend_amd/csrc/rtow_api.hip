@@ -910,14 +910,15 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     const bool wide = compiled.entityCount > 65535 || compiled.layout.nodeCount > 65535u || (ctx->flags & RTOW_CONTEXT_FORCE_WIDE_CODES) != 0;
     ctx->wideCodes = wide;
     if (!ctx->userTune) {
-        // Box-walk slice (node visits per trip).  16 is the measured optimum for trees whose nodes come from LDS or L2 (cover 12 / 16 / 20 visits:
-        // 7.93 / 8.23 / 8.01 Gsamples/s; 10 000 spheres 16 / 24 / 32: 6.77 / 6.54 / 6.18).  A tree of hundreds of thousands of nodes is read from
-        // HBM at several times the latency per visit, and a ray visits twice as many nodes: longer slices amortise the trip around them
-        // (250 882-triangle mesh, 16 / 24 / 32 / 48 / 64 visits: 1.28 / 1.39 / 1.46 / 1.44 / 1.41 Gsamples/s; profiles/r03_runs/run_r03h.sh).
+        // Box-walk slice (node visits per trip).  16 for trees whose nodes come from LDS or L2 (with the hand-over at 3 candidates: cover 12 / 16 / 20
+        // visits 9.34 / 9.48 / 9.23 Gsamples/s; 10 000 spheres, tree partly in LDS, 16 / 20 / 24: 8.00 / 7.81 / 7.45).  A tree of hundreds of
+        // thousands of nodes is read from HBM at several times the latency per visit, and a ray visits twice as many nodes: longer slices amortise the
+        // trip around them (250 882-triangle mesh, 24 / 32 / 40 visits: 2.04 / 1.97 / 1.86 Gsamples/s; gpurun_out/r03bc.  With walks that ran until the
+        // candidate list was full the optima were 16 / 20 / 32: r03h, r03ap).
         static const int kDefault[9] = {RTOW_DEFAULT_TUNE}, kGeneral[9] = {RTOW_GENERAL_TUNE};
         const int* base = compiled.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? kDefault : kGeneral;      // measured per family: see RTOW_DEFAULT_TUNE
         for (int k = 0; k < 9; k++) ctx->tune[k] = base[k];
-        if (compiled.layout.nodeCount > 65535u) ctx->tune[8] = 32;
+        if (compiled.layout.nodeCount > 65535u) ctx->tune[8] = 24;
     }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - (wide ? kStackBytesWide : kStackBytes) - kQueueBytes);
@@ -931,9 +932,6 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         if (nodes > ctx->scene.layout.nodeCount) nodes = ctx->scene.layout.nodeCount;
         ctx->ldsNodeCount = nodes;
         ctx->ldsSceneBytes = nodes * (uint32_t)sizeof(GpuNode);
-        // sphere scenes whose tree is only partly LDS resident: 20 visits per slice (10 000 spheres under the thresholds above, 12 / 16 / 20 / 24 visits:
-        // 6.78 / 7.08 / 7.48 / 7.26 Gsamples/s, gpurun_out/r03ap; the cover scene, all in LDS, keeps 16: 14 / 16 / 18 / 20 = 9.12 / 9.25 / 9.23 / 9.03)
-        if (!ctx->userTune && ctx->scene.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION && ctx->scene.layout.nodeCount <= 65535u) ctx->tune[8] = 20;
     }
     ctx->haveScene = true;
     ctx->sceneSerial++;
