@@ -53,6 +53,9 @@ def feature_cases(rt):
         "chain_of_three_batches": (S.cover_scene(), dict(width=64, height=36, spp=4, trace_depth=8), None, dict(chain_seeds=[21, 22, 23])),
         "chain_of_three_batches_moving_slice": (S.moving_scene(), dict(width=64, height=36, spp=3, trace_depth=8, slice_offset=1, slice_divider=2), None, dict(chain_seeds=[5, 6, 7])),
         "mesh_grid_250k_triangles_wide_codes": (S.mesh_grid_scene(), dict(width=1280, height=720, spp=4, trace_depth=8, focus=None), None, dict(sparse=(400, 3), focus_from_meta=True)),
+        # ---- round 3, late: volume kinds with 32-bit codes; frame shapes whose tickets are tiles + a row-major remainder, sliced and chained ----
+        "mesh_grid_82k_with_fog_volumes_wide_codes": (S.mesh_grid_fog_scene(), dict(width=1280, height=720, spp=4, trace_depth=8, focus=None), None, dict(sparse=(300, 5), focus_from_meta=True)),
+        "chain_of_three_batches_tiles_and_remainder": (S.cover_scene(), dict(width=72, height=29, spp=3, trace_depth=8, slice_offset=1, slice_divider=2), None, dict(chain_seeds=[31, 32, 33])),
     }
 
 
