@@ -409,12 +409,15 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         a.chunkOrder = haveOrder ? ctx->dChunkOrder : nullptr;
 
         // ---- stage thresholds: measured once per scene on this batch's own kernel, frame and view (see kTuneProbeSamples) ----
-        if (!ctx->userTune && !(ctx->flags & RTOW_CONTEXT_NO_THRESHOLD_TUNING) && ctx->tunedScene != ctx->sceneSerial && !a.unitRecords && haveOrder) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;                   // a stream that is being captured into a graph cannot be waited on: no measurement then
+        if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+        if (!ctx->userTune && !(ctx->flags & RTOW_CONTEXT_NO_THRESHOLD_TUNING) && ctx->tunedScene != ctx->sceneSerial && !a.unitRecords && haveOrder &&
+            capturing == hipStreamCaptureStatusNone) {
             static const int kSets[2][9] = {{RTOW_DEFAULT_TUNE}, {RTOW_GENERAL_TUNE}};     // (the ninth value, the walk slice, is set by rtowUploadScene)
             const bool volumes = a.layout.sceneKind == SCENE_KIND_VOLUMES || a.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
             const int candidates = volumes ? 4 : 2;                                          // volume kinds: each family also with the volume stage from half of the live lanes
             const int launches = candidates * kTuneProbeRepeats;
-            std::vector<hipEvent_t> ev((size_t)launches + 1);
+            std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
             bool ok = true;
             for (auto& e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
             SampleKernelArgs probe = a;
@@ -449,7 +452,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
                 ctx->tunedCandidate = winner;
                 logf(ctx, 4, "tune", "stage thresholds measured on this scene: candidate %d of %d (%.3f ms per %d-sample probe)", winner, candidates, best, kTuneProbeSamples);
             }
-            for (auto& e : ev) (void)hipEventDestroy(e);
+            for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (!ok) ctx->tunedCandidate = -1;
             ctx->tunedScene = ctx->sceneSerial;                 // measured (or not measurable): do not try again for this scene
             if (!ok) { (void)hipGetLastError(); logf(ctx, 2, "tune", "threshold probes failed; the per-kind values stay"); }
