@@ -54,6 +54,7 @@ struct ChainBatch {
 // moving + defocus +3 %, 4K +2.8 %, 250 k-triangle mesh +2.5 %).  Results do not depend on the numbering (a pixel's samples depend on its index
 // and the seed only).  Tiles need a width that is a multiple of 8; the owned rows beyond the last whole tile row (fewer than 8) are numbered row by
 // row behind the tiles.  RTOW_TICKET_TILES=0 builds strips only, for A/B runs.
+// [ticket numbering: begin]  (tests/test_ticket_numbering.py compiles the text between the two markers for the host and checks that it is a bijection)
 #ifndef RTOW_TICKET_TILES
 #define RTOW_TICKET_TILES 1
 #endif
@@ -79,6 +80,7 @@ __host__ __device__ inline void owned_pixel_xy(unsigned n, unsigned width, unsig
         cx = (int)(n - (unsigned)ownedRow * width);
     }
 }
+// [ticket numbering: end]
 
 struct SampleKernelArgs {
     // accumulators (JOBS/SampleBatchJob.cs:41-51)
