@@ -297,17 +297,55 @@ __global__ void __launch_bounds__(256) combine_kernel(RtowCombineParams p, const
     }
 }
 
+// Grid of the streaming post passes: one block of 256 lanes per 256 elements, dispatched in order, streams through memory front to back.  The 2 048
+// resident blocks of rounds 2 / 3 each walked the arrays with a stride of 2 048 x 256 elements - every block on the same few channels at the same time:
+// at 3840 x 2160 combine 5.4 -> 5.9 - 6.2 TB/s, add 5.2 -> 5.6 - 5.7, finalize 4.9 -> 5.1 (5.3 -> 5.9 at 1080p); 1 024 / 4 096 / 8 192 blocks in between
+// (gpurun_out/r03bp, r03bq).  The caps below only matter beyond 268 M elements; the kernels keep their grid-stride loops for that case.
+#ifndef RTOW_COMBINE_BLOCKS
+#define RTOW_COMBINE_BLOCKS 1048576
+#endif
+#ifndef RTOW_FINALIZE_BLOCKS
+#define RTOW_FINALIZE_BLOCKS 1048576
+#endif
+#ifndef RTOW_ADD_VARIANT
+#define RTOW_ADD_VARIANT 0          // 2, 3: timing experiments (see the kernel)
+#endif
+#ifndef RTOW_ADD_BLOCKS
+#define RTOW_ADD_BLOCKS 1048576     // grid-stride loop over at most this many blocks of 256 lanes (see RTOW_COMBINE_BLOCKS)
+#endif
 // dst += src over a flat float array (the four accumulators are added as 16 B / 4 B streams; HBM bound: 8 B read + 4 B written per float)
 __global__ void __launch_bounds__(256) add_kernel(size_t n4, float4* __restrict__ dst, const float4* __restrict__ src, size_t tailStart, size_t n, float* __restrict__ dstS,
                                                   const float* __restrict__ srcS)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+#if RTOW_ADD_VARIANT == 2
+    // TIMING EXPERIMENT: two elements per iteration, all four loads issued before the first add
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        float4 a0 = dst[i], a1 = dst[i + stride];
+        const float4 b0 = src[i], b1 = src[i + stride];
+        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+        dst[i] = a0; dst[i + stride] = a1;
+    }
+    for (; i < n4; i += stride) { float4 a = dst[i]; const float4 b = src[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; dst[i] = a; }
+#elif RTOW_ADD_VARIANT == 3
+    // TIMING EXPERIMENT: streaming hints - the source is read once, the sum is not read again soon
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = dst[i];
+        float4 b;
+        b.x = __builtin_nontemporal_load(&src[i].x); b.y = __builtin_nontemporal_load(&src[i].y); b.z = __builtin_nontemporal_load(&src[i].z); b.w = __builtin_nontemporal_load(&src[i].w);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        __builtin_nontemporal_store(a.x, &dst[i].x); __builtin_nontemporal_store(a.y, &dst[i].y); __builtin_nontemporal_store(a.z, &dst[i].z); __builtin_nontemporal_store(a.w, &dst[i].w);
+    }
+#else
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 a = dst[i];
         const float4 b = src[i];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         dst[i] = a;
     }
+#endif
     for (size_t i = tailStart + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dstS[i] += srcS[i];
 }
 
@@ -473,7 +511,7 @@ hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const
                          float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream)
 {
     const int n = p.width * p.height;
-    const int blocks = n < 256 * 2048 ? (n + 255) / 256 : 2048;
+    const int blocks = n < 256 * RTOW_COMBINE_BLOCKS ? (n + 255) / 256 : RTOW_COMBINE_BLOCKS;
     hipLaunchKernelGGL(combine_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, p, reinterpret_cast<const float4*>(inColor), inNormal, inAlbedo,
                        outColor, outNormal, outAlbedo);
     return hipGetLastError();
@@ -490,7 +528,7 @@ hipError_t launchBuildByteThresholds(float* thresholds, hipStream_t stream)
 hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
                           uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream)
 {
-    const int blocks = pixelCount < 256 * 2048 ? (pixelCount + 255) / 256 : 2048;
+    const int blocks = pixelCount < 256 * RTOW_FINALIZE_BLOCKS ? (pixelCount + 255) / 256 : RTOW_FINALIZE_BLOCKS;
     hipLaunchKernelGGL(finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, pixelCount, inColor, inNormal, inAlbedo,
                        reinterpret_cast<uchar4*>(outColor), reinterpret_cast<uchar4*>(outNormal), reinterpret_cast<uchar4*>(outAlbedo), thresholds);
     return hipGetLastError();
@@ -502,7 +540,7 @@ hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t st
     const size_t n4 = aligned ? floats / 4 : 0;
     const size_t work = n4 + (floats - n4 * 4);
     size_t blocks = (work + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > RTOW_ADD_BLOCKS) blocks = RTOW_ADD_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n4, reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(src), n4 * 4, floats, dst, src);
     return hipGetLastError();
