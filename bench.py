@@ -534,7 +534,7 @@ def main():
                 "launches": m["launches"],
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds), "wide_codes": bool(info.wideCodes),
                 "entities": int(info.entityCount), "hit_spill_bytes": int(info.hitSpillBytes),
-                # stage thresholds in use: -1 = the kernel kind's built-in ones, 0..3 = the set the first (warm-up) batch measured as fastest for this scene
+                # stage thresholds in use: -1 = the kernel kind's built-in ones, 0..5 = the set the first (warm-up) batch measured as fastest for this scene
                 "threshold_set": int(tuned.thresholdSet), "scheduler_tune": [int(x) for x in tuned.schedulerTune],
             },
             "kernel_ms_per_step": round(avg_kernel_ms, 3),

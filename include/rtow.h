@@ -186,8 +186,8 @@ typedef struct RtowSceneInfo {
     int32_t hitListCapacity;        /* most surfaces one ray may meet in this scene before the batch reports RTOW_ERROR_CAPACITY (0: only the nearest hit is kept) */
     int32_t wideCodes;              /* 1: more than 65 535 entities or tree nodes - the kernels that keep 32-bit candidate / stack codes run (tree read from HBM) */
     int32_t thresholdSet;           /* stage thresholds in use for this scene: -1 the built-in ones of its kernel kind (nothing measured yet, tiny frames, tuning off, or
-                                       RtowContextOptions.schedulerTune given); 0 / 1 the sphere / general family as measured by the first batch, 2 / 3 the same with the
-                                       volume stage waiting too (RTOW_CONTEXT_NO_THRESHOLD_TUNING) */
+                                       RtowContextOptions.schedulerTune given); 0 / 1 / 2 the sphere family / the general family / the general family with REGEN and SKY
+                                       from 1/8, as measured by the first batch; 3 / 4 / 5 the same with the volume stage waiting too (RTOW_CONTEXT_NO_THRESHOLD_TUNING) */
     int32_t schedulerTune[9];       /* the values themselves (REGEN TRAV TEST HIT SKY VOL | hand-over count | - | walk slice), as RtowContextOptions.schedulerTune would set them */
 } RtowSceneInfo;
 
@@ -308,7 +308,7 @@ typedef enum RtowContextFlags {
     RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5,       /* development: run the scene through the kernels with 32-bit candidate / stack codes (every scene kind has them)
                                                     * (what scenes beyond 65 535 entities or tree nodes use; the tree is then read from HBM) */
     RTOW_CONTEXT_NO_THRESHOLD_TUNING = 1u << 6     /* keep the built-in stage thresholds of the scene's kernel kind.  By default the first batch after rtowUploadScene measures
-                                                    * two (volume scenes: four) threshold sets with 4-sample probes of its own frame - a few milliseconds to ~0.1 s, waited for
+                                                    * three (volume scenes: six) threshold sets with 4-sample probes of its own frame - a few milliseconds to ~0.1 s, waited for
                                                     * inside that call, once per scene - and keeps the fastest; thresholds are pure scheduling and never change a result */
 } RtowContextFlags;
 

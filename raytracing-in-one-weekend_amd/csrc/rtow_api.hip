@@ -44,15 +44,22 @@ constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice
 #ifndef RTOW_GENERAL_TUNE
 #define RTOW_GENERAL_TUNE 16, 48, 1, 1, 1, 1, 3, 1, 16
 #endif
+// A second general family - REGEN and SKY from 1/8 - is what the 250 k-triangle mesh wants (2 167 against 2 037 Msamples/s) and the Cornell box with
+// volumes does not (840 against 920; mixed primitives +0.7 %; gpurun_out/r03bv): a third candidate for the per-scene measurement below.
+#ifndef RTOW_GENERAL_TUNE_2
+#define RTOW_GENERAL_TUNE_2 8, 48, 1, 1, 8, 1, 3, 1, 16
+#endif
 // Which of the two families suits a scene is a property of the scene, not of its kernel kind: an image-textured scene of spheres runs 25 % faster
 // on the sphere kinds' thresholds (10 160 against 8 100 Msamples/s), a scene of rects, boxes and triangles 9 % slower (3 220 against 3 540), a mesh with
 // fog volumes 15 % faster when the volume stage too waits for half of the live lanes (460 against 399; gpurun_out/r03ax).  So the first batch after
-// rtowUploadScene MEASURES them: each candidate renders kTuneProbeSamples samples per pixel through the batch's own kernel (a probe: nothing is
-// stored), twice, timed with events on the batch's stream; the fastest one stays for the scene.  A probe of a few samples per pixel ranks the
+// rtowUploadScene MEASURES them: each candidate (three families; six for volume scenes) renders kTuneProbeSamples samples per pixel through the batch's own kernel (a probe:
+// nothing is stored), twice, timed with events on the batch's stream; the fastest one stays for the scene.  A probe of a few samples per pixel ranks the
 // candidates like the full workload does (cover, textured, mixed, volumes, 10 000 spheres at 2 / 4 / 8 / 64 samples per pixel: same order every
 // time, gpurun_out/r03ay).  Thresholds never change a result (tests/test_gpu_fullsize.py: frames under every schedule).  The call that tunes
 // waits for its probes (a few milliseconds to ~0.1 s, once per scene); RTOW_CONTEXT_NO_THRESHOLD_TUNING keeps the per-kind values above.
-constexpr int kTuneProbeSamples = 4, kTuneProbeRepeats = 2;
+constexpr int kTuneProbeSamples = 4, kTuneProbeRepeats = 3;
+constexpr float kTuneMargin = 0.98f;      // a candidate replaces the kind's built-in family only if its best probe is more than 2 % faster: single probes (1 - 10 ms)
+                                          // scatter by a few per cent, and a wrong pick costs more than a missed one (10 000 spheres: family 2 picked once in r03bw, -7 %)
 
 using namespace rtow;
 
@@ -413,9 +420,10 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
         if (!ctx->userTune && !(ctx->flags & RTOW_CONTEXT_NO_THRESHOLD_TUNING) && ctx->tunedScene != ctx->sceneSerial && !a.unitRecords && haveOrder &&
             capturing == hipStreamCaptureStatusNone) {
-            static const int kSets[2][9] = {{RTOW_DEFAULT_TUNE}, {RTOW_GENERAL_TUNE}};     // (the ninth value, the walk slice, is set by rtowUploadScene)
+            constexpr int kFamilies = 3;
+            static const int kSets[kFamilies][9] = {{RTOW_DEFAULT_TUNE}, {RTOW_GENERAL_TUNE}, {RTOW_GENERAL_TUNE_2}};     // (the ninth value, the walk slice, is set by rtowUploadScene)
             const bool volumes = a.layout.sceneKind == SCENE_KIND_VOLUMES || a.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
-            const int candidates = volumes ? 4 : 2;                                          // volume kinds: each family also with the volume stage from half of the live lanes
+            const int candidates = volumes ? 2 * kFamilies : kFamilies;                      // volume kinds: each family also with the volume stage from half of the live lanes
             const int launches = candidates * kTuneProbeRepeats;
             std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
             bool ok = true;
@@ -425,17 +433,21 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             probe.pixelCost = nullptr;                           // the cost map stays the cost probe's (or the previous batch's)
             probe.cancelFlag = nullptr;
             probe.chainCount = 1;
+            // one untimed probe first: clocks, L2 and the instruction cache are warm before the first timed one
+            for (int k = 0; k < 8; k++) probe.tune[k] = kSets[0][k];
+            if (ok) ok = hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream) == hipSuccess && launchSampleBatch(probe, blocks, stream) == hipSuccess;
             if (ok) ok = hipEventRecord(ev[0], stream) == hipSuccess;
             for (int l = 0; ok && l < launches; l++) {
                 const int c = l % candidates;
-                for (int k = 0; k < 8; k++) probe.tune[k] = kSets[c & 1][k];
-                if (c >= 2) probe.tune[5] = 32;
+                for (int k = 0; k < 8; k++) probe.tune[k] = kSets[c % kFamilies][k];
+                if (c >= kFamilies) probe.tune[5] = 32;
                 ok = hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream) == hipSuccess && launchSampleBatch(probe, blocks, stream) == hipSuccess &&
                      hipEventRecord(ev[(size_t)l + 1], stream) == hipSuccess;
             }
             if (ok) ok = hipEventSynchronize(ev[(size_t)launches]) == hipSuccess;
             if (ok) {
-                float best = 0.0f;
+                const int builtin = a.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? 0 : 1;       // what rtowUploadScene set for this kernel kind
+                float best = 0.0f, builtinMs = 0.0f;
                 int winner = -1;
                 for (int c = 0; c < candidates; c++) {
                     float t = 0.0f;
@@ -444,10 +456,12 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
                         if (hipEventElapsedTime(&ms, ev[(size_t)(r * candidates + c)], ev[(size_t)(r * candidates + c) + 1]) != hipSuccess) ms = 1e30f;
                         t = (r == 0 || ms < t) ? ms : t;
                     }
+                    if (c == builtin) builtinMs = t;
                     if (winner < 0 || t < best) { best = t; winner = c; }
                 }
-                for (int k = 0; k < 8; k++) ctx->tune[k] = kSets[winner & 1][k];
-                if (winner >= 2) ctx->tune[5] = 32;
+                if (winner != builtin && !(best < kTuneMargin * builtinMs)) { winner = builtin; best = builtinMs; }
+                for (int k = 0; k < 8; k++) ctx->tune[k] = kSets[winner % kFamilies][k];
+                if (winner >= kFamilies) ctx->tune[5] = 32;
                 for (int k = 0; k < 8; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
                 ctx->tunedCandidate = winner;
                 logf(ctx, 4, "tune", "stage thresholds measured on this scene: candidate %d of %d (%.3f ms per %d-sample probe)", winner, candidates, best, kTuneProbeSamples);

@@ -175,8 +175,9 @@ def test_stage_thresholds_are_measured_per_scene_and_change_nothing(rt, gpu_cont
     assert gpu_context.scene_info().thresholdSet == -1                      # nothing measured before the first batch
     tuned = _device_render(rt, gpu_context, p, n, 4)
     info = gpu_context.scene_info()
-    assert 0 <= info.thresholdSet < (4 if name == "volumes" else 2)
-    sets = {0: [24, 32, 1, 32, 28, 1], 1: [16, 48, 1, 1, 1, 1], 2: [24, 32, 1, 32, 28, 32], 3: [16, 48, 1, 1, 1, 32]}      # (+ hand-over count 3, unused, walk slice)
+    assert 0 <= info.thresholdSet < (6 if name == "volumes" else 3)
+    fam = {0: [24, 32, 1, 32, 28], 1: [16, 48, 1, 1, 1], 2: [8, 48, 1, 1, 8]}
+    sets = {k: fam[k % 3] + [32 if k >= 3 else 1] for k in range(6)}          # (+ hand-over count 3, unused, walk slice)
     assert list(info.schedulerTune)[:6] == sets[info.thresholdSet]
     again = _device_render(rt, gpu_context, p, n, 4)                        # measured once per scene: the choice stays
     assert gpu_context.scene_info().thresholdSet == info.thresholdSet
