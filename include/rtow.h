@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 8
+#define RTOW_API_VERSION 9
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -469,12 +469,49 @@ typedef struct RtowCommId { char bytes[128]; } RtowCommId;        /* ncclUniqueI
  * RTOW_ERROR_INVALID_VALUE; the library is loaded once).  tests/ point it at a stand-in transport (tests/native/fake_rccl.cpp: the same eight
  * nccl* entry points over shared memory) so that the multi-rank gather runs on a box with one GPU, which RCCL itself refuses. */
 RTOW_API int rtowCommSetLibraryPath(const char* path);
-typedef enum RtowGatherMask { RTOW_GATHER_COLOR = 1, RTOW_GATHER_NORMAL = 2, RTOW_GATHER_ALBEDO = 4, RTOW_GATHER_SAMPLE_COUNT_WEIGHT = 8, RTOW_GATHER_ALL = 15 } RtowGatherMask;
+typedef enum RtowGatherMask {
+    RTOW_GATHER_COLOR = 1, RTOW_GATHER_NORMAL = 2, RTOW_GATHER_ALBEDO = 4, RTOW_GATHER_SAMPLE_COUNT_WEIGHT = 8, RTOW_GATHER_ALL = 15,
+    RTOW_GATHER_NO_BATCH_WAIT = 16   /* rtowGatherRowsDevice / rtowExchangeAccumDevice normally start after the context's most recent sample batch, whatever
+                                      * stream that batch was given (its rows are what travels).  With this bit the call is ordered by `stream` alone: for rows
+                                      * that do not come out of that batch - the output of rtowExchangeAccumDevice on the same stream, or a partial result
+                                      * whose batch the caller has already ordered before `stream` itself - while the NEXT batch is already enqueued */
+} RtowGatherMask;
 RTOW_API int rtowCommGetUniqueId(RtowCommId* outId);
 RTOW_API int rtowCommInit(RtowContext context, const RtowCommId* id, int32_t rank, int32_t worldSize);
 RTOW_API int rtowCommDestroy(RtowContext context);
 RTOW_API int rtowGatherRowsDevice(RtowContext context, int32_t width, int32_t height, int32_t sliceDivider,
                                   const RtowAccumBuffers* mine, const RtowAccumBuffers* frame, int32_t what, int32_t root, void* stream);
+
+/* ---- multi-GPU, tiles x batches: G ranks = T row slices x B seed groups (G = T * B) ----
+ * The tile partition alone stops scaling where a GPU owns about one pixel per resident lane: under the reference's random stream a pixel's
+ * samples are one sequential unit of work (JOBS/SampleBatchJob.cs:91,132-157), so the slowest pixel bounds the batch.  What the reference itself
+ * splits a frame's samples into is BATCHES: successive batches with a fresh Seed (frameSeed, UNITY/Raytracer.cs:656-661), each feeding its sums to
+ * the next (:798-802).  Batches are independent of each other, so B of them can run at the same time: rank r = tile + T * group renders the rows
+ * of slice `tile` of T (the reference's slice fields) with its share of the batch's samples and the Seed of batch `group`, FROM ZEROED accumulators
+ * (a partial sum); afterwards the B ranks of a tile exchange their partial sums so that every row is folded on ONE rank -
+ *     accum[row] += partial_0[row]; accum[row] += partial_1[row]; ... += partial_{B-1}[row]        (group order; row % G == rank)
+ * - the same float additions in the same order wherever the row is folded, so the frame is reproducible bit for bit, and equal to the
+ * reference's sequential accumulation of those B batches up to the association of the float sums (each partial is summed from zero instead
+ * of on top of its predecessor: <= 1e-4 of the mean at the sample counts of the benchmark configurations, asserted in tests/).  The folded rows are
+ * then gathered like a tile partition's: rtowGatherRowsDevice(..., sliceDivider = G, mine = accum, ...).
+ *   plan:   rtowHybridPlan(G, rank, T, samplesPerBatch, step, &plan)        pure arithmetic: this rank's slice fields, sample share and Seed
+ *   batch:  rtowSampleBatchDevice(params{sliceOffset, sliceDivider, seed, sampleCountRange = plan}, in = zeros, out = partial)
+ *           rtowExchangeAccumDevice(ctx, W, H, T, &partial, &accum, what, stream)      all ranks; one grouped ncclSend / ncclRecv per peer of the tile
+ *           rtowGatherRowsDevice(ctx, W, H, G, &accum, &frame, what | RTOW_GATHER_NO_BATCH_WAIT, root, stream)
+ * T = 1 splits only the samples (every rank renders the whole frame), T = G only the rows (then the exchange folds a rank's own rows and nothing
+ * travels).  `partial` and `accum` are full-frame buffers that must not overlap; rows outside a rank's tile are never read, rows it does not
+ * fold are never written.  Traffic per rank and batch: (B - 1) / B of its tile's rows out and as much in, spread over its B - 1 direct xGMI links. */
+typedef struct RtowHybridPlan {
+    int32_t tileCount, groupCount;      /* T, B = worldSize / T */
+    int32_t tile, group;                /* of this rank: rank % T, rank / T */
+    int32_t sliceOffset, sliceDivider;  /* what this rank renders with: (tile, T) */
+    uint32_t samples;                   /* this rank's share of samplesPerBatch: samplesPerBatch / B, the remainder to the low groups */
+    uint32_t seed;                      /* Seed of this rank's sub-batch of step `step` (1-based): (step - 1) * B + group + 1 - consecutive integers over
+                                           the groups and steps, like frameSeed over the host's successive batches (UNITY/Raytracer.cs:660) */
+} RtowHybridPlan;
+RTOW_API int rtowHybridPlan(int32_t worldSize, int32_t rank, int32_t tileCount, uint32_t samplesPerBatch, uint32_t step, RtowHybridPlan* outPlan);
+RTOW_API int rtowExchangeAccumDevice(RtowContext context, int32_t width, int32_t height, int32_t tileCount,
+                                     const RtowAccumBuffers* partial, const RtowAccumBuffers* accum, int32_t what, void* stream);
 
 RTOW_API int rtowDeviceAlloc(RtowContext context, size_t sizeInBytes, void** outPointer);
 RTOW_API int rtowDeviceFree(RtowContext context, void* pointer);

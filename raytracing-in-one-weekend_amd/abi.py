@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 8
+RTOW_API_VERSION = 9
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -137,7 +137,7 @@ LogCallback = C.CFUNCTYPE(None, C.c_int32, C.c_char_p, C.c_char_p, C.c_void_p)
 # RtowContextFlags
 CONTEXT_EXACT_TIES_ALWAYS, CONTEXT_EXACT_TIES_NEVER, CONTEXT_REFERENCE_DIAGNOSTICS, CONTEXT_NO_CAMERA_RAY_LISTS, CONTEXT_NO_CHUNK_ORDER, CONTEXT_FORCE_WIDE_CODES, CONTEXT_NO_THRESHOLD_TUNING = 1, 2, 4, 8, 16, 32, 64
 # RtowGatherMask
-GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_ALL = 1, 2, 4, 8, 15
+GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_ALL, GATHER_NO_BATCH_WAIT = 1, 2, 4, 8, 15, 16
 
 
 class ContextOptions(C.Structure):
@@ -148,6 +148,11 @@ class ContextOptions(C.Structure):
 
 class CommId(C.Structure):
     _fields_ = [("bytes", C.c_char * 128)]
+
+
+class HybridPlan(C.Structure):
+    _fields_ = [("tileCount", C.c_int32), ("groupCount", C.c_int32), ("tile", C.c_int32), ("group", C.c_int32),
+                ("sliceOffset", C.c_int32), ("sliceDivider", C.c_int32), ("samples", C.c_uint32), ("seed", C.c_uint32)]
 
 
 class Metrics(C.Structure):
@@ -166,4 +171,5 @@ EXPORTED_SYMBOLS = [
     "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize", "rtowGetBatchStatus", "rtowRegisterHostBuffer", "rtowUnregisterHostBuffer",
     "rtowSampleBatchChainDevice", "rtowSampleBatchChain", "rtowCommSetLibraryPath", "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
+    "rtowHybridPlan", "rtowExchangeAccumDevice",
 ]

@@ -1385,15 +1385,17 @@ RTOW_API int rtowCommDestroy(RtowContext ctx)
 RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height, int32_t sliceDivider, const RtowAccumBuffers* mine,
                                   const RtowAccumBuffers* frame, int32_t what, int32_t root, void* stream)
 {
-    if (!ctx || !mine || width <= 0 || height <= 0 || sliceDivider < 1 || (what & ~RTOW_GATHER_ALL) || !(what & RTOW_GATHER_ALL)) return RTOW_ERROR_INVALID_VALUE;
+    if (!ctx || !mine || width <= 0 || height <= 0 || sliceDivider < 1 || (what & ~(RTOW_GATHER_ALL | RTOW_GATHER_NO_BATCH_WAIT)) || !(what & RTOW_GATHER_ALL)) return RTOW_ERROR_INVALID_VALUE;
+    const bool waitForBatch = !(what & RTOW_GATHER_NO_BATCH_WAIT);
+    what &= RTOW_GATHER_ALL;
     std::lock_guard<std::mutex> lock(ctx->mu);
     const int world = ctx->comm ? ctx->commWorld : 1, rank = ctx->comm ? ctx->commRank : 0;
     if (sliceDivider != world || root < 0 || root >= world) return RTOW_ERROR_INVALID_VALUE;   // rank g owns the rows of slice g: one slice per rank
     if (rank == root && !frame) return RTOW_ERROR_INVALID_VALUE;
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    // the rows being gathered were written by the last sample batch, whatever stream that was enqueued on
-    if (ctx->haveBatchDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evBatchDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+    // the rows being gathered were written by the last sample batch, whatever stream that was enqueued on (RTOW_GATHER_NO_BATCH_WAIT: they were not)
+    if (waitForBatch && ctx->haveBatchDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evBatchDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
 
     static const int kComponents[4] = {4, 3, 3, 1};
     float* const mineBuf[4] = {mine->color, mine->normal, mine->albedo, mine->sampleCountWeight};
@@ -1480,6 +1482,119 @@ RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height
             }
     }
     return gatherEnds();
+}
+
+RTOW_API int rtowHybridPlan(int32_t worldSize, int32_t rank, int32_t tileCount, uint32_t samplesPerBatch, uint32_t step, RtowHybridPlan* out)
+{
+    if (!out || worldSize < 1 || rank < 0 || rank >= worldSize || tileCount < 1 || worldSize % tileCount != 0 || step < 1u) return RTOW_ERROR_INVALID_VALUE;
+    const int32_t groups = worldSize / tileCount;
+    RtowHybridPlan p{};
+    p.tileCount = tileCount;
+    p.groupCount = groups;
+    p.tile = rank % tileCount;
+    p.group = rank / tileCount;
+    p.sliceOffset = p.tile;
+    p.sliceDivider = tileCount;
+    p.samples = samplesPerBatch / (uint32_t)groups + ((uint32_t)p.group < samplesPerBatch % (uint32_t)groups ? 1u : 0u);
+    p.seed = (step - 1u) * (uint32_t)groups + (uint32_t)p.group + 1u;
+    *out = p;
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowExchangeAccumDevice(RtowContext ctx, int32_t width, int32_t height, int32_t tileCount, const RtowAccumBuffers* partial, const RtowAccumBuffers* accum,
+                                     int32_t what, void* stream)
+{
+    if (!ctx || !partial || !accum || width <= 0 || height <= 0 || tileCount < 1 || (what & ~(RTOW_GATHER_ALL | RTOW_GATHER_NO_BATCH_WAIT)) || !(what & RTOW_GATHER_ALL))
+        return RTOW_ERROR_INVALID_VALUE;
+    const bool waitForBatch = !(what & RTOW_GATHER_NO_BATCH_WAIT);
+    what &= RTOW_GATHER_ALL;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int world = ctx->comm ? ctx->commWorld : 1, rank = ctx->comm ? ctx->commRank : 0;
+    if (world % tileCount != 0) return RTOW_ERROR_INVALID_VALUE;                      // G = T x B
+    const int groups = world / tileCount, tile = rank % tileCount, own = rank / tileCount;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // the partial sums were written by the last sample batch, whatever stream that was enqueued on (RTOW_GATHER_NO_BATCH_WAIT: the caller ordered it)
+    if (waitForBatch && ctx->haveBatchDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evBatchDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+
+    static const int kComponents[4] = {4, 3, 3, 1};
+    float* const partBuf[4] = {partial->color, partial->normal, partial->albedo, partial->sampleCountWeight};
+    float* const accBuf[4] = {accum->color, accum->normal, accum->albedo, accum->sampleCountWeight};
+    unsigned floatsPerPixel = 0;
+    for (int b = 0; b < 4; b++)
+        if (what & (1 << b)) {
+            if (!partBuf[b] || !accBuf[b] || partBuf[b] == accBuf[b]) return RTOW_ERROR_INVALID_VALUE;      // the fold reads partial rows while it writes accum rows
+            floatsPerPixel += (unsigned)kComponents[b];
+        }
+    // rank p folds the rows with row % G == p; they all lie in the tile p % T, i.e. in what every rank of that tile rendered
+    auto packedFloats = [&](int r) { return (size_t)rowsOwnedBy(r, world, height) * (size_t)width * floatsPerPixel; };
+    const unsigned myRows = rowsOwnedBy(rank, world, height);
+    const size_t regionFloats = packedFloats(rank);                                     // what every peer of the tile sends here: this rank's rows of ITS partial
+
+    if (groups > 1) {
+        RcclApi* api = rccl();
+        if (!api) return RTOW_ERROR_UNSUPPORTED;
+        // staging (shared with rtowGatherRowsDevice, ordered by the same event): packed rows for every peer | one region per group for what arrives
+        if (ctx->haveGatherDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evGatherDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+        size_t sendTotal = 0;
+        std::vector<size_t> sendOffset((size_t)groups, 0);
+        for (int g = 0; g < groups; g++) { sendOffset[(size_t)g] = sendTotal; if (g != own) sendTotal += packedFloats(tile + tileCount * g); }
+        const size_t recvTotal = regionFloats * (size_t)groups;
+        if (sendTotal > ctx->gatherSendFloats) {
+            HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);          // the old block may still be travelling
+            if (ctx->haveGatherDone) HIP_TRY(ctx, hipEventSynchronize(ctx->evGatherDone), RTOW_ERROR_LAUNCH_FAILURE);
+            if (ctx->dGatherSend) (void)hipFree(ctx->dGatherSend);
+            ctx->dGatherSend = nullptr; ctx->gatherSendFloats = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dGatherSend, sendTotal * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->gatherSendFloats = sendTotal;
+        }
+        if (recvTotal > ctx->gatherRecvFloats) {
+            HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
+            if (ctx->haveGatherDone) HIP_TRY(ctx, hipEventSynchronize(ctx->evGatherDone), RTOW_ERROR_LAUNCH_FAILURE);
+            if (ctx->dGatherRecv) (void)hipFree(ctx->dGatherRecv);
+            ctx->dGatherRecv = nullptr; ctx->gatherRecvFloats = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dGatherRecv, recvTotal * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->gatherRecvFloats = recvTotal;
+        }
+        for (int g = 0; g < groups; g++) {
+            if (g == own) continue;
+            const int peer = tile + tileCount * g;
+            const unsigned rows = rowsOwnedBy(peer, world, height);
+            size_t at = sendOffset[(size_t)g];
+            for (int b = 0; b < 4; b++)
+                if (what & (1 << b)) {
+                    HIP_TRY(ctx, launchCopyRows(partBuf[b], ctx->dGatherSend + at, (unsigned)(width * kComponents[b]), rows, (unsigned)peer, (unsigned)world, false, s), RTOW_ERROR_LAUNCH_FAILURE);
+                    at += (size_t)rows * width * kComponents[b];
+                }
+        }
+        // one group: a send and a receive per peer of the tile, each pair on its own xGMI link.  The group is closed on every path.
+        RCCL_TRY(ctx, api, api->GroupStart());
+        int posted = 0;
+        for (int g = 0; g < groups && posted == 0; g++) {
+            if (g == own) continue;
+            const int peer = tile + tileCount * g;
+            if (packedFloats(peer)) posted = api->Send(ctx->dGatherSend + sendOffset[(size_t)g], packedFloats(peer), kRcclFloat32, peer, ctx->comm, s);
+            if (posted == 0 && regionFloats) posted = api->Recv(ctx->dGatherRecv + (size_t)g * regionFloats, regionFloats, kRcclFloat32, peer, ctx->comm, s);
+        }
+        const int closed = api->GroupEnd();
+        if (posted != 0 || closed != 0) {
+            logf(ctx, 2, "rccl", "exchange of partial sums failed: ncclSend / ncclRecv %s, ncclGroupEnd %s", api->GetErrorString(posted), api->GetErrorString(closed));
+            return RTOW_ERROR_LAUNCH_FAILURE;
+        }
+    }
+    // the fold: this rank's rows, group order, own partial in place
+    size_t at = 0;
+    for (int b = 0; b < 4; b++)
+        if (what & (1 << b)) {
+            HIP_TRY(ctx, launchFoldRows(accBuf[b], partBuf[b], groups > 1 ? ctx->dGatherRecv + at : partBuf[b], regionFloats, (unsigned)(width * kComponents[b]), myRows, (unsigned)rank,
+                                        (unsigned)world, (unsigned)groups, (unsigned)own, s), RTOW_ERROR_LAUNCH_FAILURE);
+            at += (size_t)myRows * width * kComponents[b];
+        }
+    if (groups > 1) {
+        HIP_TRY(ctx, hipEventRecord(ctx->evGatherDone, s), RTOW_ERROR_LAUNCH_FAILURE);
+        ctx->haveGatherDone = true;
+    }
+    return RTOW_SUCCESS;
 }
 
 RTOW_API int rtowDeviceAlloc(RtowContext ctx, size_t sizeInBytes, void** outPointer)

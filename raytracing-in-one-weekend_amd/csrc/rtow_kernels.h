@@ -219,6 +219,9 @@ hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inN
 hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t stream); // dst += src
 // rows first, first + step, ... (`rows` of them, `rowFloats` floats each) of a full-frame buffer -> / <- one contiguous block
 hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, bool toFrame, hipStream_t stream);
+// accum[row] += src_0[row] ... += src_{groups-1}[row] (group order) for rows first, first + step, ...; src_g = ownPartial (frame layout) for g == own, else packed rows at recv + g * regionFloats
+hipError_t launchFoldRows(float* accum, const float* ownPartial, const float* recv, size_t regionFloats, unsigned rowFloats, unsigned rows, unsigned first, unsigned step,
+                          unsigned groups, unsigned own, hipStream_t stream);
 
 // Per-block partial results of the metrics reduction; the host folds them in block order.
 struct MetricsPartial {

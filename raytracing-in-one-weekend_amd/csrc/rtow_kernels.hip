@@ -472,6 +472,43 @@ hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsig
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// rtowExchangeAccumDevice: accum[row] += src_0[row]; accum[row] += src_1[row]; ... for the rows first, first + step, ... of a full-frame buffer,
+// in group order with one rounding per addition - what `groups` successive add passes compute - in ONE pass that reads and writes accum once.
+// Source g is the rank's own partial sum (frame layout, in place) for g == own, else region g of the receive block (packed rows).
+// ------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T add_units(T a, T b);
+template <> __device__ __forceinline__ float add_units<float>(float a, float b) { return a + b; }
+template <> __device__ __forceinline__ float4 add_units<float4>(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+template <typename T>
+__global__ void __launch_bounds__(256) fold_rows_kernel(T* __restrict__ accum, const T* __restrict__ ownPartial, const T* __restrict__ recv, size_t regionUnits, unsigned rowUnits,
+                                                        unsigned rows, unsigned first, unsigned step, unsigned groups, unsigned own)
+{
+    for (unsigned k = blockIdx.y; k < rows; k += gridDim.y) {
+        const size_t frameRow = ((size_t)first + (size_t)k * step) * rowUnits, packedRow = (size_t)k * rowUnits;
+        for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < rowUnits; j += gridDim.x * blockDim.x) {
+            T a = accum[frameRow + j];
+            for (unsigned g = 0; g < groups; g++) a = add_units<T>(a, g == own ? ownPartial[frameRow + j] : recv[(size_t)g * regionUnits + packedRow + j]);
+            accum[frameRow + j] = a;
+        }
+    }
+}
+
+hipError_t launchFoldRows(float* accum, const float* ownPartial, const float* recv, size_t regionFloats, unsigned rowFloats, unsigned rows, unsigned first, unsigned step,
+                          unsigned groups, unsigned own, hipStream_t stream)
+{
+    if ((size_t)rows * rowFloats == 0 || groups == 0) return hipSuccess;
+    const bool wide = (rowFloats & 3u) == 0u && (regionFloats & 3u) == 0u &&
+                      ((reinterpret_cast<uintptr_t>(accum) | reinterpret_cast<uintptr_t>(ownPartial) | reinterpret_cast<uintptr_t>(recv)) & 15u) == 0u;
+    const unsigned units = wide ? rowFloats / 4u : rowFloats;
+    const unsigned bx = units < 256u * 8u ? (units + 255u) / 256u : 8u;
+    const unsigned by = rows < 4096u ? rows : 4096u;
+    if (wide) hipLaunchKernelGGL(fold_rows_kernel<float4>, dim3(bx, by), dim3(256), 0, stream, reinterpret_cast<float4*>(accum), reinterpret_cast<const float4*>(ownPartial),
+                                 reinterpret_cast<const float4*>(recv), regionFloats / 4u, units, rows, first, step, groups, own);
+    else hipLaunchKernelGGL(fold_rows_kernel<float>, dim3(bx, by), dim3(256), 0, stream, accum, ownPartial, recv, regionFloats, units, rows, first, step, groups, own);
+    return hipGetLastError();
+}
+
 hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream)
 {
     const unsigned pixels = args.totalWork / args.groupsPerPixel;

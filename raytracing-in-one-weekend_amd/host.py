@@ -123,6 +123,17 @@ class Context:
         check(load().rtowGatherRowsDevice(self.handle, width, height, divider, C.byref(mine), C.byref(frame) if frame is not None else None, what, root, stream),
               "rtowGatherRowsDevice")
 
+    @staticmethod
+    def hybrid_plan(world, rank, tiles, samples_per_batch, step):
+        """rtowHybridPlan: this rank's slice fields, sample share and Seed in a tiles x batches partition (G = T x B)."""
+        plan = abi.HybridPlan()
+        check(load().rtowHybridPlan(world, rank, tiles, samples_per_batch, step, C.byref(plan)), "rtowHybridPlan")
+        return plan
+
+    def exchange_accum(self, width, height, tiles, partial, accum, what=abi.GATHER_ALL, stream=None):
+        """rtowExchangeAccumDevice: partial sums of this rank's tile -> folded into `accum` on the rank that owns each row (row % G)."""
+        check(load().rtowExchangeAccumDevice(self.handle, width, height, tiles, C.byref(partial), C.byref(accum), what, stream), "rtowExchangeAccumDevice")
+
     def close(self):
         if self.handle:
             load().rtowDestroyContext(self.handle)   # drops the registrations (hipHostUnregister) while the arrays are still alive ...

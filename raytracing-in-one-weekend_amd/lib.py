@@ -73,6 +73,8 @@ def load():
     lib.rtowCommInit.argtypes = [vp, C.POINTER(abi.CommId), C.c_int32, C.c_int32]
     lib.rtowCommDestroy.argtypes = [vp]
     lib.rtowGatherRowsDevice.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, AB, AB, C.c_int32, C.c_int32, vp]
+    lib.rtowHybridPlan.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(abi.HybridPlan)]
+    lib.rtowExchangeAccumDevice.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, AB, AB, C.c_int32, vp]
     for name in abi.EXPORTED_SYMBOLS:
         if name not in ("rtowErrorString",):
             getattr(lib, name).restype = C.c_int

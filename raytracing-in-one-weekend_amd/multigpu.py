@@ -155,3 +155,64 @@ def render_batches(render_full, acc_slice, n, rank, world, add_flat, group=None,
     gather_list = list(frame.view(world, m).unbind(0)) if rank == dst else None
     dist.gather(acc_slice, gather_list, dst=dst, group=group)
     return frame if rank == dst else None
+
+
+# ---------------------------------------------------------------------------------------------------
+# tiles x batches (rtowHybridPlan / rtowExchangeAccumDevice, include/rtow.h): G ranks = T row slices x B seed groups
+# ---------------------------------------------------------------------------------------------------
+def hybrid_plan(world, rank, tiles, samples_per_batch, step):
+    """The arithmetic of rtowHybridPlan (csrc/rtow_api.hip), for the hosts that run without the library (CPU tests): rank = tile + T * group renders
+    slice `tile` of T with its share of the batch's samples and the Seed of sub-batch `group` of step `step` (1-based)."""
+    if world < 1 or not 0 <= rank < world or tiles < 1 or world % tiles or step < 1:
+        raise ValueError("hybrid_plan: world = tiles x groups, 0 <= rank < world, step >= 1")
+    groups = world // tiles
+    tile, group = rank % tiles, rank // tiles
+    return {"tiles": tiles, "groups": groups, "tile": tile, "group": group, "slice_offset": tile, "slice_divider": tiles,
+            "samples": samples_per_batch // groups + (1 if group < samples_per_batch % groups else 0), "seed": (step - 1) * groups + group + 1}
+
+
+def default_tiles(world, samples_per_batch):
+    """T of the partition bench.py reports: as many seed groups as there are samples to give each at least one (B = the largest divisor of the
+    world size that is <= samples per batch), the rest of the world size as row slices.  256 samples on 8 GPUs: 1 x 8."""
+    groups = max(b for b in range(1, world + 1) if world % b == 0 and b <= max(1, samples_per_batch))
+    return world // groups
+
+
+def exchange_accum(partial, accum, height, rank, world, tiles, group=None):
+    """torch.distributed mirror of rtowExchangeAccumDevice (same rows, same order of additions; gloo on CPU, RCCL with backend "nccl").
+    partial / accum: lists of [H, W, C] tensors (full-frame buffers).  Rank p folds the rows with row % world == p; the ranks of its tile
+    (p % tiles) send it those rows of their partial sums, and it adds them to `accum` in group order, its own partial in place."""
+    groups, tile, own = world // tiles, rank % tiles, rank // tiles
+    recv = {}
+    ops = []
+    for g in range(groups):
+        peer = tile + tiles * g
+        if g == own:
+            continue
+        for k, buf in enumerate(partial):
+            rows = buf[peer::world].contiguous()
+            if rows.numel():
+                ops.append(dist.isend(rows, dst=peer, group=group))
+            mine = torch.empty_like(buf[rank::world])
+            if mine.numel():
+                ops.append(dist.irecv(mine, src=peer, group=group))
+            recv[(g, k)] = mine
+    for op in ops:
+        op.wait()
+    for k, (acc, part) in enumerate(zip(accum, partial)):
+        rows = acc[rank::world]                              # a view: the adds below land in `accum`
+        for g in range(groups):
+            rows += part[rank::world] if g == own else recv[(g, k)]
+    return accum
+
+
+def render_hybrid(render_partial, accum, height, width, rank, world, tiles, samples_per_batch, step, group=None, dst=0):
+    """One step of the tiles x batches partition over torch.distributed: plan -> render_partial(plan) -> exchange + fold -> gather of colour.
+    `render_partial(plan)` returns this rank's partial sums from ZEROED inputs as [color [H*W,4], normal, albedo, scw [H*W]] tensors in which only
+    the rows of its tile are meaningful.  `accum`: the running accumulators, same shapes (rows with row % world == rank are this rank's).
+    Returns the colour frame [H, W, 4] on `dst` (None elsewhere)."""
+    plan = hybrid_plan(world, rank, tiles, samples_per_batch, step)
+    part = render_partial(plan)
+    shapes = (4, 3, 3, 1)
+    exchange_accum([t.view(height, width, c) for t, c in zip(part, shapes)], [t.view(height, width, c) for t, c in zip(accum, shapes)], height, rank, world, tiles, group)
+    return gather_frame(pack_owned(accum[0].view(height, width, 4), rank, world), height, rank, world, group, dst)

@@ -224,3 +224,167 @@ def test_bench_with_two_ranks_runs_end_to_end_through_the_c_abi_gather(rt):
     parts = out["partitions"]
     assert set(parts) >= {"tiles", "batches"} and all(v["value"] > 0 for v in parts.values())
     assert abs(parts["tiles"]["value"] - out["value"]) < 1e-6 * max(out["value"], 1.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# tiles x batches: rtowHybridPlan / rtowExchangeAccumDevice (G ranks = T row slices x B seed groups)
+# ---------------------------------------------------------------------------------------------------
+HYBRID_SCRIPT = r"""
+import ctypes, importlib, json, os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+rank, world, idfile, outdir, transport = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+cases = json.load(open(os.path.join(outdir, "cases.json")))
+rt = importlib.import_module("raytracing-in-one-weekend_amd")
+a = rt.abi
+lib = rt.lib.load()
+device = 0
+if transport != "rccl":
+    rt.Context.comm_set_library_path(transport)
+else:
+    device = rank
+ctx = rt.Context(device)
+if rank == 0:
+    uid = rt.Context.comm_unique_id()
+    open(idfile + ".tmp", "wb").write(uid)
+    os.rename(idfile + ".tmp", idfile)
+else:
+    for _ in range(2400):
+        if os.path.exists(idfile):
+            break
+        time.sleep(0.05)
+    uid = open(idfile, "rb").read()
+ctx.comm_init(uid, rank, world)
+scene = rt.scenes.cover_scene()
+ctx.upload_scene(scene.desc())
+for ci, case in enumerate(cases):
+    w, h, spp, tiles, what, root, steps = case["w"], case["h"], case["spp"], case["tiles"], case["what"], case["root"], case["steps"]
+    n = w * h
+    comps = (4, 3, 3, 1)
+    zero = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in comps]
+    part = [rt.DeviceBuffer(ctx).upload(np.full((n, c), np.nan, np.float32)) for c in comps]       # rows outside this rank's tile stay NaN: the exchange must never read them
+    start = [np.full((n, c), v, np.float32) for c, v in zip(comps, (0.5, 0.25, 0.125, 2.0))]       # a non-trivial running accumulation
+    acc = [rt.DeviceBuffer(ctx).upload(x) for x in start]
+    frame = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in comps] if rank == root else None
+    bp, ba = a.AccumBuffers(*[b.ptr for b in part]), a.AccumBuffers(*[b.ptr for b in acc])
+    bf = a.AccumBuffers(*[b.ptr for b in frame]) if frame else None
+    bad = lib.rtowExchangeAccumDevice(ctx.handle, w, h, tiles, ctypes.byref(ba), ctypes.byref(ba), what, None)
+    assert bad == a.RTOW_ERROR_INVALID_VALUE, bad                                                  # partial and accum must be different buffers
+    assert lib.rtowExchangeAccumDevice(ctx.handle, w, h, world + 1, ctypes.byref(bp), ctypes.byref(ba), what, None) == a.RTOW_ERROR_INVALID_VALUE   # T does not divide G
+    for step in range(1, steps + 1):
+        plan = rt.Context.hybrid_plan(world, rank, tiles, spp, step)
+        p = rt.scenes.make_params(scene, w, h, spp=plan.samples, trace_depth=6, seed=plan.seed, slice_offset=plan.sliceOffset, slice_divider=plan.sliceDivider)
+        job = rt.SampleBatchJob(ctx, p)
+        job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = zero
+        job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = part
+        rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
+        ctx.exchange_accum(w, h, tiles, bp, ba, what=what)
+        ctx.gather_rows(w, h, world, ba, bf, what=what | a.GATHER_NO_BATCH_WAIT, root=root)
+    ctx.synchronize()
+    np.savez(os.path.join(outdir, "case%d.rank%d.npz" % (ci, rank)), **{k: b.download(np.float32, (n, c)) for k, b, c in zip(("color", "normal", "albedo", "scw"), acc, comps)})
+    if rank == root:
+        np.savez(os.path.join(outdir, "case%d.npz" % ci), **{k: b.download(np.float32, (n, c)) for k, b, c in zip(("color", "normal", "albedo", "scw"), frame, comps)})
+    for b in zero + part + acc + (frame or []):
+        b.free()
+ctx.comm_destroy()
+ctx.close()
+"""
+
+
+def _run_hybrid(rt, gpu_context, world, cases, transport):
+    """`world` processes run every case's steps as a tiles x batches partition; asserts that the gathered frame and every rank's folded rows equal,
+    bit for bit, the sub-batches ONE process renders (whole frame, the plan's sample share and Seed, zeroed inputs) folded in group order."""
+    import json
+    with tempfile.TemporaryDirectory() as tmp:
+        script = os.path.join(tmp, "rank.py")
+        open(script, "w").write(HYBRID_SCRIPT)
+        json.dump(cases, open(os.path.join(tmp, "cases.json"), "w"))
+        idfile = os.path.join(tmp, "uid")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
+        procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), idfile, tmp, transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for r in range(world)]
+        outs = []
+        for pr in procs:
+            try:
+                outs.append(pr.communicate(timeout=420)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                pytest.fail("rank processes hung: " + "\n".join(outs))
+        assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
+        scene = rt.scenes.cover_scene()
+        gpu_context.upload_scene(scene.desc())
+        for ci, case in enumerate(cases):
+            w, h, spp, tiles, what = case["w"], case["h"], case["spp"], case["tiles"], case["what"]
+            n, groups = w * h, world // tiles
+            start = {k: np.full((n, c), v, np.float32) for (k, c, _), v in zip(KEYS, (0.5, 0.25, 0.125, 2.0))}
+            want = {k: v.copy() for k, v in start.items()}
+            for step in range(1, case["steps"] + 1):
+                for g in range(groups):
+                    plan = rt.Context.hybrid_plan(world, g * tiles, tiles, spp, step)
+                    assert (plan.group, plan.tile, plan.seed) == (g, 0, (step - 1) * groups + g + 1)
+                    part = rt.sample_batch_host(gpu_context, rt.scenes.make_params(scene, w, h, spp=plan.samples, trace_depth=6, seed=plan.seed))
+                    for k, c, _ in KEYS:
+                        want[k] = want[k] + part[k].reshape(n, c)                           # group order, one float32 rounding per addition
+            rows = np.arange(n) // w
+            got = np.load(os.path.join(tmp, "case%d.npz" % ci))
+            for k, c, bit in KEYS:
+                if what & bit:
+                    assert np.array_equal(got[k].reshape(n, c).view(np.uint32), want[k].view(np.uint32)), (world, ci, case, k, "gathered frame")
+                else:
+                    assert not got[k].any(), (world, ci, case, k, "outside the mask: not gathered")
+            for r in range(world):
+                acc = np.load(os.path.join(tmp, "case%d.rank%d.npz" % (ci, r)))
+                mine = rows % world == r
+                for k, c, bit in KEYS:
+                    expect = want[k] if (what & bit) else start[k]                          # outside the mask the running accumulation is not touched
+                    assert np.array_equal(acc[k].reshape(n, c)[mine].view(np.uint32), expect[mine].view(np.uint32)), (world, ci, case, r, k, "folded rows")
+                    assert np.array_equal(acc[k].reshape(n, c)[~mine].view(np.uint32), start[k][~mine].view(np.uint32)), (world, ci, case, r, k, "rows of other ranks")
+
+
+def _hybrid_cases(world):
+    if world == 2:
+        return [dict(w=96, h=54, spp=5, tiles=1, what=15, root=0, steps=2), dict(w=97, h=53, spp=4, tiles=2, what=15, root=1, steps=2),
+                dict(w=64, h=33, spp=3, tiles=1, what=1 | 4, root=0, steps=1), dict(w=33, h=1, spp=2, tiles=1, what=15, root=0, steps=1)]      # rank 1 folds no row
+    if world == 3:
+        return [dict(w=96, h=55, spp=7, tiles=1, what=15, root=2, steps=2), dict(w=50, h=7, spp=3, tiles=3, what=1, root=1, steps=1)]
+    return [dict(w=96, h=54, spp=16, tiles=1, what=15, root=0, steps=2), dict(w=96, h=54, spp=8, tiles=2, what=15, root=0, steps=1),
+            dict(w=40, h=13, spp=5, tiles=4, what=1 | 8, root=5, steps=2), dict(w=64, h=5, spp=9, tiles=1, what=1, root=3, steps=1)]               # fewer rows than ranks
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_hybrid_exchange_folds_the_reference_batches_in_group_order(rt, gpu_context, world):
+    """rtowExchangeAccumDevice + rtowGatherRowsDevice with 2, 3 and 8 processes: 1 x G, T x B and G x 1 splits, ragged sample shares, root != 0, masks,
+    fewer rows than ranks, two steps accumulated - bit-identical to the sub-batches of one process folded in group order."""
+    _run_hybrid(rt, gpu_context, world, _hybrid_cases(world), _build_fake_rccl())
+    count = C.c_int(0)
+    C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(count))
+    if count.value >= world:                                                # a GPU per rank: the same over the real RCCL
+        _run_hybrid(rt, gpu_context, world, _hybrid_cases(world)[:2], "rccl")
+
+
+def test_hybrid_plan_and_single_rank_exchange(rt, gpu_context):
+    """world = 1: the exchange is the fold of the rank's own partial sum (accum += partial, every row); the plan is the whole batch."""
+    a = rt.abi
+    ctx = gpu_context
+    plan = rt.Context.hybrid_plan(1, 0, 1, 256, 7)
+    assert (plan.tileCount, plan.groupCount, plan.sliceOffset, plan.sliceDivider, plan.samples, plan.seed) == (1, 1, 0, 1, 256, 7)
+    plan = rt.Context.hybrid_plan(8, 5, 2, 10, 3)
+    assert (plan.tile, plan.group, plan.sliceOffset, plan.sliceDivider, plan.samples, plan.seed) == (1, 2, 1, 2, 2, 11)
+    lib = rt.lib.load()
+    assert lib.rtowHybridPlan(8, 0, 3, 10, 1, C.byref(plan)) == a.RTOW_ERROR_INVALID_VALUE and lib.rtowHybridPlan(8, 8, 2, 10, 1, C.byref(plan)) == a.RTOW_ERROR_INVALID_VALUE
+    assert lib.rtowHybridPlan(8, 0, 2, 10, 0, C.byref(plan)) == a.RTOW_ERROR_INVALID_VALUE
+    w, h = 37, 11
+    n = w * h
+    rng = np.random.default_rng(5)
+    src = [rng.random((n, c)).astype(np.float32) for c in (4, 3, 3, 1)]
+    dst = [rng.random((n, c)).astype(np.float32) for c in (4, 3, 3, 1)]
+    part = [rt.DeviceBuffer(ctx).upload(x) for x in src]
+    acc = [rt.DeviceBuffer(ctx).upload(x) for x in dst]
+    ctx.exchange_accum(w, h, 1, a.AccumBuffers(*[b.ptr for b in part]), a.AccumBuffers(*[b.ptr for b in acc]), what=a.GATHER_COLOR | a.GATHER_SAMPLE_COUNT_WEIGHT)
+    ctx.synchronize()
+    got = [b.download(np.float32, (n, c)) for b, c in zip(acc, (4, 3, 3, 1))]
+    assert np.array_equal(got[0], dst[0] + src[0]) and np.array_equal(got[3], dst[3] + src[3])
+    assert np.array_equal(got[1], dst[1]) and np.array_equal(got[2], dst[2])
+    for b in part + acc:
+        b.free()
