@@ -17,15 +17,18 @@ batch is stored.  The same K steps as plain one-launch-per-batch calls and the h
 are measured after the timed region and reported next to `value` (`plain_batches`, `host_buffer_ms_per_step`).
 
 N > 1: one process per GPU, no data-path collective inside a batch; the batch's results are combined over RCCL afterwards.  The total work is fixed
-(same frame, same spp), so scaling is "strong".  `value` is the TILE partition north_star names:
-  tiles    the frame is row-interleaved with the reference's slice contract (SliceOffset = rank, SliceDivider = N,
-           JOBS/SampleBatchJob.cs:69-70) and the colour rows are gathered on rank 0 by ONE RCCL gather per batch behind the C ABI
-           (rtowCommInit / rtowGatherRowsDevice); bit-identical to the single-GPU frame; limited by lane-per-pixel granularity under
-           the reference RNG stream (a GPU with one pixel per lane finishes when its slowest pixel does);
+(same frame, same spp), so scaling is "strong".  `value` is the reference-stream partition that scales (`--partition hybrid`, the default):
+  hybrid   tiles x batches behind the C ABI (rtowHybridPlan / rtowExchangeAccumDevice / rtowGatherRowsDevice, include/rtow.h): G GPUs = T row slices x
+           B seed groups; rank tile + T * group renders slice `tile` of T (the reference's SliceOffset / SliceDivider, JOBS/SampleBatchJob.cs:69-70) with
+           spp / B samples and the Seed of sub-batch `group` from zeroed accumulators - the reference's own successive batches of a frame
+           (fresh frameSeed, sums carried on: UNITY/Raytracer.cs:656-661,798-802) run at the same time instead of one after the other; ONE grouped
+           ncclSend / ncclRecv exchange folds every row on the rank that owns it (row % G) in group order, ONE gather of colour rows per batch brings
+           the frame to rank 0.  T = 1 (samples only) unless spp < G (`--tiles`); bit-identical to the sub-batches folded in group order on one GPU,
+           within 1e-4 of the mean of the sequential accumulation (tests/);
 and the line also carries, measured in the same run (`partitions`):
-  batches  every rank renders the whole frame with spp/N samples and its own seed from zeroed accumulators; the partials are
-           exchanged (all-to-all), every rank folds one slice of the frame in rank order, and the frame is gathered on rank 0
-           (the reference's batch accumulation, Raytracer.cs:656-661,798-802, run concurrently; raytracing-in-one-weekend_amd/multigpu.py);
+  tiles    north_star's partition: the frame row-interleaved over the GPUs (SliceDivider = N), one gather of colour rows per batch
+           (rtowCommInit / rtowGatherRowsDevice); bit-identical to the single-GPU frame; limited by lane-per-pixel granularity under
+           the reference RNG stream (a GPU with one pixel per lane finishes when its slowest pixel's sequential samples do: DESIGN.md 6);
   tiles under --rng per-sample (RTOW_RNG_PER_SAMPLE, NOT the reference's random stream: a pixel's samples become independent units).
 
 Rank 0 prints ONE JSON line (see the task contract) that also carries `roofline`, `cpu_baseline` (the C2 sample), `cpu_baseline_c1`
@@ -237,7 +240,9 @@ def main():
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
     ap.add_argument("--context-flags", type=int, default=0, help="development: RtowContextOptions.flags (e.g. 1 = exact-tie kernels always)")
     ap.add_argument("--post-only", default=None, metavar="WxH", help="profiling aid: run only the post-pass measurement at this frame size and print its block (profiles/collect.sh)")
-    ap.add_argument("--partition", choices=("tiles", "batches"), default="tiles", help="which N > 1 partition `value` reports (the other is reported beside it)")
+    ap.add_argument("--partition", choices=("hybrid", "tiles", "batches"), default="hybrid", help="which N > 1 partition `value` reports (the other is reported beside it): hybrid = tiles x batches "
+                    "behind the C ABI (the reference stream's scalable split), tiles = rows only (north_star's), batches = hybrid with one tile")
+    ap.add_argument("--tiles", type=int, default=None, help="T of the hybrid partition (must divide the number of GPUs); default: 1 unless spp < GPUs")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     overridden = [k for k in ("scene", "width", "height", "spp", "depth") if getattr(args, k) is not None]
@@ -345,20 +350,21 @@ def main():
     def measure(partition, rng, chain, steps, warmup):
         """Time `steps` batches (after `warmup` untimed ones) under one partition / RNG policy / chain length; max over ranks.
         Returns wall seconds, mean kernel ms per step, and the buffers of the last batch (for the ray / success statistics)."""
-        batches = world > 1 and partition == "batches"
+        hybrid = world > 1 and partition in ("hybrid", "batches")
+        tiles_t = 1 if partition == "batches" else (args.tiles or mg.default_tiles(world, spp))
+        if hybrid and world % tiles_t:
+            raise SystemExit("--tiles %d does not divide %d GPUs" % (tiles_t, world))
 
         def flat():
-            # batches: padded so that the flat accumulator splits into `world` equal slices of whole 11-float units (multigpu.slice_floats)
-            return torch.zeros(mg.padded_floats(n, world) if batches else mg.ACCUM_FLOATS * n, device=dev)
+            return torch.zeros(mg.ACCUM_FLOATS * n, device=dev)
 
         state = {"ping_flat": flat(), "pong_flat": flat()}
         state["ping"], state["pong"] = mg.accum_views(state["ping_flat"], n), mg.accum_views(state["pong_flat"], n)
-        zero_flat = flat() if batches else None           # never written: the input of every rank's sub-batch
-        acc_slice = torch.zeros(mg.slice_floats(n, world), device=dev) if batches else None
-        exchange = flat() if batches else None
+        zero_flat = flat() if hybrid else None            # never written: the input of every rank's sub-batch
         diags = [torch.zeros(n, device=dev) for _ in range(max(1, chain))]
-        if batches:
-            base = rt.scenes.make_params(scene, W, H, spp=mg.batch_split(spp, rank, world), trace_depth=depth, focus=focus)
+        plan0 = rt.Context.hybrid_plan(world, rank, tiles_t, spp, 1) if hybrid else None
+        if hybrid:
+            base = rt.scenes.make_params(scene, W, H, spp=int(plan0.samples), trace_depth=depth, slice_offset=int(plan0.sliceOffset), slice_divider=int(plan0.sliceDivider), focus=focus)
         else:
             base = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, slice_offset=rank, slice_divider=world, focus=focus)
         kernel_ms = []
@@ -368,13 +374,6 @@ def main():
             p.seed = seed
             p.rngPolicy = {"per-sample": abi.RNG_PER_SAMPLE, "per-sample-xoroshiro": abi.RNG_PER_SAMPLE_XOROSHIRO}.get(rng, abi.RNG_REFERENCE)
             return p
-
-        def add_flat(dst, src):
-            # dst += src over a flat slice of 11 * k floats, as the 4-buffer device add over k "pixels" (element for element the same adds)
-            k = dst.numel() // mg.ACCUM_FLOATS
-            d = abi.AccumBuffers(*[dst.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
-            s_ = abi.AccumBuffers(*[src.data_ptr() + 4 * o * k for o in (0, 4, 7, 10)])
-            rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, k, C.byref(d), C.byref(s_), stream.cuda_stream), "rtowAddAccumDevice")
 
         def launch(plist, src, dst):
             bi = abi.AccumBuffers(*[t.data_ptr() for t in src])
@@ -392,16 +391,29 @@ def main():
             i = first
             while i < first + count:
                 c = min(chain, first + count - i)
-                if batches:
-                    # every rank: whole frame, its share of the samples, its own seed, zeroed inputs; all-to-all + ordered fold of the slices; gather of the frame
-                    p = params_for(mg.batch_seed(i + 1, rank, world))
+                if hybrid:
+                    # this rank's sub-batch of step i + 1 from zeroed inputs (pong = the partial sums), the exchange + ordered fold into the running
+                    # accumulation (ping: this rank's rows, row % world == rank), the gather of the colour rows on rank 0 (in place: ping is the frame there)
                     c = 1
-
-                    def render_full():
-                        launch([p], mg.accum_views(zero_flat, n), state["pong"])
-                        return state["pong_flat"]
-
-                    mg.render_batches(render_full, acc_slice, n, rank, world, add_flat, exchange=exchange, frame=state["ping_flat"], via_host=shared_gpu)   # ping = this batch's frame (rank 0)
+                    plan = rt.Context.hybrid_plan(world, rank, tiles_t, spp, i + 1)
+                    launch([params_for(int(plan.seed))], mg.accum_views(zero_flat, n), state["pong"])
+                    part, acc = abi.AccumBuffers(*[t.data_ptr() for t in state["pong"]]), abi.AccumBuffers(*[t.data_ptr() for t in state["ping"]])
+                    if have_comm:
+                        ctx.exchange_accum(W, H, tiles_t, part, acc, what=abi.GATHER_ALL, stream=stream.cuda_stream)
+                        ctx.gather_rows(W, H, world, acc, acc if rank == 0 else None, what=abi.GATHER_COLOR | abi.GATHER_NO_BATCH_WAIT, root=0, stream=stream.cuda_stream)
+                    else:
+                        shapes = (4, 3, 3, 1)
+                        src = [t.view(H, W, k) for t, k in zip(state["pong"], shapes)]
+                        dst = [t.view(H, W, k) for t, k in zip(state["ping"], shapes)]
+                        if shared_gpu:                        # gloo has no device point-to-point: host copies (development only)
+                            hs, hd = [t.cpu() for t in src], [t.cpu() for t in dst]
+                            mg.exchange_accum(hs, hd, H, rank, world, tiles_t)
+                            for t, hcopy in zip(dst, hd):
+                                t.copy_(hcopy)
+                            mg.gather_frame(mg.pack_owned(hd[0], rank, world), H, rank, world)
+                        else:
+                            mg.exchange_accum(src, dst, H, rank, world, tiles_t)
+                            mg.gather_frame(mg.pack_owned(dst[0], rank, world), H, rank, world)
                 else:
                     launch([params_for(i + 1 + k) for k in range(c)], state["ping"], state["pong"])
                     if world > 1:
@@ -425,12 +437,12 @@ def main():
         ctx.batch_status()                                  # the asynchronous batches report here (hit-list capacity)
         avg_kernel_ms = max_over_ranks(sum(kernel_ms) / max(steps, 1))
         launches = len(kernel_ms)
-        return {"elapsed": elapsed, "kernel_ms_per_step": avg_kernel_ms, "launches": launches, "last": state["ping"], "diag": diags[0 if batches else ((steps % chain) or min(chain, steps)) - 1],
-                "batches": batches, "base": base}
+        return {"elapsed": elapsed, "kernel_ms_per_step": avg_kernel_ms, "launches": launches, "last": state["ping"], "diag": diags[0 if hybrid else ((steps % chain) or min(chain, steps)) - 1],
+                "hybrid": hybrid, "base": base, "tiles": tiles_t if hybrid else world, "groups": world // tiles_t if hybrid else 1, "rank_spp": int(plan0.samples) if hybrid else spp}
 
     main_partition = args.partition if world > 1 else "single"
     m = measure(args.partition, args.rng, args.chain, args.steps, args.warmup)
-    batches = m["batches"]
+    hybrid = m["hybrid"]
 
     def summary(mm):
         return {"value": round(float(n) * spp * args.steps / mm["elapsed"] / 1e6, 2), "ms_per_step": round(mm["elapsed"] / args.steps * 1e3, 3),
@@ -478,7 +490,7 @@ def main():
                 extras["host_buffer_chain_ms_per_step"] = round(min(ctimes) / args.chain * 1e3, 3)
             ctx.unregister_host_buffers()
         else:
-            other = "batches" if args.partition == "tiles" else "tiles"
+            other = "hybrid" if args.partition == "tiles" else "tiles"
             extras["partitions"] = {args.partition: summary(m), other: summary(measure(other, args.rng, 1, args.steps, 1))}
             if args.rng == "reference":
                 extras["partitions"]["tiles, RTOW_RNG_PER_SAMPLE (not the reference stream)"] = summary(measure("tiles", "per-sample", 1, args.steps, 1))
@@ -492,8 +504,8 @@ def main():
         rays = float(m["diag"].sum().item()) * (world if world > 1 else 1)  # every rank traces a statistically equal share
         # algorithmic HBM bytes per launch of the sample kernel: 44 B read + 44 B write + 4 B diagnostics per
         # owned pixel AND batch of the launch, plus the scene image once
-        owned_pixels = n if (batches or world == 1) else len(range(rank, H, world)) * W
-        rank_spp = mg.batch_split(spp, rank, world) if batches else spp
+        owned_pixels = n if world == 1 else len(range(rank % m["tiles"], H, m["tiles"])) * W     # rank 0's launch: its tile's rows
+        rank_spp = m["rank_spp"]
         steps_per_launch = args.steps / max(m["launches"], 1)
         alg_bytes = int(owned_pixels * 92 * steps_per_launch) + int(info.sceneBytesDevice)
         launch_ms = avg_kernel_ms * steps_per_launch
@@ -516,7 +528,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
-            "batches_per_launch": args.chain if not batches else 1,   # `value` is measured with this many successive batches fused into one launch (1 = plain batches)
+            "batches_per_launch": args.chain if not hybrid else 1,   # `value` is measured with this many successive batches fused into one launch (1 = plain batches)
             "launches": m["launches"],
             "higher_is_better": True,
             "scaling": "strong",
@@ -527,10 +539,13 @@ def main():
                 "workload": "%s%s, %dx%d, %d spp per batch, "
                             "%d bounces, white noise, jitter on, %s" % ("BASELINE.json " + cfg["label"] + " = " if not overridden else "", SCENE_TEXT[args.scene], W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_%s (NOT the reference stream; lane per 16-sample group)" % args.rng.upper().replace("-", "_")),
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
-                              "batches: every rank renders the whole frame with spp/%d samples and its own seed; RCCL all-to-all of the partial accumulators, rank-ordered fold of one slice per rank, RCCL gather of the frame on rank 0" % world
-                              if batches else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),
+                              "hybrid: %d row slices x %d seed groups (rtowHybridPlan): every rank renders its slice with %d of the %d samples and the Seed of its sub-batch from zeroed accumulators; "
+                              "one grouped ncclSend / ncclRecv exchange + rank-ordered fold of every row on its owner (rtowExchangeAccumDevice), one RCCL gather of colour rows per batch on rank 0 "
+                              "(rtowGatherRowsDevice); the reference's successive batches (UNITY/Raytracer.cs:656-661,798-802) run concurrently" % (m["tiles"], m["groups"], rank_spp, spp)
+                              if hybrid else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),
+                "tiles": m["tiles"] if world > 1 else None, "seed_groups": m["groups"] if world > 1 else None,
                 "gather": None if world == 1 else ("rtowGatherRowsDevice (DEBUG: the tests' stand-in transport instead of RCCL, ranks share one GPU)" if (have_comm and shared_gpu) else "rtowGatherRowsDevice (RCCL behind the C ABI)" if have_comm else "torch.distributed (debug: ranks share one GPU)" if shared_gpu else "torch.distributed (the C-ABI communicator was not available)"),
-                "batches_per_launch": args.chain if not batches else 1,
+                "batches_per_launch": args.chain if not hybrid else 1,
                 "launches": m["launches"],
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds), "wide_codes": bool(info.wideCodes),
                 "entities": int(info.entityCount), "hit_spill_bytes": int(info.hitSpillBytes),

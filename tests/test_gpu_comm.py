@@ -202,7 +202,8 @@ def test_gather_closes_the_rccl_group_on_a_failed_receive(rt, gpu_context):
 def test_bench_with_two_ranks_runs_end_to_end_through_the_c_abi_gather(rt):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on this one-GPU box in its debug mode: both ranks on
     cuda:0, torch.distributed over gloo, the tile partition's gather through rtowCommInit / rtowGatherRowsDevice on the stand-in transport.  The
-    N > 1 JSON line - `value` from the tile partition, `partitions` beside it, `config.gather` naming the C-ABI path - prints and is consistent."""
+    N > 1 JSON line - `value` from the tiles x batches partition (rtowExchangeAccumDevice + rtowGatherRowsDevice on the stand-in transport), the tile
+    partition beside it in `partitions`, `config.gather` naming the C-ABI path - prints and is consistent."""
     import json
     import socket
     _build_fake_rccl()
@@ -220,10 +221,11 @@ def test_bench_with_two_ranks_runs_end_to_end_through_the_c_abi_gather(rt):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["gather"].startswith("rtowGatherRowsDevice"), out["config"]["gather"]
-    assert out["config"]["partition"].startswith("DEBUG")
+    assert out["config"]["partition"].startswith("DEBUG") and "hybrid: 1 row slices x 2 seed groups" in out["config"]["partition"]
+    assert (out["config"]["tiles"], out["config"]["seed_groups"]) == (1, 2)
     parts = out["partitions"]
-    assert set(parts) >= {"tiles", "batches"} and all(v["value"] > 0 for v in parts.values())
-    assert abs(parts["tiles"]["value"] - out["value"]) < 1e-6 * max(out["value"], 1.0)
+    assert set(parts) >= {"tiles", "hybrid"} and all(v["value"] > 0 for v in parts.values())
+    assert abs(parts["hybrid"]["value"] - out["value"]) < 1e-6 * max(out["value"], 1.0)       # `value` is the reference-stream partition that scales
 
 
 # ---------------------------------------------------------------------------------------------------
