@@ -328,9 +328,8 @@ typedef struct RtowContextOptions {
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per
                                      * entry, sized at rtowUploadScene to min(this, the most the scene can produce: 2 per entity with volumes, else 1).
                                      * 0 = 1024 in scenes with volumes, 128 elsewhere.  A ray beyond it makes the batch report RTOW_ERROR_CAPACITY */
-    int32_t sliceBlockThreads;      /* development: lanes per workgroup of the sample kernel.  0 = chosen per launch (1024; 512 or 256 for launches that own
-                                     * about one pixel per resident lane - a GPU's slice of a frame split over several - which end when their slowest
-                                     * pixel does); 256 / 512 / 1024 forces it where such a kernel exists.  Never changes a result */
+    int32_t sliceBlockThreads;      /* reserved: 0 (or 1024).  Rounds 2 - 3 could run 512 / 256 lanes per workgroup for launches that own about one pixel per
+                                     * resident lane; measured slower at every slice count and removed.  Other values: RTOW_ERROR_INVALID_VALUE */
 } RtowContextOptions;
 
 RTOW_API int rtowGetApiVersion(void);

@@ -29,8 +29,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override the config's samples per pixel")
     ap.add_argument("--slices", default="1,2,4,8")
     ap.add_argument("--tune", default=None, help="RtowContextOptions.schedulerTune: 8 stage thresholds + the box-walk slice, comma separated")
-    ap.add_argument("--block-threads", default="0", help="RtowContextOptions.sliceBlockThreads for the slices, comma separated list: 0 = the library's own choice per launch, "
-                    "256 / 512 / 1024 forced; the whole frame (G = 1) always runs the default geometry")
+    ap.add_argument("--block-threads", default="0", help="kept for old command lines: only 0 / 1024 exist since round 4 (the 512- / 256-lane workgroups were measured slower and removed)")
     args = ap.parse_args()
     name, w, h, spp, depth = CONFIGS[args.config]
     if args.spp:

@@ -22,15 +22,6 @@
 #include "rtow_bvh.h"
 #include "rtow_kernels.h"
 
-// Launches that own at most this many pixels per resident lane (CUs x 1024) run 256 / 512 lanes per workgroup instead of 1024 (launchSample).
-#ifndef RTOW_SLICE_256_PIXELS_PER_LANE
-#define RTOW_SLICE_256_PIXELS_PER_LANE 0.0
-#endif
-#ifndef RTOW_SLICE_512_PIXELS_PER_LANE
-#define RTOW_SLICE_512_PIXELS_PER_LANE 0.0
-#endif
-constexpr double kSlice256PixelsPerLane = RTOW_SLICE_256_PIXELS_PER_LANE, kSlice512PixelsPerLane = RTOW_SLICE_512_PIXELS_PER_LANE;
-
 // minimum lane population per stage, in 64ths of the wave's live lanes: REGEN TRAV TEST HIT SKY VOL | candidates that end a walk (hand-over to TEST) | unused | box-walk slice (node visits per trip).
 // Sphere kinds: REGEN from 3/8, the walk and HIT from 1/2, SKY from 7/16, TEST at once.  Since a chunk's 64 tickets are an 8 x 8 tile of the image
 // (rtow_kernels.h) the lanes of a wave meet the same few materials, and a HIT stage that waits for half of them runs its class bodies a third as
@@ -136,7 +127,6 @@ struct RtowContext_t {
     MetricsPartial* dPartials = nullptr;
 
     // RtowContextOptions: behaviour switches and development knobs (nothing is read from the environment)
-    int sliceBlockThreads = 0;            // 0 = chosen per launch; 256 / 512 / 1024 forces (development)
     bool wideCodes = false;               // current scene: more than 65 535 entities or tree nodes (32-bit candidate / stack codes, tree read from HBM)
     uint32_t flags = 0;
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
@@ -318,19 +308,10 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         }
         a.unitRecords = ctx->dUnitRecords;
     }
-    // ---- launch geometry.  One persistent workgroup per CU; how many lanes it has is a property of the launch.  1024 (four waves per SIMD) is the
-    // throughput shape.  A launch that owns only about one pixel per resident lane - one GPU's slice of a frame split over several - is not
-    // bound by throughput but by its slowest pixel: `spp` samples that can only run one after the other under the reference stream
-    // (JOBS/SampleBatchJob.cs:91,132-157), each a chain of trips of the stage loop, and a wave that shares its SIMD with fewer others gets
-    // through a trip sooner.  Such launches run 512 or 256 lanes per CU (two / one wave per SIMD); the thresholds are measured
-    // (profiles/emulate_tile_split.py).  Results do not depend on it: pixels are independent.
+    // ---- launch geometry: one persistent 1024-lane workgroup per CU (four waves per SIMD).  Smaller workgroups for launches that own about one pixel
+    // per resident lane were built, measured and removed: results never depended on it.
     a.wideCodes = ctx->wideCodes ? 1 : 0;
     a.blockThreads = kBlockThreads;
-    {
-        const double pixelsPerLane = (double)a.totalWork / ((double)ctx->cuCount * kBlockThreads);
-        int want = ctx->sliceBlockThreads ? ctx->sliceBlockThreads : (pixelsPerLane <= kSlice256PixelsPerLane ? 256 : pixelsPerLane <= kSlice512PixelsPerLane ? 512 : kBlockThreads);
-        if (want != kBlockThreads && sliceGeometryAvailable(a, want)) a.blockThreads = want;
-    }
     int blocks = (int)((a.totalWork + (uint32_t)a.blockThreads - 1) / (uint32_t)a.blockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
     if (blocks < 1) blocks = 1;
@@ -782,8 +763,7 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
         if ((ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) && (ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER)) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
         if (options->ldsSceneBudgetBytes > 0) ctx->ldsSceneBudget = (uint32_t)options->ldsSceneBudgetBytes;
         if (options->hitListCapacity < 0) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
-        if (options->sliceBlockThreads != 0 && options->sliceBlockThreads != 256 && options->sliceBlockThreads != 512 && options->sliceBlockThreads != 1024) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }
-        ctx->sliceBlockThreads = options->sliceBlockThreads;
+        if (options->sliceBlockThreads != 0 && options->sliceBlockThreads != 1024) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }     // reserved (round 3: 256 / 512)
         ctx->hitListCapacity = (uint32_t)options->hitListCapacity;
         bool anyTune = false;
         for (int i = 0; i < 9; i++) anyTune = anyTune || options->schedulerTune[i] != 0;

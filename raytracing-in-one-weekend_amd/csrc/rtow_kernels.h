@@ -166,8 +166,8 @@ struct SampleKernelArgs {
     unsigned int* chunkDone;              // [chunkCount] pixels stored so far, all batches of this launch; zeroed before the launch
     XcdState* xcdState;                   // chunk ownership per XCD + the lists behind it (chained launches only)
 
-    // launch geometry (rtow_sample_kernel.hip.h, GEO): lanes per workgroup of THIS launch (1024, or 512 / 256 for slices that own about one pixel
-    // per resident lane) and whether candidate / stack codes are 32 bits wide (scenes beyond 65 535 entities or tree nodes)
+    // launch geometry (rtow_sample_kernel.hip.h, GEO): lanes per workgroup of THIS launch (1024) and whether candidate / stack codes are 32 bits
+    // wide (scenes beyond 65 535 entities or tree nodes)
     int32_t blockThreads;
     int32_t wideCodes;
 
@@ -201,8 +201,6 @@ hipError_t launchSampleTrianglesTies(const SampleKernelArgs& args, int numBlocks
 hipError_t launchSampleTrianglesTextured(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
 hipError_t launchSampleTrianglesTexturedTies(const SampleKernelArgs& args, int numBlocks, hipStream_t stream, bool allLds);
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream);
-// can this batch run with `blockThreads` lanes per workgroup (512 / 256: the slice geometries exist for the sphere kinds, reference stream, short records, depth <= 16)?
-bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads);
 hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipStream_t stream); // derived material constants, on device
 hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream);
 hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream);

@@ -432,15 +432,6 @@ hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStr
     }
 }
 
-bool sliceGeometryAvailable(const SampleKernelArgs& args, int blockThreads)
-{
-    if (blockThreads == kBlockThreads) return true;
-    if (blockThreads != 512 && blockThreads != 256) return false;
-    const bool kind = (args.layout.sceneKind == SCENE_KIND_SPHERES || args.layout.sceneKind == SCENE_KIND_SPHERES_MOTION) && !args.layout.exactTies;
-    return kind && !args.wideCodes && args.noiseColor == RTOW_NOISE_WHITE && !args.unitRecords && !(args.diagnostics && args.diagnosticsStride >= 16) && args.traceDepth <= 16;
-}
-
-
 // ------------------------------------------------------------------------------------------------------------
 // rtowGatherRowsDevice: rows first, first + step, ... of a full-frame buffer <-> one contiguous block (what travels over xGMI).
 // HBM bound, 4 B read + 4 B written per float; at most 11 floats per owned pixel per batch.

@@ -43,10 +43,6 @@
 #define RTOW_EXACT_MATH 1
 #endif
 // ballot / prefix-sum compaction of the exact tests (TEST stage, sphere kinds): see the stage.  0 = every lane loops over its own candidates
-// the exact-tie kernels also exist with the 4-word path history (trace depth <= 8): +3.8 % on the 250 882-triangle mesh
-#ifndef RTOW_TIES_SHORT_HISTORY
-#define RTOW_TIES_SHORT_HISTORY 1
-#endif
 #ifndef RTOW_COMPACT_TESTS
 #define RTOW_COMPACT_TESTS 0
 #endif
@@ -1051,12 +1047,12 @@ __device__ __noinline__ __attribute__((unused)) float2 reference_counts(const ui
     return make_float2(bh, cc);
 }
 
-// Launch geometry of a variant (template parameter GEO): bits 0..1 = lanes per workgroup (one workgroup per CU: 1024 = four waves per SIMD, the
-// throughput shape; 512 / 256 = two / one wave per SIMD, for launches that own about one pixel per resident lane - a slice of a frame split over
-// GPUs - where the launch ends when its slowest pixel's sequential samples do and a wave that shares its SIMD with fewer others gets there sooner);
-// bit 2 = 32-bit traversal-stack / candidate codes (scenes of more than 65 535 entities or tree nodes; the tree is then read from HBM).
+// Launch geometry of a variant (template parameter GEO): one workgroup of 1024 lanes per CU (four waves per SIMD: the throughput shape; 512- and
+// 256-lane workgroups for launches that own about one pixel per resident lane were built in round 3, measured - a lone wave gains 1.55 x, the machine
+// loses 2.6 x - and removed in round 4); bit 2 = 32-bit traversal-stack / candidate codes (scenes of more than 65 535 entities or tree
+// nodes; the tree is then read from HBM).
 constexpr int kGeoWide = 4;
-constexpr int geo_block_threads(int geo) { return (geo & 3) == 0 ? 1024 : (geo & 3) == 1 ? 512 : 256; }
+constexpr int geo_block_threads(int) { return kBlockThreads; }
 constexpr size_t geo_stack_bytes(int geo) { return (size_t)(RTOW_STACK_CAPACITY + kCandCapacity) * (size_t)geo_block_threads(geo) * ((geo & kGeoWide) ? 4u : 2u); }
 
 template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
@@ -2232,8 +2228,6 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_
 // diagnostics record, the texture-driven noise sources and the per-sample policy beyond depth 8 (the counters cost ~2 % there; the record
 // format is chosen at run time from diagnosticsStride).  Scenes that need the exact-tie resolver (kExactTiesBit) are rare: depth <= 16 shares
 // the 8-word variant.  On top of these 144 (tests/test_gpu_variants.py runs every variant on every build):
-//   * slice geometries (args.blockThreads 512 / 256, chosen per launch by the host side): the two sphere kinds, reference stream, short records,
-//     depth <= 8 and <= 16 - the launches of a tile split; everything else runs 1024 lanes per workgroup;
 //   * wide codes (args.wideCodes, scenes beyond 65 535 entities / nodes; the tree is read from HBM, so ALL_LDS = false only): every scene kind
 //     (a host that ingests triangle meshes produces spheres, general entities, triangles, textured ones - and a volume scene as soon as one fog
 //     volume stands among the meshes), each with and without the exact-tie resolver where the kind has one - as the specialised
@@ -2241,7 +2235,7 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_
 // the exact-tie kinds get the 4-word history variant (depth <= 8) too (round 2 let them share the 8-word one up to depth 16; on the kinds whose
 // kernels spill - general, textured, triangles - the four registers are worth 3-4 %)
 template <int KIND>
-constexpr bool kTiesWithShortHistory = RTOW_TIES_SHORT_HISTORY != 0;
+constexpr bool kTiesWithShortHistory = true;
 
 template <bool ALL_LDS, int KIND, int GEO>
 hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
@@ -2267,9 +2261,6 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
     }
 }
 
-// does a slice geometry (512 / 256 lanes per workgroup) exist for this batch?  (rtow_api.hip asks before it sizes the grid)
-template <int KIND>
-constexpr bool kind_has_slice_geometry() { return KIND == SCENE_KIND_SPHERES || KIND == SCENE_KIND_SPHERES_MOTION; }
 template <int KIND>
 constexpr bool kind_has_wide_codes() { return true; }   // every scene kind (volume kinds since round 3: a triangle-mesh scene with one fog volume is a volume scene)
 
@@ -2280,14 +2271,7 @@ hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, hipStream_t
         if (args.wideCodes) return launchByDiagGeo<false, KIND, kGeoWide>(args, numBlocks, stream);
     }
     if (args.wideCodes) return hipErrorInvalidValue;                                    // refused at upload (rtow_api.hip): never reached
-    if constexpr (kind_has_slice_geometry<KIND>()) {
-        const bool sliceable = args.noiseColor == RTOW_NOISE_WHITE && !args.unitRecords && !(args.diagnostics && args.diagnosticsStride >= 16) && args.traceDepth <= 16;
-        if (sliceable && args.blockThreads == 512) return args.traceDepth <= 8 ? launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, 1>(args, numBlocks, stream)
-                                                                                : launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, 1>(args, numBlocks, stream);
-        if (sliceable && args.blockThreads == 256) return args.traceDepth <= 8 ? launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, 2>(args, numBlocks, stream)
-                                                                                : launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, 2>(args, numBlocks, stream);
-    }
-    if (args.blockThreads != kBlockThreads) return hipErrorInvalidValue;                // the host side only asks for a geometry that exists (sliceGeometryAvailable)
+    if (args.blockThreads != kBlockThreads) return hipErrorInvalidValue;
     return launchByDiagGeo<ALL_LDS, KIND, 0>(args, numBlocks, stream);
 }
 

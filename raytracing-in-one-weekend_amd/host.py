@@ -76,7 +76,7 @@ class Context:
             for i, v in enumerate(scheduler_tune):
                 opts.schedulerTune[i] = int(v)
         opts.hitListCapacity = int(hit_list_capacity)
-        opts.sliceBlockThreads = int(slice_block_threads)      # development: 0 = per launch; 256 / 512 / 1024 forces the sample kernel's lanes per workgroup
+        opts.sliceBlockThreads = int(slice_block_threads)      # reserved: 0 (or 1024); the 512- / 256-lane workgroups of round 3 were removed
         self.handle = C.c_void_p()
         check(load().rtowCreateContext(C.byref(opts), C.byref(self.handle)), "rtowCreateContext")
         self._scene_keepalive = None

@@ -47,8 +47,6 @@ def main():
         ("mixed wide codes", S.mixed_scene, 1280, 720, 8, 8, {"_context": dict(flags=abi.CONTEXT_FORCE_WIDE_CODES)}),
         ("moving wide codes", S.moving_scene, 1280, 720, 8, 8, {"_context": dict(flags=abi.CONTEXT_FORCE_WIDE_CODES)}),
         ("mesh grid 250k", S.mesh_grid_scene, 1280, 720, 3, 8, {"_focus_from_meta": True}),
-        ("cover 512 lanes", S.cover_scene, 1920, 1080, 12, 8, {"_context": dict(slice_block_threads=512)}),
-        ("moving 256 lanes", S.moving_scene, 1280, 720, 8, 8, {"_context": dict(slice_block_threads=256)}),
     ]
     main_ctx = rt.Context(0)
     main_ctx.upload_blue_noise(noise.blue_desc())

@@ -96,7 +96,7 @@ def _random_scene(rt, seed, only_triangles=False):
 def geometry_contexts(rt):
     """Contexts that force the kernels a small scene would not pick by itself: 32-bit candidate codes (what scenes beyond 65 535 entities use) and
     the 512- / 256-lane launch geometries (what a tile-split launch may pick)."""
-    ctxs = {"wide": rt.Context(0, flags=rt.abi.CONTEXT_FORCE_WIDE_CODES), "lanes512": rt.Context(0, slice_block_threads=512), "lanes256": rt.Context(0, slice_block_threads=256)}
+    ctxs = {"wide": rt.Context(0, flags=rt.abi.CONTEXT_FORCE_WIDE_CODES)}
     yield ctxs
     for c in ctxs.values():
         c.close()
@@ -110,7 +110,7 @@ def test_random_scene(rt, oracle, gpu_context, geometry_contexts, seed):
     only_triangles = bool(extra.random() < 0.12)
     scene, rng = _random_scene(rt, 1000 + seed, only_triangles)
     desc = scene.desc(max_bvh_depth=int(rng.choice([32, 32, 3])))
-    which = str(extra.choice(["default", "default", "default", "wide", "lanes512", "lanes256"]))
+    which = str(extra.choice(["default", "default", "default", "wide"]))
     chain = bool(extra.random() < 0.25)
     ctx = gpu_context if which == "default" else geometry_contexts[which]
     ctx.upload_scene(desc)

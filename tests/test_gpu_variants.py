@@ -131,28 +131,11 @@ def _compare_modes(rt, oracle, ctx, scene, desc, modes, where):
         osc.close()
 
 
-@pytest.mark.parametrize("in_lds", [True, False], ids=["lds", "hbm"])
-@pytest.mark.parametrize("block_threads", [512, 256])
-@pytest.mark.parametrize("kind", ["spheres", "spheres_motion"])
-def test_slice_geometry_variants(rt, oracle, kind, block_threads, in_lds):
-    """The 16 kernels with 512 / 256 lanes per workgroup (RtowContextOptions.sliceBlockThreads forces the geometry a tile-split launch picks by
-    itself): sphere kinds, reference stream, short records, history width 4 and 8.  Same image, bit for bit."""
-    abi = rt.abi
-    scene = _scene(rt, kind)
-    desc = scene.desc()
-    with rt.Context(0, lds_scene_budget=0 if in_lds else 1024, slice_block_threads=block_threads) as ctx:
-        ctx.upload_scene(desc)
-        assert bool(ctx.scene_info().sceneInLds) == in_lds
-        _compare_modes(rt, oracle, ctx, scene, desc, [(5, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4), (12, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4),
-                                                      (20, abi.NOISE_WHITE, abi.RNG_REFERENCE, 4), (5, abi.NOISE_WHITE, abi.RNG_REFERENCE, 16)],      # the last two: no such geometry - 1024 lanes, same image
-                       (kind, block_threads, in_lds))
-
-
 @pytest.mark.parametrize("kind", KINDS)
 def test_wide_code_variants(rt, oracle, kind):
     """The kernels with 32-bit candidate / stack codes and 4 x 32-bit camera-ray lists (scenes beyond 65 535 entities or tree nodes), forced onto
-    small scenes with RTOW_CONTEXT_FORCE_WIDE_CODES: five per scene kind (the volume kinds included) - the specialised reference-stream variant and
-    the generic one per noise source / RNG policy."""
+    small scenes with RTOW_CONTEXT_FORCE_WIDE_CODES: per scene kind (the volume kinds included) the reference-stream variants of every history width and
+    record format, and the generic one per noise source / RNG policy."""
     abi = rt.abi
     scene = _scene(rt, kind)
     desc = scene.desc()

@@ -6,7 +6,7 @@ that moves the allocation, can silently undo either - and the next GPU run would
 kernel under a chain.  So every CPU-suite run recompiles the two sphere translation units (~20 s each, in parallel) and asserts:
 
   * resource usage (-Rpass-analysis=kernel-resource-usage) of the reference-stream variants at trace depth <= 8 / <= 16, tree in LDS and in
-    HBM, all three launch geometries: no VGPR spill, at most 128 VGPRs at four waves per SIMD, no scratch at all for the static-sphere kernels
+    HBM: no VGPR spill, at most 128 VGPRs at four waves per SIMD, no scratch at all for the static-sphere kernels
     with the scene in LDS (the headline), at most the known 36 / 68 bytes elsewhere;
   * ISA (-save-temps): inside those kernels no scratch_ instruction at all; in EVERY kernel of the unit no write-through (`sc1`) store is left -
     round 2's chained path stored its accumulators with inline-asm `global_store_dwordx3/x4 ... sc1`, each needing an `s_nop 1` behind it (a VMEM
@@ -95,10 +95,10 @@ def test_hot_variants_stay_spill_free(compiled, unit, kind):
             continue
         all_lds, k, hw, full_diag, noise, per_sample, geo = _variant(name)
         assert k == kind
-        waves = {0: 4, 1: 2, 2: 1}[geo & 3]                                                 # waves per SIMD of one workgroup per CU: 1024 / 512 / 256 lanes
-        assert u["vgprs"] <= 512 // waves and u["agprs"] == 0 and u["occupancy"] >= waves, (name, u)      # the workgroup must fit the CU in EVERY variant (128 VGPRs at 1024 lanes)
+        assert (geo & 3) == 0, name                                                         # one launch geometry since round 4: 1024 lanes per workgroup
+        assert u["vgprs"] <= 128 and u["agprs"] == 0 and u["occupancy"] >= 4, (name, u)     # the workgroup must fit the CU in EVERY variant (128 VGPRs at four waves per SIMD)
         if hw in (4, 8) and not full_diag and noise == 0 and not per_sample and not (geo & 4):
-            # the reference stream at depth <= 8 / <= 16: the benchmark's kernels and their slice geometries
+            # the reference stream at depth <= 8 / <= 16: the benchmark's kernels
             hot += 1
             assert u["vgpr_spill"] == 0 and u["sgpr_spill"] <= 32, (name, u)      # SGPRs spill into VGPR lanes (22 - 28 since the per-XCD chain hand-out, 30 in the moving kind's 512-lane tree-in-HBM variant since the walk's hand-over count; same speed)
             if all_lds and kind == 0:
@@ -110,7 +110,7 @@ def test_hot_variants_stay_spill_free(compiled, unit, kind):
                 # moving spheres (36 B since round 2: SGPRs saved to memory around the motion record's loads) and trees in HBM (the node fetch's
                 # 64-bit pointers): a known, bounded amount - growth means the allocator went over the edge
                 assert u["scratch"] <= (36 if all_lds else 68), (name, u)
-    assert hot == 12, hot                                    # 2 history widths x (LDS | HBM) x 3 geometries
+    assert hot == 4, hot                                     # 2 history widths x (LDS | HBM)
     headline = [u for n, u in usage.items() if "sample_batch_kernel" in n and _variant(n) == (1, kind, 4, 0, 0, 0, 0)]
     assert len(headline) == 1 and headline[0]["vgprs"] <= 126, headline
 
@@ -129,4 +129,4 @@ def test_coherent_accesses_of_the_chained_path(compiled, unit):
                 loads += 1
                 assert re.match(r"s_waitcnt vmcnt\(0\)", lines[i + 1]), (name, line, lines[i + 1])
     # every reference-stream variant has the chained path: three wide loads per pixel (colour x4, normal and albedo x3), no write-through store
-    assert stores == 0 and loads >= 3 * 12, (stores, loads)
+    assert stores == 0 and loads >= 3 * 4, (stores, loads)
