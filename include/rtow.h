@@ -389,6 +389,20 @@ RTOW_API int rtowSampleBatchChainDevice(RtowContext context, int32_t count, cons
                                         const RtowAccumBuffers* in, const RtowAccumBuffers* out,
                                         void* const* diagnostics /* [count] or NULL */, void* stream, const volatile uint8_t* cancel);
 
+/* `count` INDEPENDENT batches of one frame, enqueued together: exactly what
+ *     rtowSampleBatchDevice(params[k], in, &outs[k], diagnostics[k])   for k = 0 .. count-1
+ * computes, bit for bit - every batch reads the same `in` and stores to its own outs[k] (count > 1: no output may share a buffer with another output
+ * or with `in`).  When the batches differ in nothing but `seed` they run as ONE launch whose work queue holds (pixel chunk, batch) pairs, so the launch
+ * ends when its slowest PIXEL-BATCH does, not `count` of them one after the other: under the reference's random stream a pixel's samples are one
+ * sequential unit of work, and a chain (above) adds the pixel's successive batches to that sequence - at the reference host's own default
+ * traceDepth 32 the cover scene's slowest pixel (6 429 path segments per 256 samples, ~13 us each) holds a batch for 87 ms where the machine's
+ * throughput needs 57 (profiles/r04g_ray_count_stats.txt).  What this is for: the sub-batches of a tiles x batches partition (below; a rank renders the
+ * sub-batches of several steps, each from zeroed inputs, in one launch), and hosts that accept the reference's accumulation up to the association of
+ * its float sums (render B batches from zero, fold them in order with rtowAddAccumDevice).  Up to 16 batches per launch. */
+RTOW_API int rtowSampleBatchGroupDevice(RtowContext context, int32_t count, const RtowSampleParams* params /* [count] */,
+                                        const RtowAccumBuffers* in, const RtowAccumBuffers* outs /* [count] */,
+                                        void* const* diagnostics /* [count] or NULL */, void* stream, const volatile uint8_t* cancel);
+
 /* The same chain with HOST buffers, blocking like rtowSampleBatch: the inputs travel once, the batches accumulate in place on the device, the
  * final accumulators (rows this slice owns) and each batch's diagnostics travel back.  All batches share size, slice and diagnosticsStride.
  * For hosts that keep their accumulators in NativeArrays and have more than one batch queued. */

@@ -12,7 +12,7 @@ The directory name contains '-' so it is loaded with importlib (see tests/confte
 """
 from . import abi, host, lib, scenes  # noqa: F401
 from .host import (CombineJob, Context, DeviceBuffer, FinalizeTexturesJob, ReduceMetricsJob, SampleBatchJob,  # noqa: F401
-                   sample_batch_chain_device, sample_batch_chain_host, sample_batch_host)
+                   sample_batch_chain_device, sample_batch_chain_host, sample_batch_group_device, sample_batch_host)
 
 __all__ = ["abi", "host", "lib", "scenes", "Context", "DeviceBuffer", "SampleBatchJob", "CombineJob", "FinalizeTexturesJob",
-           "ReduceMetricsJob", "sample_batch_host", "sample_batch_chain_device", "sample_batch_chain_host"]
+           "ReduceMetricsJob", "sample_batch_host", "sample_batch_chain_device", "sample_batch_chain_host", "sample_batch_group_device"]

@@ -171,5 +171,5 @@ EXPORTED_SYMBOLS = [
     "rtowReduceMetricsDevice", "rtowCombineDevice", "rtowFinalizeDevice", "rtowAddAccumDevice", "rtowDeviceAlloc", "rtowDeviceFree",
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize", "rtowGetBatchStatus", "rtowRegisterHostBuffer", "rtowUnregisterHostBuffer",
     "rtowSampleBatchChainDevice", "rtowSampleBatchChain", "rtowCommSetLibraryPath", "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
-    "rtowHybridPlan", "rtowExchangeAccumDevice",
+    "rtowHybridPlan", "rtowExchangeAccumDevice", "rtowSampleBatchGroupDevice",
 ]

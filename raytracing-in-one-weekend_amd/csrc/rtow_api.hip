@@ -197,7 +197,8 @@ int ownedRows(const RtowSampleParams* p)
 
 // chain (optional): {count, seeds[count], diagnostics[count]} - `count` successive batches of the frame in this one launch (seeds[0] / diags[0] are
 // batch 0's; p->seed and diag are ignored then)
-struct ChainSpec { int count; const uint32_t* seeds; void* const* diags; };
+// outs (optional): a batch group - batch b stores to outs[b] and every batch reads `in` (rtowSampleBatchGroupDevice); null: a chain, batch b reads what b - 1 stored to `out`
+struct ChainSpec { int count; const uint32_t* seeds; void* const* diags; const RtowAccumBuffers* outs; };
 
 int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuffers* in, const RtowAccumBuffers* out, void* diag,
                  hipStream_t stream, bool useCancelFlag, const ChainSpec* chain = nullptr)
@@ -226,6 +227,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.sliceOffset = p->sliceOffset; a.sliceDivider = p->sliceDivider;
     a.seed = chain ? chain->seeds[0] : p->seed;
     a.chainCount = chain ? (uint32_t)chain->count : 1u;
+    a.chainIndependent = (chain && chain->outs) ? 1 : 0;
     if (chain) {
         if (diag == nullptr && chain->diags) diag = chain->diags[0];
         a.diagnostics = (uint8_t*)diag;
@@ -454,7 +456,18 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         }
     }
 
-    if (a.chainCount > 1u) {
+    if (a.chainCount > 1u && a.chainIndependent) {
+        // a batch group: nothing is handed over between its batches; only the per-batch table (seed, diagnostics, outputs)
+        if (!ctx->dChainBatches) HIP_TRY(ctx, hipMalloc(&ctx->dChainBatches, sizeof(ChainBatch) * kMaxChain), RTOW_ERROR_MEMORY_ALLOCATION);
+        ChainBatch table[kMaxChain] = {};
+        for (int b = 0; b < chain->count; b++) {
+            table[b].seed = chain->seeds[b];
+            table[b].diagnostics = chain->diags ? (uint8_t*)chain->diags[b] : nullptr;
+            table[b].outColor = chain->outs[b].color; table[b].outNormal = chain->outs[b].normal; table[b].outAlbedo = chain->outs[b].albedo; table[b].outScw = chain->outs[b].sampleCountWeight;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dChainBatches, table, sizeof(ChainBatch) * (size_t)chain->count, hipMemcpyHostToDevice, stream), RTOW_ERROR_LAUNCH_FAILURE);
+        a.chainBatches = ctx->dChainBatches;
+    } else if (a.chainCount > 1u) {
         // per-chunk hand-off counters of the chain: pixels stored so far (all batches); batch b of a chunk waits for b x its pixels
         if (a.chunkCount > ctx->chunkDoneCapacity) {
             if (ctx->dChunkDone) (void)hipFree(ctx->dChunkDone);
@@ -709,7 +722,7 @@ int enqueueChain(RtowContext ctx, int count, const RtowSampleParams* params, con
         } else {
             uint32_t seeds[kMaxChain];
             for (int b = 0; b < n; b++) seeds[b] = params[first + b].seed;
-            const ChainSpec chain{n, seeds, diagnostics ? diagnostics + first : nullptr};
+            const ChainSpec chain{n, seeds, diagnostics ? diagnostics + first : nullptr, nullptr};
             rc = launchSample(ctx, &params[first], src, out, nullptr, s, cancel != nullptr, &chain);
         }
         if (rc == RTOW_SUCCESS && cancel) rc = waitWithCancel(ctx, cancel);
@@ -1075,6 +1088,55 @@ RTOW_API int rtowSampleBatchChainDevice(RtowContext ctx, int32_t count, const Rt
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     *ctx->hCancel = 0u;
     return enqueueChain(ctx, count, params, in, out, diagnostics, s, cancel);
+}
+
+RTOW_API int rtowSampleBatchGroupDevice(RtowContext ctx, int32_t count, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* outs,
+                                        void* const* diagnostics, void* stream, const volatile uint8_t* cancel)
+{
+    if (!ctx || !in || !outs || !params || count < 1) return RTOW_ERROR_INVALID_VALUE;
+    for (int b = 0; b < count; b++) {
+        const int v = validateParams(&params[b]);
+        if (v != RTOW_SUCCESS) return v;
+        if (!outs[b].color || !outs[b].normal || !outs[b].albedo || !outs[b].sampleCountWeight) return RTOW_ERROR_INVALID_VALUE;
+        for (int c = 0; c < b; c++)                                                 // every batch its own outputs (a batch may store over the shared inputs only if it is alone)
+            if (outs[b].color == outs[c].color || outs[b].normal == outs[c].normal || outs[b].albedo == outs[c].albedo || outs[b].sampleCountWeight == outs[c].sampleCountWeight) return RTOW_ERROR_INVALID_VALUE;
+        if (count > 1 && (outs[b].color == in->color || outs[b].normal == in->normal || outs[b].albedo == in->albedo || outs[b].sampleCountWeight == in->sampleCountWeight)) return RTOW_ERROR_INVALID_VALUE;
+    }
+    if (!in->color || !in->normal || !in->albedo || !in->sampleCountWeight) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    *ctx->hCancel = 0u;
+    // one launch needs batches that differ in nothing but Seed, the reference RNG policy, fewer than 2^27 padded pixels, and diagnostics for all batches or for none
+    bool fusable = params[0].rngPolicy == RTOW_RNG_REFERENCE;
+    for (int b = 1; b < count && fusable; b++) {
+        RtowSampleParams q = params[b];
+        q.seed = params[0].seed;
+        fusable = memcmp(&q, &params[0], sizeof(q)) == 0;
+    }
+    const uint64_t paddedPixels = ((uint64_t)ownedRows(&params[0]) * (uint64_t)(int)params[0].size.x + 63u) & ~63ull;
+    if (paddedPixels >= (1ull << 27)) fusable = false;
+    if (diagnostics) {
+        int withDiag = 0;
+        for (int b = 0; b < count; b++) withDiag += diagnostics[b] != nullptr ? 1 : 0;
+        if (withDiag != 0 && withDiag != count) fusable = false;
+    }
+    int rc = RTOW_SUCCESS;
+    for (int first = 0; first < count && rc == RTOW_SUCCESS;) {
+        const int n = fusable ? std::min(count - first, (int)kMaxChain) : 1;
+        if (n == 1) {
+            rc = launchSample(ctx, &params[first], in, &outs[first], diagnostics ? diagnostics[first] : nullptr, s, cancel != nullptr);
+        } else {
+            uint32_t seeds[kMaxChain];
+            for (int b = 0; b < n; b++) seeds[b] = params[first + b].seed;
+            const ChainSpec group{n, seeds, diagnostics ? diagnostics + first : nullptr, outs + first};
+            rc = launchSample(ctx, &params[first], in, &outs[first], nullptr, s, cancel != nullptr, &group);
+        }
+        if (rc == RTOW_SUCCESS && cancel) rc = waitWithCancel(ctx, cancel);
+        first += n;
+    }
+    return rc;
 }
 
 RTOW_API int rtowSampleBatchChain(RtowContext ctx, int32_t count, const RtowSampleParams* params, const RtowAccumBuffers* in, const RtowAccumBuffers* out,

@@ -45,6 +45,7 @@ struct ChainBatch {
     uint8_t* diagnostics;   // of this batch, may be null
     uint32_t seed;          // Seed (JOBS/SampleBatchJob.cs:28,91)
     uint32_t pad;
+    float *outColor, *outNormal, *outAlbedo, *outScw;   // batch groups (rtowSampleBatchGroupDevice): this batch's own outputs; unused in a chain
 };
 
 // Everything the sample kernel needs, passed by value (kernarg segment).
@@ -162,6 +163,8 @@ struct SampleKernelArgs {
     // chained batches (rtowSampleBatchChainDevice): this launch runs chainCount successive batches of the same frame; batch b of a
     // 64-pixel chunk starts as soon as batch b - 1 of that chunk is stored (chunkDone), whichever CU traced it
     uint32_t chainCount;                  // >= 1; 1 = a plain batch
+    int32_t chainIndependent;             // batch group (rtowSampleBatchGroupDevice): the chainCount batches all read the launch's inputs and store to their own outputs
+                                          // (ChainBatch.out*): no hand-off between them, tickets are (chunk, batch) pairs from the one queue
     const ChainBatch* chainBatches;       // [chainCount] what differs between the batches of the chain (device memory: indexed per lane)
     unsigned int* chunkDone;              // [chunkCount] pixels stored so far, all batches of this launch; zeroed before the launch
     XcdState* xcdState;                   // chunk ownership per XCD + the lists behind it (chained launches only)

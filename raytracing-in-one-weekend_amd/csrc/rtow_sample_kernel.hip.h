@@ -1091,6 +1091,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     const int traceDepth = A.traceDepth;
     const bool refDiag = FULL_DIAG && A.refTree != nullptr;   // BoundsHitCount / CandidateCount count the reference's tree (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS)
     const bool chained = A.chainCount > 1u;      // several successive batches in this launch (wave-uniform): coherent accumulator accesses, per-chunk hand-off
+    const bool grouped = chained && A.chainIndependent != 0;   // ... or several INDEPENDENT batches (a batch group): same inputs, own outputs, nothing handed over
     // a one-entity scene has a root whose second child is a placeholder; its (inverted) box cannot be told from a real one by the
     // symmetric slab test, so it is masked explicitly (wave-uniform, costs one scalar AND per node visit)
     const bool twoChildren = L.sphereCount > 1u;
@@ -1182,8 +1183,11 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         } else if (smp == 0 && !A.probeOnly) {
             // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
             // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
-            A.outNormal[3 * (size_t)pix + 0] = sampleNormal.x; A.outNormal[3 * (size_t)pix + 1] = sampleNormal.y; A.outNormal[3 * (size_t)pix + 2] = sampleNormal.z;
-            A.outAlbedo[3 * (size_t)pix + 0] = sampleAlbedo.x; A.outAlbedo[3 * (size_t)pix + 1] = sampleAlbedo.y; A.outAlbedo[3 * (size_t)pix + 2] = sampleAlbedo.z;
+            float* fbN = A.outNormal;
+            float* fbA = A.outAlbedo;
+            if (grouped) { fbN = A.chainBatches[tick >> kChainShift].outNormal; fbA = A.chainBatches[tick >> kChainShift].outAlbedo; }      // a batch group: this batch's own buffers
+            fbN[3 * (size_t)pix + 0] = sampleNormal.x; fbN[3 * (size_t)pix + 1] = sampleNormal.y; fbN[3 * (size_t)pix + 2] = sampleNormal.z;
+            fbA[3 * (size_t)pix + 0] = sampleAlbedo.x; fbA[3 * (size_t)pix + 1] = sampleAlbedo.y; fbA[3 * (size_t)pix + 2] = sampleAlbedo.z;
         }
         smp++;
         st = ST_REGEN;
@@ -1280,13 +1284,15 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     }
                     if (pix >= 0 && chained) {
                         // ---- pixel done, chained batches: the same stores (:159-163), then publish the pixel ----
-                        reinterpret_cast<float4*>(C.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
+                        float *oc = C.outColor, *on = C.outNormal, *oa = C.outAlbedo, *os = C.outScw;
+                        if (grouped) { const ChainBatch cb = C.chainBatches[batch]; oc = cb.outColor; on = cb.outNormal; oa = cb.outAlbedo; os = cb.outScw; }   // a batch group: this batch's own outputs
+                        reinterpret_cast<float4*>(oc)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
                         if (sampleCount != 0 || nsamp == 0) {
                             const V3 nrm = sampleCount != 0 ? normalAcc : v3(0, 0, 0), alb = sampleCount != 0 ? albedoAcc : v3(0, 0, 0);
-                            C.outNormal[3 * (size_t)pix + 0] = nrm.x; C.outNormal[3 * (size_t)pix + 1] = nrm.y; C.outNormal[3 * (size_t)pix + 2] = nrm.z;
-                            C.outAlbedo[3 * (size_t)pix + 0] = alb.x; C.outAlbedo[3 * (size_t)pix + 1] = alb.y; C.outAlbedo[3 * (size_t)pix + 2] = alb.z;
+                            on[3 * (size_t)pix + 0] = nrm.x; on[3 * (size_t)pix + 1] = nrm.y; on[3 * (size_t)pix + 2] = nrm.z;
+                            oa[3 * (size_t)pix + 0] = alb.x; oa[3 * (size_t)pix + 1] = alb.y; oa[3 * (size_t)pix + 2] = alb.z;
                         }
-                        C.outScw[pix] = scwAcc;
+                        os[pix] = scwAcc;
                         uint8_t* dg = C.chainBatches[batch].diagnostics;
                         if (dg) {
                             if (FULL_DIAG && C.diagnosticsStride >= 16)
@@ -1296,9 +1302,12 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         }
                         // every store above has reached this XCD's L2 (s_waitcnt vmcnt(0); the workgroup-scope release keeps the compiler from reordering)
                         // before the chunk's counter moves; the chunk's next batch runs on this XCD too and reads through that L2
-                        coherent_flush();
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __hip_atomic_fetch_add(C.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (a batch group hands nothing over: its stores are a plain batch's)
+                        if (!grouped) {
+                            coherent_flush();
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __hip_atomic_fetch_add(C.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         pix = -1;
                     }
                     if (pix >= 0) {
@@ -1350,8 +1359,14 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                 unsigned slot = cancelled ? 0xffffffffu : atomicAdd(C.workCounter, 1u);
                                 unsigned b = 0u, chunk = 0u;
                                 bool exhausted = slot >= C.chunkCount, notReady = false;
+                                if (grouped) {
+                                    // a batch group: the queue holds (chunk, batch) pairs, every batch of the most expensive chunk first - no batch waits for another
+                                    exhausted = cancelled || slot >= C.chunkCount * C.chainCount;
+                                    b = slot % C.chainCount;
+                                    slot = slot / C.chainCount;
+                                }
                                 if (!exhausted) chunk = C.chunkOrder ? C.chunkOrder[slot] : slot;
-                                if (chained && !cancelled) {
+                                if (chained && !grouped && !cancelled) {
                                     // Batch 0 of every chunk comes from the one device-wide queue above; the XCD whose wave takes it owns the chunk for
                                     // the rest of the chain (its accumulator lines then live in that XCD's L2: see the note on chained batches).
                                     // Batches 1 .. chainCount - 1 are handed out per XCD, batch after batch over the XCD's own list in the order it
@@ -1381,7 +1396,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                 else {
                                     const unsigned base = chunk * 64u;
                                     const unsigned last = (C.totalWork - base < 64u) ? C.totalWork : base + 64u;
-                                    waveQueue[2] = b * (last - base);                // pixels of this chunk that must be stored before batch b may read them
+                                    waveQueue[2] = grouped ? 0u : b * (last - base); // pixels of this chunk that must be stored before batch b may read them (a group's batches read the inputs)
                                     waveQueue[3] = chunk;
                                     waveQueue[0] = base | (b << kChainShift);
                                     waveQueue[1] = last | (b << kChainShift);
@@ -1426,7 +1441,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         // a unit only needs what decides the pixel's sample count (:118-126); the fold kernel reads the accumulators
                         last.w = C.inColor[4 * (size_t)pix + 3];
                         scwAcc = C.inScw[pix];
-                    } else if (chained) {
+                    } else if (chained && !grouped) {
                         // batch 0 reads the launch's inputs, every later batch what the batch before it stored for this pixel (device-coherent loads)
                         const float* ic = (newBatch == 0u ? C.inColor : C.outColor) + 4 * (size_t)pix;
                         const float* in_ = (newBatch == 0u ? C.inNormal : C.outNormal) + 3 * (size_t)pix;

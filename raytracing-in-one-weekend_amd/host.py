@@ -279,6 +279,19 @@ def sample_batch_chain_device(context, params_list, ins, outs, diags=None, strea
     return load().rtowSampleBatchChainDevice(context.handle, count, arr, C.byref(bi), C.byref(bo), dptr, stream, cancel)
 
 
+def sample_batch_group_device(context, params_list, ins, outs_list, diags=None, stream=None, cancel=None):
+    """rtowSampleBatchGroupDevice: `len(params_list)` INDEPENDENT batches of one frame in one launch; every batch reads `ins` (four DeviceBuffers) and stores
+    to its own four DeviceBuffers outs_list[k]; diags: one DeviceBuffer (or None) per batch."""
+    count = len(params_list)
+    arr = (abi.SampleParams * count)(*params_list)
+    bi = _buffers(*[b.ptr for b in ins])
+    bo = (abi.AccumBuffers * count)(*[_buffers(*[b.ptr for b in o]) for o in outs_list])
+    dptr = None
+    if diags is not None:
+        dptr = (C.c_void_p * count)(*[d.ptr if d is not None else None for d in diags])
+    return load().rtowSampleBatchGroupDevice(context.handle, count, arr, C.byref(bi), bo, dptr, stream, cancel)
+
+
 def sample_batch_chain_host(context, params_list, inputs=None, want_diag=True):
     """rtowSampleBatchChain: `len(params_list)` successive batches on HOST buffers in one blocking call; returns the final accumulators like
     sample_batch_host, with out["diag"] = one record array per batch."""

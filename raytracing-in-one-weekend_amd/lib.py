@@ -54,6 +54,7 @@ def load():
     lib.rtowSampleBatch.argtypes = [vp, C.POINTER(abi.SampleParams), AB, AB, vp, vp]
     lib.rtowSampleBatchDevice.argtypes = [vp, C.POINTER(abi.SampleParams), AB, AB, vp, vp, vp]
     lib.rtowSampleBatchChainDevice.argtypes = [vp, C.c_int32, C.POINTER(abi.SampleParams), AB, AB, C.POINTER(vp), vp, vp]
+    lib.rtowSampleBatchGroupDevice.argtypes = [vp, C.c_int32, C.POINTER(abi.SampleParams), AB, AB, C.POINTER(vp), vp, vp]
     lib.rtowSampleBatchChain.argtypes = [vp, C.c_int32, C.POINTER(abi.SampleParams), AB, AB, C.POINTER(vp), vp]
     lib.rtowGetLastSampleKernelMs.argtypes = [vp, C.POINTER(C.c_float)]
     lib.rtowReduceMetricsDevice.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, vp, C.POINTER(abi.Metrics)]
