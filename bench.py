@@ -242,6 +242,7 @@ def main():
     ap.add_argument("--post-only", default=None, metavar="WxH", help="profiling aid: run only the post-pass measurement at this frame size and print its block (profiles/collect.sh)")
     ap.add_argument("--partition", choices=("hybrid", "tiles", "batches"), default="hybrid", help="which N > 1 partition `value` reports (the other is reported beside it): hybrid = tiles x batches "
                     "behind the C ABI (the reference stream's scalable split), tiles = rows only (north_star's), batches = hybrid with one tile")
+    ap.add_argument("--group", type=int, default=None, help="N > 1, hybrid partition: sub-batches (steps) a rank renders per launch (rtowSampleBatchGroupDevice; 1 .. 16); default min(8, steps)")
     ap.add_argument("--tiles", type=int, default=None, help="T of the hybrid partition (must divide the number of GPUs); default: 1 unless spp < GPUs")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -361,7 +362,9 @@ def main():
         state = {"ping_flat": flat(), "pong_flat": flat()}
         state["ping"], state["pong"] = mg.accum_views(state["ping_flat"], n), mg.accum_views(state["pong_flat"], n)
         zero_flat = flat() if hybrid else None            # never written: the input of every rank's sub-batch
-        diags = [torch.zeros(n, device=dev) for _ in range(max(1, chain))]
+        group = max(1, min(16, args.group if args.group else min(8, steps))) if hybrid else 1
+        partial_views = [mg.accum_views(flat(), n) for _ in range(group)] if hybrid else None     # one set of partial-sum buffers per sub-batch of a launch
+        diags = [torch.zeros(n, device=dev) for _ in range(max(1, chain, group))]
         plan0 = rt.Context.hybrid_plan(world, rank, tiles_t, spp, 1) if hybrid else None
         if hybrid:
             base = rt.scenes.make_params(scene, W, H, spp=int(plan0.samples), trace_depth=depth, slice_offset=int(plan0.sliceOffset), slice_divider=int(plan0.sliceDivider), focus=focus)
@@ -392,28 +395,36 @@ def main():
             while i < first + count:
                 c = min(chain, first + count - i)
                 if hybrid:
-                    # this rank's sub-batch of step i + 1 from zeroed inputs (pong = the partial sums), the exchange + ordered fold into the running
-                    # accumulation (ping: this rank's rows, row % world == rank), the gather of the colour rows on rank 0 (in place: ping is the frame there)
-                    c = 1
-                    plan = rt.Context.hybrid_plan(world, rank, tiles_t, spp, i + 1)
-                    launch([params_for(int(plan.seed))], mg.accum_views(zero_flat, n), state["pong"])
-                    part, acc = abi.AccumBuffers(*[t.data_ptr() for t in state["pong"]]), abi.AccumBuffers(*[t.data_ptr() for t in state["ping"]])
-                    if have_comm:
-                        ctx.exchange_accum(W, H, tiles_t, part, acc, what=abi.GATHER_ALL, stream=stream.cuda_stream)
-                        ctx.gather_rows(W, H, world, acc, acc if rank == 0 else None, what=abi.GATHER_COLOR | abi.GATHER_NO_BATCH_WAIT, root=0, stream=stream.cuda_stream)
-                    else:
-                        shapes = (4, 3, 3, 1)
-                        src = [t.view(H, W, k) for t, k in zip(state["pong"], shapes)]
-                        dst = [t.view(H, W, k) for t, k in zip(state["ping"], shapes)]
-                        if shared_gpu:                        # gloo has no device point-to-point: host copies (development only)
-                            hs, hd = [t.cpu() for t in src], [t.cpu() for t in dst]
-                            mg.exchange_accum(hs, hd, H, rank, world, tiles_t)
-                            for t, hcopy in zip(dst, hd):
-                                t.copy_(hcopy)
-                            mg.gather_frame(mg.pack_owned(hd[0], rank, world), H, rank, world)
+                    # this rank's sub-batches of steps i + 1 .. i + c, each from zeroed inputs into its own partial-sum buffers, as ONE launch (a batch group: the
+                    # launch ends with its slowest pixel-batch, not c of them in a row); then per step the exchange + ordered fold into the running accumulation
+                    # (ping: this rank's rows, row % world == rank) and the gather of the colour rows on rank 0 (in place: ping is the frame there)
+                    c = min(group, first + count - i)
+                    plans = [rt.Context.hybrid_plan(world, rank, tiles_t, spp, i + 1 + k) for k in range(c)]
+                    plist = [params_for(int(pl.seed)) for pl in plans]
+                    bi = abi.AccumBuffers(*[t.data_ptr() for t in mg.accum_views(zero_flat, n)])
+                    bo = (abi.AccumBuffers * c)(*[abi.AccumBuffers(*[t.data_ptr() for t in partial_views[k]]) for k in range(c)])
+                    arr = (abi.SampleParams * c)(*plist)
+                    dptr = (C.c_void_p * c)(*[diags[k].data_ptr() for k in range(c)])
+                    rt.lib.check(lib.rtowSampleBatchGroupDevice(ctx.handle, c, arr, C.byref(bi), bo, dptr, stream.cuda_stream, None), "rtowSampleBatchGroupDevice")
+                    acc = abi.AccumBuffers(*[t.data_ptr() for t in state["ping"]])
+                    for k in range(c):
+                        part = bo[k]
+                        if have_comm:
+                            ctx.exchange_accum(W, H, tiles_t, part, acc, what=abi.GATHER_ALL, stream=stream.cuda_stream)
+                            ctx.gather_rows(W, H, world, acc, acc if rank == 0 else None, what=abi.GATHER_COLOR | abi.GATHER_NO_BATCH_WAIT, root=0, stream=stream.cuda_stream)
                         else:
-                            mg.exchange_accum(src, dst, H, rank, world, tiles_t)
-                            mg.gather_frame(mg.pack_owned(dst[0], rank, world), H, rank, world)
+                            shapes = (4, 3, 3, 1)
+                            src = [t.view(H, W, q) for t, q in zip(partial_views[k], shapes)]
+                            dst = [t.view(H, W, q) for t, q in zip(state["ping"], shapes)]
+                            if shared_gpu:                        # gloo has no device point-to-point: host copies (development only)
+                                hs, hd = [t.cpu() for t in src], [t.cpu() for t in dst]
+                                mg.exchange_accum(hs, hd, H, rank, world, tiles_t)
+                                for t, hcopy in zip(dst, hd):
+                                    t.copy_(hcopy)
+                                mg.gather_frame(mg.pack_owned(hd[0], rank, world), H, rank, world)
+                            else:
+                                mg.exchange_accum(src, dst, H, rank, world, tiles_t)
+                                mg.gather_frame(mg.pack_owned(dst[0], rank, world), H, rank, world)
                 else:
                     launch([params_for(i + 1 + k) for k in range(c)], state["ping"], state["pong"])
                     if world > 1:
@@ -438,7 +449,53 @@ def main():
         avg_kernel_ms = max_over_ranks(sum(kernel_ms) / max(steps, 1))
         launches = len(kernel_ms)
         return {"elapsed": elapsed, "kernel_ms_per_step": avg_kernel_ms, "launches": launches, "last": state["ping"], "diag": diags[0 if hybrid else ((steps % chain) or min(chain, steps)) - 1],
-                "hybrid": hybrid, "base": base, "tiles": tiles_t if hybrid else world, "groups": world // tiles_t if hybrid else 1, "rank_spp": int(plan0.samples) if hybrid else spp}
+                "hybrid": hybrid, "base": base, "tiles": tiles_t if hybrid else world, "groups": world // tiles_t if hybrid else 1, "rank_spp": int(plan0.samples) if hybrid else spp,
+                "steps_per_launch": group if hybrid else chain}
+
+    def timed_batches(mode, t_depth, t_spp, t_stride, steps, per_launch, warm_launches=1):
+        """`steps` batches of this frame at another (depth, spp, record size), `per_launch` per launch, one GPU: mode "chain" = rtowSampleBatchChainDevice accumulating
+        in place (bit-identical to the batches one after the other); mode "group_fold" = rtowSampleBatchGroupDevice from zeroed inputs into per-batch partial sums,
+        then the partial sums added to the accumulators in batch order (rtowAddAccumDevice): the same samples, another association of the float sums.
+        Wall time between synchronisations, after `warm_launches` untimed launches; returns a summary dict."""
+        acc = mg.accum_views(torch.zeros(mg.ACCUM_FLOATS * n, device=dev), n)
+        zero = mg.accum_views(torch.zeros(mg.ACCUM_FLOATS * n, device=dev), n)
+        parts = [mg.accum_views(torch.zeros(mg.ACCUM_FLOATS * n, device=dev), n) for _ in range(per_launch)] if mode == "group_fold" else None
+        dg = [torch.zeros(n * (t_stride // 4), device=dev) for _ in range(per_launch)]
+        basep = rt.scenes.make_params(scene, W, H, spp=t_spp, trace_depth=t_depth, diagnostics_stride=t_stride, focus=focus)
+        ba = abi.AccumBuffers(*[t.data_ptr() for t in acc])
+        bz = abi.AccumBuffers(*[t.data_ptr() for t in zero])
+        kms = []
+
+        def go(first, count):
+            i = first
+            while i < first + count:
+                c = min(per_launch, first + count - i)
+                arr = (abi.SampleParams * c)()
+                for k in range(c):
+                    arr[k] = abi.SampleParams.from_buffer_copy(basep)
+                    arr[k].seed = i + 1 + k
+                dptr = (C.c_void_p * c)(*[dg[k].data_ptr() for k in range(c)])
+                if mode == "chain":
+                    rt.lib.check(lib.rtowSampleBatchChainDevice(ctx.handle, c, arr, C.byref(ba), C.byref(ba), dptr, stream.cuda_stream, None), "rtowSampleBatchChainDevice")
+                else:
+                    bo = (abi.AccumBuffers * c)(*[abi.AccumBuffers(*[t.data_ptr() for t in parts[k]]) for k in range(c)])
+                    rt.lib.check(lib.rtowSampleBatchGroupDevice(ctx.handle, c, arr, C.byref(bz), bo, dptr, stream.cuda_stream, None), "rtowSampleBatchGroupDevice")
+                    for k in range(c):
+                        rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, n, C.byref(ba), C.byref(bo[k]), stream.cuda_stream), "rtowAddAccumDevice")
+                kms.append(ctx.last_sample_kernel_ms())
+                i += c
+
+        go(0, warm_launches * per_launch)
+        kms.clear()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        go(warm_launches * per_launch, steps)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ctx.batch_status()
+        rays_last = float(dg[0].view(n, t_stride // 4)[:, 0].sum().item())
+        return {"value": round(float(n) * t_spp * steps / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms_per_step": round(sum(kms) / steps, 3),
+                "mrays_per_s": round(rays_last * steps / dt / 1e6, 1), "steps": steps, "batches_per_launch": per_launch}
 
     main_partition = args.partition if world > 1 else "single"
     m = measure(args.partition, args.rng, args.chain, args.steps, args.warmup)
@@ -460,6 +517,20 @@ def main():
                 extras["chain2"] = {"value": round(float(n) * spp * steps2 / m2["elapsed"] / 1e6, 2), "ms_per_step": round(m2["elapsed"] / steps2 * 1e3, 3), "kernel_ms_per_step": round(m2["kernel_ms_per_step"], 3),
                                     "batches_per_launch": 2, "steps": steps2,
                                     "note": "two batches per launch (rtowSampleBatchChainDevice, count = 2): what a host with the reference's queue depth of two gets (UNITY/Raytracer.cs:586-593); INTEGRATION.md 3 shows the edit that queues more"}
+            if args.chain > 1:
+                extras["group_fold"] = dict(timed_batches("group_fold", depth, spp, 4, args.steps, args.chain),
+                                            note="the same steps as batch groups (rtowSampleBatchGroupDevice: every batch from zeroed inputs into its own partial sums, one launch per group) "
+                                                 "+ the partial sums added in batch order (rtowAddAccumDevice): the reference's samples, bit-identical to that fold order, within 1e-4 of the mean "
+                                                 "of the sequential accumulation `value` computes exactly; a launch ends with its slowest pixel-batch instead of a pixel's batches in a row")
+                # the reference host as committed: FULL_DIAGNOSTICS records (ProjectSettings/ProjectSettings.asset:590), traceDepth 32, up to 50 samples per batch
+                # (Assets/Prefabs/Raytracer.prefab:383-391), same scene and frame
+                hd_steps = 2 * args.chain
+                extras["host_default"] = {
+                    "config": "16-byte FULL_DIAGNOSTICS records, traceDepth 32, 50 samples per batch (the reference host's committed defines and prefab), %s %dx%d" % (args.scene, W, H),
+                    "chain": timed_batches("chain", 32, 50, 16, hd_steps, args.chain),
+                    "group_fold": timed_batches("group_fold", 32, 50, 16, hd_steps, args.chain),
+                    "note": "a chain is bound by its slowest pixel's batches in a row (cover scene at depth 32: 6 429 sequential path segments per 256 samples of one pixel, ~13 us each; "
+                            "profiles/r04g_ray_count_stats.txt), a group by the slowest pixel-batch: DESIGN.md 4.1"}
             # the drop-in form of INTEGRATION.md: rtowSampleBatch on the host's own (pinned, registered) accumulation arrays
             import numpy as np
             pool = [np.zeros((n, c), np.float32) for c in (4, 3, 3)] + [np.zeros(n, np.float32)]
@@ -506,7 +577,7 @@ def main():
         # owned pixel AND batch of the launch, plus the scene image once
         owned_pixels = n if world == 1 else len(range(rank % m["tiles"], H, m["tiles"])) * W     # rank 0's launch: its tile's rows
         rank_spp = m["rank_spp"]
-        steps_per_launch = args.steps / max(m["launches"], 1)
+        steps_per_launch = args.steps / max(m["launches"], 1)      # batches one launch of the sample kernel holds: a chain's (one GPU) or a batch group's (hybrid partition)
         alg_bytes = int(owned_pixels * 92 * steps_per_launch) + int(info.sceneBytesDevice)
         launch_ms = avg_kernel_ms * steps_per_launch
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
@@ -528,7 +599,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
-            "batches_per_launch": args.chain if not hybrid else 1,   # `value` is measured with this many successive batches fused into one launch (1 = plain batches)
+            "batches_per_launch": m["steps_per_launch"],   # `value` is measured with this many successive batches fused into one launch (1 = plain batches)
             "launches": m["launches"],
             "higher_is_better": True,
             "scaling": "strong",
@@ -539,13 +610,14 @@ def main():
                 "workload": "%s%s, %dx%d, %d spp per batch, "
                             "%d bounces, white noise, jitter on, %s" % ("BASELINE.json " + cfg["label"] + " = " if not overridden else "", SCENE_TEXT[args.scene], W, H, spp, depth, "reference RNG stream (lane per pixel)" if args.rng == "reference" else "RTOW_RNG_%s (NOT the reference stream; lane per 16-sample group)" % args.rng.upper().replace("-", "_")),
                 "partition": ("DEBUG: %d ranks sharing one GPU over gloo - not a measurement; " % world if shared_gpu else "") + ("single GPU" if world == 1 else
-                              "hybrid: %d row slices x %d seed groups (rtowHybridPlan): every rank renders its slice with %d of the %d samples and the Seed of its sub-batch from zeroed accumulators; "
+                              "hybrid: %d row slices x %d seed groups (rtowHybridPlan): every rank renders its slice with %d of the %d samples and the Seed of its sub-batch from zeroed accumulators "
+                              "(the sub-batches of up to %d steps as one launch, rtowSampleBatchGroupDevice); "
                               "one grouped ncclSend / ncclRecv exchange + rank-ordered fold of every row on its owner (rtowExchangeAccumDevice), one RCCL gather of colour rows per batch on rank 0 "
-                              "(rtowGatherRowsDevice); the reference's successive batches (UNITY/Raytracer.cs:656-661,798-802) run concurrently" % (m["tiles"], m["groups"], rank_spp, spp)
+                              "(rtowGatherRowsDevice); the reference's successive batches (UNITY/Raytracer.cs:656-661,798-802) run concurrently" % (m["tiles"], m["groups"], rank_spp, spp, m["steps_per_launch"])
                               if hybrid else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),
                 "tiles": m["tiles"] if world > 1 else None, "seed_groups": m["groups"] if world > 1 else None,
                 "gather": None if world == 1 else ("rtowGatherRowsDevice (DEBUG: the tests' stand-in transport instead of RCCL, ranks share one GPU)" if (have_comm and shared_gpu) else "rtowGatherRowsDevice (RCCL behind the C ABI)" if have_comm else "torch.distributed (debug: ranks share one GPU)" if shared_gpu else "torch.distributed (the C-ABI communicator was not available)"),
-                "batches_per_launch": args.chain if not hybrid else 1,
+                "batches_per_launch": m["steps_per_launch"],
                 "launches": m["launches"],
                 "bvh_nodes": int(info.bvhNodeCount), "bvh_depth": int(info.bvhDepth), "scene_in_lds": bool(info.sceneInLds), "wide_codes": bool(info.wideCodes),
                 "entities": int(info.entityCount), "hit_spill_bytes": int(info.hitSpillBytes),
