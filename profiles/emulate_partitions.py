@@ -14,8 +14,9 @@ Estimates (stated, not measured - one GPU has no xGMI): exchange = every rank se
 4 TB/s; gather = n / G x 16 B on the root's links (colour rows) + 30 us.  Measured on this GPU and reported beside it: the pack + fold + scatter
 kernels' actual time for the G = 8 case.
 
-`--pipelined K`: additionally runs K consecutive steps of ONE rank's workload (fresh Seed each, as the rank of a node would) back to back and
-reports wall time per step: what a rank sustains when the host keeps its queue full (launch gaps, chunk-order refresh included).
+`--group K` (default 8): additionally renders K consecutive steps' sub-batches of ONE rank as one launch (rtowSampleBatchGroupDevice: what bench.py --gpus N
+does) and reports kernel time per step, and the whole frame as the chain of 10 batches bench.py times at N = 1 - so that `predicted_speedup_vs_n1_bench`
+is the ratio of the two numbers the driver's scaling run would compare.
 
   python profiles/emulate_partitions.py --config 2 > gpurun_out/partitions_c2.json
 """
@@ -40,7 +41,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--worlds", default="1,2,4,8")
-    ap.add_argument("--pipelined", type=int, default=6, help="steps of one rank's workload run back to back for the sustained per-step time (0 = skip)")
+    ap.add_argument("--group", type=int, default=8, help="sub-batches (steps) of one rank per launch for the batch-group figure (0 = skip)")
+    ap.add_argument("--pipelined", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--context-flags", type=int, default=0)
     args = ap.parse_args()
     name, w, h, spp, depth = CONFIGS[args.config]
@@ -73,26 +75,34 @@ def main():
             cache[key] = ms
             return ms
 
-        def pipelined(t, T, samples, first_seed, steps):
-            """`steps` consecutive steps of one rank's workload, enqueued without waiting in between: wall time per step."""
-            p = rt.scenes.make_params(scene, w, h, spp=samples, trace_depth=depth, slice_offset=t, slice_divider=T, seed=first_seed)
-            job = rt.SampleBatchJob(ctx, p)
-            job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = zero
-            job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = outs
-            job.OutputDiagnostics = diag
-            rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                p.seed = first_seed + 8 * (k + 1)
-                rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
-            ctx.synchronize()
-            return (time.perf_counter() - t0) * 1e3 / steps
+        group_outs = [[rt.DeviceBuffer(ctx, n * k * 4).zero() for k in (4, 3, 3, 1)] for _ in range(max(args.group, 1))] if args.group else []
+
+        def grouped(t, T, samples, rank_of_world, world, tiles):
+            """kernel ms per step when the rank renders args.group steps' sub-batches in one launch"""
+            plist = []
+            for step in range(1, args.group + 1):
+                plan = rt.Context.hybrid_plan(world, rank_of_world, tiles, spp, step)
+                plist.append(rt.scenes.make_params(scene, w, h, spp=samples, trace_depth=depth, slice_offset=t, slice_divider=T, seed=int(plan.seed)))
+            ms = None
+            for rep in range(2):
+                rt.lib.check(rt.sample_batch_group_device(ctx, plist, zero, group_outs[:len(plist)]), "rtowSampleBatchGroupDevice")
+                ctx.synchronize()
+                ms = ctx.last_sample_kernel_ms()
+            return ms / len(plist)
+
+        def whole_chain(count=10):
+            plist = [rt.scenes.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=1 + k) for k in range(count)]
+            ms = None
+            for rep in range(2):
+                rt.lib.check(rt.sample_batch_chain_device(ctx, plist, outs, outs), "rtowSampleBatchChainDevice")
+                ctx.synchronize()
+                ms = ctx.last_sample_kernel_ms()
+            return ms / count
 
         whole = render(0, 1, spp, 1)
         out["whole_frame_ms"] = round(whole, 3)
-        if args.pipelined:
-            out["whole_frame_pipelined_ms_per_step"] = round(pipelined(0, 1, spp, 1, max(2, args.pipelined // 2)), 3)
+        if args.group:
+            out["whole_frame_chain10_ms_per_step"] = round(whole_chain(10 if args.config != 3 else 2), 3)      # what bench.py times at N = 1 (4K / 1024 spp: chains of 2 keep the run short; the chain gains < 1 % there)
         for G in [int(x) for x in args.worlds.split(",")]:
             if G == 1:
                 continue
@@ -113,10 +123,11 @@ def main():
                 entry = {"tiles": T, "groups": B, "samples_per_rank": spp // B, "render_ms": times, "slowest_render_ms": slowest, "exchange_ms_estimate": round(exchange_ms, 3),
                          "gather_ms_estimate": round(gather_ms, 3), "predicted_step_ms": round(step, 3), "predicted_speedup_vs_whole_frame": round(whole / step, 3),
                          "predicted_msamples_per_s": round(n * spp / step / 1e3, 1)}
-                if args.pipelined and (T == 1 or T == G):
-                    pm = pipelined(0, T, spp // B, 1, args.pipelined)
-                    entry["pipelined_render_ms_per_step"] = round(pm, 3)
-                    entry["predicted_speedup_pipelined_vs_pipelined_whole"] = round(out["whole_frame_pipelined_ms_per_step"] / (pm + exchange_ms + gather_ms), 3)
+                if args.group and (T == 1 or T == G or T * T == G):
+                    gm = max(grouped(t, T, spp // B, t + T * (B - 1), G, T) for t in sorted({0, T - 1}))
+                    entry["group_render_ms_per_step"] = round(gm, 3)
+                    entry["predicted_step_ms_grouped"] = round(gm + exchange_ms + gather_ms, 3)
+                    entry["predicted_speedup_vs_n1_bench"] = round(out["whole_frame_chain10_ms_per_step"] / (gm + exchange_ms + gather_ms), 3)
                 out["partitions"]["%d GPUs: %d tiles x %d groups" % (G, T, B)] = entry
         # the exchange's own kernels at G = 8, T = 1, measured: pack 7 peers' rows, fold 8 sources, on this GPU (no transport)
         a = rt.abi
@@ -129,14 +140,15 @@ def main():
             ctx.exchange_accum(w, h, 1, bp, ba)
         ctx.synchronize()
         out["single_rank_fold_ms_measured"] = round((time.perf_counter() - t0) * 100, 4)      # accum += partial over the whole frame: 8 x what one of 8 ranks folds per source
-        for b in zero + outs + acc + [diag]:
+        for b in zero + outs + acc + [diag] + [x for o in group_outs for x in o]:
             b.free()
     best = {}
+    key = "predicted_speedup_vs_n1_bench" if args.group else "predicted_speedup_vs_whole_frame"
     for k, v in out["partitions"].items():
         G = int(k.split()[0])
-        if G not in best or v["predicted_speedup_vs_whole_frame"] > out["partitions"][best[G]]["predicted_speedup_vs_whole_frame"]:
+        if key in v and (G not in best or v[key] > out["partitions"][best[G]][key]):
             best[G] = k
-    out["best_partition_per_world"] = {str(G): {"partition": k, "predicted_speedup_vs_whole_frame": out["partitions"][k]["predicted_speedup_vs_whole_frame"]} for G, k in sorted(best.items())}
+    out["best_partition_per_world"] = {str(G): {"partition": k, key: out["partitions"][k][key]} for G, k in sorted(best.items())}
     print(json.dumps(out))
 
 
