@@ -169,7 +169,8 @@ def cpu_baseline_c1(rt):
 def post_passes(rt, ctx, lib, torch, dev, stream, sizes=((1920, 1080), (3840, 2160)), iters=20):
     """Achieved HBM GB/s of the post passes next to the sample kernel (JOBS/CombineJob.cs:29-71, JOBS/FinalizeTexturesJob.cs:23-55,
     JOBS/ReduceMetricsJob.cs:22-45, rtowAddAccumDevice), timed with HIP events on the stream they are launched on.  Bytes per pixel are the
-    algorithmic ones: combine 44 read + 36 written, finalize 36 + 12, metrics 24 read, add 88 read + 44 written.
+    algorithmic ones: combine 44 read + 36 written, finalize 36 + 12, combine_finalize (the two fused: the reference's default chain) 40 + 12,
+    metrics 24 read, add 88 read + 44 written.
     Peak 8 TB/s (spec), ~6.3 TB/s is what a float4 copy reaches on this part (MI355X_MICROARCH.md).  A 1080p working set (91-166 MB) partly
     lives in the 256 MB Infinity Cache between iterations - the 4K figures (365-663 MB) are the HBM ones."""
     import ctypes as C
@@ -187,6 +188,7 @@ def post_passes(rt, ctx, lib, torch, dev, stream, sizes=((1920, 1080), (3840, 21
         acc2 = [torch.zeros(n, c, device=dev) for c in (4, 3, 3)] + [torch.zeros(n, device=dev)]
         cp = abi.CombineParams(w, h, 0, 1)
         metrics = abi.Metrics()
+        metrics_dev = torch.zeros(16, device=dev, dtype=torch.int32)      # the asynchronous reduction's record (device memory; a host would register a pinned record)
         # a stream of its own with a real handle: the C ABI maps a NULL stream to the CONTEXT's stream, which torch's events would not see
         ps = torch.cuda.Stream(dev)
         torch.cuda.synchronize(dev)
@@ -199,6 +201,9 @@ def post_passes(rt, ctx, lib, torch, dev, stream, sizes=((1920, 1080), (3840, 21
             "finalize": (48, lambda: lib.rtowFinalizeDevice(ctx.handle, n, o3[0].data_ptr(), o3[1].data_ptr(), o3[2].data_ptr(), rgba[0].data_ptr(), rgba[1].data_ptr(), rgba[2].data_ptr(), sp)),
             "reduce_metrics": (24, lambda: lib.rtowReduceMetricsDevice(ctx.handle, n, diag.data_ptr(), 4, color4.data_ptr(), scw.data_ptr(), sp, C.byref(metrics))),
             "add_accum": (132, lambda: lib.rtowAddAccumDevice(ctx.handle, n, C.byref(dst), C.byref(src), sp)),
+            # the reference's default post chain (denoiseMode 0) fused: accumulators in, three RGBA32 textures out
+            "combine_finalize": (52, lambda: lib.rtowCombineFinalizeDevice(ctx.handle, C.byref(cp), color4.data_ptr(), normal.data_ptr(), albedo.data_ptr(), rgba[0].data_ptr(), rgba[1].data_ptr(), rgba[2].data_ptr(), sp)),
+            "reduce_metrics_async": (24, lambda: lib.rtowReduceMetricsDeviceAsync(ctx.handle, n, diag.data_ptr(), 4, color4.data_ptr(), scw.data_ptr(), sp, metrics_dev.data_ptr())),
         }
         res = {}
         for name, (bytes_per_px, fn) in passes.items():

@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 9
+#define RTOW_API_VERSION 10
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -436,6 +436,14 @@ RTOW_API int rtowReduceMetricsDevice(RtowContext context, int32_t pixelCount, co
                                      int32_t diagnosticsStride, const float* color, const float* sampleCountWeight,
                                      void* stream, RtowMetrics* outMetrics);
 
+/* The same reduction without the wait: the per-block partial results are folded on the device and the record is written to `outMetrics` in stream
+ * order - memory the device can write: a range given to rtowRegisterHostBuffer, pinned host memory of this process (hipHostMalloc) or device memory; pageable
+ * host memory is RTOW_ERROR_INVALID_VALUE.  The reference consumes these numbers a frame later (UNITY/Raytracer.cs:518-550): the host reads the record when the
+ * batch's other results are in (rtowSynchronize / a stream event), and the call costs what its kernels cost. */
+RTOW_API int rtowReduceMetricsDeviceAsync(RtowContext context, int32_t pixelCount, const void* diagnostics,
+                                          int32_t diagnosticsStride, const float* color, const float* sampleCountWeight,
+                                          void* stream, RtowMetrics* outMetrics);
+
 /* replaces: CombineJob.Execute (JOBS/CombineJob.cs:29-71): sum -> mean, interlace look-around, NaN handling. */
 typedef struct RtowCombineParams {
     int32_t width, height;          /* CombineJob.Size */
@@ -450,6 +458,13 @@ RTOW_API int rtowCombineDevice(RtowContext context, const RtowCombineParams* par
 RTOW_API int rtowFinalizeDevice(RtowContext context, int32_t pixelCount,
                                 const float* inColor /*float3*/, const float* inNormal, const float* inAlbedo,
                                 uint8_t* outColor /*RGBA32*/, uint8_t* outNormal, uint8_t* outAlbedo, void* stream);
+
+/* replaces: CombineJob -> FinalizeTexturesJob back to back, the reference's default chain (denoiseMode 0, Assets/Prefabs/Raytracer.prefab:391; UNITY/Raytracer.cs:806-807),
+ * in ONE pass: the accumulators in, the three RGBA32 textures out - 40 B read + 12 B written per pixel instead of 80 + 48 through the float3 intermediates.  The same
+ * bytes as rtowCombineDevice followed by rtowFinalizeDevice. */
+RTOW_API int rtowCombineFinalizeDevice(RtowContext context, const RtowCombineParams* params,
+                                       const float* inColor /*float4*/, const float* inNormal, const float* inAlbedo,
+                                       uint8_t* outColor /*RGBA32*/, uint8_t* outNormal, uint8_t* outAlbedo, void* stream);
 
 /* dst += src for the four accumulation buffers (device pointers, `pixelCount` elements each).  The reference accumulates
  * successive batches by feeding a batch's outputs to the next one as inputs (UNITY/Raytracer.cs:798-802); when batches run

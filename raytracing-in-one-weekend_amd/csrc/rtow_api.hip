@@ -147,6 +147,8 @@ struct RtowContext_t {
     float* dByteThresholds = nullptr;     // FinalizeTexturesJob's float -> byte step table (rtow_finalize.hip.h), built when the context is created
     hipEvent_t evGatherDone = nullptr;    // end of the last gather: the staging blocks are per context, gathers may come on different streams
     bool haveGatherDone = false;
+    hipEvent_t evMetricsDone = nullptr;   // end of the last metrics reduction (the per-block partials are per context)
+    bool haveMetricsDone = false;
 
     std::mutex mu;
 };
@@ -787,6 +789,7 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     ok = ok && hipEventCreate(&ctx->evStart) == hipSuccess && hipEventCreate(&ctx->evStop) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->evBatchDone, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->evGatherDone, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->evMetricsDone, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dWorkCounter, sizeof(unsigned int)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->dPartials, sizeof(MetricsPartial) * kMetricsBlocks) == hipSuccess;
     // the finalize pass may be given any stream later: the table is complete before the context exists for the caller
@@ -836,6 +839,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     if (ctx->evBatchDone) (void)hipEventDestroy(ctx->evBatchDone);
     if (ctx->evGatherDone) (void)hipEventDestroy(ctx->evGatherDone);
+    if (ctx->evMetricsDone) (void)hipEventDestroy(ctx->evMetricsDone);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RTOW_SUCCESS;
@@ -1304,6 +1308,7 @@ RTOW_API int rtowReduceMetricsDevice(RtowContext ctx, int32_t pixelCount, const 
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (ctx->haveMetricsDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evMetricsDone, 0), RTOW_ERROR_LAUNCH_FAILURE);      // an asynchronous reduction may still be folding the partials
     HIP_TRY(ctx, launchReduceMetrics(pixelCount, (const uint8_t*)diagnostics, diagnosticsStride, color, sampleCountWeight, ctx->dPartials, s),
             RTOW_ERROR_LAUNCH_FAILURE);
     std::vector<MetricsPartial> parts(kMetricsBlocks);
@@ -1359,11 +1364,46 @@ RTOW_API int rtowAddAccumDevice(RtowContext ctx, int32_t pixelCount, const RtowA
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    const size_t n = (size_t)pixelCount;
-    HIP_TRY(ctx, launchAdd(n * 4, dst->color, src->color, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, launchAdd(n * 3, dst->normal, src->normal, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, launchAdd(n * 3, dst->albedo, src->albedo, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, launchAdd(n, dst->sampleCountWeight, src->sampleCountWeight, s), RTOW_ERROR_LAUNCH_FAILURE);
+    float* const d[4] = {dst->color, dst->normal, dst->albedo, dst->sampleCountWeight};
+    const float* const q[4] = {src->color, src->normal, src->albedo, src->sampleCountWeight};
+    HIP_TRY(ctx, launchAddAccum((size_t)pixelCount, d, q, s), RTOW_ERROR_LAUNCH_FAILURE);      // one launch for the four buffers
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowCombineFinalizeDevice(RtowContext ctx, const RtowCombineParams* params, const float* inColor, const float* inNormal, const float* inAlbedo,
+                                       uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, void* stream)
+{
+    if (!ctx || !params || !inColor || !inNormal || !inAlbedo || !outColor || !outNormal || !outAlbedo) return RTOW_ERROR_INVALID_VALUE;
+    if (params->width <= 0 || params->height <= 0) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(ctx, launchCombineFinalize(*params, inColor, inNormal, inAlbedo, outColor, outNormal, outAlbedo, ctx->dByteThresholds, s), RTOW_ERROR_LAUNCH_FAILURE);
+    return RTOW_SUCCESS;
+}
+
+RTOW_API int rtowReduceMetricsDeviceAsync(RtowContext ctx, int32_t pixelCount, const void* diagnostics, int32_t diagnosticsStride, const float* color,
+                                          const float* sampleCountWeight, void* stream, RtowMetrics* outMetrics)
+{
+    if (!ctx || !diagnostics || !color || !sampleCountWeight || !outMetrics || pixelCount <= 0) return RTOW_ERROR_INVALID_VALUE;
+    if (diagnosticsStride != 4 && diagnosticsStride != 16) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // where the record goes: memory registered with rtowRegisterHostBuffer (the device writes it over PCIe), else a device pointer (any HIP allocation)
+    RtowMetrics* target = (RtowMetrics*)mappedHost(ctx, outMetrics, sizeof(RtowMetrics));
+    if (!target) {
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, outMetrics) != hipSuccess) { (void)hipGetLastError(); return RTOW_ERROR_INVALID_VALUE; }   // plain pageable host memory: the device cannot write it
+        if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged) return RTOW_ERROR_INVALID_VALUE;
+        target = attr.type == hipMemoryTypeHost && attr.devicePointer ? (RtowMetrics*)attr.devicePointer : outMetrics;
+    }
+    // the partials are one block per context: this reduction starts after the previous one's fold has read them
+    if (ctx->haveMetricsDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evMetricsDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchReduceMetrics(pixelCount, (const uint8_t*)diagnostics, diagnosticsStride, color, sampleCountWeight, ctx->dPartials, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, launchFoldMetrics(ctx->dPartials, target, s), RTOW_ERROR_LAUNCH_FAILURE);
+    HIP_TRY(ctx, hipEventRecord(ctx->evMetricsDone, s), RTOW_ERROR_LAUNCH_FAILURE);
+    ctx->haveMetricsDone = true;
     return RTOW_SUCCESS;
 }
 

@@ -217,7 +217,11 @@ hipError_t launchBuildByteThresholds(float* thresholds, hipStream_t stream);
 hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inNormal, const float* inAlbedo,
                           uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream);
 
-hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t stream); // dst += src
+// CombineJob -> FinalizeTexturesJob in one pass (the bytes of the two kernels one after the other)
+hipError_t launchCombineFinalize(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
+                                 uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream);
+// dst[k] += src[k] for the four accumulators (float4 / float3 / float3 / float per pixel) in one launch
+hipError_t launchAddAccum(size_t pixels, float* const dst[4], const float* const src[4], hipStream_t stream);
 // rows first, first + step, ... (`rows` of them, `rowFloats` floats each) of a full-frame buffer -> / <- one contiguous block
 hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, bool toFrame, hipStream_t stream);
 // accum[row] += src_0[row] ... += src_{groups-1}[row] (group order) for rows first, first + step, ...; src_g = ownPartial (frame layout) for g == own, else packed rows at recv + g * regionFloats
@@ -232,5 +236,7 @@ struct MetricsPartial {
 constexpr int kMetricsBlocks = 2048;   // 8 workgroups of 256 lanes per CU: 256 blocks (one per CU) left the reduction at 3.5 TB/s, latency bound (profiles/r03a_post_passes.json)
 hipError_t launchReduceMetrics(int pixelCount, const uint8_t* diagnostics, int stride, const float* color, const float* scw,
                                MetricsPartial* partials, hipStream_t stream);
+// the partials of launchReduceMetrics -> one RtowMetrics record in device-visible memory (the asynchronous form of the reduction)
+hipError_t launchFoldMetrics(const MetricsPartial* partials, RtowMetrics* out, hipStream_t stream);
 
 } // namespace rtow

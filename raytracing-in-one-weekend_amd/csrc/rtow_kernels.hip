@@ -261,36 +261,39 @@ __global__ void prepare_materials_kernel(uint8_t* blob, SceneLayout L)
 // post passes
 // ------------------------------------------------------------------------------------------------------------
 
-// CombineJob.Execute (JOBS/CombineJob.cs:29-71)
+// CombineJob.Execute (JOBS/CombineJob.cs:29-71) for one pixel: sum -> mean, interlace look-around, NaN / zero-sample handling
+__device__ __forceinline__ void combine_pixel(const RtowCombineParams& p, const float4* __restrict__ inColor, int index, float4 c, V3 nIn, V3 aIn, V3& finalColor, V3& nn, V3& alb)
+{
+    int count = (int)c.w;
+    if (!p.debugMode && count == 0) {
+        int tentative = index;
+        while (count == 0 && (tentative -= p.width) >= 0) { // look-around for interlaced buffers (:40-50)
+            c = inColor[tentative];
+            count = (int)c.w;
+        }
+    }
+    const bool anyNan = (c.x != c.x) || (c.y != c.y) || (c.z != c.z) || (c.w != c.w);
+    if (count == 0) finalColor = p.debugMode ? v3(1, 0, 1) : v3(0, 0, 0);
+    else if (anyNan) finalColor = p.debugMode ? v3(0, 1, 1) : v3(0, 0, 0);
+    else finalColor = v3(c.x / (float)count, c.y / (float)count, c.z / (float)count);
+
+    const float denom = (float)(count > 1 ? count : 1);
+    alb = v3(aIn.x / denom, aIn.y / denom, aIn.z / denom);
+    if (p.ldrAlbedo) alb = v3(um_min(alb.x, 1.0f), um_min(alb.y, 1.0f), um_min(alb.z, 1.0f));
+    const V3 nv = v3(nIn.x / denom, nIn.y / denom, nIn.z / denom);
+    const float len = dot(nv, nv);
+    nn = v3(0, 0, 0);
+    if (len > 1.175494351e-38f) { const float r = 1.0f / __builtin_sqrtf(len); nn = v3(nv.x * r, nv.y * r, nv.z * r); } // normalizesafe
+}
+
 __global__ void __launch_bounds__(256) combine_kernel(RtowCombineParams p, const float4* __restrict__ inColor, const float* __restrict__ inNormal,
                                                       const float* __restrict__ inAlbedo, float* __restrict__ outColor, float* __restrict__ outNormal,
                                                       float* __restrict__ outAlbedo)
 {
     const int n = p.width * p.height;
     for (int index = (int)(blockIdx.x * blockDim.x + threadIdx.x); index < n; index += (int)(gridDim.x * blockDim.x)) {
-        float4 c = inColor[index];
-        const V3 nIn = load3(inNormal, (size_t)index), aIn = load3(inAlbedo, (size_t)index);
-        int count = (int)c.w;
-        if (!p.debugMode && count == 0) {
-            int tentative = index;
-            while (count == 0 && (tentative -= p.width) >= 0) { // look-around for interlaced buffers (:40-50)
-                c = inColor[tentative];
-                count = (int)c.w;
-            }
-        }
-        const bool anyNan = (c.x != c.x) || (c.y != c.y) || (c.z != c.z) || (c.w != c.w);
-        V3 finalColor;
-        if (count == 0) finalColor = p.debugMode ? v3(1, 0, 1) : v3(0, 0, 0);
-        else if (anyNan) finalColor = p.debugMode ? v3(0, 1, 1) : v3(0, 0, 0);
-        else finalColor = v3(c.x / (float)count, c.y / (float)count, c.z / (float)count);
-
-        const float denom = (float)(count > 1 ? count : 1);
-        V3 alb = v3(aIn.x / denom, aIn.y / denom, aIn.z / denom);
-        if (p.ldrAlbedo) alb = v3(um_min(alb.x, 1.0f), um_min(alb.y, 1.0f), um_min(alb.z, 1.0f));
-        const V3 nv = v3(nIn.x / denom, nIn.y / denom, nIn.z / denom);
-        const float len = dot(nv, nv);
-        V3 nn = v3(0, 0, 0);
-        if (len > 1.175494351e-38f) { const float r = 1.0f / __builtin_sqrtf(len); nn = v3(nv.x * r, nv.y * r, nv.z * r); } // normalizesafe
+        V3 finalColor, nn, alb;
+        combine_pixel(p, inColor, index, inColor[index], load3(inNormal, (size_t)index), load3(inAlbedo, (size_t)index), finalColor, nn, alb);
         store3(outColor, (size_t)index, finalColor);
         store3(outNormal, (size_t)index, nn);
         store3(outAlbedo, (size_t)index, alb);
@@ -307,48 +310,6 @@ __global__ void __launch_bounds__(256) combine_kernel(RtowCombineParams p, const
 #ifndef RTOW_FINALIZE_BLOCKS
 #define RTOW_FINALIZE_BLOCKS 1048576
 #endif
-#ifndef RTOW_ADD_VARIANT
-#define RTOW_ADD_VARIANT 0          // 2, 3: timing experiments (see the kernel)
-#endif
-#ifndef RTOW_ADD_BLOCKS
-#define RTOW_ADD_BLOCKS 1048576     // grid-stride loop over at most this many blocks of 256 lanes (see RTOW_COMBINE_BLOCKS)
-#endif
-// dst += src over a flat float array (the four accumulators are added as 16 B / 4 B streams; HBM bound: 8 B read + 4 B written per float)
-__global__ void __launch_bounds__(256) add_kernel(size_t n4, float4* __restrict__ dst, const float4* __restrict__ src, size_t tailStart, size_t n, float* __restrict__ dstS,
-                                                  const float* __restrict__ srcS)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-#if RTOW_ADD_VARIANT == 2
-    // TIMING EXPERIMENT: two elements per iteration, all four loads issued before the first add
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + stride < n4; i += 2 * stride) {
-        float4 a0 = dst[i], a1 = dst[i + stride];
-        const float4 b0 = src[i], b1 = src[i + stride];
-        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
-        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
-        dst[i] = a0; dst[i + stride] = a1;
-    }
-    for (; i < n4; i += stride) { float4 a = dst[i]; const float4 b = src[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; dst[i] = a; }
-#elif RTOW_ADD_VARIANT == 3
-    // TIMING EXPERIMENT: streaming hints - the source is read once, the sum is not read again soon
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 a = dst[i];
-        float4 b;
-        b.x = __builtin_nontemporal_load(&src[i].x); b.y = __builtin_nontemporal_load(&src[i].y); b.z = __builtin_nontemporal_load(&src[i].z); b.w = __builtin_nontemporal_load(&src[i].w);
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        __builtin_nontemporal_store(a.x, &dst[i].x); __builtin_nontemporal_store(a.y, &dst[i].y); __builtin_nontemporal_store(a.z, &dst[i].z); __builtin_nontemporal_store(a.w, &dst[i].w);
-    }
-#else
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 a = dst[i];
-        const float4 b = src[i];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        dst[i] = a;
-    }
-#endif
-    for (size_t i = tailStart + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dstS[i] += srcS[i];
-}
-
 // FinalizeTexturesJob.Execute (JOBS/FinalizeTexturesJob.cs:23-55).  The nine float -> byte conversions per pixel go through the step table
 // (rtow_finalize.hip.h: same byte as the deterministic-pow form for every float operand, a fifth of its instructions), staged in LDS.
 __global__ void __launch_bounds__(256, 8) finalize_kernel(int n, const float* __restrict__ inColor, const float* __restrict__ inNormal,
@@ -415,7 +376,143 @@ __global__ void __launch_bounds__(256) reduce_metrics_kernel(int n, const uint8_
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
+// CombineJob + FinalizeTexturesJob in one pass (the reference's default chain with denoiseMode 0, Assets/Prefabs/Raytracer.prefab:391: combine -> finalize back to
+// back, UNITY/Raytracer.cs:806-807): 40 B read and 12 B written per pixel instead of 80 + 48 through the float3 intermediates.  Same float program as the two
+// kernels one after the other (combine_pixel, to_bytes_table), so the bytes equal oracle.combine -> oracle.finalize.
+__global__ void __launch_bounds__(256, 8) combine_finalize_kernel(RtowCombineParams p, const float4* __restrict__ inColor, const float* __restrict__ inNormal,
+                                                                  const float* __restrict__ inAlbedo, uchar4* __restrict__ outColor, uchar4* __restrict__ outNormal,
+                                                                  uchar4* __restrict__ outAlbedo, const float* __restrict__ thresholds)
+{
+    __shared__ float T[kByteThresholdFloats];
+    for (int i = (int)threadIdx.x; i < kByteThresholdFloats; i += (int)blockDim.x) T[i] = thresholds[i];
+    __syncthreads();
+    const ByteZones Z = load_byte_zones(T);
+    const int n = p.width * p.height;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    float4 c4 = make_float4(0, 0, 0, 0);
+    V3 nm = v3(0, 0, 0), al = v3(0, 0, 0);
+    if (i < n) { c4 = inColor[i]; nm = load3(inNormal, (size_t)i); al = load3(inAlbedo, (size_t)i); }
+    while (i < n) {
+        const int j = i + stride;
+        float4 c42 = make_float4(0, 0, 0, 0);
+        V3 nm2 = v3(0, 0, 0), al2 = v3(0, 0, 0);
+        if (j < n) { c42 = inColor[j]; nm2 = load3(inNormal, (size_t)j); al2 = load3(inAlbedo, (size_t)j); }      // the next pixel's loads are in flight during this pixel's conversions
+        V3 c, nn, alb;
+        combine_pixel(p, inColor, i, c4, nm, al, c, nn, alb);
+        const float v[9] = {c.x, c.y, c.z, nn.x * 0.5f + 0.5f, nn.y * 0.5f + 0.5f, nn.z * 0.5f + 0.5f, alb.x, alb.y, alb.z};
+        unsigned b[9];
+        to_bytes_table<9>(v, b, T, Z);
+        outColor[i] = make_uchar4((unsigned char)b[0], (unsigned char)b[1], (unsigned char)b[2], 255);
+        outNormal[i] = make_uchar4((unsigned char)b[3], (unsigned char)b[4], (unsigned char)b[5], 255);
+        outAlbedo[i] = make_uchar4((unsigned char)b[6], (unsigned char)b[7], (unsigned char)b[8], 255);
+        c4 = c42; nm = nm2; al = al2;
+        i = j;
+    }
+}
+
+// rtowAddAccumDevice: the four accumulators in ONE launch (round 3: four).  Blocks [0, b0) add colour, [b0, b1) normal, ... - each range a flat stream of
+// 16-byte (or, unaligned / the tail, 4-byte) units, dispatched front to back.
+struct AddSpan { float* dst; const float* src; size_t floats; unsigned firstBlock; unsigned wide; };
+struct AddSpans { AddSpan s[4]; };
+__global__ void __launch_bounds__(256) add_accum_kernel(AddSpans a)
+{
+    int k = 0;
+    if (blockIdx.x >= a.s[1].firstBlock) k = 1;
+    if (blockIdx.x >= a.s[2].firstBlock) k = 2;
+    if (blockIdx.x >= a.s[3].firstBlock) k = 3;
+    const AddSpan sp = a.s[k];
+    const size_t i = (size_t)(blockIdx.x - sp.firstBlock) * blockDim.x + threadIdx.x;
+    if (sp.wide) {
+        const size_t n4 = sp.floats / 4;
+        if (i < n4) {
+            float4 x = reinterpret_cast<float4*>(sp.dst)[i];
+            const float4 y = reinterpret_cast<const float4*>(sp.src)[i];
+            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+            reinterpret_cast<float4*>(sp.dst)[i] = x;
+        } else {
+            const size_t t = n4 * 4 + (i - n4);          // the (at most three) floats behind the last whole unit
+            if (t < sp.floats) sp.dst[t] += sp.src[t];
+        }
+    } else if (i < sp.floats) {
+        sp.dst[i] += sp.src[i];
+    }
+}
+
+// second stage of ReduceMetricsJob for the asynchronous form: the per-block partials -> one RtowMetrics record (integer sums and min / max: any order gives
+// the host-side fold's result)
+__global__ void __launch_bounds__(256) fold_metrics_kernel(const MetricsPartial* __restrict__ parts, int count, RtowMetrics* __restrict__ out)
+{
+    MetricsPartial mine;
+    mine.rays = 0; mine.samples = 0; mine.minW = __builtin_inff(); mine.maxW = -__builtin_inff(); mine.minS = __builtin_inff(); mine.maxS = -__builtin_inff();
+    for (int i = (int)threadIdx.x; i < count; i += (int)blockDim.x) {
+        const MetricsPartial p = parts[i];
+        mine.rays += p.rays; mine.samples += p.samples;
+        mine.minW = um_min(mine.minW, p.minW); mine.maxW = um_max(mine.maxW, p.maxW);
+        mine.minS = um_min(mine.minS, p.minS); mine.maxS = um_max(mine.maxS, p.maxS);
+    }
+    __shared__ MetricsPartial sh[256];
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            MetricsPartial a = sh[threadIdx.x];
+            const MetricsPartial b = sh[threadIdx.x + s];
+            a.rays += b.rays; a.samples += b.samples;
+            a.minW = um_min(a.minW, b.minW); a.maxW = um_max(a.maxW, b.maxW);
+            a.minS = um_min(a.minS, b.minS); a.maxS = um_max(a.maxS, b.maxS);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const MetricsPartial t = sh[0];
+        RtowMetrics m;
+        m.totalRayCount = (int32_t)(uint32_t)(uint64_t)t.rays;         // the reference accumulates in int32 (wraps)
+        m.totalSamples = (int32_t)(uint32_t)(uint64_t)t.samples;
+        m.sampleCountWeightExtrema = RtowFloat2{t.minW, t.maxW};
+        m.sampleCountExtrema[0] = (int32_t)t.minS;
+        m.sampleCountExtrema[1] = (int32_t)t.maxS;
+        m.totalRayCount64 = t.rays;
+        m.totalSamples64 = t.samples;
+        *out = m;
+    }
+}
+
 } // namespace
+
+hipError_t launchCombineFinalize(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
+                                 uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream)
+{
+    const int n = p.width * p.height;
+    const int blocks = n < 256 * RTOW_FINALIZE_BLOCKS ? (n + 255) / 256 : RTOW_FINALIZE_BLOCKS;
+    hipLaunchKernelGGL(combine_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, p, reinterpret_cast<const float4*>(inColor), inNormal, inAlbedo,
+                       reinterpret_cast<uchar4*>(outColor), reinterpret_cast<uchar4*>(outNormal), reinterpret_cast<uchar4*>(outAlbedo), thresholds);
+    return hipGetLastError();
+}
+
+hipError_t launchAddAccum(size_t pixels, float* const dst[4], const float* const src[4], hipStream_t stream)
+{
+    static const size_t comps[4] = {4, 3, 3, 1};
+    AddSpans a;
+    unsigned blocks = 0;
+    for (int k = 0; k < 4; k++) {
+        const size_t floats = pixels * comps[k];
+        const bool wide = ((reinterpret_cast<uintptr_t>(dst[k]) | reinterpret_cast<uintptr_t>(src[k])) & 15u) == 0;
+        const size_t units = wide ? floats / 4 + (floats & 3) : floats;
+        a.s[k] = AddSpan{dst[k], src[k], floats, blocks, wide ? 1u : 0u};
+        blocks += (unsigned)((units + 255) / 256);
+    }
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(add_accum_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launchFoldMetrics(const MetricsPartial* partials, RtowMetrics* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(256), 0, stream, partials, kMetricsBlocks, out);
+    return hipGetLastError();
+}
 
 hipError_t launchSampleBatch(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
@@ -559,18 +656,6 @@ hipError_t launchFinalize(int pixelCount, const float* inColor, const float* inN
     const int blocks = pixelCount < 256 * RTOW_FINALIZE_BLOCKS ? (pixelCount + 255) / 256 : RTOW_FINALIZE_BLOCKS;
     hipLaunchKernelGGL(finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, pixelCount, inColor, inNormal, inAlbedo,
                        reinterpret_cast<uchar4*>(outColor), reinterpret_cast<uchar4*>(outNormal), reinterpret_cast<uchar4*>(outAlbedo), thresholds);
-    return hipGetLastError();
-}
-
-hipError_t launchAdd(size_t floats, float* dst, const float* src, hipStream_t stream)
-{
-    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0;
-    const size_t n4 = aligned ? floats / 4 : 0;
-    const size_t work = n4 + (floats - n4 * 4);
-    size_t blocks = (work + 255) / 256;
-    if (blocks > RTOW_ADD_BLOCKS) blocks = RTOW_ADD_BLOCKS;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n4, reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(src), n4 * 4, floats, dst, src);
     return hipGetLastError();
 }
 

@@ -60,6 +60,8 @@ def load():
     lib.rtowReduceMetricsDevice.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, vp, C.POINTER(abi.Metrics)]
     lib.rtowCombineDevice.argtypes = [vp, C.POINTER(abi.CombineParams), vp, vp, vp, vp, vp, vp, vp]
     lib.rtowFinalizeDevice.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    lib.rtowCombineFinalizeDevice.argtypes = [vp, C.POINTER(abi.CombineParams), vp, vp, vp, vp, vp, vp, vp]
+    lib.rtowReduceMetricsDeviceAsync.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, vp, vp]
     lib.rtowAddAccumDevice.argtypes = [vp, C.c_int32, AB, AB, vp]
     lib.rtowDeviceAlloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.rtowDeviceFree.argtypes = [vp, vp]

@@ -571,3 +571,117 @@ def test_reference_identical_full_diagnostics(rt, oracle, name, w, h, spp, depth
         own = rt.sample_batch_host(plain, S.make_params(scene, w, h, spp=spp, trace_depth=depth, seed=17, diagnostics_stride=16, focus=6.0 if name != "cover" else None))
         assert np.array_equal(own["diag"][:, 0], ref["diag"][:, 0])
         assert not np.array_equal(own["diag"][:, 1], ref["diag"][:, 1])
+
+
+def test_fused_combine_finalize_equals_the_two_passes_and_the_oracle(rt, oracle, gpu_context):
+    """rtowCombineFinalizeDevice (the reference's default chain, denoiseMode 0: CombineJob -> FinalizeTexturesJob) writes the bytes of rtowCombineDevice followed by
+    rtowFinalizeDevice and of oracle.combine -> oracle.finalize: rendered accumulators, an interlaced buffer (look-around), NaNs, zero-sample pixels,
+    debug colours, LDR albedo, sizes that are no multiple of the block."""
+    ctx = gpu_context
+    lib = rt.lib.load()
+    a = rt.abi
+    rng = np.random.default_rng(4)
+    scene = rt.scenes.cover_scene()
+    ctx.upload_scene(scene.desc())
+    cases = []
+    w, h = 96, 54
+    r = rt.sample_batch_host(ctx, rt.scenes.make_params(scene, w, h, spp=5, trace_depth=8))
+    cases.append((w, h, r["color"], r["normal"], r["albedo"]))
+    w, h = 41, 29
+    n = w * h
+    color = np.concatenate([rng.uniform(0, 40, (n, 3)), rng.integers(0, 6, (n, 1))], axis=1).astype(np.float32)
+    color[np.repeat(np.arange(h) % 3 != 0, w), 3] = 0
+    color[7, 1] = np.nan
+    cases.append((w, h, color, rng.normal(size=(n, 3)).astype(np.float32), rng.uniform(0, 3, (n, 3)).astype(np.float32)))
+    for w, h, color, normal, albedo in cases:
+        n = w * h
+        for debug, ldr in ((False, True), (True, False), (False, False)):
+            ins = [_dev(rt, ctx, x) for x in (color, normal, albedo)]
+            r8 = [rt.DeviceBuffer(ctx, n * 4).zero() for _ in range(3)]
+            cp = a.CombineParams(w, h, int(debug), int(ldr))
+            rt.lib.check(lib.rtowCombineFinalizeDevice(ctx.handle, C.byref(cp), ins[0].ptr, ins[1].ptr, ins[2].ptr, r8[0].ptr, r8[1].ptr, r8[2].ptr, None), "rtowCombineFinalizeDevice")
+            ctx.synchronize()
+            oc, on, oa = oracle.combine(w, h, color, normal, albedo, debug, ldr)
+            want = oracle.finalize(oc, on, oa)
+            for got, wv, name in zip(r8, want, ("color", "normal", "albedo")):
+                assert np.array_equal(got.download(np.uint8, (n, 4)), wv), (w, h, debug, ldr, name)
+            # and the two separate passes
+            f3 = [rt.DeviceBuffer(ctx, n * 12) for _ in range(3)]
+            s8 = [rt.DeviceBuffer(ctx, n * 4).zero() for _ in range(3)]
+            rt.lib.check(lib.rtowCombineDevice(ctx.handle, C.byref(cp), ins[0].ptr, ins[1].ptr, ins[2].ptr, f3[0].ptr, f3[1].ptr, f3[2].ptr, None), "rtowCombineDevice")
+            rt.lib.check(lib.rtowFinalizeDevice(ctx.handle, n, f3[0].ptr, f3[1].ptr, f3[2].ptr, s8[0].ptr, s8[1].ptr, s8[2].ptr, None), "rtowFinalizeDevice")
+            ctx.synchronize()
+            for got, sep in zip(r8, s8):
+                assert np.array_equal(got.download(np.uint8, (n, 4)), sep.download(np.uint8, (n, 4)))
+            for b in ins + r8 + f3 + s8:
+                b.free()
+    cp = a.CombineParams(0, 4, 0, 0)
+    assert lib.rtowCombineFinalizeDevice(ctx.handle, C.byref(cp), 1, 1, 1, 1, 1, 1, None) == a.RTOW_ERROR_INVALID_VALUE
+
+
+@pytest.mark.parametrize("n", [1, 3, 255, 256, 1000, 96 * 54, 1920 * 1080])
+def test_add_accum_is_one_exact_pass_over_the_four_buffers(rt, gpu_context, n):
+    """rtowAddAccumDevice: dst += src, element for element one float32 addition, whatever the sizes and alignments of the four buffers (views into larger
+    allocations at odd float offsets take the unaligned path)."""
+    ctx = gpu_context
+    a = rt.abi
+    lib = rt.lib.load()
+    rng = np.random.default_rng(n)
+    comps = (4, 3, 3, 1)
+    for shift in (0, 1):                                      # shift 1: every buffer starts 4 bytes into its allocation
+        dst = [rng.normal(size=n * c + shift).astype(np.float32) for c in comps]
+        src = [rng.normal(size=n * c + shift).astype(np.float32) for c in comps]
+        dd = [_dev(rt, ctx, x) for x in dst]
+        ds = [_dev(rt, ctx, x) for x in src]
+        bd = a.AccumBuffers(*[b.ptr + 4 * shift for b in dd])
+        bs = a.AccumBuffers(*[b.ptr + 4 * shift for b in ds])
+        rt.lib.check(lib.rtowAddAccumDevice(ctx.handle, n, C.byref(bd), C.byref(bs), None), "rtowAddAccumDevice")
+        ctx.synchronize()
+        for d, s_, b, c in zip(dst, src, dd, comps):
+            got = b.download(np.float32, (n * c + shift,))
+            want = d.copy()
+            want[shift:] = d[shift:] + s_[shift:]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, shift, c)
+        for b in dd + ds:
+            b.free()
+
+
+def test_reduce_metrics_async_writes_the_record_in_stream_order(rt, oracle, gpu_context):
+    """rtowReduceMetricsDeviceAsync: the same numbers as the blocking form and the oracle, written by the device into registered host memory and into device
+    memory; pageable host memory is refused."""
+    ctx = gpu_context
+    a = rt.abi
+    lib = rt.lib.load()
+    rng = np.random.default_rng(8)
+    n = 320 * 180
+    diag = rng.integers(0, 3000, (n, 4)).astype(np.float32)
+    color = np.concatenate([rng.uniform(0, 40, (n, 3)), rng.integers(0, 300, (n, 1))], axis=1).astype(np.float32)
+    scw = rng.uniform(0, 50, n).astype(np.float32)
+    dd, dc, ds = _dev(rt, ctx, diag), _dev(rt, ctx, color), _dev(rt, ctx, scw)
+    want = oracle.reduce_metrics(diag, color, scw)
+
+    def same(m):
+        return ((m.totalRayCount, m.totalSamples, m.totalRayCount64, m.totalSamples64, m.sampleCountExtrema[0], m.sampleCountExtrema[1]) ==
+                (want.totalRayCount, want.totalSamples, want.totalRayCount64, want.totalSamples64, want.sampleCountExtrema[0], want.sampleCountExtrema[1]) and
+                np.float32(m.sampleCountWeightExtrema.x) == np.float32(want.sampleCountWeightExtrema.x) and np.float32(m.sampleCountWeightExtrema.y) == np.float32(want.sampleCountWeightExtrema.y))
+
+    blocking = a.Metrics()
+    rt.lib.check(lib.rtowReduceMetricsDevice(ctx.handle, n, dd.ptr, 16, dc.ptr, ds.ptr, None, C.byref(blocking)), "rtowReduceMetricsDevice")
+    assert same(blocking)
+    # registered host memory: a numpy array that holds the record
+    host = np.zeros(C.sizeof(a.Metrics) // 4 + 16, np.uint32)
+    ctx.register_host_buffers(host)
+    for rep in range(3):                                      # back to back: the per-context partials are ordered by the library
+        rt.lib.check(lib.rtowReduceMetricsDeviceAsync(ctx.handle, n, dd.ptr, 16, dc.ptr, ds.ptr, None, host.ctypes.data), "rtowReduceMetricsDeviceAsync")
+    ctx.synchronize()
+    assert same(a.Metrics.from_buffer_copy(host.tobytes()[:C.sizeof(a.Metrics)]))
+    ctx.unregister_host_buffers()
+    # device memory
+    dm = rt.DeviceBuffer(ctx, C.sizeof(a.Metrics)).zero()
+    rt.lib.check(lib.rtowReduceMetricsDeviceAsync(ctx.handle, n, dd.ptr, 16, dc.ptr, ds.ptr, None, dm.ptr), "rtowReduceMetricsDeviceAsync")
+    ctx.synchronize()
+    assert same(a.Metrics.from_buffer_copy(dm.download(np.uint8, (C.sizeof(a.Metrics),)).tobytes()))
+    pageable = np.zeros(64, np.uint32)
+    assert lib.rtowReduceMetricsDeviceAsync(ctx.handle, n, dd.ptr, 16, dc.ptr, ds.ptr, None, pageable.ctypes.data) == a.RTOW_ERROR_INVALID_VALUE
+    for b in (dd, dc, ds, dm):
+        b.free()
