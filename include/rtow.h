@@ -185,9 +185,9 @@ typedef struct RtowSceneInfo {
                                        0 where no ray can need it.  Grow-only per context; RtowContextOptions.hitListCapacity sizes it */
     int32_t hitListCapacity;        /* most surfaces one ray may meet in this scene before the batch reports RTOW_ERROR_CAPACITY (0: only the nearest hit is kept) */
     int32_t wideCodes;              /* 1: more than 65 535 entities or tree nodes - the kernels that keep 32-bit candidate / stack codes run (tree read from HBM) */
-    int32_t thresholdSet;           /* stage thresholds in use for this scene: -1 the built-in ones of its kernel kind (nothing measured yet, tiny frames, tuning off, or
-                                       RtowContextOptions.schedulerTune given); 0 / 1 / 2 the sphere family / the general family / the general family with REGEN and SKY
-                                       from 1/8, as measured by the first batch; 3 / 4 / 5 the same with the volume stage waiting too (RTOW_CONTEXT_NO_THRESHOLD_TUNING) */
+    int32_t thresholdSet;           /* stage thresholds in use for this scene: -1 the built-in ones of its kernel kind (nothing measured yet - the probes of a measurement may be in
+                                       flight -, too few samples asked for so far, tuning off, or RtowContextOptions.schedulerTune given); 0 / 1 / 2 the sphere family / the general family /
+                                       the general family with REGEN and SKY from 1/8, as measured (or as measured earlier for a like scene); 3 / 4 / 5 the same with the volume stage waiting too */
     int32_t schedulerTune[9];       /* the values themselves (REGEN TRAV TEST HIT SKY VOL | hand-over count | - | walk slice), as RtowContextOptions.schedulerTune would set them */
 } RtowSceneInfo;
 
@@ -307,9 +307,10 @@ typedef enum RtowContextFlags {
     RTOW_CONTEXT_NO_CHUNK_ORDER = 1u << 4,         /* development: hand out pixel chunks in row order, not most-expensive-first */
     RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5,       /* development: run the scene through the kernels with 32-bit candidate / stack codes (every scene kind has them)
                                                     * (what scenes beyond 65 535 entities or tree nodes use; the tree is then read from HBM) */
-    RTOW_CONTEXT_NO_THRESHOLD_TUNING = 1u << 6     /* keep the built-in stage thresholds of the scene's kernel kind.  By default the first batch after rtowUploadScene measures
-                                                    * three (volume scenes: six) threshold sets with 4-sample probes of its own frame - a few milliseconds to ~0.1 s, waited for
-                                                    * inside that call, once per scene - and keeps the fastest; thresholds are pure scheduling and never change a result */
+    RTOW_CONTEXT_NO_THRESHOLD_TUNING = 1u << 6     /* keep the built-in stage thresholds of the scene's kernel kind.  By default a scene that has been asked for 64 samples per pixel
+                                                    * since its upload gets three (volume scenes: six) threshold sets measured with 4-sample probes of the batch's own frame, enqueued in front
+                                                    * of that batch and timed with events that a LATER call reads - no call waits for them - and the fastest set runs from then on; a re-upload of
+                                                    * a scene of the same kind and size reuses what was measured.  Thresholds are pure scheduling and never change a result */
 } RtowContextFlags;
 
 typedef struct RtowContextOptions {
@@ -320,9 +321,9 @@ typedef struct RtowContextOptions {
     uint32_t flags;                 /* RtowContextFlags, 0 = defaults */
     int32_t ldsSceneBudgetBytes;    /* development: cap on the bytes of scene image staged into LDS (0 = all that fits); smaller scenes then run
                                      * through the kernels that read the tree from HBM */
-    int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL), the number of candidates at which
-                                     * a box walk hands over to the exact tests (1 .. 7), one unused value, and the box-walk slice (node visits per trip);
-                                     * all zero = the built-in values, measured per scene */
+    int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL; values below 1 mean 1 = any lane), the number of
+                                     * candidates at which a box walk hands over to the exact tests (1 .. 7; 0 = the built-in 3), one unused value, and the box-walk slice (node visits
+                                     * per trip; 0 = the built-in value of the scene); all zero = everything built in, thresholds measured per scene */
     int32_t hitListCapacity;        /* most surfaces one ray may meet where every hit of a ray is kept (scenes with ProbabilisticVolume materials, and
                                      * the exact-tie procedure): the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71);
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per

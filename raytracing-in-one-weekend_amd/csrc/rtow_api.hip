@@ -49,6 +49,7 @@
 // time, gpurun_out/r03ay).  Thresholds never change a result (tests/test_gpu_fullsize.py: frames under every schedule).  The call that tunes
 // waits for its probes (a few milliseconds to ~0.1 s, once per scene); RTOW_CONTEXT_NO_THRESHOLD_TUNING keeps the per-kind values above.
 constexpr int kTuneProbeSamples = 4, kTuneProbeRepeats = 3;
+constexpr uint64_t kTuneMinSamplesPerPixel = 64;    // ... and the scene must have been asked for this many samples per pixel since its upload before it is worth 40 - 76 of probes
 constexpr float kTuneMargin = 0.98f;      // a candidate replaces the kind's built-in family only if its best probe is more than 2 % faster: single probes (1 - 10 ms)
                                           // scatter by a few per cent, and a wrong pick costs more than a missed one (10 000 spheres: family 2 picked once in r03bw, -7 %)
 
@@ -113,7 +114,7 @@ struct RtowContext_t {
     RtowCubemapDesc cubemap{};   // .faces is not kept (host pointer): dCubemap holds the copy, null when none
     // camera-ray candidate lists (primary_candidates_kernel): valid for one (scene upload, view, size, slice, jitter) configuration
     uint2* dPixCand = nullptr;
-    size_t pixCandCapacity = 0;
+    size_t pixCandCapacity = 0;           // bytes
     bool pixCandValid = false;
     uint64_t sceneSerial = 0, pixCandScene = 0;
     RtowView pixCandView{};
@@ -132,8 +133,18 @@ struct RtowContext_t {
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
     int tune[9] = {RTOW_DEFAULT_TUNE};
     bool userTune = false;                // RtowContextOptions.schedulerTune was given: no per-scene adjustment
+    bool userSliceDefault = false;        // ... with a zero walk slice: the per-scene built-in value
     uint64_t tunedScene = ~0ull;          // sceneSerial whose thresholds were measured (tuneThresholds)
     int tunedCandidate = -1;              // which candidate won (rtowGetSceneInfo-independent; logged)
+    bool tunePending = false;             // probes of scene tunePendingScene are enqueued; their events are read by a later call, never waited for
+    uint64_t tunePendingScene = 0;
+    int tuneCandidates = 0, tuneBuiltin = 0;
+    std::vector<hipEvent_t> tuneEvents;
+    uint32_t* dProbeSink = nullptr;       // where probes report rays beyond the hit-list capacity (not the batch's flag)
+    uint64_t sppSinceUpload = 0;          // samples per pixel this scene has been asked for since its upload: a measurement must be worth its probes
+    uint64_t sceneSignatureNow = 0;       // of the current scene
+    struct TuneCacheEntry { uint64_t signature; int winner; };
+    std::vector<TuneCacheEntry> tuneCache;   // winners by scene signature: a re-upload of a like scene does not measure again
 
     // rtowRegisterHostBuffer: pinned + device-mapped ranges of caller memory
     struct HostRange { uint8_t* base; size_t size; uint8_t* device; };
@@ -201,6 +212,61 @@ int ownedRows(const RtowSampleParams* p)
 // batch 0's; p->seed and diag are ignored then)
 // outs (optional): a batch group - batch b stores to outs[b] and every batch reads `in` (rtowSampleBatchGroupDevice); null: a chain, batch b reads what b - 1 stored to `out`
 struct ChainSpec { int count; const uint32_t* seeds; void* const* diags; const RtowAccumBuffers* outs; };
+
+// per-scene threshold measurement (launchSample): forget a measurement in flight (new scene, context going away)
+void dropThresholdTuning(RtowContext ctx)
+{
+    for (auto& e : ctx->tuneEvents) if (e) (void)hipEventDestroy(e);
+    ctx->tuneEvents.clear();
+    ctx->tunePending = false;
+}
+
+// Which scenes get the same thresholds without being measured again: a host that re-uploads on every scene edit (sceneSerial moves) keeps what was
+// measured for a scene of the same kernel kind and size.
+uint64_t sceneSignature(const CompiledScene& sc, bool wide)
+{
+    return ((uint64_t)sc.layout.sceneKind << 60) ^ ((uint64_t)(sc.layout.exactTies ? 1 : 0) << 59) ^ ((uint64_t)(wide ? 1 : 0) << 58) ^ ((uint64_t)sc.layout.nodeCount << 29) ^
+           (uint64_t)(uint32_t)sc.entityCount ^ ((uint64_t)sc.layout.materialCount << 44);
+}
+
+// read the probes' events if they are all complete (wait == false: otherwise leave them for a later call) and switch to the fastest candidate; true = thresholds changed or confirmed
+bool finishThresholdTuning(RtowContext ctx, bool wait)
+{
+    if (!ctx->tunePending || ctx->tuneEvents.empty()) return false;
+    const hipError_t q = wait ? hipEventSynchronize(ctx->tuneEvents.back()) : hipEventQuery(ctx->tuneEvents.back());
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return false; }
+    constexpr int kFamilies = 3;
+    static const int kSets[kFamilies][9] = {{RTOW_DEFAULT_TUNE}, {RTOW_GENERAL_TUNE}, {RTOW_GENERAL_TUNE_2}};
+    const int candidates = ctx->tuneCandidates, builtin = ctx->tuneBuiltin;
+    bool ok = q == hipSuccess;
+    float best = 0.0f, builtinMs = 0.0f;
+    int winner = -1;
+    for (int c = 0; ok && c < candidates; c++) {
+        float t = 0.0f;
+        for (int r = 0; r < kTuneProbeRepeats; r++) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ctx->tuneEvents[(size_t)(r * candidates + c)], ctx->tuneEvents[(size_t)(r * candidates + c) + 1]) != hipSuccess) { ms = 1e30f; (void)hipGetLastError(); }
+            t = (r == 0 || ms < t) ? ms : t;
+        }
+        if (c == builtin) builtinMs = t;
+        if (winner < 0 || t < best) { best = t; winner = c; }
+    }
+    if (ok && winner >= 0) {
+        if (winner != builtin && !(best < kTuneMargin * builtinMs)) { winner = builtin; best = builtinMs; }
+        for (int k = 0; k < 8; k++) ctx->tune[k] = kSets[winner % kFamilies][k];
+        if (winner >= kFamilies) ctx->tune[5] = 32;
+        ctx->tunedCandidate = winner;
+        ctx->tuneCache.push_back({ctx->sceneSignatureNow, winner});
+        logf(ctx, 4, "tune", "stage thresholds measured on this scene: candidate %d of %d (%.3f ms per %d-sample probe)", winner, candidates, best, kTuneProbeSamples);
+    } else {
+        (void)hipGetLastError();
+        ctx->tunedCandidate = -1;
+        logf(ctx, 2, "tune", "threshold probes failed; the per-kind values stay");
+    }
+    ctx->tunedScene = ctx->tunePendingScene;                    // measured (or not measurable): do not try again for this scene
+    dropThresholdTuning(ctx);
+    return true;
+}
 
 int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuffers* in, const RtowAccumBuffers* out, void* diag,
                  hipStream_t stream, bool useCancelFlag, const ChainSpec* chain = nullptr)
@@ -327,12 +393,13 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     // ---- camera-ray candidate lists: one conservative beam walk per pixel, reused by all its samples (and by later batches of the same view) ----
     if (!(ctx->flags & RTOW_CONTEXT_NO_CAMERA_RAY_LISTS)) {
         const size_t pixels = (size_t)a.width * (size_t)a.height;
-        if (pixels > ctx->pixCandCapacity) {
+        const size_t listBytes = pixels * (ctx->wideCodes ? sizeof(uint4) : sizeof(uint2));      // 4 x 16-bit node codes per pixel; 4 x 32-bit with wide codes
+        if (listBytes > ctx->pixCandCapacity) {
             if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
             ctx->dPixCand = nullptr;
             ctx->pixCandCapacity = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dPixCand, pixels * sizeof(uint4)), RTOW_ERROR_MEMORY_ALLOCATION);   // uint2 records; uint4 with wide codes
-            ctx->pixCandCapacity = pixels;
+            HIP_TRY(ctx, hipMalloc(&ctx->dPixCand, listBytes), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->pixCandCapacity = listBytes;
             ctx->pixCandValid = false;
         }
         const bool same = ctx->pixCandValid && ctx->pixCandScene == ctx->sceneSerial && memcmp(&ctx->pixCandView, &a.view, sizeof(RtowView)) == 0 &&
@@ -344,11 +411,11 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             HIP_TRY(ctx, launchPrimaryCandidates(perPixel, ctx->dPixCand, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->pixCandValid = true;
 #ifdef RTOW_STATS
-            if (const char* dump = getenv("RTOW_DUMP_PRIMARY_LISTS")) {      // development aid: the lists as raw uint2[width * height]
-                std::vector<uint2> host(pixels);
+            if (const char* dump = getenv("RTOW_DUMP_PRIMARY_LISTS")) {      // development aid: the lists as raw uint2 (wide codes: uint4) [width * height]
+                std::vector<uint8_t> host(listBytes);
                 (void)hipStreamSynchronize(stream);
-                (void)hipMemcpy(host.data(), ctx->dPixCand, pixels * sizeof(uint2), hipMemcpyDeviceToHost);
-                if (FILE* f = fopen(dump, "wb")) { fwrite(host.data(), sizeof(uint2), pixels, f); fclose(f); }
+                (void)hipMemcpy(host.data(), ctx->dPixCand, listBytes, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(dump, "wb")) { fwrite(host.data(), 1, listBytes, f); fclose(f); }
             }
 #endif
             ctx->pixCandScene = ctx->sceneSerial;
@@ -401,60 +468,58 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         a.chunkOrder = haveOrder ? ctx->dChunkOrder : nullptr;
 
         // ---- stage thresholds: measured once per scene on this batch's own kernel, frame and view (see kTuneProbeSamples) ----
-        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;                   // a stream that is being captured into a graph cannot be waited on: no measurement then
+        // Never waited for: the probes are enqueued in front of a batch, timed with events, and a LATER call that finds the last event complete reads them
+        // and switches the thresholds (scheduling only: no result depends on when that happens).  Until then the kernel kind's built-in values run.
+        for (int k = 0; k < 8; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
+        if (ctx->tunePending && ctx->tunePendingScene == ctx->sceneSerial && finishThresholdTuning(ctx, /*wait*/ false))
+            for (int k = 0; k < 8; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
+        ctx->sppSinceUpload += (uint64_t)a.chainCount * (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;                   // a stream that is being captured into a graph cannot carry the event pairs: no measurement then
         if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
-        if (!ctx->userTune && !(ctx->flags & RTOW_CONTEXT_NO_THRESHOLD_TUNING) && ctx->tunedScene != ctx->sceneSerial && !a.unitRecords && haveOrder &&
-            capturing == hipStreamCaptureStatusNone) {
+        // worth it only where the scene is rendered for longer than the probes take (3 or 6 candidates x 3 repeats x 4 samples per pixel: 40 - 76 samples per
+        // pixel): a one-shot render of a few samples per pixel (BASELINE.json configs[0]: 8) must not pay several times its own work first
+        const bool worthIt = ctx->sppSinceUpload >= kTuneMinSamplesPerPixel;
+        if (!ctx->userTune && !(ctx->flags & RTOW_CONTEXT_NO_THRESHOLD_TUNING) && ctx->tunedScene != ctx->sceneSerial && !ctx->tunePending && !a.unitRecords && haveOrder &&
+            worthIt && capturing == hipStreamCaptureStatusNone) {
             constexpr int kFamilies = 3;
             static const int kSets[kFamilies][9] = {{RTOW_DEFAULT_TUNE}, {RTOW_GENERAL_TUNE}, {RTOW_GENERAL_TUNE_2}};     // (the ninth value, the walk slice, is set by rtowUploadScene)
             const bool volumes = a.layout.sceneKind == SCENE_KIND_VOLUMES || a.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
             const int candidates = volumes ? 2 * kFamilies : kFamilies;                      // volume kinds: each family also with the volume stage from half of the live lanes
             const int launches = candidates * kTuneProbeRepeats;
-            std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
+            ctx->tuneEvents.assign((size_t)launches + 1, nullptr);
             bool ok = true;
-            for (auto& e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+            for (auto& e : ctx->tuneEvents) ok = ok && hipEventCreate(&e) == hipSuccess;
+            if (!ctx->dProbeSink) ok = ok && hipMalloc(&ctx->dProbeSink, 64) == hipSuccess;
             SampleKernelArgs probe = a;
             probe.probeOnly = kTuneProbeSamples;
             probe.pixelCost = nullptr;                           // the cost map stays the cost probe's (or the previous batch's)
             probe.cancelFlag = nullptr;
+            probe.overflowFlag = ctx->dProbeSink;                // a probe's ray beyond the hit-list capacity is not the batch's (which may trace fewer samples than a probe)
             probe.chainCount = 1;
+            probe.chainIndependent = 0;
             // one untimed probe first: clocks, L2 and the instruction cache are warm before the first timed one
             for (int k = 0; k < 8; k++) probe.tune[k] = kSets[0][k];
             if (ok) ok = hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream) == hipSuccess && launchSampleBatch(probe, blocks, stream) == hipSuccess;
-            if (ok) ok = hipEventRecord(ev[0], stream) == hipSuccess;
+            if (ok) ok = hipEventRecord(ctx->tuneEvents[0], stream) == hipSuccess;
             for (int l = 0; ok && l < launches; l++) {
                 const int c = l % candidates;
                 for (int k = 0; k < 8; k++) probe.tune[k] = kSets[c % kFamilies][k];
                 if (c >= kFamilies) probe.tune[5] = 32;
                 ok = hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream) == hipSuccess && launchSampleBatch(probe, blocks, stream) == hipSuccess &&
-                     hipEventRecord(ev[(size_t)l + 1], stream) == hipSuccess;
+                     hipEventRecord(ctx->tuneEvents[(size_t)l + 1], stream) == hipSuccess;
             }
-            if (ok) ok = hipEventSynchronize(ev[(size_t)launches]) == hipSuccess;
             if (ok) {
-                const int builtin = a.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? 0 : 1;       // what rtowUploadScene set for this kernel kind
-                float best = 0.0f, builtinMs = 0.0f;
-                int winner = -1;
-                for (int c = 0; c < candidates; c++) {
-                    float t = 0.0f;
-                    for (int r = 0; r < kTuneProbeRepeats; r++) {
-                        float ms = 0.0f;
-                        if (hipEventElapsedTime(&ms, ev[(size_t)(r * candidates + c)], ev[(size_t)(r * candidates + c) + 1]) != hipSuccess) ms = 1e30f;
-                        t = (r == 0 || ms < t) ? ms : t;
-                    }
-                    if (c == builtin) builtinMs = t;
-                    if (winner < 0 || t < best) { best = t; winner = c; }
-                }
-                if (winner != builtin && !(best < kTuneMargin * builtinMs)) { winner = builtin; best = builtinMs; }
-                for (int k = 0; k < 8; k++) ctx->tune[k] = kSets[winner % kFamilies][k];
-                if (winner >= kFamilies) ctx->tune[5] = 32;
-                for (int k = 0; k < 8; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
-                ctx->tunedCandidate = winner;
-                logf(ctx, 4, "tune", "stage thresholds measured on this scene: candidate %d of %d (%.3f ms per %d-sample probe)", winner, candidates, best, kTuneProbeSamples);
+                ctx->tunePending = true;
+                ctx->tunePendingScene = ctx->sceneSerial;
+                ctx->tuneCandidates = candidates;
+                ctx->tuneBuiltin = a.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? 0 : 1;       // what rtowUploadScene set for this kernel kind
+            } else {
+                (void)hipGetLastError();
+                dropThresholdTuning(ctx);
+                ctx->tunedCandidate = -1;
+                ctx->tunedScene = ctx->sceneSerial;             // not measurable: do not try again for this scene
+                logf(ctx, 2, "tune", "threshold probes failed; the per-kind values stay");
             }
-            for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-            if (!ok) ctx->tunedCandidate = -1;
-            ctx->tunedScene = ctx->sceneSerial;                 // measured (or not measurable): do not try again for this scene
-            if (!ok) { (void)hipGetLastError(); logf(ctx, 2, "tune", "threshold probes failed; the per-kind values stay"); }
         }
     }
 
@@ -782,7 +847,12 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
         ctx->hitListCapacity = (uint32_t)options->hitListCapacity;
         bool anyTune = false;
         for (int i = 0; i < 9; i++) anyTune = anyTune || options->schedulerTune[i] != 0;
-        if (anyTune) for (int i = 0; i < 9; i++) ctx->tune[i] = options->schedulerTune[i] < 1 ? 1 : options->schedulerTune[i];
+        if (anyTune) {
+            // stage thresholds below 1 mean "any lane" (1); a zero hand-over count or walk slice means "the built-in value" (3; per scene at upload), as in API v6
+            for (int i = 0; i < 9; i++) ctx->tune[i] = options->schedulerTune[i] < 1 ? 1 : options->schedulerTune[i];
+            if (options->schedulerTune[6] < 1) ctx->tune[6] = 3;
+            ctx->userSliceDefault = options->schedulerTune[8] < 1;
+        }
         ctx->userTune = anyTune;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
@@ -827,6 +897,8 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dUnitRecords) (void)hipFree(ctx->dUnitRecords);
     if (ctx->dPartials) (void)hipFree(ctx->dPartials);
     if (ctx->dByteThresholds) (void)hipFree(ctx->dByteThresholds);
+    dropThresholdTuning(ctx);
+    if (ctx->dProbeSink) (void)hipFree(ctx->dProbeSink);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
     if (ctx->dDiag) (void)hipFree(ctx->dDiag);
@@ -933,6 +1005,8 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         const int* base = compiled.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? kDefault : kGeneral;      // measured per family: see RTOW_DEFAULT_TUNE
         for (int k = 0; k < 9; k++) ctx->tune[k] = base[k];
         if (compiled.layout.nodeCount > 65535u) ctx->tune[8] = 24;
+    } else if (ctx->userSliceDefault) {
+        ctx->tune[8] = compiled.layout.nodeCount > 65535u ? 24 : 16;
     }
     ctx->scene = std::move(compiled);
     uint32_t budget = (uint32_t)(kLdsBytesMax - (wide ? kStackBytesWide : kStackBytes) - kQueueBytes);
@@ -950,6 +1024,19 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     ctx->haveScene = true;
     ctx->sceneSerial++;
     ctx->orderValid = false;
+    dropThresholdTuning(ctx);                                   // (the device is idle: rtowUploadScene synchronised it above)
+    ctx->sppSinceUpload = 0;
+    ctx->sceneSignatureNow = sceneSignature(ctx->scene, wide);
+    if (!ctx->userTune && !(ctx->flags & RTOW_CONTEXT_NO_THRESHOLD_TUNING))
+        for (const RtowContext_t::TuneCacheEntry& e : ctx->tuneCache)
+            if (e.signature == ctx->sceneSignatureNow) {
+                // a scene like one this context has measured before (same kernel kind, entity / node / material counts): its thresholds, no new probes
+                static const int kSets[3][9] = {{RTOW_DEFAULT_TUNE}, {RTOW_GENERAL_TUNE}, {RTOW_GENERAL_TUNE_2}};
+                for (int k = 0; k < 8; k++) ctx->tune[k] = kSets[e.winner % 3][k];
+                if (e.winner >= 3) ctx->tune[5] = 32;
+                ctx->tunedCandidate = e.winner;
+                ctx->tunedScene = ctx->sceneSerial;
+            }
     logf(ctx, 4, "scene", "%d entities, %u BVH nodes, depth %u, %u bytes (%u in LDS)%s", ctx->scene.entityCount, ctx->scene.layout.nodeCount,
          ctx->scene.layout.bvhDepth, ctx->scene.layout.totalBytes, ctx->ldsSceneBytes,
          ctx->scene.layout.exactTies ? ", exact-tie kernels" : "");
@@ -1041,6 +1128,7 @@ RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
     if (!ctx || !info) return RTOW_ERROR_INVALID_VALUE;
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    if (ctx->tunePending && hipSetDevice(ctx->device) == hipSuccess) (void)finishThresholdTuning(ctx, /*wait*/ false);     // a measurement whose probes are done by now
     info->entityCount = ctx->scene.entityCount;
     info->materialCount = ctx->scene.materialCount;
     info->bvhNodeCount = (int32_t)ctx->scene.layout.nodeCount;

@@ -158,11 +158,12 @@ def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, name):
 
 
 @pytest.mark.parametrize("name", ["cover", "mixed", "volumes", "textured"])
-def test_stage_thresholds_are_measured_per_scene_and_change_nothing(rt, gpu_context, name):
-    """The first batch after an upload measures the candidate threshold sets with probes of its own frame and keeps the fastest
-    (csrc/rtow_api.hip: kTuneProbeSamples; RtowSceneInfo.thresholdSet / schedulerTune say which).  Probes store nothing and thresholds are
-    scheduling only: the frame equals the one of a context that keeps the built-in values (RTOW_CONTEXT_NO_THRESHOLD_TUNING), bit for bit, as
-    do the next batch on top of it and a chained launch.  Tiny frames are not worth a measurement; thresholds given by the caller are kept."""
+def test_stage_thresholds_are_measured_per_scene_and_change_nothing(rt, name):
+    """A scene that has been asked for 64 samples per pixel gets the candidate threshold sets measured with probes of the batch's own frame, enqueued in front of
+    that batch; no call waits for them - a later call reads their events and keeps the fastest (csrc/rtow_api.hip: kTuneProbeSamples, finishThresholdTuning;
+    RtowSceneInfo.thresholdSet / schedulerTune say which).  Probes store nothing and thresholds are scheduling only: every frame equals the one of a context that
+    keeps the built-in values (RTOW_CONTEXT_NO_THRESHOLD_TUNING), bit for bit - the batch in front of which the probes ran, the batches after the switch, a chained
+    launch.  Few samples are not worth a measurement; a re-upload of the same scene reuses what was measured; thresholds given by the caller are kept."""
     a = rt.abi
     S = rt.scenes
     scene = {"cover": S.cover_scene, "mixed": S.mixed_scene, "volumes": S.volume_scene, "textured": S.textured_scene}[name]()
@@ -170,49 +171,76 @@ def test_stage_thresholds_are_measured_per_scene_and_change_nothing(rt, gpu_cont
     w, h = 1280, 720
     n = w * h
     focus = 6.5 if name == "volumes" else None
-    p = rt.scenes.make_params(scene, w, h, spp=4, trace_depth=8, focus=focus)
-    gpu_context.upload_scene(desc)
-    assert gpu_context.scene_info().thresholdSet == -1                      # nothing measured before the first batch
-    tuned = _device_render(rt, gpu_context, p, n, 4)
-    info = gpu_context.scene_info()
-    assert 0 <= info.thresholdSet < (6 if name == "volumes" else 3)
-    fam = {0: [24, 32, 1, 32, 28], 1: [16, 48, 1, 1, 1], 2: [8, 48, 1, 1, 8]}
-    sets = {k: fam[k % 3] + [32 if k >= 3 else 1] for k in range(6)}          # (+ hand-over count 3, unused, walk slice)
-    assert list(info.schedulerTune)[:6] == sets[info.thresholdSet]
-    again = _device_render(rt, gpu_context, p, n, 4)                        # measured once per scene: the choice stays
-    assert gpu_context.scene_info().thresholdSet == info.thresholdSet
-    with rt.Context(0, flags=a.CONTEXT_NO_THRESHOLD_TUNING) as ctx:
+    few = rt.scenes.make_params(scene, w, h, spp=4, trace_depth=8, focus=focus)
+    many = rt.scenes.make_params(scene, w, h, spp=64, trace_depth=8, focus=focus, seed=5)
+    with rt.Context(0) as ctx, rt.Context(0, flags=a.CONTEXT_NO_THRESHOLD_TUNING) as plain_ctx:
         ctx.upload_scene(desc)
-        plain = _device_render(rt, ctx, p, n, 4)
-        assert ctx.scene_info().thresholdSet == -1
-    for k in ("color", "normal", "albedo", "scw", "diag"):
-        assert np.array_equal(tuned[k].view(np.uint32), plain[k].view(np.uint32)), (name, k)
-        assert np.array_equal(again[k].view(np.uint32), plain[k].view(np.uint32)), (name, "second batch", k)
-    # a new upload is a new scene: measured again; a chained first launch measures too and equals the batches one after the other
-    gpu_context.upload_scene(desc)
-    assert gpu_context.scene_info().thresholdSet == -1
-    plist = [rt.scenes.make_params(scene, w, h, spp=3, trace_depth=8, seed=s, focus=focus) for s in (3, 4)]
-    bufs = [rt.DeviceBuffer(gpu_context, n * c * 4).zero() for c in (4, 3, 3, 1)]
-    rt.lib.check(rt.sample_batch_chain_device(gpu_context, plist, bufs, bufs), "rtowSampleBatchChainDevice")
-    gpu_context.synchronize()
-    assert gpu_context.scene_info().thresholdSet >= 0
-    chained = [b.download(np.uint32, (n, c)) for b, c in zip(bufs, (4, 3, 3, 1))]
-    with rt.Context(0, scheduler_tune=(16, 48, 1, 1, 28, 1, 1, 1, 16)) as ctx:
+        plain_ctx.upload_scene(desc)
+        assert ctx.scene_info().thresholdSet == -1                          # nothing measured before the first batch
+        r_few = _device_render(rt, ctx, few, n, 4)
+        assert ctx.scene_info().thresholdSet == -1                          # 4 samples per pixel: not worth 40 - 76 of probes
+        r_many = _device_render(rt, ctx, many, n, 4)                        # 68 asked for by now: the probes run in front of this batch ...
+        info = ctx.scene_info()                                             # ... and are over (the render was waited for): this call reads them
+        assert 0 <= info.thresholdSet < (6 if name == "volumes" else 3)
+        fam = {0: [24, 32, 1, 32, 28], 1: [16, 48, 1, 1, 1], 2: [8, 48, 1, 1, 8]}
+        sets = {k: fam[k % 3] + [32 if k >= 3 else 1] for k in range(6)}      # (+ hand-over count 3, unused, walk slice)
+        assert list(info.schedulerTune)[:6] == sets[info.thresholdSet]
+        r_after = _device_render(rt, ctx, few, n, 4)                        # with the measured thresholds
+        assert ctx.scene_info().thresholdSet == info.thresholdSet           # measured once per scene: the choice stays
+        for params, got, what in ((few, r_few, "before the measurement"), (many, r_many, "the batch the probes ran in front of"), (few, r_after, "after the switch")):
+            want = _device_render(rt, plain_ctx, params, n, 4)
+            assert plain_ctx.scene_info().thresholdSet == -1
+            for k in ("color", "normal", "albedo", "scw", "diag"):
+                assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (name, what, k)
+        # a new upload of the same scene: what was measured for it is reused, at once, without probes
+        ctx.upload_scene(desc)
+        assert ctx.scene_info().thresholdSet == info.thresholdSet
+        # a chained launch equals the batches one after the other on a context with the caller's own thresholds
+        plist = [rt.scenes.make_params(scene, w, h, spp=3, trace_depth=8, seed=s, focus=focus) for s in (3, 4)]
+        bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+        rt.lib.check(rt.sample_batch_chain_device(ctx, plist, bufs, bufs), "rtowSampleBatchChainDevice")
+        ctx.synchronize()
+        chained = [b.download(np.uint32, (n, c)) for b, c in zip(bufs, (4, 3, 3, 1))]
+    with rt.Context(0, scheduler_tune=(16, 48, 1, 1, 28, 1, 0, 1, 0)) as ctx:
         ctx.upload_scene(desc)
         seq = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
-        for q in plist:
+        for q in plist + [many]:
             job = rt.SampleBatchJob(ctx, q)
             job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = seq
             job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = seq
             rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
+            if q is plist[-1]:
+                ctx.synchronize()
+                for got, b, c in zip(chained, seq, (4, 3, 3, 1)):
+                    assert np.array_equal(got, b.download(np.uint32, (n, c))), (name, "chain")
         ctx.synchronize()
-        assert ctx.scene_info().thresholdSet == -1 and list(ctx.scene_info().schedulerTune) == [16, 48, 1, 1, 28, 1, 1, 1, 16]      # the caller's values are kept
-        for got, b, c in zip(chained, seq, (4, 3, 3, 1)):
-            assert np.array_equal(got, b.download(np.uint32, (n, c))), (name, "chain")
-    # a frame too small to be worth a measurement keeps the built-in values
-    gpu_context.upload_scene(desc)
-    _device_render(rt, gpu_context, rt.scenes.make_params(scene, 64, 36, spp=2, trace_depth=4, focus=focus), 64 * 36, 4)
-    assert gpu_context.scene_info().thresholdSet == -1
+        # the caller's values are kept (a zero hand-over count / walk slice = the built-in 3 / 16), nothing is measured however many samples are asked for
+        assert ctx.scene_info().thresholdSet == -1 and list(ctx.scene_info().schedulerTune) == [16, 48, 1, 1, 28, 1, 3, 1, 16]
+
+
+def test_threshold_probes_do_not_block_and_do_not_report_overflow(rt):
+    """the call in front of which the probes are enqueued returns at once (no hipEventSynchronize under the context's lock), and a probe's ray beyond
+    the hit-list capacity is not blamed on the batch: a volume scene with the smallest capacity, batches of ONE sample per pixel (probes trace four)."""
+    import time
+    S = rt.scenes
+    scene = S.cover_scene()
+    w, h = 1920, 1080
+    n = w * h
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene.desc())
+        bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+        p = rt.scenes.make_params(scene, w, h, spp=256, trace_depth=8)
+        job = rt.SampleBatchJob(ctx, p)
+        job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = bufs
+        job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = bufs
+        rt.lib.check(job.Schedule().Complete(), "warm-up")                   # cost probe, chunk order; 256 samples asked for: the next call measures
+        ctx.synchronize()
+        t = time.perf_counter()
+        rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")     # probes (10 launches) + a 60 ms batch are enqueued ...
+        dt = time.perf_counter() - t
+        assert dt < 0.02, dt                                                 # ... and the call does not wait for any of it
+        ctx.synchronize()
+        assert ctx.scene_info().thresholdSet >= 0
 
 
 @pytest.mark.parametrize("name,spp", [("cover", 6), ("stress", 4), ("moving", 4)])
