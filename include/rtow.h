@@ -307,6 +307,9 @@ typedef enum RtowContextFlags {
     RTOW_CONTEXT_NO_CHUNK_ORDER = 1u << 4,         /* development: hand out pixel chunks in row order, not most-expensive-first */
     RTOW_CONTEXT_FORCE_WIDE_CODES = 1u << 5,       /* development: run the scene through the kernels with 32-bit candidate / stack codes (every scene kind has them)
                                                     * (what scenes beyond 65 535 entities or tree nodes use; the tree is then read from HBM) */
+    RTOW_CONTEXT_NO_CHAIN_FUSION = 1u << 7,        /* run chained batches (rtowSampleBatchChain*) one launch per batch - what a context does by itself when its same-XCD hand-over
+                                                    * litmus fails (rtowCreateContext measures, on the device it runs on, that plain stores + sc1 loads hand data over inside an XCD
+                                                    * the way a chained launch relies on; logged at level 4, a failure at level 3).  Same results either way */
     RTOW_CONTEXT_NO_THRESHOLD_TUNING = 1u << 6     /* keep the built-in stage thresholds of the scene's kernel kind.  By default a scene that has been asked for 64 samples per pixel
                                                     * since its upload gets three (volume scenes: six) threshold sets measured with 4-sample probes of the batch's own frame, enqueued in front
                                                     * of that batch and timed with events that a LATER call reads - no call waits for them - and the fastest set runs from then on; a re-upload of

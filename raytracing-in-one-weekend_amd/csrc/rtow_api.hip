@@ -134,6 +134,7 @@ struct RtowContext_t {
     int tune[9] = {RTOW_DEFAULT_TUNE};
     bool userTune = false;                // RtowContextOptions.schedulerTune was given: no per-scene adjustment
     bool userSliceDefault = false;        // ... with a zero walk slice: the per-scene built-in value
+    bool chainFusion = true;              // the same-XCD hand-over litmus passed on this device (rtowCreateContext): chains may run as one launch
     uint64_t tunedScene = ~0ull;          // sceneSerial whose thresholds were measured (tuneThresholds)
     int tunedCandidate = -1;              // which candidate won (rtowGetSceneInfo-independent; logged)
     bool tunePending = false;             // probes of scene tunePendingScene are enqueued; their events are read by a later call, never waited for
@@ -765,7 +766,7 @@ int enqueueChain(RtowContext ctx, int count, const RtowSampleParams* params, con
 {
     // One launch needs batches that differ in nothing but Seed (the reference's successive batches of a frame: UNITY/Raytracer.cs:656-661),
     // the reference RNG policy (per-sample units fold through records) and a frame of fewer than 2^27 padded pixels.
-    bool fusable = params[0].rngPolicy == RTOW_RNG_REFERENCE;
+    bool fusable = params[0].rngPolicy == RTOW_RNG_REFERENCE && ctx->chainFusion;
     for (int b = 1; b < count && fusable; b++) {
         RtowSampleParams q = params[b];
         q.seed = params[0].seed;
@@ -872,6 +873,17 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     ctx->hCancel[0] = 0u;
     ctx->hCancel[1] = 0u;
     logf(ctx, 4, "rtow", "context on device %d (%s, %d CUs)", ordinal, prop.gcnArchName, ctx->cuCount);
+    // chained launches hand accumulators over inside an XCD with plain stores + sc1 loads: measured on THIS device before it is relied on
+    if (ctx->flags & RTOW_CONTEXT_NO_CHAIN_FUSION) {
+        ctx->chainFusion = false;
+    } else {
+        unsigned pairs = 0, stale = 0, timeouts = 0;
+        const hipError_t le = runXcdCoherenceLitmus(ctx->cuCount, ctx->stream, &pairs, &stale, &timeouts);
+        ctx->chainFusion = le == hipSuccess && pairs > 0 && stale == 0 && timeouts == 0;
+        if (le != hipSuccess) (void)hipGetLastError();
+        logf(ctx, ctx->chainFusion ? 4 : 3, "rtow", "same-XCD hand-over litmus: %u pairs, %u stale dwords, %u timeouts%s", pairs, stale, timeouts,
+             ctx->chainFusion ? "" : " - chained batches will run one launch per batch");
+    }
     *outContext = ctx;
     return RTOW_SUCCESS;
 }

@@ -228,6 +228,9 @@ hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsig
 hipError_t launchFoldRows(float* accum, const float* ownPartial, const float* recv, size_t regionFloats, unsigned rowFloats, unsigned rows, unsigned first, unsigned step,
                           unsigned groups, unsigned own, hipStream_t stream);
 
+// same-XCD hand-over litmus of the chained launches (rtow_kernels.hip): pairs of workgroups that ran on one XCD, stale dwords seen, waits that timed out
+hipError_t runXcdCoherenceLitmus(int cuCount, hipStream_t stream, unsigned* outPairs, unsigned* outStale, unsigned* outTimeouts);
+
 // Per-block partial results of the metrics reduction; the host folds them in block order.
 struct MetricsPartial {
     long long rays, samples;

@@ -479,7 +479,117 @@ __global__ void __launch_bounds__(256) fold_metrics_kernel(const MetricsPartial*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Same-XCD hand-over litmus (run once per context, rtowCreateContext).  A chained launch hands a pixel chunk's accumulators from batch b to batch b + 1 inside
+// the running kernel with PLAIN stores + s_waitcnt vmcnt(0) on the writing side and sc1 loads on the reading side, both on the XCD that owns the chunk
+// (rtow_sample_kernel.hip.h, "Chained batches").  That those loads see those stores is measured behaviour of this part (profiles/calib/xcd_affinity_probe.hip),
+// not an architectural guarantee - a partition mode, firmware or memory-type change could break it silently.  So the context measures it on the device it
+// runs on: workgroups pair up by the XCD they land on (s_getreg XCC_ID), the writer of a pair fills 1 KiB with the round number exactly like the sample kernel
+// stores a pixel, publishes a flag; the reader - which read the same lines a round earlier, so its L1 and the L2 hold them - reads them back exactly like the
+// sample kernel loads a pixel.  Any stale dword, or a pair that does not finish, and the context runs chains batch by batch instead (rtow_api.hip).
+// Every wait is bounded: a litmus must not be able to hang the device.
+// state: [0] registered workgroups, [1..16] workgroups per XCD, [17] stale dwords, [18] timeouts, [19] pairs that ran
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) xcd_coherence_litmus_kernel(unsigned* state, unsigned* flag, unsigned* ack, unsigned* data, int rounds, unsigned pairsPerXcd)
+{
+    constexpr int kSpin = 1 << 18;
+    __shared__ unsigned shRole, shXcd, shGo;
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 15u;
+        shXcd = x;
+        shRole = atomicAdd(&state[1 + x], 1u);
+        __threadfence();
+        atomicAdd(&state[0], 1u);
+        int spins = 0;
+        while (__hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < kSpin) __builtin_amdgcn_s_sleep(4);
+        const unsigned total = __hip_atomic_load(&state[1 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned go = spins < kSpin ? 1u : 0u;
+        if (!go) atomicAdd(&state[18], 1u);
+        if ((shRole | 1u) >= total || (shRole >> 1) >= pairsPerXcd) go = 0u;           // no partner on this XCD (odd count) or beyond the buffers
+        shGo = go;
+    }
+    __syncthreads();
+    if (!shGo) return;
+    const bool writer = (shRole & 1u) == 0u;
+    const unsigned pair = shXcd * pairsPerXcd + (shRole >> 1);
+    unsigned* d = data + (size_t)pair * 256u + threadIdx.x * 4u;
+    unsigned stale = 0;
+    bool timedOut = false;
+    for (int r = 1; r <= rounds && !timedOut; r++) {
+        if (writer) {
+            d[0] = (unsigned)r; d[1] = (unsigned)r; d[2] = (unsigned)r; d[3] = (unsigned)r;              // plain (write-back) stores, like a pixel's accumulators
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");                                          // coherent_flush()
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(flag + pair * 32u, (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (__hip_atomic_load(ack + pair * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)r && ++spins < kSpin) __builtin_amdgcn_s_sleep(2);
+                shGo = spins < kSpin ? 1u : 0u;
+            }
+            __syncthreads();
+            timedOut = shGo == 0u;
+        } else {
+            if (threadIdx.x == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(flag + pair * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)r && ++spins < kSpin) __builtin_amdgcn_s_sleep(2);
+                shGo = spins < kSpin ? 1u : 0u;
+            }
+            __syncthreads();
+            timedOut = shGo == 0u;
+            if (!timedOut) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                u4 q;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(d) : "memory");      // coherent_load4()
+                stale += (q.x != (unsigned)r) + (q.y != (unsigned)r) + (q.z != (unsigned)r) + (q.w != (unsigned)r);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(ack + pair * 32u, (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+    }
+    if (timedOut && threadIdx.x == 0) atomicAdd(&state[18], 1u);
+    if (!writer) {
+        if (stale) atomicAdd(&state[17], stale);
+        if (threadIdx.x == 0 && !timedOut) atomicAdd(&state[19], 1u);
+    }
+}
+
 } // namespace
+
+hipError_t runXcdCoherenceLitmus(int cuCount, hipStream_t stream, unsigned* outPairs, unsigned* outStale, unsigned* outTimeouts)
+{
+    const unsigned grid = (unsigned)(cuCount * 2 < 64 ? 64 : (cuCount * 2 > 1024 ? 1024 : cuCount * 2));
+    const unsigned pairsPerXcd = grid / 2;
+    const int rounds = 48;
+    unsigned *state = nullptr, *flag = nullptr, *ack = nullptr, *data = nullptr;
+    const size_t pairs = (size_t)kMaxXcds * pairsPerXcd;
+    hipError_t e = hipMalloc(&state, 32 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&flag, pairs * 32 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&ack, pairs * 32 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&data, pairs * 256 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(state, 0, 32 * sizeof(unsigned), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(flag, 0, pairs * 32 * sizeof(unsigned), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ack, 0, pairs * 32 * sizeof(unsigned), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(data, 0, pairs * 256 * sizeof(unsigned), stream);
+    unsigned host[32] = {0};
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(xcd_coherence_litmus_kernel, dim3(grid), dim3(64), 0, stream, state, flag, ack, data, rounds, pairsPerXcd);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, state, sizeof(host), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (state) (void)hipFree(state);
+    if (flag) (void)hipFree(flag);
+    if (ack) (void)hipFree(ack);
+    if (data) (void)hipFree(data);
+    *outPairs = host[19]; *outStale = host[17]; *outTimeouts = host[18];
+    return e;
+}
 
 hipError_t launchCombineFinalize(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
                                  uint8_t* outColor, uint8_t* outNormal, uint8_t* outAlbedo, const float* thresholds, hipStream_t stream)

@@ -1387,7 +1387,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                         if (mine != 0u && t < mine * (C.chainCount - 1u)) {
                                             b = 1u + t / mine;
                                             chunk = __hip_atomic_load(list + (t - (b - 1u) * mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                            exhausted = false;
+                                            exhausted = chunk >= C.chunkCount;       // 0xffffffff = an entry that was never written: cannot happen once `listed` is complete - and if it
+                                                                                     // ever did, the ticket is dropped (the host sees a batch that did not finish its pixels) rather than read as a chunk
                                         }
                                     }
                                 }

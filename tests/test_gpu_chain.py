@@ -273,3 +273,27 @@ def test_cancelled_chain_returns_promptly_and_leaves_the_context_usable(rt, gpu_
         b.free()
     small = _params(rt, scene, 160, 90, 3, 8, [11, 12, 13])
     _same(_chained(rt, ctx, small, 160 * 90, 4), _sequential(rt, ctx, small, 160 * 90, 4), "after the cancelled chains")
+
+
+def test_same_xcd_handover_litmus_runs_at_context_creation_and_chains_fall_back_without_it(rt):
+    """the chained launch's hand-over (plain stores + sc1 loads inside one XCD) is measured behaviour, so every context measures it on its own device
+    (rtowCreateContext: pairs of workgroups per XCD, 48 rounds) and logs the outcome; RTOW_CONTEXT_NO_CHAIN_FUSION is what a context does when the litmus
+    fails - chains run one launch per batch, same result."""
+    log = []
+    S = rt.scenes
+    scene = S.cover_scene()
+    w, h, n = 320, 180, 320 * 180
+    plist = _params(rt, scene, w, h, 4, 8, [5, 6, 7], diagnostics_stride=4)
+    with rt.Context(0, log=lambda lvl, tag, msg, ud: log.append((lvl, msg.decode())), log_level=4) as ctx:
+        lines = [m for _, m in log if "same-XCD hand-over litmus" in m]
+        assert len(lines) == 1, log
+        pairs, stale, timeouts = (int(x) for x in __import__("re").findall(r"(\d+) pairs, (\d+) stale dwords, (\d+) timeouts", lines[0])[0])
+        assert pairs >= 64 and stale == 0 and timeouts == 0, lines[0]          # 512 workgroups over 8 XCDs: 256 pairs when they all find a partner
+        ctx.upload_scene(scene.desc())
+        fused = _chained(rt, ctx, plist, n, 4)
+    with rt.Context(0, flags=rt.abi.CONTEXT_NO_CHAIN_FUSION) as ctx:
+        ctx.upload_scene(scene.desc())
+        unfused = _chained(rt, ctx, plist, n, 4)
+        seq = _sequential(rt, ctx, plist, n, 4)
+    _same(fused, seq, "fused chain")
+    _same(unfused, seq, "chain run batch by batch")
