@@ -289,9 +289,6 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.totalWork = (uint32_t)ownedRows(p) * (uint32_t)a.width;
     a.tilesPerRow = (RTOW_TICKET_TILES && a.width % (int)kTileW == 0) ? (uint32_t)a.width / kTileW : 0u;
     a.tiledPixels = a.tilesPerRow ? ((uint32_t)ownedRows(p) / kTileH) * kTileH * (uint32_t)a.width : 0u;
-#ifdef RTOW_EXPERIMENT_SCATTER_TICKETS
-    if (p->sliceDivider > 1) { a.tilesPerRow = 0u; a.tiledPixels = a.totalWork; }      // timing experiment: see owned_pixel_xy
-#endif
     a.sizeX = p->size.x; a.sizeY = p->size.y;
     a.sliceOffset = p->sliceOffset; a.sliceDivider = p->sliceDivider;
     a.seed = chain ? chain->seeds[0] : p->seed;
@@ -340,14 +337,6 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice (RtowContextOptions.schedulerTune overrides)
     for (int i = 0; i < 8; i++) a.tune[i] = ctx->tune[i] < 1 ? 1 : ctx->tune[i];
     a.travSlice = ctx->tune[8] < 1 ? 1 : ctx->tune[8];
-    a.stats = nullptr;
-#ifdef RTOW_STATS
-    static unsigned long long* dStats = nullptr;
-    if (!dStats) (void)hipMalloc(&dStats, 32768 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dStats, 0, 32768 * sizeof(unsigned long long), stream);
-    a.stats = dStats;
-    a.debugPixel = getenv("RTOW_DEBUG_PIXEL") ? atoi(getenv("RTOW_DEBUG_PIXEL")) : -2;
-#endif
     const uint32_t ownedPixels = a.totalWork;
     if (ownedPixels == 0) {
         // a slice that owns no row (SliceOffset >= height): Execute returns for every index (JOBS/SampleBatchJob.cs:69-70) - nothing is
@@ -411,14 +400,6 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             perPixel.totalWork = ownedPixels;
             HIP_TRY(ctx, launchPrimaryCandidates(perPixel, ctx->dPixCand, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->pixCandValid = true;
-#ifdef RTOW_STATS
-            if (const char* dump = getenv("RTOW_DUMP_PRIMARY_LISTS")) {      // development aid: the lists as raw uint2 (wide codes: uint4) [width * height]
-                std::vector<uint8_t> host(listBytes);
-                (void)hipStreamSynchronize(stream);
-                (void)hipMemcpy(host.data(), ctx->dPixCand, listBytes, hipMemcpyDeviceToHost);
-                if (FILE* f = fopen(dump, "wb")) { fwrite(host.data(), 1, listBytes, f); fclose(f); }
-            }
-#endif
             ctx->pixCandScene = ctx->sceneSerial;
             ctx->pixCandView = a.view;
             ctx->pixCandW = a.width; ctx->pixCandH = a.height; ctx->pixCandOff = a.sliceOffset; ctx->pixCandDiv = a.sliceDivider;
@@ -570,52 +551,6 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evBatchDone, stream), RTOW_ERROR_LAUNCH_FAILURE);
     ctx->haveBatchDone = true;
-#ifdef RTOW_STATS
-    {
-        unsigned long long h[16];
-        (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(h, a.stats, sizeof(h), hipMemcpyDeviceToHost);
-        static const char* names[16] = {"trips*64", "regen runs*64", "regen lanes", "walk iters", "walk lanes", "test iters", "test lanes", "hit runs*64", "hit lanes",
-                                        "lambert runs", "lambert lanes", "general runs", "general lanes", "diel runs", "diel lanes", "sky runs*lanes"};
-        for (int i = 0; i < 16; i++) fprintf(stderr, "[stats] %-16s %llu\n", names[i], h[i]);
-        unsigned long long w[3];
-        (void)hipMemcpy(w, a.stats + 16, sizeof(w), hipMemcpyDeviceToHost);
-        {
-            unsigned long long st[8];
-            (void)hipMemcpy(st, a.stats + 24, sizeof(st), hipMemcpyDeviceToHost);
-            static const char* stageNames[8] = {"regen", "walk", "test", "hit", "sky", "vol", "vol probe", "scheduler"};
-            unsigned long long total = 0;
-            for (int i = 0; i < 8; i++) total += st[i];
-            for (int i = 0; i < 8; i++) if (st[i]) fprintf(stderr, "[stats] wave time in %-10s %5.1f %%\n", stageNames[i], 100.0 * (double)st[i] / (double)(total ? total : 1));
-        }
-        if (getenv("RTOW_DEBUG_PIXEL")) {
-            std::vector<unsigned long long> t(8 * 500 + 8);
-            (void)hipMemcpy(t.data(), a.stats + 5000, 8 * 500 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            unsigned long long cnt = 0; (void)hipMemcpy(&cnt, a.stats + 20, 8, hipMemcpyDeviceToHost);
-            for (unsigned long long k = 0; k < cnt && k < 500; k++) { float tv; unsigned tb = (unsigned)t[k * 8 + 4]; memcpy(&tv, &tb, 4);
-                fprintf(stderr, "[trace] smp %llu depth %llu kind %llu prim %llu t %.9g curVol %d nHits %llu rng %llu\n", t[k*8], t[k*8+1], t[k*8+2], t[k*8+3], tv, (int)t[k*8+5], t[k*8+6], t[k*8+7]); }
-        }
-        if (w[2]) fprintf(stderr, "[stats] wave residency: mean %.3f ms, max %.3f ms over %llu waves -> tail idle fraction %.3f\n", w[0] / (double)w[2] / 1e5, w[1] / 1e5, w[2],
-                          1.0 - (w[0] / (double)w[2]) / (double)w[1]);
-        {
-            std::vector<unsigned long long> r(4096);
-            (void)hipMemcpy(r.data(), a.stats + 32, r.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            std::sort(r.begin(), r.end());
-            {
-                std::vector<unsigned long long> rec(4096 * 4);
-                (void)hipMemcpy(rec.data(), a.stats + 9000, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-                std::vector<int> idx(4096);
-                for (int i = 0; i < 4096; i++) idx[i] = i;
-                std::sort(idx.begin(), idx.end(), [&](int x, int y) { return rec[x * 4] > rec[y * 4]; });
-                for (int k = 0; k < 4096; k += (k < 16 ? 1 : 512))
-                    fprintf(stderr, "[stats] wave #%d by end time: last pixel ended %.2f ms, started %.2f ms (took %.2f), %llu rays, ticket %llu (chunk %llu)\n", k, rec[idx[k] * 4] / 1e5,
-                            rec[idx[k] * 4 + 1] / 1e5, (rec[idx[k] * 4] - rec[idx[k] * 4 + 1]) / 1e5, rec[idx[k] * 4 + 2], rec[idx[k] * 4 + 3], rec[idx[k] * 4 + 3] / 64);
-            }
-            fprintf(stderr, "[stats] residency quantiles ms: min %.2f p10 %.2f p25 %.2f p50 %.2f p75 %.2f p90 %.2f p99 %.2f max %.2f\n", r[0] / 1e5, r[409] / 1e5, r[1024] / 1e5,
-                    r[2048] / 1e5, r[3072] / 1e5, r[3686] / 1e5, r[4055] / 1e5, r[4095] / 1e5);
-        }
-    }
-#endif
     ctx->haveTiming = true;
     return RTOW_SUCCESS;
 }

@@ -75,9 +75,6 @@ __global__ void __launch_bounds__(256) build_byte_thresholds_kernel(float* __res
 // T[k], T[k + 1] -> fix-up, with the (one) mixed zone handled after all of them by a wave-rare branch into an out-of-line copy of the exact
 // form.  Nine inlined copies of "estimate, read, wait, read, wait, or else the exact form" serialised 18 LDS round trips per pixel behind
 // branches and held the kernel at 4.4 TB/s (profiles/r03zb_post_passes.json).
-#ifndef RTOW_FINALIZE_EXPERIMENT
-#define RTOW_FINALIZE_EXPERIMENT 0      // 1: no table fix-up, 2: no transcendentals, 3: both - timing-only builds (wrong bytes), never shipped
-#endif
 // A mixed zone [first, end) of non-negative floats as a range of bit patterns (ordered like the floats): x is inside iff bits(x) - first < end - first
 // as unsigned numbers - a subtraction and one comparison per operand.  No zone (NaN, NaN in the table): length 0.
 struct ByteZones { unsigned first[kByteZones], length[kByteZones]; };
@@ -110,20 +107,12 @@ __device__ __forceinline__ void to_bytes_table(const float (&v)[N], unsigned (&o
         mixed[c] = m;
         any = any | m;
         // estimate: exp2(log2(x) / 2.4) on the transcendental unit (x = 0: log2 = -inf, exp2 = 0); any error below one step is repaired next
-#if RTOW_FINALIZE_EXPERIMENT & 2
-        const float g = x;                                        // TIMING EXPERIMENT ONLY (wrong bytes): no transcendentals
-#else
         const float g = 1.055f * __builtin_amdgcn_exp2f(0.416666667f * __builtin_amdgcn_logf(x)) - 0.055f;
-#endif
         const float s = __builtin_amdgcn_fmed3f(g, 0.0f, 1.0f);   // clamp; a NaN estimate (NaN operand) gives 0 or NaN here and k = 0 either way
         const int k = (int)(s * 255.0f);
-#if RTOW_FINALIZE_EXPERIMENT & 1
-        out[c] = (unsigned)k;                                     // TIMING EXPERIMENT ONLY (wrong bytes): no table fix-up
-#else
         const float lo = T[k], hi = T[k + 1];                     // one ds_read2_b32; T[256] = NaN never compares
         // at most one of the two holds (T[k] < T[k + 1]); written as a sum so that both thresholds are read up front, not one behind a branch
         out[c] = (unsigned)(k + (x >= hi ? 1 : 0) - (x < lo ? 1 : 0));
-#endif
     }
     if (any) {
 #pragma unroll

@@ -66,11 +66,6 @@ constexpr unsigned kTileW = RTOW_TICKET_TILE_W, kTileH = 64u / kTileW;
 static_assert(kTileW * kTileH == 64u && (kTileW & (kTileW - 1u)) == 0u, "a tile is one 64-ticket chunk");
 __host__ __device__ inline void owned_pixel_xy(unsigned n, unsigned width, unsigned tilesPerRow, unsigned tiledPixels, int& cx, int& ownedRow)
 {
-#ifdef RTOW_EXPERIMENT_SCATTER_TICKETS
-    // TIMING EXPERIMENT ONLY (same image): consecutive tickets are pixels far apart (a multiplicative permutation of the owned pixels; 17017 = 7 * 11 * 13 * 17
-    // shares no factor with the frame sizes tried), so every wave gets its share of the expensive pixels instead of a whole tile of them
-    if (tilesPerRow == 0u && tiledPixels != 0u) { n = (unsigned)(((unsigned long long)n * 17017ull) % tiledPixels); tiledPixels = 0u; }
-#endif
     if (n < tiledPixels) {
         const unsigned tile = n >> 6, i = n & 63u;
         const unsigned ty = tile / tilesPerRow, tx = tile - ty * tilesPerRow;
@@ -177,8 +172,6 @@ struct SampleKernelArgs {
     // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice
     int32_t tune[8];
     int32_t travSlice;
-    unsigned long long* stats; // development statistics (RTOW_STATS builds only), may be null
-    int32_t debugPixel;        // RTOW_STATS builds: pixel whose path segments are traced
 };
 
 struct KernelInfo {

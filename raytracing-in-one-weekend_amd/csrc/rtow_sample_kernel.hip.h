@@ -42,10 +42,6 @@
 #ifndef RTOW_EXACT_MATH
 #define RTOW_EXACT_MATH 1
 #endif
-// ballot / prefix-sum compaction of the exact tests (TEST stage, sphere kinds): see the stage.  0 = every lane loops over its own candidates
-#ifndef RTOW_COMPACT_TESTS
-#define RTOW_COMPACT_TESTS 0
-#endif
 #if RTOW_EXACT_MATH
 #define RTOW_RCP(x) rtow::exact_rcp(x)
 #define RTOW_RCP_NAN_TO_INF(x) rtow::exact_rcp_nan_to_inf(x)
@@ -815,8 +811,6 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// Development-only wave-level statistics (make stats -> librtow_hip_stats.so): how often each stage runs and with how
-// many lanes.  Compiled out of the product build.
 // Wave priority per stage (s_setprio at every stage entry; two bits per stage number: REGEN TRAV TEST HIT SKY VOL - scheduler).  The exact
 // tests run with a third of the lanes through dependent sqrt / division chains; letting a wave in that stage issue ahead of its three
 // SIMD neighbours gets it back to the walk sooner: +2 ... +3.5 % on the headline workload, same box, alternating runs (DESIGN.md 4.1,
@@ -827,23 +821,14 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 // (The first build with these instructions exposed a miscompiled tie update in the general-entity kernels - see the TEST stage - which
 // is how that one was found; with the update written as selects every variant equals the oracle with and without them.)
 #define STAGE_PRIO(k) do { if ((RTOW_STAGE_PRIO) != 0) __builtin_amdgcn_s_setprio((short)(((RTOW_STAGE_PRIO) >> (2 * (k))) & 3)); } while (0)
-#ifdef RTOW_STATS
-#define STAT_DECL unsigned long long stat[16] = {0}
-#define STAT_ADD(i, v) stat[i] += (unsigned long long)(v)
-#define STAT_LANES(i) stat[i] += 1ull
-// wall time (100 MHz ticks) per stage, wave level: the time since the previous mark belongs to the stage marked then (7 = scheduler)
-#define STAGE_DECL unsigned long long stageT[8] = {0}; unsigned long long stLast = wall_clock64(); int stCur = 7
-#define STAGE_MARK(k) do { const unsigned long long n_ = wall_clock64(); stageT[stCur] += n_ - stLast; stLast = n_; stCur = (k); STAGE_PRIO(k); } while (0)
-// per-segment trace of one pixel: {smp, depth, kind, prim, t bits, curVol, nHits, rng}
-#define DBG_TRACE(kind, primv, tv) do { if (A.stats && pix == A.debugPixel) { const unsigned long long k_ = atomicAdd(&A.stats[20], 1ull); if (k_ < 500) { unsigned long long* d_ = A.stats + 5000 + k_ * 8; d_[0] = smp; d_[1] = (unsigned)depth; d_[2] = (kind); d_[3] = (unsigned)(primv); d_[4] = __float_as_uint(tv); d_[5] = (unsigned)curVol; d_[6] = (unsigned)nHits; d_[7] = rng.trace_value(); } } } while (0)
-#else
+// instrumentation hooks: empty in the product.  profiles/experiments/instrumentation.patch (applied by profiles/experiments/build.sh to a COPY of this
+// directory, never to the shipped sources) defines them for the stage-statistics build and adds the timing experiments of HISTORY.md.
 #define DBG_TRACE(kind, primv, tv)
 #define STAT_DECL
 #define STAGE_DECL
 #define STAGE_MARK(k) STAGE_PRIO(k)
 #define STAT_ADD(i, v)
 #define STAT_LANES(i)
-#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // path history: one 16-bit code per surface hit (bit 15 = "reflectance was overridden to 1", bits 0..14 = material).
@@ -1218,10 +1203,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     unsigned trip = 0;          // chained batches only: paces the polls of parked lanes
     STAT_DECL;
     STAGE_DECL;
-#ifdef RTOW_STATS
-    const unsigned long long statT0 = wall_clock64();
-    unsigned long long pixT0 = statT0;
-#endif
     for (;;) {
         STAT_ADD(0, 1);
         STAGE_MARK(7);
@@ -1257,13 +1238,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     const SampleKernelArgs& C = *coldArgs;
                     const unsigned tk = chained ? (tick & kChainTicketMask) : tick;      // owned-pixel (unit) number inside its batch
                     const unsigned batch = chained ? (tick >> kChainShift) : 0u;         // which batch of the chain the finished pixel belongs to
-#ifdef RTOW_STATS
-                    if (pix >= 0 && C.stats) {
-                        // last pixel this wave finished: {end, start, rays, tick} (100 MHz ticks since the wave started); later stores overwrite earlier ones
-                        unsigned long long* rec = C.stats + 9000 + (size_t)(blockIdx.x * (BT / 64) + (threadIdx.x >> 6)) * 4;
-                        rec[0] = wall_clock64() - statT0; rec[1] = pixT0 - statT0; rec[2] = (unsigned long long)rayCount; rec[3] = tick;
-                    }
-#endif
                     if (pix >= 0 && C.pixelCost) {
                         // cost map for the next launch's chunk order: this pixel's ray count, in ticket order (a plain 2-byte store that
                         // merges in L2 with its chunk's other 63; per-chunk atomics cost a memory-side transaction each)
@@ -1423,15 +1397,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     const unsigned newBatch = chained ? (ticket >> kChainShift) : 0u;
                     if (chained) ticket &= kChainTicketMask;
                     if (PER_SAMPLE) { unitGroup = ticket % C.groupsPerPixel; ticket = ticket / C.groupsPerPixel; }   // unit = (owned pixel, sample group)
-#ifdef RTOW_STATS
-                    pixT0 = wall_clock64();
-#endif
-#ifdef RTOW_EXPERIMENT_COHERENT_WAVES
-                    // TIMING EXPERIMENT ONLY (wrong image): all 64 lanes of a chunk trace the chunk's FIRST pixel - same seed, same paths, so every lane of a
-                    // wave is in the same stage on every trip and every loop runs with all 64 lanes.  Rays per second of this build is the ceiling of ANY
-                    // regrouping of rays between lanes (walk, exact tests and shading at once; DESIGN.md 4.1 "Regrouping").
-                    ticket &= ~63u;
-#endif
                     int ownedRow;
                     owned_pixel_xy(ticket, (unsigned)C.width, C.tilesPerRow, C.tiledPixels, cx, ownedRow);   // a chunk's 64 tickets: an 8 x 8 tile of the owned pixels (rtow_kernels.h), or a strip
                     cy = C.sliceOffset + ownedRow * C.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
@@ -1608,22 +1573,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     // inner child (padded box): conservative, pruned by the nearest hit so far.  Leaf child (the reference's own entity box):
                     // AxisAlignedBoundingBox.Hit itself, tMin < tMax (RT/HitTests.cs:15-20) - pruning by `best` on top (<=, so that a tie at
                     // exactly `best` is still tested) cannot change which hit is nearest.
-#ifdef RTOW_EXPERIMENT_DOUBLE_WALK
-                    // TIMING EXPERIMENT ONLY (same image): the slab arithmetic of the visit a second time on laundered operands (see RTOW_EXPERIMENT_DOUBLE_TEST)
-                    {
-                        f2 ix = invx, iy = invy, iz = invz;
-                        asm volatile("" : "+v"(ix), "+v"(iy), "+v"(iz));
-                        const f2 ulx = (f2{q0.x, q0.y} - ox) * ix, uhx = (f2{q1.z, q1.w} - ox) * ix;
-                        const f2 uly = (f2{q0.z, q0.w} - oy) * iy, uhy = (f2{q2.x, q2.y} - oy) * iy;
-                        const f2 ulz = (f2{q1.x, q1.y} - oz) * iz, uhz = (f2{q2.z, q2.w} - oz) * iz;
-                        const float um0 = vmax3(vmin(ulx.x, uhx.x), vmin(uly.x, uhy.x), vmax(vmin(ulz.x, uhz.x), 0.0f));
-                        const float uf0 = vmin3(vmax(ulx.x, uhx.x), vmax(uly.x, uhy.x), vmax(ulz.x, uhz.x));
-                        const float um1 = vmax3(vmin(ulx.y, uhx.y), vmin(uly.y, uhy.y), vmax(vmin(ulz.y, uhz.y), 0.0f));
-                        const float uf1 = vmin3(vmax(ulx.y, uhx.y), vmax(uly.y, uhy.y), vmax(ulz.y, uhz.y));
-                        const bool g0 = um0 <= vmin(uf0, bestPrune), g1 = um1 <= vmin(uf1, bestPrune);
-                        asm volatile("" : : "v"((int)g0), "v"((int)g1), "v"(um0 < uf0 ? 1.0f : 0.0f), "v"(um1 < uf1 ? 1.0f : 0.0f));
-                    }
-#endif
                     const bool hit0 = tmin0 <= vmin(tfar0, bestPrune);
                     const bool hit1 = tmin1 <= vmin(tfar1, bestPrune) && twoChildren;
                     const bool leaf0 = c0 < 0 && hit0 && tmin0 < tfar0, leaf1 = c1 < 0 && hit1 && tmin1 < tfar1;
@@ -1652,94 +1601,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
             ran = true;
             STAGE_MARK(2);
             // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
-#if RTOW_COMPACT_TESTS
-            // ---- ballot / prefix-sum compaction of the candidate tests (sphere kinds without the exact-tie resolver, 16-bit codes) ----
-            // The loop below runs max(nc) iterations with a third of the lanes.  Here the wave's candidates - (owner lane, list slot) pairs - are
-            // numbered with a prefix sum over the lanes' counts (bit-sliced ballots), written as a dense list into two unused rows of the traversal
-            // stack, and tested 64 at a time: lane j of a round takes item 64 r + j, pulls the owner's ray through ds_bpermute, runs the same
-            // sphere_at / sphere_hit on it and hands (t, rank, primitive) back as one 64-bit key; the owner takes the minimum of its items' keys
-            // and its own (best, rank[prim], prim): the lexicographic minimum over (t, rank) is exactly what the sequential
-            // `t <= best && (t < best || rank[i] < rank[prim])` update leaves, whatever the order (ranks are unique).  Same float program per test,
-            // same result; only which lane evaluates it changes.
-            constexpr bool kCompactTests = !GENERAL && !VOLUMES && !EXACT_TIES && !WIDE;
-            if (kCompactTests && L.bvhDepth <= RTOW_STACK_CAPACITY - 3) {
-                const int lane = tid & 63;
-                const unsigned cnt = st == ST_TEST ? (unsigned)nc : 0u;
-                // exclusive prefix sum of cnt (0..8) over the wave, total in an SGPR
-                unsigned start = 0, total = 0;
-                for (int bit = 0; bit < 4; bit++) {
-                    const unsigned long long m = __ballot((cnt >> bit) & 1u);
-                    start += (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << bit;
-                    total += (unsigned)__popcll(m) << bit;
-                }
-                if (FULL_DIAG && !refDiag) candidates += (float)cnt;
-                // the dense list: byte g = owner lane of item g, in rows 22 and 23 of this wave's slice of the stack (never reached: depth <= 21)
-                unsigned char* const itemList = reinterpret_cast<unsigned char*>(reinterpret_cast<Code*>(smem) + (RTOW_STACK_CAPACITY - 2) * BT) + (tid >> 6) * 256;
-                const unsigned long long ownerKey = st == ST_TEST && prim >= 0
-                    ? ((unsigned long long)__float_as_uint(best) << 32) | (reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset))[prim] << 16) | (unsigned)prim
-                    : ((unsigned long long)__float_as_uint(best) << 32) | 0xffffffffull;
-                unsigned long long bestKey = ownerKey;
-                const float a = dot(rd, rd);
-                const unsigned kmax = (unsigned)(32 - __builtin_clz(((__ballot(cnt & 8u) ? 8u : 0u) | (__ballot(cnt & 4u) ? 4u : 0u) | (__ballot(cnt & 2u) ? 2u : 0u) | (__ballot(cnt & 1u) ? 1u : 0u)) | 1u)) ;
-                (void)kmax;
-                for (unsigned base = 0; base < total; base += 256u) {                       // a pass holds at most 256 items (the list's size)
-                    for (unsigned k = 0; k < 8u; k++) {
-                        if (__ballot(k < cnt) == 0ull) break;
-                        const unsigned g = start + k;
-                        if (k < cnt && g >= base && g < base + 256u) itemList[g - base] = (unsigned char)lane;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const unsigned passItems = total - base < 256u ? total - base : 256u;
-                    for (unsigned r = 0; r < passItems; r += 64u) {
-                        const unsigned g = base + r + (unsigned)lane;
-                        const bool have = r + (unsigned)lane < passItems;
-                        const unsigned owner = have ? (unsigned)itemList[r + lane] : (unsigned)lane;
-                        const int oaddr = (int)(owner << 2);
-                        const unsigned ostart = (unsigned)__builtin_amdgcn_ds_bpermute(oaddr, (int)start);
-                        const unsigned k = have ? g - ostart : 0u;
-                        // the owner's candidate list entry [k]: same [slot][lane] layout, the owner's column
-                        const int otid = (tid & ~63) | (int)owner;
-                        const Code* ocand = reinterpret_cast<const Code*>(smem) + (otid & ~63) + ((otid & 31) << 1) + ((otid >> 5) & 1) + (RTOW_STACK_CAPACITY + k) * BT;
-                        const int i = have ? (int)*ocand : 0;
-                        V3 oro, ord_;
-                        oro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.x)));
-                        oro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.y)));
-                        oro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.z)));
-                        ord_.x = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rd.x)));
-                        ord_.y = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rd.y)));
-                        ord_.z = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rd.z)));
-                        const float oa = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(a)));
-                        const float otime = HAS_MOTION ? __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(rtime))) : 0.0f;
-                        unsigned long long key = ~0ull;
-                        if (have) {
-                            V3 c; float rr, t;
-                            sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, otime, c, rr);
-                            if (sphere_hit(sub(oro, c), ord_, oa, rr, t))
-                                key = ((unsigned long long)__float_as_uint(t) << 32) | (reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset))[i] << 16) | (unsigned)i;
-                        }
-                        // back to the owners: item start + k of this lane sits in lane (start + k - base - r) of this round
-                        for (unsigned kk = 0; kk < 8u; kk++) {
-                            if (__ballot(kk < cnt) == 0ull) break;
-                            const unsigned src = start + kk - base - r;                     // wraps for items of other rounds
-                            const int saddr = (int)((src & 63u) << 2);
-                            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(saddr, (int)(unsigned)key);
-                            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(saddr, (int)(unsigned)(key >> 32));
-                            const unsigned long long got = ((unsigned long long)hi << 32) | lo;
-                            const bool mine = kk < cnt && src < 64u && src < passItems - r;
-                            bestKey = (mine && got < bestKey) ? got : bestKey;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (st == ST_TEST) {
-                    if (bestKey != ownerKey) { best = __uint_as_float((unsigned)(bestKey >> 32)); prim = (int)(bestKey & 0xffffu); }
-                    nc = 0;
-                    if (cur >= 0) st = ST_TRAV;
-                    else classify();
-                }
-            } else
-#endif
             if (st == ST_TEST) {
                 const float a = dot(rd, rd);
                 if (FULL_DIAG && !refDiag) candidates += (float)nc;
@@ -1792,16 +1653,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     } else {
                         V3 c; float r, t;
                         sphere_at<ALL_LDS, HAS_MOTION>(sc, L, i, rtime, c, r);
-#ifdef RTOW_EXPERIMENT_DOUBLE_TEST
-                        // TIMING EXPERIMENT ONLY (same image): the exact test runs twice on laundered operands.  What this build loses against the product
-                        // is what the TEST stage's arithmetic costs in wall time; times (1 - lane utilisation of the stage) = the ceiling of running it dense.
-                        {
-                            float r2 = r, a2 = a, t2 = 0;
-                            asm volatile("" : "+v"(r2), "+v"(a2));
-                            const bool h2 = sphere_hit(sub(ro, c), rd, a2, r2, t2);
-                            asm volatile("" : : "v"(t2), "v"((int)h2));
-                        }
-#endif
                         if (sphere_hit(sub(ro, c), rd, a, r, t) && t <= best) {
                             // same tie rule as above (duplicate or exactly tangent spheres)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
@@ -1844,11 +1695,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 if (!(VOLUMES && insideHit)) mi = *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u);
                 unsigned matIdx = mi & 0xffffu;
                 unsigned cls = (mi >> 16) & 3u;                                // shading class packed by the scene compiler
-#ifdef RTOW_EXPERIMENT_ALL_LAMBERT
-                // TIMING EXPERIMENT ONLY (wrong image): every surface shades as lambert, i.e. the general-Standard and dielectric bodies cost nothing.
-                // The speed of this build is the ceiling of what ANY regrouping of those two classes could reach (DESIGN.md 4.1 "Regrouping").
-                if (cls != MAT_CLASS_VOLUME) cls = MAT_CLASS_LAMBERT;
-#endif
                 const float t = best;
                 const V3 P = v3(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);           // ray.GetPoint(distance), world space
                 V3 N;
@@ -2213,18 +2059,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
             }
         }
     }
-#ifdef RTOW_STATS
-    // every lane counted the same wave-level events for 'per-run' slots; lane-population slots were added by all active lanes.
-    if (A.stats) for (int i = 0; i < 16; i++) atomicAdd(&A.stats[i], stat[i]);
-    if (A.stats && (threadIdx.x & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&A.stats[24 + i], stageT[i]);
-    if (A.stats && (threadIdx.x & 63) == 0) {
-        const unsigned long long dt = wall_clock64() - statT0;   // 100 MHz ticks this wave was resident
-        atomicAdd(&A.stats[16], dt);
-        atomicMax(&A.stats[17], dt);
-        atomicAdd(&A.stats[18], 1ull);
-        A.stats[32 + blockIdx.x * (BT / 64) + (threadIdx.x >> 6)] = dt;   // per-wave residency
-    }
-#endif
 }
 
 template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
