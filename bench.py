@@ -64,6 +64,9 @@ def measured_hbm_traffic():
             d = json.load(open(f))
             keys = ("valu_issue_utilisation", "valu_lane_utilisation", "simd_cycles_per_valu_inst", "valu_pipe_busy_estimate", "lds_busy_fraction")
             secondary = {k: round(float(d["derived"][k]), 4) for k in keys if k in d["derived"]}
+            if "valu_issue_utilisation" in secondary and "valu_lane_utilisation" in secondary:
+                # what actually bounds the kernel: VALU instructions issued per SIMD cycle against the peak rate x lanes doing useful work in them
+                secondary["valu_frac_of_peak_lane_issue"] = round(secondary["valu_issue_utilisation"] * secondary["valu_lane_utilisation"], 4)
             per_launch = int(d.get("bench_line_under_profiler", {}).get("config", {}).get("batches_per_launch", 1) or 1)
             return float(d["derived"]["hbm_traffic_bytes"]) / per_launch, os.path.basename(f), secondary
         except (KeyError, ValueError, OSError):
@@ -649,6 +652,9 @@ def main():
                 "kernel": "sample_batch_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "secondary": secondary,   # what actually limits the kernel: from the same committed PMC summary as `traffic`
+                "valu": None if "valu_frac_of_peak_lane_issue" not in secondary else {
+                    "bound": "valu issue x lane utilisation", "issue": secondary["valu_issue_utilisation"], "lanes": secondary["valu_lane_utilisation"],
+                    "frac": secondary["valu_frac_of_peak_lane_issue"], "source": traffic_src},
                 "note": "graph-traversal path: algorithmic HBM traffic is 92 B/pixel per batch, so the HBM fraction is tiny by construction; "
                         "the kernel is VALU-issue / divergence bound (see DESIGN.md, profiles/)",
             },
