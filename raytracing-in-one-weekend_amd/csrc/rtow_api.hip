@@ -127,6 +127,16 @@ struct RtowContext_t {
 
     MetricsPartial* dPartials = nullptr;
 
+    // nearest-hit ties of the rank-rule sphere kernels (SampleKernelArgs.tieBits / tieRedo): the bitmap the fast kernel marks, the list the fix-up launch renders, a copy
+    // of the inputs of launches that accumulate in place, and the fix-up launch's own (small) hit-list spill area
+    unsigned* dTieRedo = nullptr;
+    unsigned* dTieBits = nullptr;
+    size_t tieBitsWords = 0;
+    float* dTieInputs = nullptr;          // colour | normal | albedo | weight of `tieInputPixels` pixels
+    size_t tieInputPixels = 0;
+    uint4* dRedoSpill = nullptr;
+    uint32_t redoSpillEntries = 0;
+
     // RtowContextOptions: behaviour switches and development knobs (nothing is read from the environment)
     bool wideCodes = false;               // current scene: more than 65 535 entities or tree nodes (32-bit candidate / stack codes, tree read from HBM)
     uint32_t flags = 0;
@@ -368,6 +378,41 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         }
         a.unitRecords = ctx->dUnitRecords;
     }
+    // ---- nearest-hit ties under the rank rule: sphere kinds of more than 16 entities, reference stream - a pixel that meets two different spheres at
+    // bit-identical distance at a nearest hit is listed instead of stored, and the exact-tie kernel of the same kind renders the list in a second, tiny launch
+    const bool tieWatch = ctx->scene.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION && !ctx->scene.layout.exactTies && ctx->scene.entityCount > 16 &&
+                          !(ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER) && p->rngPolicy == RTOW_RNG_REFERENCE;
+    // in place: an output buffer that is also the input buffer (a chain's later batches always read the outputs, but they read what THIS launch stored: only batch 0's inputs count)
+    const bool inPlace = in->color == out->color || in->normal == out->normal || in->albedo == out->albedo || in->sampleCountWeight == out->sampleCountWeight;
+    if (tieWatch) {
+        if (!ctx->dTieRedo) HIP_TRY(ctx, hipMalloc(&ctx->dTieRedo, (4u + (size_t)kTieRedoCapacity) * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+        const uint32_t most = (uint32_t)std::min<uint64_t>((uint64_t)ctx->scene.entityCount, ctx->hitListCapacity ? ctx->hitListCapacity : kDefaultTieListCapacity);
+        const uint32_t entries = most > (uint32_t)kLocalHitEntries ? most - (uint32_t)kLocalHitEntries : 0u;
+        if (entries > ctx->redoSpillEntries) {
+            if (ctx->dRedoSpill) (void)hipFree(ctx->dRedoSpill);
+            ctx->dRedoSpill = nullptr;
+            ctx->redoSpillEntries = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dRedoSpill, (size_t)entries * kTieRedoBlocks * kBlockThreads * sizeof(uint4)), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->redoSpillEntries = entries;
+        }
+        const size_t framePixels = (size_t)a.width * (size_t)a.height;
+        const size_t words = (framePixels + 31u) / 32u;
+        if (words > ctx->tieBitsWords) {
+            if (ctx->dTieBits) (void)hipFree(ctx->dTieBits);
+            ctx->dTieBits = nullptr;
+            ctx->tieBitsWords = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dTieBits, words * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->tieBitsWords = words;
+        }
+        if (inPlace && framePixels > ctx->tieInputPixels) {
+            if (ctx->dTieInputs) (void)hipFree(ctx->dTieInputs);
+            ctx->dTieInputs = nullptr;
+            ctx->tieInputPixels = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dTieInputs, framePixels * 11u * sizeof(float)), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->tieInputPixels = framePixels;
+        }
+    }
+
     // ---- launch geometry: one persistent 1024-lane workgroup per CU (four waves per SIMD).  Smaller workgroups for launches that own about one pixel
     // per resident lane were built, measured and removed: results never depended on it.
     a.wideCodes = ctx->wideCodes ? 1 : 0;
@@ -542,9 +587,49 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         HIP_TRY(ctx, hipMemcpyAsync(ctx->dChainBatches, table, sizeof(ChainBatch) * (size_t)chain->count, hipMemcpyHostToDevice, stream), RTOW_ERROR_LAUNCH_FAILURE);
         a.chainBatches = ctx->dChainBatches;
     }
+    const float* redoIn[4] = {a.inColor, a.inNormal, a.inAlbedo, a.inScw};
+    if (tieWatch) {
+        const size_t framePixels = (size_t)a.width * (size_t)a.height;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dTieRedo, 0, 4u * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dTieBits, 0, ((framePixels + 31u) / 32u) * sizeof(unsigned), stream), RTOW_ERROR_LAUNCH_FAILURE);
+        if (inPlace) {
+            // the fix-up launch renders a marked pixel again from the launch's inputs, which an in-place launch overwrites: they are copied first (44 B per pixel through HBM,
+            // ~0.05 ms at 1920 x 1080 against a batch's tens of milliseconds)
+            static const size_t comps[4] = {4, 3, 3, 1};
+            float* at = ctx->dTieInputs;
+            for (int k = 0; k < 4; k++) {
+                HIP_TRY(ctx, hipMemcpyAsync(at, redoIn[k], framePixels * comps[k] * sizeof(float), hipMemcpyDeviceToDevice, stream), RTOW_ERROR_LAUNCH_FAILURE);
+                redoIn[k] = at;
+                at += framePixels * comps[k];
+            }
+        }
+        a.tieBits = ctx->dTieBits;
+    }
     HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evStart, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchSampleBatch(a, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    if (tieWatch) {
+        // the fix-up: marked pixels -> list -> the exact-tie kernel of the same kind over the list (almost always empty: that kernel then leaves before it stages the scene).
+        // A chain's pixel is listed once and carried through all its batches; a group's once per batch.
+        const size_t framePixels = (size_t)a.width * (size_t)a.height;
+        HIP_TRY(ctx, launchCollectTiedPixels(ctx->dTieBits, (unsigned)((framePixels + 31u) / 32u), ctx->dTieRedo, kTieRedoCapacity, a.chainIndependent ? a.chainCount : 1u, a.overflowFlag, stream),
+                RTOW_ERROR_LAUNCH_FAILURE);
+        SampleKernelArgs r = a;
+        r.layout.exactTies = 1u;
+        r.redoMode = 1;
+        r.tieBits = nullptr;
+        r.tieRedo = ctx->dTieRedo;
+        r.tieRedoCapacity = kTieRedoCapacity;
+        r.inColor = redoIn[0]; r.inNormal = redoIn[1]; r.inAlbedo = redoIn[2]; r.inScw = redoIn[3];
+        r.pixelCost = nullptr;
+        r.chunkOrder = nullptr;
+        r.pixelCandidates = a.pixelCandidates;
+        r.hitSpill = ctx->redoSpillEntries ? ctx->dRedoSpill : nullptr;
+        r.hitSpillEntries = ctx->redoSpillEntries;
+        r.hitSpillStride = (uint32_t)kTieRedoBlocks * (uint32_t)kBlockThreads;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, launchSampleBatch(r, kTieRedoBlocks < ctx->cuCount ? kTieRedoBlocks : ctx->cuCount, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    }
     if (a.unitRecords) HIP_TRY(ctx, launchFoldUnitRecords(a, stream), RTOW_ERROR_LAUNCH_FAILURE);   // inside the timed region: part of the batch
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
     // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
@@ -846,6 +931,10 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dByteThresholds) (void)hipFree(ctx->dByteThresholds);
     dropThresholdTuning(ctx);
     if (ctx->dProbeSink) (void)hipFree(ctx->dProbeSink);
+    if (ctx->dTieRedo) (void)hipFree(ctx->dTieRedo);
+    if (ctx->dTieBits) (void)hipFree(ctx->dTieBits);
+    if (ctx->dTieInputs) (void)hipFree(ctx->dTieInputs);
+    if (ctx->dRedoSpill) (void)hipFree(ctx->dRedoSpill);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }
     if (ctx->dDiag) (void)hipFree(ctx->dDiag);

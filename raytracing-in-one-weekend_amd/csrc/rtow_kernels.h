@@ -27,6 +27,8 @@ constexpr int kQueueBytes = 256;   // per-wave pixel-ticket chunk {next, end, ne
 constexpr int kMaxChain = 16;      // successive batches one launch can run (rtowSampleBatchChainDevice)
 constexpr int kLocalHitEntries = 24;                // entries of a ray's hit list a lane holds itself; longer lists continue in SampleKernelArgs.hitSpill
 constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0, scenes with volumes (long lists are their normal case)
+constexpr uint32_t kTieRedoCapacity = 1u << 20;     // pixel-batches one launch may hand to the tie fix-up pass (beyond it: RTOW_ERROR_CAPACITY)
+constexpr int kTieRedoBlocks = 8;                   // workgroups of the fix-up launch (it exits at once when the list is empty)
 constexpr uint32_t kDefaultTieListCapacity = 128;   // ... scenes without: only the exact-tie procedure keeps a whole list, and only for the ray that ties
 
 // Chained launches keep all batches of a pixel chunk on one XCD (rtow_sample_kernel.hip.h, "Chained batches"): per XCD, how many chunks it took for
@@ -164,6 +166,16 @@ struct SampleKernelArgs {
     unsigned int* chunkDone;              // [chunkCount] pixels stored so far, all batches of this launch; zeroed before the launch
     XcdState* xcdState;                   // chunk ownership per XCD + the lists behind it (chained launches only)
 
+    // Nearest-hit ties in the rank-rule sphere kernels.  A lane that meets two DIFFERENT spheres at bit-identical distance sets its pixel's bit in
+    // tieBits (a bitmap over the frame's pixels, zeroed before the launch); afterwards collect_tied_pixels turns the bits into tieRedo ([0] = count, [4 ...] = entries:
+    // batch << 27 | frame pixel index) and a second launch of the exact-tie kernel of the same kind (redoMode) renders the listed pixels again - every batch of the
+    // launch, from the launch's inputs (a copy of them when the launch accumulates in place) - over what the first launch stored.  Null / 0: no watch (scenes of at
+    // most 16 entities, exact-tie kernels, per-sample policies, probes).
+    unsigned* tieBits;
+    unsigned* tieRedo;
+    uint32_t tieRedoCapacity;
+    int32_t redoMode;
+
     // launch geometry (rtow_sample_kernel.hip.h, GEO): lanes per workgroup of THIS launch (1024) and whether candidate / stack codes are 32 bits
     // wide (scenes beyond 65 535 entities or tree nodes)
     int32_t blockThreads;
@@ -216,6 +228,8 @@ hipError_t launchCombineFinalize(const RtowCombineParams& p, const float* inColo
 // dst[k] += src[k] for the four accumulators (float4 / float3 / float3 / float per pixel) in one launch
 hipError_t launchAddAccum(size_t pixels, float* const dst[4], const float* const src[4], hipStream_t stream);
 // rows first, first + step, ... (`rows` of them, `rowFloats` floats each) of a full-frame buffer -> / <- one contiguous block
+// bits of tieBits -> entries of tieRedo (one per marked pixel; `batches` per pixel, batch index in bits 27.., for a batch group)
+hipError_t launchCollectTiedPixels(const unsigned* tieBits, unsigned words, unsigned* tieRedo, unsigned capacity, unsigned batches, uint32_t* overflowFlag, hipStream_t stream);
 hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, bool toFrame, hipStream_t stream);
 // accum[row] += src_0[row] ... += src_{groups-1}[row] (group order) for rows first, first + step, ...; src_g = ownPartial (frame layout) for g == own, else packed rows at recv + g * regionFloats
 hipError_t launchFoldRows(float* accum, const float* ownPartial, const float* recv, size_t regionFloats, unsigned rowFloats, unsigned rows, unsigned first, unsigned step,

@@ -559,7 +559,31 @@ __global__ void __launch_bounds__(64) xcd_coherence_litmus_kernel(unsigned* stat
     }
 }
 
+// the tie watch's bitmap -> the fix-up launch's list (rtow_kernels.h: SampleKernelArgs.tieRedo); almost always all zero
+__global__ void __launch_bounds__(256) collect_tied_pixels_kernel(const unsigned* __restrict__ bits, unsigned words, unsigned* __restrict__ redo, unsigned capacity, unsigned batches,
+                                                                  uint32_t* overflowFlag)
+{
+    const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    unsigned v = bits[w];
+    while (v) {
+        const unsigned b = (unsigned)__builtin_ctz(v);
+        v &= v - 1u;
+        const unsigned k = atomicAdd(redo, batches);
+        for (unsigned q = 0; q < batches; q++) {
+            if (k + q < capacity) redo[4u + k + q] = (q << 27) | (w * 32u + b);
+            else *overflowFlag = 1u;                              // more tied pixel-batches than the list holds: RTOW_ERROR_CAPACITY on the host side
+        }
+    }
+}
+
 } // namespace
+
+hipError_t launchCollectTiedPixels(const unsigned* tieBits, unsigned words, unsigned* tieRedo, unsigned capacity, unsigned batches, uint32_t* overflowFlag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(collect_tied_pixels_kernel, dim3((words + 255u) / 256u), dim3(256), 0, stream, tieBits, words, tieRedo, capacity, batches, overflowFlag);
+    return hipGetLastError();
+}
 
 hipError_t runXcdCoherenceLitmus(int cuCount, hipStream_t stream, unsigned* outPairs, unsigned* outStale, unsigned* outTimeouts)
 {

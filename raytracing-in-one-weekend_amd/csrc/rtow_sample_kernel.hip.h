@@ -42,6 +42,9 @@
 #ifndef RTOW_EXACT_MATH
 #define RTOW_EXACT_MATH 1
 #endif
+#ifndef RTOW_TIE_WATCH
+#define RTOW_TIE_WATCH 1      // 0: A/B build without the nearest-hit tie watch of the sphere kinds
+#endif
 #if RTOW_EXACT_MATH
 #define RTOW_RCP(x) rtow::exact_rcp(x)
 #define RTOW_RCP_NAN_TO_INF(x) rtow::exact_rcp_nan_to_inf(x)
@@ -1046,6 +1049,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = (int)threadIdx.x;
     constexpr int BT = geo_block_threads(GEO);
+    // the tie fix-up launch (SampleKernelArgs.redoMode) has nothing to do almost always: it leaves before it stages the scene
+    if (A.redoMode) { if (__hip_atomic_load(A.tieRedo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return; }
     constexpr bool WIDE = (GEO & kGeoWide) != 0;
     using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
     constexpr int kStackBytesT = (int)geo_stack_bytes(GEO);
@@ -1076,7 +1081,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     const int traceDepth = A.traceDepth;
     const bool refDiag = FULL_DIAG && A.refTree != nullptr;   // BoundsHitCount / CandidateCount count the reference's tree (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS)
     const bool chained = A.chainCount > 1u;      // several successive batches in this launch (wave-uniform): coherent accumulator accesses, per-chunk hand-off
-    const bool grouped = chained && A.chainIndependent != 0;   // ... or several INDEPENDENT batches (a batch group): same inputs, own outputs, nothing handed over
     // a one-entity scene has a root whose second child is a placeholder; its (inverted) box cannot be told from a real one by the
     // symmetric slab test, so it is masked explicitly (wave-uniform, costs one scalar AND per node visit)
     const bool twoChildren = L.sphereCount > 1u;
@@ -1088,6 +1092,12 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool GENERAL = BASE >= SCENE_KIND_GENERAL;
     constexpr bool VOLUMES = BASE == SCENE_KIND_VOLUMES || BASE == SCENE_KIND_VOLUMES_TEXTURED;   // ProbabilisticVolume materials present: every hit of a ray is needed, not only the nearest
     constexpr bool TEXTURED = BASE == SCENE_KIND_TEXTURED || BASE == SCENE_KIND_VOLUMES_TEXTURED || BASE == SCENE_KIND_TRIANGLES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
+    // Sphere kinds under the rank rule: a nearest hit shared by two DIFFERENT spheres is exact for rays of at most 16 hits only, so such a pixel is
+    // not stored but handed to the exact-tie kernel of the same kind, which runs a second, tiny launch over the listed pixels (redo)
+    constexpr bool TIE_WATCH = RTOW_TIE_WATCH && !GENERAL && !EXACT_TIES && !PER_SAMPLE;
+    constexpr bool REDO_CAPABLE = !GENERAL && EXACT_TIES && !PER_SAMPLE;
+    // (whether a launch watches / fixes up, and whether its batches are a group, are launch constants read from the kernarg segment where they are used - at pixel
+    // boundaries and in the rare fallback store - not values that live in registers through every stage: the kernel sits at the edge of its register file)
 
     // ---- per-lane persistent state ----
     int st = ST_REGEN;
@@ -1165,14 +1175,17 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
             sampleCount++;
         } else if (PER_SAMPLE) {
             if (smp == 0) { fbNormal = sampleNormal; fbAlbedo = sampleAlbedo; }
-        } else if (smp == 0 && !A.probeOnly) {
-            // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).
-            // Stored now and overwritten at the end of the pixel iff sampleCount != 0.
-            float* fbN = A.outNormal;
-            float* fbA = A.outAlbedo;
-            if (grouped) { fbN = A.chainBatches[tick >> kChainShift].outNormal; fbA = A.chainBatches[tick >> kChainShift].outAlbedo; }      // a batch group: this batch's own buffers
-            fbN[3 * (size_t)pix + 0] = sampleNormal.x; fbN[3 * (size_t)pix + 1] = sampleNormal.y; fbN[3 * (size_t)pix + 2] = sampleNormal.z;
-            fbA[3 * (size_t)pix + 0] = sampleAlbedo.x; fbA[3 * (size_t)pix + 1] = sampleAlbedo.y; fbA[3 * (size_t)pix + 2] = sampleAlbedo.z;
+        } else if (smp == 0 && sampleCount == 0 && !A.probeOnly) {
+            // sample 0 failed: its AOVs are the fallback if NO sample of this pixel succeeds (:152-156,160-161).  Stored now and overwritten at the end of the pixel iff
+            // sampleCount != 0 - so only where nothing has succeeded yet (earlier batches included: the count came in with the inputs); otherwise the record is overwritten anyway.
+            const SampleKernelArgs& R = A;
+            float* fbN = R.outNormal;
+            float* fbA = R.outAlbedo;
+            if (chained && R.chainIndependent) { fbN = R.chainBatches[tick >> kChainShift].outNormal; fbA = R.chainBatches[tick >> kChainShift].outAlbedo; }      // a batch group: this batch's own buffers
+            fbN += 3 * (size_t)pix;
+            fbA += 3 * (size_t)pix;
+            fbN[0] = sampleNormal.x; fbN[1] = sampleNormal.y; fbN[2] = sampleNormal.z;
+            fbA[0] = sampleAlbedo.x; fbA[1] = sampleAlbedo.y; fbA[2] = sampleAlbedo.z;
         }
         smp++;
         st = ST_REGEN;
@@ -1236,6 +1249,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     const SampleKernelArgs* coldArgs = &A;                                                                // host pass of the HIP compiler: never executed
 #endif
                     const SampleKernelArgs& C = *coldArgs;
+                    const bool grouped = chained && C.chainIndependent != 0;             // a batch group: same inputs, own outputs, nothing handed over
+                    const bool redo = REDO_CAPABLE && C.redoMode != 0;                   // this launch IS the fix-up launch
                     const unsigned tk = chained ? (tick & kChainTicketMask) : tick;      // owned-pixel (unit) number inside its batch
                     const unsigned batch = chained ? (tick >> kChainShift) : 0u;         // which batch of the chain the finished pixel belongs to
                     if (pix >= 0 && C.pixelCost) {
@@ -1246,6 +1261,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     }
                     if (VOLUMES && hitOverflow) { *C.overflowFlag = 1u; hitOverflow = false; }            // RTOW_ERROR_CAPACITY on the host side
                     if (pix >= 0 && C.probeOnly) pix = -1;                                                 // cost probe: nothing is stored
+                    bool redoContinue = false;
                     if (PER_SAMPLE && pix >= 0) {
                         // ---- unit done: its partial sums go to the record the fold kernel adds up in group order ----
                         const bool fallback = unitGroup == 0 && sampleCount == 0;       // then sample 0 failed: the record carries its AOVs instead of sums
@@ -1277,14 +1293,16 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         // every store above has reached this XCD's L2 (s_waitcnt vmcnt(0); the workgroup-scope release keeps the compiler from reordering)
                         // before the chunk's counter moves; the chunk's next batch runs on this XCD too and reads through that L2
                         // (a batch group hands nothing over: its stores are a plain batch's)
-                        if (!grouped) {
+                        if (!grouped && !redo) {
                             coherent_flush();
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             __hip_atomic_fetch_add(C.chunkDone + (tk >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        pix = -1;
+                        // the fix-up launch carries a listed pixel through the REST of its chain: what was just stored is the next batch's input, and it is still in registers
+                        if (REDO_CAPABLE) { if (redo && !grouped && batch + 1u < C.chainCount) { redoContinue = true; tick += 1u << kChainShift; } }
+                        if (!redoContinue) pix = -1;
                     }
-                    if (pix >= 0) {
+                    if (pix >= 0 && !redoContinue) {
                         // ---- pixel done: store (JOBS/SampleBatchJob.cs:159-163) ----
                         reinterpret_cast<float4*>(C.outColor)[pix] = make_float4(colorAcc.x, colorAcc.y, colorAcc.z, (float)sampleCount);
                         if (sampleCount != 0) {
@@ -1309,6 +1327,17 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     // from the wave's chunk by ballot rank, so every 64-byte line of the accumulator arrays is read and written
                     // by a single CU within about one pixel-time and coalesces in that XCD's L2 instead of being fetched and
                     // written back once per pixel from eight different L2s.
+                    unsigned newBatch = 0u;
+                    if (REDO_CAPABLE && redoContinue) {
+                        // the fix-up launch, same pixel, next batch of its chain: colorAcc / normalAcc / albedoAcc / scwAcc / sampleCount hold what was just stored = this batch's inputs
+                        newBatch = tick >> kChainShift;
+                        if (sampleCount == 0) {
+                            // nothing has succeeded in this pixel so far: the AOV inputs of the next batch are what was stored - zeros, or the fallback of a failed sample 0,
+                            // which went to the output record directly (endSample) and is not in registers
+                            normalAcc = v3(C.outNormal[3 * (size_t)pix], C.outNormal[3 * (size_t)pix + 1], C.outNormal[3 * (size_t)pix + 2]);
+                            albedoAcc = v3(C.outAlbedo[3 * (size_t)pix], C.outAlbedo[3 * (size_t)pix + 1], C.outAlbedo[3 * (size_t)pix + 2]);
+                        }
+                    } else {
                     unsigned ticket = 0xffffffffu;
                     bool parked = false;
                     for (bool got = false; !got;) {
@@ -1324,6 +1353,19 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                 if (lane == leader) waveQueue[2] = 0u;
                                 parked = true;
                                 break;
+                            }
+                            if (redo) {
+                                // the fix-up launch: tickets are places in the list the first launch filled, 64 at a time
+                                if (lane == leader) {
+                                    bool cancelled = false;
+                                    if (C.cancelFlag) cancelled = *C.cancelFlag != 0u;
+                                    const unsigned listed = __hip_atomic_load(C.tieRedo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    const unsigned n = listed < C.tieRedoCapacity ? listed : C.tieRedoCapacity;
+                                    const unsigned slot = cancelled ? 0xffffffffu : atomicAdd(C.workCounter, 1u);
+                                    if (cancelled || slot >= (n + 63u) / 64u) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
+                                    else { waveQueue[2] = 0u; waveQueue[3] = 0u; waveQueue[0] = slot * 64u; waveQueue[1] = n < slot * 64u + 64u ? n : slot * 64u + 64u; }
+                                }
+                                continue;
                             }
                             if (lane == leader) {
                                 bool cancelled = false;
@@ -1393,13 +1435,15 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         if (lane == leader) waveQueue[0] = next + take;
                     }
                     if (ticket == 0xffffffffu) { st = parked ? ST_IDLE : ST_DEAD; break; }
+                    if (REDO_CAPABLE) { if (redo) ticket = C.tieRedo[4u + ticket]; }          // the listed entry: batch << 27 | FRAME pixel index (a chain's pixels are listed with batch 0 and carried through)
                     tick = ticket;
-                    const unsigned newBatch = chained ? (ticket >> kChainShift) : 0u;
+                    newBatch = chained ? (ticket >> kChainShift) : 0u;
                     if (chained) ticket &= kChainTicketMask;
                     if (PER_SAMPLE) { unitGroup = ticket % C.groupsPerPixel; ticket = ticket / C.groupsPerPixel; }   // unit = (owned pixel, sample group)
                     int ownedRow;
                     owned_pixel_xy(ticket, (unsigned)C.width, C.tilesPerRow, C.tiledPixels, cx, ownedRow);   // a chunk's 64 tickets: an 8 x 8 tile of the owned pixels (rtow_kernels.h), or a strip
                     cy = C.sliceOffset + ownedRow * C.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)
+                    if (REDO_CAPABLE) { if (redo) { cy = (int)(ticket / (unsigned)C.width); cx = (int)(ticket - (unsigned)cy * (unsigned)C.width); } }      // (the fix-up launch lists frame pixels)
                     pix = cy * C.width + cx;
 
                     float4 last = make_float4(0, 0, 0, 0);
@@ -1407,7 +1451,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         // a unit only needs what decides the pixel's sample count (:118-126); the fold kernel reads the accumulators
                         last.w = C.inColor[4 * (size_t)pix + 3];
                         scwAcc = C.inScw[pix];
-                    } else if (chained && !grouped) {
+                    } else if (chained && !grouped && !redo) {
                         // batch 0 reads the launch's inputs, every later batch what the batch before it stored for this pixel (device-coherent loads)
                         const float* ic = (newBatch == 0u ? C.inColor : C.outColor) + 4 * (size_t)pix;
                         const float* in_ = (newBatch == 0u ? C.inNormal : C.outNormal) + 3 * (size_t)pix;
@@ -1424,6 +1468,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     }
                     colorAcc = v3(last.x, last.y, last.z);
                     sampleCount = (int)last.w;
+                    }      // (not a continued pixel of the fix-up launch)
                     const float scwIn = scwAcc;
                     const int countIn = sampleCount;
 
@@ -1657,7 +1702,26 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             // same tie rule as above (duplicate or exactly tangent spheres)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
                             if (EXACT_TIES) tieAtBest = !(t < best) && prim >= 0;                    // t == best here
-                            if (t < best || (prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
+                            // The watch: a second sphere at exactly the nearest distance so far - the rank rule below is exact for rays of at most 16 hits only.
+                            // The event is as good as absent from real scenes, so it costs the lane no state: the pixel's bit is set in a bitmap in memory, and after the launch the
+                            // exact-tie kernel of this kind renders the marked pixels again, from the launch's inputs, over what this kernel stored.  Per pixel and sticky: a tie at a
+                            // distance that a later, nearer hit supersedes marks the pixel too - a pixel rendered twice, never a different result.
+                            if (TIE_WATCH) {
+                                // (one rare region for the rank rule's two lookups AND the mark: an extra conditional region per accepted hit cost the headline 1 %)
+                                bool take = t < best;
+                                if (!take && prim >= 0) {
+                                    take = rank[i] < rank[prim];
+#if defined(__HIP_DEVICE_COMPILE__)
+                                    const SampleKernelArgs* rareArgs = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();      // loaded here, on use: no register holds the bitmap's address through the stages
+                                    asm volatile("" : "+s"(rareArgs));
+#else
+                                    const SampleKernelArgs* rareArgs = &A;
+#endif
+                                    unsigned* const bits = rareArgs->tieBits;
+                                    if (bits) atomicOr(bits + ((unsigned)pix >> 5), 1u << ((unsigned)pix & 31u));
+                                }
+                                if (take) { best = t; prim = i; }
+                            } else if (t < best || (prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
                         }
                     }
                 }

@@ -1,0 +1,144 @@
+"""GPU: the nearest-hit tie fix-up of the rank-rule sphere kernels.
+
+Hits at bit-identical distance are ordered by the reference's sort of the whole hit list (JOBS/SampleBatchJob.cs:473-474: an unstable introsort once the list is longer
+than 16, RT/HitRecord.cs:22-25).  The sphere kernels keep only the nearest hit and break a tie by leaf rank - exact for rays of at most 16 hits.  Since round 4 a lane
+that meets such a tie between two DIFFERENT spheres marks its pixel in a bitmap, and after the launch the exact-tie kernel of the same kind renders the marked pixels
+again - every batch of a chain or group - from the launch's inputs (a copy of them when the launch accumulates in place), over what the fast kernel stored.  Scene: two spheres mirrored about the plane x = 0 - every
+camera ray in that plane (the centre column of an odd-width frame, jitter off) meets both at bit-identical distance - in front of a row of spheres the same rays thread,
+so that the hit list has more than 16 entries."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KEYS = (("color", 4), ("normal", 3), ("albedo", 3), ("scw", 1))
+W, H = 33, 33
+
+
+def _scene(rt, behind):
+    S = rt.scenes
+    s = S.Scene("mirrored pair in front of a row")
+    s.add_sphere((-0.3, 0.0, 5.0), 0.5, S.lambertian((0.9, 0.1, 0.1)))
+    s.add_sphere((0.3, 0.0, 5.0), 0.5, S.metal((0.2, 0.9, 0.3), 0.0))
+    for k in range(behind):
+        s.add_sphere((0.0, 0.0, 3.5 - 1.0 * k), 0.3, S.lambertian((0.2 + 0.03 * k, 0.4, 0.8 - 0.03 * k)))
+    s.camera = {"position": [0.0, 0.0, 10.0], "target": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 12.0, "aperture": 0.0}
+    return s
+
+
+def _oracle_batches(oracle, scene, plist, start):
+    osc = oracle.OracleScene(scene.desc())
+    acc = {k: v.copy() for k, v in start.items()}
+    diags = []
+    for p in plist:
+        r = osc.sample_batch(p, acc)
+        acc = {k: r[k] for k, _ in KEYS}
+        diags.append(r["diag"])
+    osc.close()
+    return acc, diags
+
+
+def _start(n, seed=3):
+    rng = np.random.default_rng(seed)
+    ins = {"color": rng.random((n, 4)).astype(np.float32), "normal": rng.normal(size=(n, 3)).astype(np.float32),
+           "albedo": rng.random((n, 3)).astype(np.float32), "scw": rng.random(n).astype(np.float32)}
+    ins["color"][:, 3] = rng.integers(0, 4, n)
+    return ins
+
+
+def _differs(a, b):
+    return int(sum((a[k].reshape(b[k].shape).view(np.uint32) != b[k].view(np.uint32)).any(axis=-1).sum() if b[k].ndim > 1 else (a[k].reshape(b[k].shape).view(np.uint32) != b[k].view(np.uint32)).sum()
+                   for k, _ in KEYS))
+
+
+def test_tied_pixels_are_rendered_by_the_exact_kernel_and_equal_the_oracle(rt, oracle):
+    """Plain batches in place (inputs = outputs, non-zero), default flags: every output equals the oracle for hit lists of 19 .. 26 entries; with the fix-up switched off
+    (RTOW_CONTEXT_EXACT_TIES_NEVER: the rank rule everywhere) at least one of those scenes differs - the scene does exercise the exception."""
+    n = W * H
+    teeth = 0
+    for behind in range(17, 25):
+        scene = _scene(rt, behind)
+        desc = scene.desc()
+        plist = [rt.scenes.make_params(scene, W, H, spp=5, trace_depth=6, seed=s, jitter=False, focus=5.0, diagnostics_stride=4) for s in (11, 12)]
+        start = _start(n)
+        want, wdiag = _oracle_batches(oracle, scene, plist, start)
+        for flags, exact in ((0, True), (rt.abi.CONTEXT_EXACT_TIES_NEVER, False)):
+            with rt.Context(0, flags=flags) as ctx:
+                ctx.upload_scene(desc)
+                assert ctx.scene_info().hitListCapacity == 0                     # the rank-rule kernels: not the exact-tie variants
+                acc = {k: v.copy() for k, v in start.items()}
+                diags = []
+                for p in plist:
+                    r = rt.sample_batch_host(ctx, p, acc)
+                    acc = {k: r[k] for k, _ in KEYS}
+                    diags.append(r["diag"])
+                d = _differs(acc, want)
+                if exact:
+                    assert d == 0, (behind, "default flags", d)
+                    for got, wd in zip(diags, wdiag):
+                        assert np.array_equal(got[:, 0], wd[:, 0]), (behind, "ray counts")
+                else:
+                    teeth += 1 if d else 0
+    assert teeth >= 1, "the rank rule alone agreed with the reference's sort in every scene: the test has lost its teeth"
+
+
+@pytest.mark.parametrize("mode", ["chain", "group"])
+def test_tied_pixels_in_chains_and_groups(rt, oracle, mode):
+    """A chain of four batches in place: a pixel listed by batch b is left alone by the later batches of the launch and carried through all of them by the fix-up launch;
+    a group of four: each (pixel, batch) on its own.  Device-resident buffers, 16-byte records."""
+    n = W * H
+    for behind in (18, 21, 23):
+        scene = _scene(rt, behind)
+        desc = scene.desc()
+        plist = [rt.scenes.make_params(scene, W, H, spp=3 + (s % 2), trace_depth=5, seed=s, jitter=False, focus=5.0, diagnostics_stride=16) for s in (21, 22, 23, 24)]
+        if mode == "chain":
+            for p in plist:
+                p.sampleCountRange[0] = p.sampleCountRange[1] = 4                    # a chain's batches differ in nothing but Seed
+        start = _start(n, 8)
+        with rt.Context(0) as ctx:
+            ctx.upload_scene(desc)
+            if mode == "chain":
+                bufs = [rt.DeviceBuffer(ctx).upload(start[k]) for k, _ in KEYS]
+                diags = [rt.DeviceBuffer(ctx, n * 16).zero() for _ in plist]
+                rt.lib.check(rt.sample_batch_chain_device(ctx, plist, bufs, bufs, diags), "rtowSampleBatchChainDevice")
+                ctx.synchronize()
+                got = {k: b.download(np.float32, (n, c)) for (k, c), b in zip(KEYS, bufs)}
+                want, wdiag = _oracle_batches(oracle, scene, plist, start)
+                assert _differs(got, want) == 0, (behind, "chain")
+                for d, wd in zip(diags, wdiag):
+                    assert np.array_equal(d.download(np.float32, (n, 4))[:, 0], wd[:, 0]), (behind, "chain ray counts")
+            else:
+                for p in plist:
+                    p.sampleCountRange[0] = p.sampleCountRange[1] = 4
+                src = [rt.DeviceBuffer(ctx).upload(start[k]) for k, _ in KEYS]
+                outs = [[rt.DeviceBuffer(ctx, n * c * 4).zero() for _, c in KEYS] for _ in plist]
+                rt.lib.check(rt.sample_batch_group_device(ctx, plist, src, outs), "rtowSampleBatchGroupDevice")
+                ctx.synchronize()
+                for k, p in enumerate(plist):
+                    want, _ = _oracle_batches(oracle, scene, [p], start)
+                    got = {key: b.download(np.float32, (n, c)) for (key, c), b in zip(KEYS, outs[k])}
+                    assert _differs(got, want) == 0, (behind, "group batch", k)
+            ctx.batch_status()
+
+
+def test_fallback_aovs_with_and_without_earlier_successes(rt, oracle):
+    """trace depth 1: every path that meets a surface fails, so pixels over geometry end a first batch with no successful sample and the AOVs of their failed
+    sample 0 as fallback (JOBS/SampleBatchJob.cs:152-156,160-161); the early fallback store is skipped where earlier batches already succeeded (the record is
+    overwritten at the end of the pixel anyway).  Cover scene (486 spheres: a watched scene), in place, two batches, then a third on top of successes."""
+    scene = rt.scenes.cover_scene()
+    w, h = 120, 68
+    n = w * h
+    plist = [rt.scenes.make_params(scene, w, h, spp=3, trace_depth=1, seed=s) for s in (5, 6)] + [rt.scenes.make_params(scene, w, h, spp=3, trace_depth=8, seed=7),
+                                                                                                  rt.scenes.make_params(scene, w, h, spp=3, trace_depth=1, seed=8)]
+    start = {k: np.zeros((n, c) if c > 1 else (n,), np.float32) for k, c in KEYS}
+    want, _ = _oracle_batches(oracle, scene, plist, start)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene.desc())
+        acc = {k: v.copy() for k, v in start.items()}
+        for p in plist:
+            r = rt.sample_batch_host(ctx, p, acc)
+            acc = {k: r[k] for k, _ in KEYS}
+    assert _differs(acc, want) == 0
+    first = _oracle_batches(oracle, scene, plist[:2], start)[0]
+    assert (first["color"][:, 3] == 0).sum() > n // 4 and np.abs(first["normal"]).sum() > 0          # after two batches: many pixels without a success, their fallback normals stored
