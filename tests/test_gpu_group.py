@@ -151,6 +151,6 @@ def test_group_can_be_cancelled(rt, gpu_context):
     t = time.perf_counter()
     rc = rt.sample_batch_group_device(ctx, plist, src, outs, None, None, C.addressof(token))
     dt = time.perf_counter() - t
-    assert rc == rt.abi.RTOW_ERROR_CANCELLED and dt < 0.2, (rc, dt)                  # 4 x 512 spp at 1080p would take half a second
+    assert rc == rt.abi.RTOW_ERROR_CANCELLED and dt < 0.4, (rc, dt)                  # 4 x 512 spp at 1080p would take 0.9 s (the bound leaves room for a GPU shared with other test processes)
     for b in src + [x for o in outs for x in o]:
         b.free()
