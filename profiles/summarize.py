@@ -49,12 +49,18 @@ def main():
             probes = [d for d in durs if d <= 0.2 * longest]
             summary["kernel_trace_split"] = {"batch_launches": len(batches), "batch_avg_ns": sum(batches) / len(batches), "batch_min_ns": min(batches), "batch_max_ns": max(batches),
                                              "probe_launches": len(probes), "probe_avg_ns": (sum(probes) / len(probes)) if probes else None,
-                                             "note": "batch_* = the timed 256-spp launches (compare with bench.py kernel_ms_per_step); probe = the 1-spp cost-probe launch of the same kernel"}
+                                             "note": "batch_* = the timed 256-spp launches (compare with bench.py kernel_ms_per_step); probe = the short launches of the same kernel: the 1-spp cost probe, "
+                                                     "the ten 4-spp threshold probes, and the tie fix-up launches (exact-tie variant, 8 workgroups, leave at once)"}
     for f in glob.glob(os.path.join(SRC, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         # counters of the LAST dispatch of the kernel in each pass = the 256-spp batch (the probe launch precedes it)
         rows = [row for row in csv.DictReader(open(f)) if KERNEL in row["Kernel_Name"]]
         if not rows:
             continue
+        # (round 4: every launch of a watched scene is followed by the tie fix-up launch - the exact-tie variant of the same kernel on 8 workgroups, which leaves at once when
+        # nothing is listed; the dispatch to read is the last one on the FULL grid)
+        if "Grid_Size" in rows[0]:
+            full = max(int(row["Grid_Size"]) for row in rows)
+            rows = [row for row in rows if int(row["Grid_Size"]) == full]
         last = max(int(row["Dispatch_Id"]) for row in rows)
         sums = {}
         for row in rows:
