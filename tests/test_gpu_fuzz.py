@@ -1,6 +1,6 @@
 """GPU: seeded random scenes - random mixes of every entity type, transform, material class, texture kind, camera (also inside geometry),
-lens, noise colour, RNG policy, slice and trace depth, and (round 3) kernel family: forced 32-bit candidate codes, 512- / 256-lane launch geometries,
-a chain of two batches - rendered small and compared with the oracle bit for bit.  Catches the
+lens, noise colour, RNG policy, slice and trace depth, and kernel family: forced 32-bit candidate codes,
+a chain of two batches, (round 4) a group of two independent batches - rendered small and compared with the oracle bit for bit.  Catches the
 combinations nobody thought of writing a scene for."""
 import os
 
@@ -112,6 +112,7 @@ def test_random_scene(rt, oracle, gpu_context, geometry_contexts, seed):
     desc = scene.desc(max_bvh_depth=int(rng.choice([32, 32, 3])))
     which = str(extra.choice(["default", "default", "default", "wide"]))
     chain = bool(extra.random() < 0.25)
+    group = (not chain) and bool(extra.random() < 0.2)      # (drawn last: every seed keeps what it had)
     ctx = gpu_context if which == "default" else geometry_contexts[which]
     ctx.upload_scene(desc)
     noise_color = int(rng.choice([abi.NOISE_WHITE, abi.NOISE_WHITE, abi.NOISE_BLUE, abi.NOISE_SPATIOTEMPORAL_BLUE]))
@@ -139,6 +140,32 @@ def test_random_scene(rt, oracle, gpu_context, geometry_contexts, seed):
             if chain:                                    # two successive batches as one rtowSampleBatchChain call: defined as the batches in sequence
                 gpu = rt.sample_batch_chain_host(ctx, [p, p2], ins)
                 gpu["diag"] = gpu["diag"][-1]
+            elif group:                                  # two independent batches as one rtowSampleBatchGroupDevice call: defined as the separate calls on the same inputs
+                keys = (("color", 4), ("normal", 3), ("albedo", 3), ("scw", 1))
+                src = [rt.DeviceBuffer(ctx).upload(ins[k]) for k, _ in keys]
+                outs = [[rt.DeviceBuffer(ctx).upload(ins[k]) for k, _ in keys] for _ in range(2)]      # rows a slice does not own keep the inputs, like the host form
+                dg = [rt.DeviceBuffer(ctx, n * p.diagnosticsStride).zero() for _ in range(2)]
+                rc = rt.sample_batch_group_device(ctx, [p, p2], src, outs, dg)
+                if rc == abi.RTOW_SUCCESS:
+                    try:
+                        ctx.synchronize()
+                    except rt.lib.RtowError as e:
+                        rc = e.code
+                gpus = []
+                for o, d in zip(outs, dg):
+                    g = {k: b.download(np.float32, (n, c) if c > 1 else (n,)) for (k, c), b in zip(keys, o)}
+                    g["diag"] = d.download(np.float32, (n, p.diagnosticsStride // 4))
+                    gpus.append(g)
+                for b in src + outs[0] + outs[1] + dg:
+                    b.free()
+                if rc != abi.RTOW_SUCCESS:
+                    raise rt.lib.RtowError(rc, "rtowSampleBatchGroupDevice")
+                ref2 = osc.sample_batch(p2, ins)
+                for k in ("color", "normal", "albedo", "scw"):
+                    assert np.array_equal(gpus[1][k].reshape(ref2[k].shape).view(np.uint32), ref2[k].view(np.uint32)), (seed, which, "group batch 1", k)
+                assert np.array_equal(gpus[1]["diag"][:, 0], ref2["diag"][:, 0]), (seed, which, "group batch 1")
+                gpu = {k: gpus[0][k].reshape(ins[k].shape) for k in ("color", "normal", "albedo", "scw")}
+                gpu["diag"] = gpus[0]["diag"]
             else:
                 gpu = rt.sample_batch_host(ctx, p, ins)
         except rt.lib.RtowError as e:
@@ -147,7 +174,11 @@ def test_random_scene(rt, oracle, gpu_context, geometry_contexts, seed):
             # oracle must confirm that such a ray exists
             assert e.code == abi.RTOW_ERROR_CAPACITY, e
             _, counters = osc.sample_batch(p, ins, want_counters=True)
-            assert counters.maxHits > 1024, (seed, counters.maxHits)
+            most = counters.maxHits
+            if chain or group:
+                _, c2 = osc.sample_batch(p2, ins, want_counters=True)
+                most = max(most, c2.maxHits)
+            assert most > 1024, (seed, most)
             return
         ref = osc.sample_batch(p, ins)
         if chain:
