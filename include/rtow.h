@@ -54,9 +54,11 @@ typedef enum RtowResult {
     RTOW_ERROR_UNSUPPORTED = 5,       /* entity / material / noise kind not built yet           */
     RTOW_ERROR_LAUNCH_FAILURE = 6,    /* kernel launch or stream error (hipError in the log)    */
     RTOW_ERROR_CANCELLED = 7,         /* cancellation flag observed; outputs unspecified        */
-    RTOW_ERROR_CAPACITY = 8,          /* a bound was exceeded: at upload (entities, tree depth) or - reported by the host-buffer rtowSampleBatch, a
-                                       * cancellable rtowSampleBatchDevice or the next rtowGetBatchStatus / rtowSynchronize - by a ray that met more
-                                       * surfaces than RtowContextOptions.hitListCapacity (the reference's hit list grows without bound) */
+    RTOW_ERROR_CAPACITY = 8,          /* a bound was exceeded: at upload (entities, tree depth) or - reported by a cancellable rtowSampleBatchDevice or the
+                                       * next rtowGetBatchStatus / rtowSynchronize - by a ray that met more surfaces than the hit lists hold.  The reference's
+                                       * list grows without bound; with RtowContextOptions.hitListCapacity == 0 so do these: by the time the error is reported
+                                       * the lists are twice as long, the host-buffer calls (rtowSampleBatch, rtowSampleBatchChain) have run the batch again
+                                       * themselves and do not report it at all, and a device-resident caller issues the batch again (see hitListCapacity) */
     RTOW_ERROR_INTERNAL = 99
 } RtowResult;
 
@@ -331,7 +333,13 @@ typedef struct RtowContextOptions {
                                      * the exact-tie procedure): the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71);
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per
                                      * entry, sized at rtowUploadScene to min(this, the most the scene can produce: 2 per entity with volumes, else 1).
-                                     * 0 = 1024 in scenes with volumes, 128 elsewhere.  A ray beyond it makes the batch report RTOW_ERROR_CAPACITY */
+                                     * A ray beyond it makes the batch report RTOW_ERROR_CAPACITY, always: the caller has chosen the memory it spends.
+                                     * 0 = the lists grow like the reference's: they start at 1024 entries in scenes with volumes, 128 elsewhere, and every batch
+                                     * that meets a longer ray doubles them (up to what the scene can produce, and to a quarter of the free device memory) when its
+                                     * status is read.  rtowSampleBatch / rtowSampleBatchChain read it themselves and run the batch again from the caller's inputs
+                                     * (unless outputs registered with rtowRegisterHostBuffer ARE the inputs); the device-resident forms report RTOW_ERROR_CAPACITY
+                                     * once through rtowGetBatchStatus / rtowSynchronize and the same call, issued again from inputs it did not overwrite, has room.
+                                     * The capacity a context has grown to stays across rtowUploadScene (rtowGetSceneInfo.hitListCapacity shows it) */
     int32_t sliceBlockThreads;      /* reserved: 0 (or 1024).  Rounds 2 - 3 could run 512 / 256 lanes per workgroup for launches that own about one pixel per
                                      * resident lane; measured slower at every slice count and removed.  Other values: RTOW_ERROR_INVALID_VALUE */
 } RtowContextOptions;

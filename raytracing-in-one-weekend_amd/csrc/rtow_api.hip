@@ -100,6 +100,8 @@ struct RtowContext_t {
     uint32_t hitSpillEntries = 0;         // of the current scene (<= hitSpillCapacity)
     uint32_t hitSpillCapacity = 0;        // entries per lane the allocation holds
     uint32_t hitListCapacity = 0;         // RtowContextOptions.hitListCapacity (0 = default)
+    uint32_t grownListCapacity = 0;       // hitListCapacity == 0 only: what the capacity has grown to after batches that met longer lists (growHitList); kept across scenes
+    bool overflowGrew = false;            // the last reported overflow enlarged the capacity: the same batch, issued again, has room
     // Image-texture blob of the current scene (CompiledScene.texBlob), HBM only
     uint8_t* dTexBlob = nullptr;
     size_t texBlobCapacity = 0;
@@ -279,6 +281,8 @@ bool finishThresholdTuning(RtowContext ctx, bool wait)
     return true;
 }
 
+uint64_t listCapacity(const RtowContext_t* ctx, bool volumes);    // (defined with growHitList below)
+
 int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuffers* in, const RtowAccumBuffers* out, void* diag,
                  hipStream_t stream, bool useCancelFlag, const ChainSpec* chain = nullptr)
 {
@@ -386,7 +390,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     const bool inPlace = in->color == out->color || in->normal == out->normal || in->albedo == out->albedo || in->sampleCountWeight == out->sampleCountWeight;
     if (tieWatch) {
         if (!ctx->dTieRedo) HIP_TRY(ctx, hipMalloc(&ctx->dTieRedo, (4u + (size_t)kTieRedoCapacity) * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
-        const uint32_t most = (uint32_t)std::min<uint64_t>((uint64_t)ctx->scene.entityCount, ctx->hitListCapacity ? ctx->hitListCapacity : kDefaultTieListCapacity);
+        const uint32_t most = (uint32_t)std::min<uint64_t>((uint64_t)ctx->scene.entityCount, listCapacity(ctx, false));
         const uint32_t entries = most > (uint32_t)kLocalHitEntries ? most - (uint32_t)kLocalHitEntries : 0u;
         if (entries > ctx->redoSpillEntries) {
             if (ctx->dRedoSpill) (void)hipFree(ctx->dRedoSpill);
@@ -640,16 +644,78 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     return RTOW_SUCCESS;
 }
 
-// A ray met more surfaces than the context's hit-list capacity (RtowContextOptions.hitListCapacity; volume scenes and exact-tie kernels keep
-// every hit of a ray): the batch's result is not the reference's.
+// Most surfaces one ray may meet where whole hit lists are kept: the caller's bound if it gave one, else a default that GROWS (growHitList) - the
+// reference's list grows on the heap without bound (UTIL/HybridCollections.cs:22-36,65-71).
+uint64_t listCapacity(const RtowContext_t* ctx, bool volumes)
+{
+    if (ctx->hitListCapacity) return ctx->hitListCapacity;
+    return std::max<uint64_t>(volumes ? kDefaultHitListCapacity : kDefaultTieListCapacity, ctx->grownListCapacity);
+}
+
+// The spill area behind the lanes' own 24 entries, for a scene of this kind and size.  An entity yields at most two hits per ray (a volume hull's entry and exit,
+// JOBS/SampleBatchJob.cs:457-469), one in scenes without volumes, so that bound - capped by listCapacity - is all a scene can need.
+int sizeHitSpill(RtowContext ctx, uint32_t sceneKind, bool exactTies, int entityCount)
+{
+    const bool volumes = sceneKind == SCENE_KIND_VOLUMES || sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
+    uint64_t most = (volumes || exactTies) ? (uint64_t)entityCount * (volumes ? 2u : 1u) : 0u;
+    const uint64_t cap = listCapacity(ctx, volumes);
+    if (most > cap) most = cap;
+    const uint32_t entries = most > (uint64_t)kLocalHitEntries ? (uint32_t)(most - kLocalHitEntries) : 0u;
+    if (entries > ctx->hitSpillCapacity) {
+        if (ctx->dHitSpill) (void)hipFree(ctx->dHitSpill);
+        ctx->dHitSpill = nullptr;
+        ctx->hitSpillCapacity = 0;
+        ctx->hitSpillEntries = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->dHitSpill, (size_t)entries * (size_t)ctx->cuCount * kBlockThreads * sizeof(uint4)), RTOW_ERROR_MEMORY_ALLOCATION);
+        ctx->hitSpillCapacity = entries;
+    }
+    ctx->hitSpillEntries = entries;
+    return RTOW_SUCCESS;
+}
+
+// A batch met a ray with more surfaces than the lists hold.  Unless the caller fixed the capacity, double it - up to what the scene can produce at all and to a
+// quarter of the device's free memory - so that the batch, issued again, has room.  Called with every batch of the context finished (all callers have just waited).
+bool growHitList(RtowContext ctx)
+{
+    if (ctx->hitListCapacity || !ctx->haveScene) return false;
+    const uint32_t kind = ctx->scene.layout.sceneKind;
+    const bool volumes = kind == SCENE_KIND_VOLUMES || kind == SCENE_KIND_VOLUMES_TEXTURED;
+    const uint64_t bound = (uint64_t)ctx->scene.entityCount * (volumes ? 2u : 1u);
+    const uint64_t now = listCapacity(ctx, volumes);
+    if (now >= bound) return false;                                                      // the lists already hold everything the scene has
+    const uint64_t next = std::min<uint64_t>(bound, now * 2u);
+    if (volumes || ctx->scene.layout.exactTies) {
+        size_t freeBytes = 0, totalBytes = 0;
+        if (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const uint64_t held = (uint64_t)ctx->hitSpillCapacity * (uint64_t)ctx->cuCount * kBlockThreads * sizeof(uint4);
+        const uint64_t need = (next - kLocalHitEntries) * (uint64_t)ctx->cuCount * kBlockThreads * sizeof(uint4);
+        if (need > held && need > (freeBytes + held) / 4u) return false;
+    }
+    const uint32_t before = ctx->grownListCapacity;
+    ctx->grownListCapacity = (uint32_t)next;
+    if (sizeHitSpill(ctx, kind, ctx->scene.layout.exactTies != 0, ctx->scene.entityCount) != RTOW_SUCCESS) {
+        (void)hipGetLastError();
+        ctx->grownListCapacity = before;
+        (void)sizeHitSpill(ctx, kind, ctx->scene.layout.exactTies != 0, ctx->scene.entityCount);
+        return false;
+    }
+    return true;                                                                          // (the fix-up launch's own, small area follows at the next launch: launchSample)
+}
+
+// A ray met more surfaces than the context's hit-list capacity (volume scenes and exact-tie kernels keep every hit of a ray): the batch's result is not the
+// reference's.  With RtowContextOptions.hitListCapacity == 0 the capacity has doubled by the time this returns (growHitList): the host-buffer calls then run the
+// batch again themselves, a device-resident caller issues it again (from inputs the batch did not overwrite).
 // The flag is sticky: it is set by the kernel and cleared only here, so it covers every batch enqueued since the last report
 // (rtowSampleBatch, a cancellable rtowSampleBatchDevice, rtowGetBatchStatus, rtowSynchronize).
 int takeOverflow(RtowContext ctx)
 {
     if (ctx->hCancel[1] == 0u) return RTOW_SUCCESS;
     ctx->hCancel[1] = 0u;
-    logf(ctx, 2, "rtow", "a ray met more surfaces than the hit-list capacity of this scene (%u; RtowContextOptions.hitListCapacity): results of this batch are invalid",
-         ctx->hitSpillEntries + (uint32_t)kLocalHitEntries);
+    const bool volumes = ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
+    const uint32_t was = (uint32_t)listCapacity(ctx, volumes);
+    ctx->overflowGrew = growHitList(ctx);
+    if (ctx->overflowGrew) logf(ctx, 3, "rtow", "a ray met more than %u surfaces: results of this batch are invalid; the hit-list capacity is now %u", was, (uint32_t)listCapacity(ctx, volumes));
+    else logf(ctx, 2, "rtow", "a ray met more surfaces than the hit-list capacity of this scene (%u; RtowContextOptions.hitListCapacity): results of this batch are invalid", was);
     return RTOW_ERROR_CAPACITY;
 }
 
@@ -1010,23 +1076,9 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         if (!volumes) compiled.layout.exactTies = (ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) ? 1u : 0u;
     }
     {
-        // Rays whose hit list outgrows a lane's own 24 entries (every hit is kept in volume scenes and by the exact-tie procedure) continue in
-        // HBM.  An entity yields at most two hits per ray (a volume hull's entry and exit, JOBS/SampleBatchJob.cs:457-469), one in scenes
-        // without volumes, so that bound - capped by RtowContextOptions.hitListCapacity - is all a scene can need.
-        const bool volumes = compiled.layout.sceneKind == SCENE_KIND_VOLUMES || compiled.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
-        uint64_t most = (volumes || compiled.layout.exactTies) ? (uint64_t)compiled.entityCount * (volumes ? 2u : 1u) : 0u;
-        const uint64_t cap = ctx->hitListCapacity ? ctx->hitListCapacity : (volumes ? kDefaultHitListCapacity : kDefaultTieListCapacity);
-        if (most > cap) most = cap;
-        const uint32_t entries = most > (uint64_t)kLocalHitEntries ? (uint32_t)(most - kLocalHitEntries) : 0u;
-        if (entries > ctx->hitSpillCapacity) {
-            if (ctx->dHitSpill) (void)hipFree(ctx->dHitSpill);
-            ctx->dHitSpill = nullptr;
-            ctx->hitSpillCapacity = 0;
-            ctx->hitSpillEntries = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dHitSpill, (size_t)entries * (size_t)ctx->cuCount * kBlockThreads * sizeof(uint4)), RTOW_ERROR_MEMORY_ALLOCATION);
-            ctx->hitSpillCapacity = entries;
-        }
-        ctx->hitSpillEntries = entries;
+        // Rays whose hit list outgrows a lane's own 24 entries (every hit is kept in volume scenes and by the exact-tie procedure) continue in HBM
+        const int rc = sizeHitSpill(ctx, compiled.layout.sceneKind, compiled.layout.exactTies != 0, compiled.entityCount);
+        if (rc != RTOW_SUCCESS) return rc;
     }
     // every scene kind has kernels with 32-bit codes (volume kinds included: a triangle-mesh scene with one fog volume among the meshes)
     const bool wide = compiled.entityCount > 65535 || compiled.layout.nodeCount > 65535u || (ctx->flags & RTOW_CONTEXT_FORCE_WIDE_CODES) != 0;
@@ -1290,19 +1342,25 @@ RTOW_API int rtowSampleBatchChain(RtowContext ctx, int32_t count, const RtowSamp
     int rc = ensureStaging(ctx, n, diagnostics ? diagBytes * (size_t)count : 0);
     if (rc != RTOW_SUCCESS) return rc;
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dColor, in->color, n * 16, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dNormal, in->normal, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dAlbedo, in->albedo, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dScw, in->sampleCountWeight, n * 4, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
     // the chain accumulates in place in the staging buffers (its batches read what their predecessors wrote there); only the final
     // accumulators and each batch's diagnostics travel back
     RtowAccumBuffers dev{ctx->dColor, ctx->dNormal, ctx->dAlbedo, ctx->dScw};
     std::vector<void*> devDiag((size_t)count, nullptr);
     if (diagnostics) for (int b = 0; b < count; b++) devDiag[(size_t)b] = diagnostics[b] ? ctx->dDiag + (size_t)b * diagBytes : nullptr;
-    *ctx->hCancel = 0u;
-    rc = enqueueChain(ctx, count, params, &dev, &dev, diagnostics ? devDiag.data() : nullptr, s, cancel);
-    if (rc != RTOW_SUCCESS) return rc;
-    if (!cancel) { rc = waitWithCancel(ctx, nullptr); if (rc != RTOW_SUCCESS) return rc; }
+    for (;;) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dColor, in->color, n * 16, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dNormal, in->normal, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dAlbedo, in->albedo, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dScw, in->sampleCountWeight, n * 4, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        *ctx->hCancel = 0u;
+        ctx->overflowGrew = false;
+        rc = enqueueChain(ctx, count, params, &dev, &dev, diagnostics ? devDiag.data() : nullptr, s, cancel);
+        if (rc == RTOW_SUCCESS && !cancel) rc = waitWithCancel(ctx, nullptr);
+        // a ray outgrew the hit lists and they have grown since (hitListCapacity 0): the caller's inputs are untouched - nothing has been copied back - so the chain runs again
+        if (rc == RTOW_ERROR_CAPACITY && ctx->overflowGrew) continue;
+        if (rc != RTOW_SUCCESS) return rc;
+        break;
+    }
     const int rows = ownedRows(&params[0]);
     if (rows > 0) {
         const size_t D = (size_t)params[0].sliceDivider, O = (size_t)params[0].sliceOffset;
@@ -1340,11 +1398,6 @@ RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, co
     int rc = ensureStaging(ctx, n, diagBytes);
     if (rc != RTOW_SUCCESS) return rc;
     hipStream_t s = ctx->stream;
-    // inputs: one DMA per buffer into the grow-only staging (pinned when the caller registered its pools, pageable otherwise)
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dColor, in->color, n * 16, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dNormal, in->normal, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dAlbedo, in->albedo, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dScw, in->sampleCountWeight, n * 4, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
 
     // outputs: when every output buffer (and the diagnostics) lies in registered host memory the kernel stores straight into it - each
     // pixel's 48 + stride bytes leave over PCIe when that pixel finishes, spread over the whole batch, and there is no copy-back at all.
@@ -1354,11 +1407,25 @@ RTOW_API int rtowSampleBatch(RtowContext ctx, const RtowSampleParams* params, co
                             (float*)mappedHost(ctx, out->sampleCountWeight, n * 4)};
     uint8_t* directDiag = diagnostics ? mappedHost(ctx, diagnostics, diagBytes) : nullptr;
     const bool zeroCopyOut = direct.color && direct.normal && direct.albedo && direct.sampleCountWeight && (!diagnostics || directDiag);
-    *ctx->hCancel = 0u;
-    rc = launchSample(ctx, params, &dev, zeroCopyOut ? &direct : &dev, diagnostics ? (zeroCopyOut ? (void*)directDiag : (void*)ctx->dDiag) : nullptr, s, cancel != nullptr);
-    if (rc != RTOW_SUCCESS) return rc;
-    rc = waitWithCancel(ctx, cancel);
-    if (rc != RTOW_SUCCESS) return rc;
+    // (stores that go straight into the caller's OUTPUT arrays leave its input arrays alone unless they are the same arrays: only then a batch cannot be run twice)
+    const bool inputsSurvive = !zeroCopyOut || (in->color != out->color && in->normal != out->normal && in->albedo != out->albedo && in->sampleCountWeight != out->sampleCountWeight);
+    for (;;) {
+        // inputs: one DMA per buffer into the grow-only staging (pinned when the caller registered its pools, pageable otherwise)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dColor, in->color, n * 16, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dNormal, in->normal, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dAlbedo, in->albedo, n * 12, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dScw, in->sampleCountWeight, n * 4, hipMemcpyHostToDevice, s), RTOW_ERROR_LAUNCH_FAILURE);
+        *ctx->hCancel = 0u;
+        ctx->overflowGrew = false;
+        rc = launchSample(ctx, params, &dev, zeroCopyOut ? &direct : &dev, diagnostics ? (zeroCopyOut ? (void*)directDiag : (void*)ctx->dDiag) : nullptr, s, cancel != nullptr);
+        if (rc != RTOW_SUCCESS) return rc;
+        rc = waitWithCancel(ctx, cancel);
+        // The reference's hit list grows without bound (UTIL/HybridCollections.cs:65-71).  Here a ray that outgrew the lists made the batch invalid and the lists twice
+        // as long (hitListCapacity 0: growHitList): the batch runs again from the caller's inputs, until it fits or the scene's own bound / the memory is reached.
+        if (rc == RTOW_ERROR_CAPACITY && ctx->overflowGrew && inputsSurvive) continue;
+        if (rc != RTOW_SUCCESS) return rc;
+        break;
+    }
 
     // copy back ONLY the rows this slice owns: skipped pixels write nothing (JOBS/SampleBatchJob.cs:69-70)
     const int rows = ownedRows(params);

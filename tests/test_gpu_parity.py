@@ -372,3 +372,63 @@ def test_per_sample_rng_policy(rt, oracle, gpu_context, policy):
         q = rt.scenes.make_params(scene, **kw)
         assert not np.array_equal(osc.sample_batch(q)["color"], ref["color"])
         osc.close()
+
+
+def test_hit_lists_grow_like_the_references(rt, oracle):
+    """The reference's hit list grows on the heap without bound (UTIL/HybridCollections.cs:22-36,65-71).  With RtowContextOptions.hitListCapacity left at 0 the library's
+    lists start at 1024 entries in a scene with volumes; 560 stacked hulls put 1121 surfaces on a camera ray.  The host-buffer call notices, doubles the lists (up to the
+    2 hits per entity a scene can produce at all) and runs the batch again by itself: the caller sees the reference's frame, not RTOW_ERROR_CAPACITY."""
+    scene = rt.scenes.volume_stack_scene(560, 1.0 / 128.0)
+    with rt.Context(0) as ctx:
+        desc = scene.desc()
+        ctx.upload_scene(desc)
+        assert ctx.scene_info().hitListCapacity == 1024
+        p = rt.scenes.make_params(scene, 32, 32, spp=1, trace_depth=4, diagnostics_stride=16)
+        gpu = rt.sample_batch_host(ctx, p)
+        assert ctx.scene_info().hitListCapacity == 2 * 563                  # 2 rects + 560 boxes + 1 sphere, entry and exit each: nothing in this scene can need more
+        osc = oracle.OracleScene(desc)
+        ref, counters = osc.sample_batch(p, None, want_counters=True)
+        assert counters.maxHits > 1024
+        _compare(gpu, ref)
+        # the chain's host form likewise (a fresh context: the capacity a context has grown to stays)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(desc)
+        p2 = rt.scenes.make_params(scene, 32, 32, spp=1, trace_depth=4, diagnostics_stride=16)
+        p2.seed = p.seed + 1
+        gpu = rt.sample_batch_chain_host(ctx, [p, p2], None)
+        ref2 = osc.sample_batch(p2, ref)
+        for k in ("color", "normal", "albedo", "scw"):
+            assert np.array_equal(gpu[k].reshape(ref2[k].shape).view(np.uint32), ref2[k].view(np.uint32)), k
+        # device-resident callers are told once, and the batch - issued again from inputs it did not overwrite - then has room
+    with rt.Context(0) as ctx:
+        a = rt.abi
+        ctx.upload_scene(desc)
+        n = 32 * 32
+        ins = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+        outs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+        dg = rt.DeviceBuffer(ctx, n * 16).zero()
+        assert rt.sample_batch_chain_device(ctx, [p], ins, outs, [dg]) == a.RTOW_SUCCESS
+        with pytest.raises(rt.lib.RtowError) as e:
+            ctx.synchronize()
+        assert e.value.code == a.RTOW_ERROR_CAPACITY
+        assert rt.sample_batch_chain_device(ctx, [p], ins, outs, [dg]) == a.RTOW_SUCCESS
+        ctx.synchronize()
+        for (k, c), b in zip((("color", 4), ("normal", 3), ("albedo", 3), ("scw", 1)), outs):
+            got = b.download(np.float32, (n, c) if c > 1 else (n,))
+            assert np.array_equal(got.reshape(ref[k].shape).view(np.uint32), ref[k].view(np.uint32)), k
+        for b in ins + outs + [dg]:
+            b.free()
+    osc.close()
+
+
+def test_a_fixed_hit_list_capacity_stays_fixed(rt):
+    """A caller that sets RtowContextOptions.hitListCapacity has chosen the memory it spends: the lists do not grow, the batch reports RTOW_ERROR_CAPACITY as before."""
+    scene = rt.scenes.volume_stack_scene(48, 0.125)                            # 99 hits per camera ray
+    with rt.Context(0, hit_list_capacity=64) as ctx:
+        ctx.upload_scene(scene.desc())
+        p = rt.scenes.make_params(scene, 32, 32, spp=1, trace_depth=4)
+        for _ in range(2):
+            with pytest.raises(rt.lib.RtowError) as e:
+                rt.sample_batch_host(ctx, p)
+            assert e.value.code == rt.abi.RTOW_ERROR_CAPACITY
+            assert ctx.scene_info().hitListCapacity == 64

@@ -142,3 +142,24 @@ def test_fallback_aovs_with_and_without_earlier_successes(rt, oracle):
     assert _differs(acc, want) == 0
     first = _oracle_batches(oracle, scene, plist[:2], start)[0]
     assert (first["color"][:, 3] == 0).sum() > n // 4 and np.abs(first["normal"]).sum() > 0          # after two batches: many pixels without a success, their fallback normals stored
+
+
+@pytest.mark.parametrize("flags", [0, "always"])
+def test_tie_lists_longer_than_the_default_capacity_grow(rt, oracle, flags):
+    """142 spheres on the centre column's rays: longer than the 128 entries the exact-tie procedure's lists start with outside volume scenes.  The fix-up launch (default
+    flags) or the exact-tie kernels themselves (RTOW_CONTEXT_EXACT_TIES_ALWAYS) flag the ray, the lists double up to the scene's 142 entities, the host-buffer call runs
+    the batch again by itself - the reference's list simply grows (UTIL/HybridCollections.cs:65-71)."""
+    flags = rt.abi.CONTEXT_EXACT_TIES_ALWAYS if flags == "always" else flags
+    scene = _scene(rt, 140)
+    desc = scene.desc()
+    n = W * H
+    p = rt.scenes.make_params(scene, W, H, spp=3, trace_depth=4, seed=21, jitter=False, focus=5.0, diagnostics_stride=4)
+    start = _start(n)
+    want, wdiag = _oracle_batches(oracle, scene, [p], start)
+    with rt.Context(0, flags=flags) as ctx:
+        ctx.upload_scene(desc)
+        r = rt.sample_batch_host(ctx, p, {k: v.copy() for k, v in start.items()})
+        assert _differs({k: r[k] for k, _ in KEYS}, want) == 0
+        assert np.array_equal(r["diag"][:, 0], wdiag[0][:, 0])
+        if flags:
+            assert ctx.scene_info().hitListCapacity == 142
