@@ -273,3 +273,94 @@ def test_cosine_hemisphere_and_uniform_direction_moments(rt, oracle):
     assert np.abs(dirs.mean(axis=0)).max() < 5.0 * 0.58 / math.sqrt(n)
     m2 = dirs.T @ dirs / n
     assert np.abs(m2 - np.eye(3) / 3).max() < 5.0 * 0.3 / math.sqrt(n)
+
+
+def _scatter(lib, mat, direction, normal, state):
+    import ctypes as C
+    res = (C.c_float * 16)()
+    d = [float(x) for x in direction]
+    n = [float(x) for x in normal]
+    lib.oracle_kat_scatter(C.byref(mat), (C.c_float * 3)(*[-x for x in d]), (C.c_float * 3)(*d), 0.0, (C.c_float * 3)(0.0, 0.0, 0.0), (C.c_float * 3)(*n), 1.0,
+                           C.byref(state), res)
+    return np.array(res[:16], np.float64)
+
+
+def test_smooth_glass_obeys_snell_and_the_mirror_law_with_schlick_frequencies(rt, oracle):
+    """Optics, written down independently of the oracle: a smooth dielectric of index 1.5 sends a ray either along the mirror direction d - 2 (d.N) N or along Snell's
+    refraction (coplanar with d and N, sin t = sin i / 1.5 entering, sin t = 1.5 sin i leaving, nothing beyond the critical angle asin(1 / 1.5) = 41.8 deg), and reflects with
+    Schlick's probability r0 + (1 - r0)(1 - c)^5, r0 = ((1 - n) / (1 + n))^2 = 0.04, where c is the cosine of incidence entering and - the first book's convention, which
+    the reference keeps (RT/Material.cs: cosine = IndexOfRefraction * dot(direction, normal)) - n times it leaving."""
+    import ctypes as C
+    lib = oracle.load("strict")
+    glass = S.dielectric(1.5)
+    n_ior = 1.5
+    N = np.array((0.0, 1.0, 0.0))
+    state = C.c_uint32(2024)
+    draws = 6000
+    for entering in (True, False):
+        for deg in (0.0, 20.0, 35.0, 41.0, 43.0, 60.0, 80.0):
+            th = math.radians(deg)
+            # the ray travels in the x-y plane; entering: towards -N (from above), leaving: towards +N (from inside, the stored normal points outward)
+            d = np.array((math.sin(th), -math.cos(th) if entering else math.cos(th), 0.0))
+            mirror = d - 2.0 * (d @ N) * N
+            sin_t = math.sin(th) / n_ior if entering else math.sin(th) * n_ior
+            total_internal = sin_t >= 1.0
+            if not total_internal:
+                cos_t = math.sqrt(1.0 - sin_t * sin_t)
+                refr = np.array((sin_t, -cos_t if entering else cos_t, 0.0))
+            c = math.cos(th) if entering else n_ior * math.cos(th)
+            r0 = ((1.0 - n_ior) / (1.0 + n_ior)) ** 2
+            schlick = r0 + (1.0 - r0) * (1.0 - c) ** 5
+            reflected = 0
+            for _ in range(draws):
+                out = _scatter(lib, glass, d, N, state)
+                w = out[6:9]
+                assert abs(np.linalg.norm(w) - 1.0) < 2e-6
+                if np.abs(w - mirror).max() < 2e-6:
+                    reflected += 1
+                    assert tuple(out[0:3]) == (1.0, 1.0, 1.0)
+                else:
+                    assert not total_internal, (entering, deg)
+                    assert np.abs(w - refr).max() < 3e-6, (entering, deg, w, refr)
+            if total_internal:
+                assert reflected == draws
+            else:
+                p = min(max(schlick, 0.0), 1.0)                    # (leaving near the critical angle the book's cosine exceeds 1 and the 'probability' with it: then every draw refracts... or none)
+                if schlick >= 1.0:
+                    assert reflected == draws
+                elif schlick <= 0.0:
+                    assert reflected == 0
+                else:
+                    assert abs(reflected / draws - p) < 5.0 * math.sqrt(p * (1.0 - p) / draws) + 1e-9, (entering, deg, reflected / draws, p)
+
+
+def test_a_polished_metal_is_a_mirror_about_any_normal(rt, oracle):
+    """Standard material, metallic 1, glossiness 1 (IsPerfectSpecular): every scattered ray leaves along d - 2 (d.N) N exactly, tinted by the albedo or - the glossy
+    lobe - untinted; nothing diffuse."""
+    import ctypes as C
+    lib = oracle.load("strict")
+    albedo = (0.8, 0.6, 0.2)
+    mirror_mat = S.metal(albedo, 0.0)
+    state = C.c_uint32(77)
+    rng = np.random.default_rng(5)
+    tinted = untinted = 0
+    for _ in range(400):
+        N = rng.normal(size=3)
+        N /= np.linalg.norm(N)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if d @ N > -0.05:
+            d = d - 2.0 * (d @ N) * N if d @ N > 0.05 else -N          # arrive from the normal's side
+        N32 = np.array(N, np.float32).astype(np.float64)
+        d32 = np.array(d, np.float32).astype(np.float64)
+        out = _scatter(lib, mirror_mat, d32, N32, state)
+        assert out[12] == 1.0                                           # IsPerfectSpecular
+        want = d32 - 2.0 * (d32 @ N32) * N32
+        assert np.abs(out[6:9] - want).max() < 3e-6
+        refl = tuple(np.round(out[0:3], 6))
+        if refl == (1.0, 1.0, 1.0):
+            untinted += 1
+        else:
+            assert np.abs(out[0:3] - np.array(albedo, np.float32).astype(np.float64)).max() < 1e-7
+            tinted += 1
+    assert tinted > 0 and untinted > 0
