@@ -432,7 +432,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     // ---- camera-ray candidate lists: one conservative beam walk per pixel, reused by all its samples (and by later batches of the same view) ----
     if (!(ctx->flags & RTOW_CONTEXT_NO_CAMERA_RAY_LISTS)) {
         const size_t pixels = (size_t)a.width * (size_t)a.height;
-        const size_t listBytes = pixels * (ctx->wideCodes ? sizeof(uint4) : sizeof(uint2));      // 4 x 16-bit node codes per pixel; 4 x 32-bit with wide codes
+        const size_t listBytes = pixels * sizeof(uint4);      // 8 x 16-bit node codes per pixel; 4 x 32-bit with wide codes
         if (listBytes > ctx->pixCandCapacity) {
             if (ctx->dPixCand) (void)hipFree(ctx->dPixCand);
             ctx->dPixCand = nullptr;

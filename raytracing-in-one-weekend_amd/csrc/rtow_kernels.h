@@ -104,7 +104,7 @@ struct SampleKernelArgs {
     const unsigned int* chunkOrder;       // chunk launch order (most expensive first), null = natural order
     unsigned short* pixelCost;            // [64 * chunkCount], ticket order: ray count of every pixel of THIS launch (input of the next launch's order); null = not recorded
     uint32_t chunkCount;
-    const uint2* pixelCandidates;         // [width * height]: camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray;
+    const uint2* pixelCandidates;         // [2 x width * height] = one uint4 per pixel (8 x 16-bit node codes, or 4 x 32-bit): camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray;
                                           // wideCodes: uint4 records (4 x 32-bit node indices) behind the same pointer
     int32_t probeOnly;                    // > 0: probe - this many samples per pixel, nothing stored but pixelCost (1: the cost probe; 4: the threshold-tuning probes)
     const volatile uint32_t* cancelFlag;  // host-pinned, may be null

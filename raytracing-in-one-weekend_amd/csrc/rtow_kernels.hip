@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256) primary_candidates_kernel(SampleKernelArg
     };
 
     const unsigned none = A.wideCodes ? 0xffffffffu : 0xffffu;
-    unsigned list[4] = {none, none, none, none};
+    const int capacity = (A.wideCodes || L.sceneKind > SCENE_KIND_SPHERES_MOTION) ? 4 : 8;      // what one uint4 per pixel holds - and what the scene kind's kernels keep of it (sphere kinds: all eight)
+    unsigned list[8] = {none, none, none, none, none, none, none, none};
     int count = 0;
     int stack[RTOW_STACK_CAPACITY + 1];
     int sp = 0, cur = 0;
@@ -162,14 +163,14 @@ __global__ void __launch_bounds__(256) primary_candidates_kernel(SampleKernelArg
             else ok = false;
         }
         if (leafChildInBeam) {                                                  // the NODE goes on the list: its leaf boxes are re-tested per ray
-            if (count == 4) ok = false;
-            for (int k = 0; k < 4; k++) if (k == count) list[k] = (unsigned)node;
+            if (count == capacity) ok = false;
+            for (int k = 0; k < 8; k++) if (k == count) list[k] = (unsigned)node;
             count++;
         }
         if (cur < 0 && sp > 0) cur = stack[--sp];
     }
     if (A.wideCodes) reinterpret_cast<uint4*>(out)[pix] = ok ? make_uint4(list[0], list[1], list[2], list[3]) : make_uint4(0xffffffffu, 0u, 0u, 0u);   // first slot empty, second not: no list
-    else out[pix] = ok ? make_uint2(list[0] | (list[1] << 16), list[2] | (list[3] << 16)) : make_uint2(kNoPrimaryList, 0u);
+    else reinterpret_cast<uint4*>(out)[pix] = ok ? make_uint4(list[0] | (list[1] << 16), list[2] | (list[3] << 16), list[4] | (list[5] << 16), list[6] | (list[7] << 16)) : make_uint4(kNoPrimaryList, 0u, 0u, 0u);
 }
 
 // pixelCost[64 * chunk .. +63] -> cost[chunk] = sum, cost[n + chunk] = max; one wave per chunk

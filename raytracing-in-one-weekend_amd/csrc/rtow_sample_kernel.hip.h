@@ -1052,6 +1052,13 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // the tie fix-up launch (SampleKernelArgs.redoMode) has nothing to do almost always: it leaves before it stages the scene
     if (A.redoMode) { if (__hip_atomic_load(A.tieRedo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return; }
     constexpr bool WIDE = (GEO & kGeoWide) != 0;
+    // Camera-ray lists hold up to eight leaf-parent nodes with 16-bit codes (one uint4 per pixel, four registers), four with 32-bit codes.  Four covered 95.6 % of the
+    // cover scene's pixels (pinhole camera), 93.6 % of the 10 000 spheres', 56.7 % with moving spheres and a lens; eight cover 100 / 99.9 / 88.5 %.  The pixels beyond four
+    // are sphere edges in tiles of sky - the minority lanes whose walks wait longest for their stage (profiles/r04n): cover scene +1.1 % (10 batches per launch), +6.6 % as
+    // single launches; 10 000 spheres +4.1 %; moving + defocus +13 % (profiles/r04q_camera_ray_lists.json)
+    // Sphere kinds only: the general-entity, textured and volume kernels spill already, and two more list registers cost them more than the lists bring
+    // (image-textured spheres -13 %, mixed primitives -1.7 % with eight nodes: gpurun_out/r04am); their lists stay at four nodes (the first uint2 of the pixel's record).
+    constexpr bool LONG_LISTS = !WIDE && (KIND & 7) <= SCENE_KIND_SPHERES_MOTION;
     using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
     constexpr int kStackBytesT = (int)geo_stack_bytes(GEO);
 
@@ -1498,8 +1505,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     }
                     rayCount = 0; boundsHits = 0; candidates = 0;
                     // the pixel's camera-ray candidates (primary_candidates_kernel): up to 4 primitive indices, 0xFFFF = none
-                    if (WIDE) pcand = C.pixelCandidates ? reinterpret_cast<const uint4*>(C.pixelCandidates)[pix] : make_uint4(0xffffffffu, 0u, 0u, 0u);
-                    else { const uint2 pc = C.pixelCandidates ? C.pixelCandidates[pix] : make_uint2(kNoPrimaryList, 0u); pcand = make_uint4(pc.x, pc.y, 0u, 0u); }
+                    if (WIDE || LONG_LISTS) pcand = C.pixelCandidates ? reinterpret_cast<const uint4*>(C.pixelCandidates)[pix] : make_uint4(WIDE ? 0xffffffffu : kNoPrimaryList, 0u, 0u, 0u);
+                    else { const uint2 pc = C.pixelCandidates ? C.pixelCandidates[2 * (size_t)pix] : make_uint2(kNoPrimaryList, 0u); pcand = make_uint4(pc.x, pc.y, 0u, 0u); }
                 }
                 if (st == ST_REGEN) {
                     // ---- camera ray (:134-135, RT/View.cs:38-48) ----
@@ -1538,10 +1545,10 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     pendRE = 0;
                     startRay();
                     if (WIDE ? !(pcand.x == 0xffffffffu && pcand.y != 0xffffffffu) : pcand.x != kNoPrimaryList) {
-                        // Every camera ray of this pixel can only hit primitives under the (at most four) leaf-parent nodes of the pixel's
-                        // list: instead of walking the tree, visit just those nodes - with the walk's own slab test of this very ray against
-                        // their leaf boxes (same expressions, so the same candidates the walk would find: a ray that misses a leaf's box must
-                        // not reach that leaf's exact test, whose rounding can report a hit for a far, small sphere it passes closely).
+                        // Every camera ray of this pixel can only hit primitives under the leaf-parent nodes of the pixel's list (at most eight; four with 32-bit
+                        // codes): instead of walking the tree, visit just those nodes - with the walk's own slab test
+                        // of this very ray against their leaf boxes (same expressions, so the same candidates the walk would find: a ray that misses a leaf's
+                        // box must not reach that leaf's exact test, whose rounding can report a hit for a far, small sphere it passes closely).
                         const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
                         const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
                         cur = -1;
@@ -1567,7 +1574,9 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             cand[nc * BT] = (Code)~c1;
                             nc += leaf1 ? 1 : 0;
                         }
-                        if (nc == 0) classify(); else st = ST_TEST;
+                        // nodes five to eight: the exact-test stage comes back for them when these candidates are done (cur = -2 - k: node k is next)
+                        if (LONG_LISTS) { if ((pcand.z & 0xffffu) != 0xffffu) cur = -6; }
+                        if (nc == 0 && cur == -1) classify(); else st = ST_TEST;
                     }
                 }
             }
@@ -1648,6 +1657,39 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
             // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
             if (st == ST_TEST) {
                 const float a = dot(rd, rd);
+                for (;;) {
+                if (LONG_LISTS) {
+                    if (cur <= -2) {
+                        // ---- the rest of a camera ray's long list: as many nodes at a time as the candidate list has room for (see REGEN) ----
+                        const f2 invx = {inv.x, inv.x}, invy = {inv.y, inv.y}, invz = {inv.z, inv.z};
+                        const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
+                        int k = -2 - cur;
+                        cur = -1;
+                        for (; k < 8; k++) {
+                            if (nc > kCandCapacity - 2) { cur = -2 - k; break; }                    // no room for two more: test what is here, then come back
+                            const unsigned word = k < 6 ? pcand.z : pcand.w;
+                            const unsigned node = (word >> (16 * (k & 1))) & 0xffffu;
+                            if (node == 0xffffu) break;
+                            float4 q0, q1, q2;
+                            int c0, c1;
+                            load_node<ALL_LDS>(sc, L, (int)node, q0, q1, q2, c0, c1);
+                            const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
+                            const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
+                            const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
+                            const float tmin0 = vmax3(vmin(tlx.x, thx.x), vmin(tly.x, thy.x), vmax(vmin(tlz.x, thz.x), 0.0f));
+                            const float tfar0 = vmin3(vmax(tlx.x, thx.x), vmax(tly.x, thy.x), vmax(tlz.x, thz.x));
+                            const float tmin1 = vmax3(vmin(tlx.y, thx.y), vmin(tly.y, thy.y), vmax(vmin(tlz.y, thz.y), 0.0f));
+                            const float tfar1 = vmin3(vmax(tlx.y, thx.y), vmax(tly.y, thy.y), vmax(tlz.y, thz.y));
+                            const bool leaf0 = c0 < 0 && tmin0 < tfar0;
+                            const bool leaf1 = c1 < 0 && tmin1 < tfar1 && twoChildren;
+                            if (FULL_DIAG && !refDiag) boundsHits += (leaf0 ? 1.0f : 0.0f) + (leaf1 ? 1.0f : 0.0f);
+                            cand[nc * BT] = (Code)~c0;
+                            nc += leaf0 ? 1 : 0;
+                            cand[nc * BT] = (Code)~c1;
+                            nc += leaf1 ? 1 : 0;
+                        }
+                    }
+                }
                 if (FULL_DIAG && !refDiag) candidates += (float)nc;
                 while (nc > 0) {
                     STAT_ADD(5, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0);
@@ -1724,6 +1766,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             } else if (t < best || (prim >= 0 && rank[i] < rank[prim])) { best = t; prim = i; }
                         }
                     }
+                }
+                if (!LONG_LISTS || cur > -2) break;               // (else: more of the camera ray's list)
                 }
                 if (cur >= 0) st = ST_TRAV;        // the list was full: resume the walk, now pruned by `best`
                 else classify();

@@ -112,7 +112,7 @@ def test_hot_variants_stay_spill_free(compiled, unit, kind):
                 assert u["scratch"] <= 68, (name, u)       # (the moving kind with the scene in LDS: 36 until round 3, 68 since the batch groups' per-batch output table)
     assert hot == 4, hot                                     # 2 history widths x (LDS | HBM)
     headline = [u for n, u in usage.items() if "sample_batch_kernel" in n and _variant(n) == (1, kind, 4, 0, 0, 0, 0)]
-    assert len(headline) == 1 and headline[0]["vgprs"] <= 126, headline
+    assert len(headline) == 1 and headline[0]["vgprs"] <= (124 if kind == 0 else 128), headline      # (round 4: two more for camera-ray lists of eight nodes)
 
 
 @pytest.mark.parametrize("unit", ["rtow_sample_spheres", "rtow_sample_spheres_motion"])
