@@ -208,7 +208,7 @@ def _hybrid_worker(rank, world, port, tiles, out_path):
     osc.close()
 
 
-@pytest.mark.parametrize("world,tiles", [(2, 1), (2, 2), (3, 1), (4, 2)])
+@pytest.mark.parametrize("world,tiles", [(2, 1), (2, 2), (3, 1), (4, 2), (6, 2), (6, 3)])
 def test_hybrid_tiles_x_batches_equals_the_ordered_fold_of_the_reference_batches(rt, oracle, tmp_path, world, tiles):
     """G = T x B ranks, two steps: the gathered colour frame and every rank's rows of all four accumulators equal - bit for bit - the oracle's B
     sub-batches per step folded in group order on top of the running accumulation, and agree with the reference's own SEQUENTIAL accumulation of the
