@@ -432,3 +432,23 @@ def test_a_fixed_hit_list_capacity_stays_fixed(rt):
                 rt.sample_batch_host(ctx, p)
             assert e.value.code == rt.abi.RTOW_ERROR_CAPACITY
             assert ctx.scene_info().hitListCapacity == 64
+
+
+@pytest.mark.parametrize("aperture", [0.0, 0.2])
+@pytest.mark.parametrize("w,h", [(6, 6), (12, 8), (48, 32)])
+def test_camera_ray_lists_of_many_nodes_and_several_rounds(rt, oracle, gpu_context, w, h, aperture):
+    """Few, wide pixels over a dense grid of small spheres: a pixel's beam meets up to eight leaf parents (the list's capacity for the sphere kinds) or more (no list: the
+    camera ray walks), and a long list fills the eight candidate slots more than once (continuation rounds in the exact-test stage).  With a lens the beams widen further."""
+    S = rt.scenes
+    s = S.Scene("dense grid under wide pixels")
+    rng = np.random.default_rng(3)
+    for ix in range(7):
+        for iy in range(5):
+            for iz in range(2):
+                s.add_sphere((-0.9 + 0.3 * ix + 0.02 * rng.random(), -0.6 + 0.3 * iy + 0.02 * rng.random(), -0.4 * iz), 0.11 + 0.03 * rng.random(),
+                             S.lambertian((0.2 + 0.1 * ix, 0.3 + 0.1 * iy, 0.5)) if (ix + iy + iz) % 3 else S.metal((0.8, 0.8, 0.6), 0.1))
+    s.add_sphere((0.0, -100.8, 0.0), 100.0, S.lambertian((0.5, 0.5, 0.5)))
+    s.camera = {"position": [0.1, 0.05, 3.0], "target": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": aperture}
+    gpu, ref = _run_both(rt, oracle, gpu_context, s, w, h, 16, 6, diagnostics_stride=16, focus=3.0)
+    _compare(gpu, ref)
+    assert gpu["color"][:, 3].sum() > 0
