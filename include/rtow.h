@@ -338,7 +338,8 @@ typedef struct RtowContextOptions {
                                      * that meets a longer ray doubles them (up to what the scene can produce, and to a quarter of the free device memory) when its
                                      * status is read.  rtowSampleBatch / rtowSampleBatchChain read it themselves and run the batch again from the caller's inputs
                                      * (unless outputs registered with rtowRegisterHostBuffer ARE the inputs); the device-resident forms report RTOW_ERROR_CAPACITY
-                                     * once through rtowGetBatchStatus / rtowSynchronize and the same call, issued again from inputs it did not overwrite, has room.
+                                     * once through rtowGetBatchStatus / rtowSynchronize and the same call, issued again from inputs it did not overwrite, has room (if
+                                     * rtowGetSceneInfo.hitListCapacity did not change across the error the lists could not grow - device memory - and the error is final).
                                      * The capacity a context has grown to stays across rtowUploadScene (rtowGetSceneInfo.hitListCapacity shows it) */
     int32_t sliceBlockThreads;      /* reserved: 0 (or 1024).  Rounds 2 - 3 could run 512 / 256 lanes per workgroup for launches that own about one pixel per
                                      * resident lane; measured slower at every slice count and removed.  Other values: RTOW_ERROR_INVALID_VALUE */
