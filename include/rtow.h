@@ -42,7 +42,7 @@ extern "C" {
 #define RTOW_API __attribute__((visibility("default")))
 #endif
 
-#define RTOW_API_VERSION 10
+#define RTOW_API_VERSION 11
 
 /* ---- result codes (0 == success, like CudaError/OptixResult in OptixApi.cs:24-78) ---- */
 typedef enum RtowResult {
@@ -431,6 +431,19 @@ RTOW_API int rtowSampleBatchChain(RtowContext context, int32_t count, const Rtow
  * (JOBS/DenoiseJobs.cs:75-117); this is that pattern with the copies taken off the critical path. */
 RTOW_API int rtowRegisterHostBuffer(RtowContext context, void* pointer, size_t sizeInBytes);
 RTOW_API int rtowUnregisterHostBuffer(RtowContext context, void* pointer);
+
+/* One ray against the resident scene: the nearest Entity.Hit (tMin 0, tMax +inf) along origin + t * direction at ray time `time`.
+ * replaces: HitWorld (UNITY/Raytracer.cs:1353: BvhRoot->Hit(r, 0, float.PositiveInfinity, out hitRec) -> the recursive HitTests.Hit(BvhNode),
+ * RT/HitTests.cs:152-196), which ScheduleSample calls with the camera's centre ray before EVERY batch to set the focus distance
+ * (UNITY/Raytracer.cs:608-609: `if (HitWorld(new Ray(origin, forward), out hitRec)) focusDistance = hitRec.Distance;` - ray time 0).  With this call the host
+ * no longer needs a tree of its own, i.e. its serial RebuildBvh (UNITY/Raytracer.cs:1306-1351), once the scene is uploaded.
+ * *distance: hitRec.Distance, bit for bit (the path's own float program; +INFINITY on a miss).  *entityIndex: index of the hit entity in
+ * RtowSceneDesc.entities, -1 on a miss; of several entities at the bit-identical nearest distance the one that comes first in the reference tree's
+ * leaf order - the one the sample path shades (the reference's recursion prefers its right subtree on such a tie; the host reads the distance only).
+ * Either pointer may be NULL.  Walked on the host through the tree rtowUploadScene built (its image stays in host memory): microseconds, no device work, so batches
+ * in flight are neither waited for nor disturbed - the host calls this from ScheduleSample while the previous batch is still tracing (UNITY/Raytracer.cs:586-611), and a
+ * launch could only start when that batch ends.  RTOW_ERROR_NO_SCENE before rtowUploadScene. */
+RTOW_API int rtowProbeNearestHit(RtowContext context, const RtowFloat3* origin, const RtowFloat3* direction, float time, float* distance, int32_t* entityIndex);
 
 /* Device time (ms) of the most recent sample kernel of this context, measured with HIP events recorded on the
  * stream the kernel was launched on (the RecordTimeJob 0/1 bracket, JOBS/UtilJobs.cs:77-86). Synchronises on the end event. */

@@ -96,6 +96,8 @@ def load(kind="strict"):
     lib.oracle_kat_scatter.argtypes = [C.POINTER(abi.Material), fp, fp, C.c_float, fp, fp, C.c_float, C.POINTER(C.c_uint32), fp]
     lib.oracle_kat_get_ray.argtypes = [C.POINTER(abi.View), C.c_float, C.c_float, C.POINTER(C.c_uint32), fp]
     lib.oracle_kat_nearest_hit.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]
+    lib.oracle_hit_world.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]
+    lib.oracle_hit_world.restype = C.c_int
     _libs[kind] = lib
     return lib
 
@@ -185,6 +187,12 @@ class OracleScene:
         res = {k: v[idx] for k, v in out.items()}
         res["diag"] = diag[idx]
         return res
+
+    def hit_world(self, origin, direction, time=0.0):
+        """Raytracer.HitWorld (the recursive HitTests.Hit(BvhNode), RT/HitTests.cs:152-196): (hit, [distance, point, normal, entity index])."""
+        o = (C.c_float * 8)()
+        hit = self.lib.oracle_hit_world(self.handle, _f3(origin), _f3(direction), float(time), o)
+        return bool(hit), list(o)
 
     def nearest_hit(self, origin, direction, time=0.0):
         o = (C.c_float * 8)()

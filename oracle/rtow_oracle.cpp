@@ -2080,6 +2080,52 @@ ORACLE_API int oracle_kat_nearest_hit(void* scenePtr, const float* ro, const flo
     return (int)s.hitRecordBuffer.size();
 }
 
+/* HitTests.Hit(this BvhNode n, Ray r, float tMin, float tMax, out HitRecord rec) (RT/HitTests.cs:152-196): the recursion behind Raytracer.HitWorld
+ * (UNITY/Raytracer.cs:1353), the auto-focus probe of ScheduleSample (:608-609).  Not the job's FindHitCandidates / FindHits pair: the reciprocal
+ * direction is taken as it comes (no NaN -> INFINITY step), a leaf keeps its FIRST entity on equal distances (:167 `thisRec.Distance < rec.Distance`),
+ * an inner node its RIGHT child's hit (:185 `leftRecord.Distance < rightRecord.Distance ? leftRecord : rightRecord`). */
+static bool HitBvhNode(const OracleScene* scene, int nodeIndex, const Ray& r, float tMin, float tMax, HitRecord* rec)
+{
+    const BvhNode& n = scene->nodes[nodeIndex];
+    memset(rec, 0, sizeof(*rec));                                                                  /* rec = default */
+    const float3 rayInvDirection = f3(um_rcp(r.Direction.x), um_rcp(r.Direction.y), um_rcp(r.Direction.z));
+    if (!HitAabb(n.Bounds, r.Origin, rayInvDirection)) return false;
+    if (n.IsLeaf()) {
+        bool anyHit = false;
+        for (int i = 0; i < n.EntityCount; i++) {
+            HitRecord thisRec;
+            const bool thisHit = scene->bvhEntities[n.EntitiesStart + i].Hit(r, tMin, tMax, &thisRec);
+            if (thisHit && (!anyHit || thisRec.Distance < rec->Distance)) {
+                anyHit = true;
+                *rec = thisRec;
+                rec->EntityPtr = &scene->bvhEntities[n.EntitiesStart + i];
+            }
+        }
+        return anyHit;
+    }
+    HitRecord leftRecord, rightRecord;
+    const bool hitLeft = HitBvhNode(scene, n.Left, r, tMin, tMax, &leftRecord);
+    const bool hitRight = HitBvhNode(scene, n.Right, r, tMin, tMax, &rightRecord);
+    if (!hitLeft && !hitRight) return false;
+    if (hitLeft && hitRight) { *rec = leftRecord.Distance < rightRecord.Distance ? leftRecord : rightRecord; return true; }
+    if (hitLeft) { *rec = leftRecord; return true; }
+    *rec = rightRecord;
+    return true;
+}
+/* Raytracer.HitWorld: BvhRoot->Hit(r, 0, float.PositiveInfinity, out hitRec).  out = {distance, point[3], normal[3], entityIndex}; returns 1 on a hit. */
+ORACLE_API int oracle_hit_world(void* scenePtr, const float* ro, const float* rd, float time, float* out)
+{
+    const OracleScene* scene = (const OracleScene*)scenePtr;
+    const Ray ray(f3(ro[0], ro[1], ro[2]), f3(rd[0], rd[1], rd[2]), time);
+    HitRecord r;
+    if (!HitBvhNode(scene, 0, ray, 0.0f, INFINITY, &r)) return 0;
+    out[0] = r.Distance;
+    out[1] = r.Point.x; out[2] = r.Point.y; out[3] = r.Point.z;
+    out[4] = r.Normal.x; out[5] = r.Normal.y; out[6] = r.Normal.z;
+    out[7] = (float)r.EntityPtr->SourceIndex;
+    return 1;
+}
+
 /* sizeof() of every boundary struct as the C++ compiler sees include/rtow.h; tests compare them with the ctypes mirror. */
 ORACLE_API void oracle_abi_sizes(int* out)
 {

@@ -6,7 +6,7 @@ library is compiled from the same header and exposes the sizes it saw).
 """
 import ctypes as C
 
-RTOW_API_VERSION = 10
+RTOW_API_VERSION = 11
 
 # RtowResult
 RTOW_SUCCESS = 0
@@ -172,5 +172,5 @@ EXPORTED_SYMBOLS = [
     "rtowDeviceCopy", "rtowDeviceMemset", "rtowSynchronize", "rtowGetBatchStatus", "rtowRegisterHostBuffer", "rtowUnregisterHostBuffer",
     "rtowSampleBatchChainDevice", "rtowSampleBatchChain", "rtowCommSetLibraryPath", "rtowCommGetUniqueId", "rtowCommInit", "rtowCommDestroy", "rtowGatherRowsDevice",
     "rtowHybridPlan", "rtowExchangeAccumDevice", "rtowSampleBatchGroupDevice",
-    "rtowCombineFinalizeDevice", "rtowReduceMetricsDeviceAsync",
+    "rtowCombineFinalizeDevice", "rtowReduceMetricsDeviceAsync", "rtowProbeNearestHit",
 ]

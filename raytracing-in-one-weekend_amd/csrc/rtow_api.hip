@@ -29,6 +29,9 @@
 // cover 9 417 against 8 685 Msamples/s (+8.4 %), 10 000 spheres 7 513 against 7 042 (+6.7 %), moving + defocus 6 306 against 5 958 (+5.8 %),
 // 4K / 1024 spp / 16 bounces 9 464 against 8 851 (+6.9 %).  The general-entity kinds keep REGEN 1/4, walk 3/4, HIT and SKY at once (kGeneralTune):
 // on the 250 k-triangle mesh HIT from 1/2 loses 6 % (1 732 against 1 840), SKY from 1/2 3 %.
+#ifndef RTOW_DEFAULT_REGROUP_SIDE
+#define RTOW_DEFAULT_REGROUP_SIDE 4     // pixels regrouped by cost inside super-tiles of 4 x 4 tiles = 32 x 32 pixels (launchSample; regroup_tickets_kernel)
+#endif
 #ifndef RTOW_DEFAULT_TUNE
 #define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 3, 1, 16
 #endif
@@ -84,6 +87,8 @@ struct RtowContext_t {
     uint32_t chunkDoneCapacity = 0;
     unsigned int *dChunkCost = nullptr, *dChunkOrder = nullptr;
     unsigned short* dPixelCost = nullptr;
+    unsigned int* dTicketMap = nullptr;   // ticket -> owned pixel (SampleKernelArgs.ticketMap), chunkCapacity * 64 entries; re-sorted from every launch's cost map
+    bool orderMapped = false;             // the cost map / order on hand were recorded under dTicketMap (else under the tiles themselves)
     uint32_t chunkCapacity = 0;
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
@@ -145,6 +150,7 @@ struct RtowContext_t {
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
     int tune[9] = {RTOW_DEFAULT_TUNE};
     bool userTune = false;                // RtowContextOptions.schedulerTune was given: no per-scene adjustment
+    int regroupSide = RTOW_DEFAULT_REGROUP_SIDE;   // RtowContextOptions.schedulerTune[7]: super-tile side (in 8 x 8 tiles) of the pixel regrouping, 1 = off
     bool userSliceDefault = false;        // ... with a zero walk slice: the per-scene built-in value
     bool chainFusion = true;              // the same-XCD hand-over litmus passed on this device (rtowCreateContext): chains may run as one launch
     uint64_t tunedScene = ~0ull;          // sceneSerial whose thresholds were measured (tuneThresholds)
@@ -460,20 +466,34 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     // ---- chunk order: most expensive 64-pixel chunks first, from the ray counts of the previous launch (or of a probe) ----
     a.chunkCount = (a.totalWork + 63u) / 64u;
     const bool wantOrder = a.chunkCount >= (uint32_t)(4 * ctx->cuCount) && !(ctx->flags & RTOW_CONTEXT_NO_CHUNK_ORDER);   // tiny frames: not worth it
+    // ---- and which pixels share a chunk (a wave): the pixels of a super-tile of regroupSide x regroupSide tiles sorted by the ray counts of the previous launch and dealt out
+    // 64 at a time (regroup_tickets_kernel), re-sorted behind every launch like the order.  Reference stream only (per-sample units are alike by construction).
+    const unsigned regroupSide = (ctx->regroupSide & 15) >= 2 ? std::min<unsigned>((unsigned)(ctx->regroupSide & 15), kRegroupMaxSide) : 0u;
+    // (development: schedulerTune[7] = side + 16 * mode; mode 0 sorts by the ray count itself, 1 by sky / not sky, 2 by four classes of rays per sample - pixels of a class in tile order)
+    const unsigned regroupMode = (unsigned)ctx->regroupSide >> 4;
+    auto regroupClasses = [&](unsigned floorCost, unsigned out[3]) {
+        out[0] = regroupMode == 0u ? 0u : floorCost; out[1] = regroupMode >= 2u ? (floorCost * 11u) / 4u : 0xffffffffu; out[2] = regroupMode >= 2u ? floorCost * 4u : 0xffffffffu;
+    };
+    const bool wantMap = wantOrder && regroupSide >= 2u && a.tiledPixels != 0u && !a.unitRecords;
+    const unsigned tileRows = a.tilesPerRow ? a.tiledPixels / (64u * a.tilesPerRow) : 0u;
     if (wantOrder) {
         if (a.chunkCount > ctx->chunkCapacity) {
-            if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
+            if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); (void)hipFree(ctx->dTicketMap); }
             ctx->dChunkCost = ctx->dChunkOrder = nullptr;
             ctx->dPixelCost = nullptr;
+            ctx->dTicketMap = nullptr;
             ctx->chunkCapacity = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkCost, 2 * a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkOrder, a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             HIP_TRY(ctx, hipMalloc(&ctx->dPixelCost, (size_t)a.chunkCount * 64 * sizeof(unsigned short)), RTOW_ERROR_MEMORY_ALLOCATION);
+            HIP_TRY(ctx, hipMalloc(&ctx->dTicketMap, (size_t)a.chunkCount * 64 * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             ctx->chunkCapacity = a.chunkCount;
             ctx->orderValid = false;
         }
-        if (ctx->orderW != a.width || ctx->orderH != a.height || ctx->orderOff != a.sliceOffset || ctx->orderDiv != a.sliceDivider || ctx->orderGroups != a.groupsPerPixel) ctx->orderValid = false;
+        if (ctx->orderW != a.width || ctx->orderH != a.height || ctx->orderOff != a.sliceOffset || ctx->orderDiv != a.sliceDivider || ctx->orderGroups != a.groupsPerPixel ||
+            ctx->orderMapped != wantMap) ctx->orderValid = false;
         a.pixelCost = ctx->dPixelCost;
+        a.ticketMap = wantMap ? ctx->dTicketMap : nullptr;
         bool haveOrder = true;
         if (!ctx->orderValid && a.unitRecords) {
             // per-sample units are small and alike: the first batch simply runs in natural order and records the map for the next
@@ -481,20 +501,25 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             haveOrder = false;
             ctx->orderValid = true;
             ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider; ctx->orderGroups = a.groupsPerPixel;
+            ctx->orderMapped = false;
         }
         if (!ctx->orderValid) {
             // no cost map yet for this frame configuration: a 1-sample-per-pixel probe of the same kernel (stores nothing else)
             SampleKernelArgs probe = a;
             probe.probeOnly = 1;
             probe.chunkOrder = nullptr;
+            probe.ticketMap = nullptr;                           // the probe runs over the tiles themselves; the map starts from them
+            if (wantMap) HIP_TRY(ctx, launchInitTicketMap(ctx->dTicketMap, a.tiledPixels, stream), RTOW_ERROR_LAUNCH_FAILURE);
             probe.cancelFlag = nullptr;
             probe.chainCount = 1;                                // one pass over the pixels, whatever the launch it prepares
             HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream), RTOW_ERROR_LAUNCH_FAILURE);
             HIP_TRY(ctx, hipMemsetAsync(ctx->dPixelCost, 0, (size_t)a.chunkCount * 64 * sizeof(unsigned short), stream), RTOW_ERROR_LAUNCH_FAILURE);   // the last chunk's tail
             HIP_TRY(ctx, launchSampleBatch(probe, blocks, stream), RTOW_ERROR_LAUNCH_FAILURE);
+            if (wantMap) { unsigned cls[3]; regroupClasses(1u, cls); HIP_TRY(ctx, launchRegroupTickets(ctx->dPixelCost, ctx->dTicketMap, a.tilesPerRow, tileRows, regroupSide, cls, stream), RTOW_ERROR_LAUNCH_FAILURE); }
             HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 0, stream), RTOW_ERROR_LAUNCH_FAILURE);
             ctx->orderValid = true;
             ctx->orderW = a.width; ctx->orderH = a.height; ctx->orderOff = a.sliceOffset; ctx->orderDiv = a.sliceDivider; ctx->orderGroups = a.groupsPerPixel;
+            ctx->orderMapped = wantMap;
         }
         a.chunkOrder = haveOrder ? ctx->dChunkOrder : nullptr;
 
@@ -637,6 +662,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     if (a.unitRecords) HIP_TRY(ctx, launchFoldUnitRecords(a, stream), RTOW_ERROR_LAUNCH_FAILURE);   // inside the timed region: part of the batch
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
     // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
+    if (wantMap) { unsigned cls[3]; regroupClasses(std::max(1u, a.sampleCountMin), cls); HIP_TRY(ctx, launchRegroupTickets(ctx->dPixelCost, ctx->dTicketMap, a.tilesPerRow, tileRows, regroupSide, cls, stream), RTOW_ERROR_LAUNCH_FAILURE); }
     if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evBatchDone, stream), RTOW_ERROR_LAUNCH_FAILURE);
     ctx->haveBatchDone = true;
@@ -933,7 +959,8 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
         if (options->sliceBlockThreads != 0 && options->sliceBlockThreads != 1024) { delete ctx; return RTOW_ERROR_INVALID_VALUE; }     // reserved (round 3: 256 / 512)
         ctx->hitListCapacity = (uint32_t)options->hitListCapacity;
         bool anyTune = false;
-        for (int i = 0; i < 9; i++) anyTune = anyTune || options->schedulerTune[i] != 0;
+        for (int i = 0; i < 9; i++) anyTune = anyTune || (i != 7 && options->schedulerTune[i] != 0);
+        if (options->schedulerTune[7] > 0) ctx->regroupSide = options->schedulerTune[7];     // its own knob: says nothing about the thresholds
         if (anyTune) {
             // stage thresholds below 1 mean "any lane" (1); a zero hand-over count or walk slice means "the built-in value" (3; per scene at upload), as in API v6
             for (int i = 0; i < 9; i++) ctx->tune[i] = options->schedulerTune[i] < 1 ? 1 : options->schedulerTune[i];
@@ -981,7 +1008,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->dScene) (void)hipFree(ctx->dScene);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
-    if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); }
+    if (ctx->dChunkCost) { (void)hipFree(ctx->dChunkCost); (void)hipFree(ctx->dChunkOrder); (void)hipFree(ctx->dPixelCost); (void)hipFree(ctx->dTicketMap); }
     if (ctx->dChunkDone) (void)hipFree(ctx->dChunkDone);
     if (ctx->dXcdState) (void)hipFree(ctx->dXcdState);
     if (ctx->dChainBatches) (void)hipFree(ctx->dChainBatches);
@@ -1071,6 +1098,10 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     HIP_TRY(ctx, launchPrepareMaterials(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, launchPrepareEntities(ctx->dScene, compiled.layout, ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream), RTOW_ERROR_LAUNCH_FAILURE);
+    // rtowProbeNearestHit walks the HOST image of the scene: bring back what the device derived for the entities (inverse rotations / translations of the GpuPrim records)
+    if (compiled.layout.sceneKind >= SCENE_KIND_GENERAL && compiled.entityCount > 0)
+        HIP_TRY(ctx, hipMemcpy(compiled.blob.data() + compiled.layout.primOffset, ctx->dScene + compiled.layout.primOffset, (size_t)compiled.entityCount * sizeof(GpuPrim), hipMemcpyDeviceToHost),
+                RTOW_ERROR_LAUNCH_FAILURE);
     if (ctx->flags & (RTOW_CONTEXT_EXACT_TIES_ALWAYS | RTOW_CONTEXT_EXACT_TIES_NEVER)) {   // exact-tie kernels for every scene without volumes (slower), or never
         const bool volumes = compiled.layout.sceneKind == SCENE_KIND_VOLUMES || compiled.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
         if (!volumes) compiled.layout.exactTies = (ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS) ? 1u : 0u;
@@ -1230,6 +1261,7 @@ RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
     info->wideCodes = ctx->wideCodes ? 1 : 0;
     info->thresholdSet = ctx->tunedScene == ctx->sceneSerial ? ctx->tunedCandidate : -1;
     for (int k = 0; k < 9; k++) info->schedulerTune[k] = ctx->tune[k];
+    info->schedulerTune[7] = ctx->regroupSide;
     return RTOW_SUCCESS;
 }
 
@@ -1478,6 +1510,20 @@ RTOW_API int rtowUnregisterHostBuffer(RtowContext ctx, void* pointer)
             return RTOW_SUCCESS;
         }
     return RTOW_ERROR_INVALID_VALUE;
+}
+
+RTOW_API int rtowProbeNearestHit(RtowContext ctx, const RtowFloat3* origin, const RtowFloat3* direction, float time, float* distance, int32_t* entityIndex)
+{
+    if (!ctx || !origin || !direction) return RTOW_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
+    const float o[3] = {origin->x, origin->y, origin->z}, d[3] = {direction->x, direction->y, direction->z};
+    float t = 0.0f;
+    int prim = -1;
+    (void)probeNearestHitHost(ctx->scene.blob.data(), ctx->scene.layout, o, d, time, &t, &prim);      // no device work: batches in flight are neither waited for nor disturbed
+    if (distance) *distance = t;
+    if (entityIndex) *entityIndex = prim;
+    return RTOW_SUCCESS;
 }
 
 RTOW_API int rtowGetLastSampleKernelMs(RtowContext ctx, float* outMs)

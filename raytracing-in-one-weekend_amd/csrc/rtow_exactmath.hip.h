@@ -88,4 +88,11 @@ __device__ __forceinline__ void exact_div3(float ax, float ay, float az, float b
     }
 }
 
+// Host overloads (the host pass of hipcc; rtow_probe.hip walks one ray on the CPU with the sample kernel's own hit tests): the IEEE operations themselves -
+// which is what the device forms above are for every operand (enumerated, see the head of this file).
+__host__ inline float exact_rcp(float x) { return 1.0f / x; }
+__host__ inline float exact_rcp_nan_to_inf(float x) { const float r = 1.0f / x; return r != r ? __builtin_inff() : r; }
+__host__ inline float exact_sqrt(float x) { return __builtin_sqrtf(x); }
+__host__ inline void exact_div3(float ax, float ay, float az, float b, float& qx, float& qy, float& qz) { qx = ax / b; qy = ay / b; qz = az / b; }
+
 } // namespace rtow

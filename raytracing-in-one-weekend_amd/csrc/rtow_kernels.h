@@ -103,6 +103,8 @@ struct SampleKernelArgs {
     unsigned int* workCounter;            // zeroed before the launch; counts 64-pixel ticket chunks
     const unsigned int* chunkOrder;       // chunk launch order (most expensive first), null = natural order
     unsigned short* pixelCost;            // [64 * chunkCount], ticket order: ray count of every pixel of THIS launch (input of the next launch's order); null = not recorded
+    const unsigned int* ticketMap;        // [tiledPixels] ticket -> owned-pixel number (owned_pixel_xy's argument): which pixels share a chunk, i.e. a wave (regroup_tickets_kernel: the pixels of a
+                                          // super-tile of tiles sorted by ray count and dealt out 64 at a time); a permutation inside every super-tile; null = the tiles themselves
     uint32_t chunkCount;
     const uint2* pixelCandidates;         // [2 x width * height] = one uint4 per pixel (8 x 16-bit node codes, or 4 x 32-bit): camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray;
                                           // wideCodes: uint4 records (4 x 32-bit node indices) behind the same pointer
@@ -213,6 +215,14 @@ hipError_t launchPrepareMaterials(uint8_t* blob, const SceneLayout& layout, hipS
 hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hipStream_t stream);
 hipError_t launchFoldUnitRecords(const SampleKernelArgs& args, hipStream_t stream);
 hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream);
+// ticketMap[t] = t for t < count (the tiles themselves)
+hipError_t launchInitTicketMap(unsigned* ticketMap, unsigned count, hipStream_t stream);
+// Which pixels share a wave.  Per super-tile of side x side tiles (8 x 8 pixels each; tile t = chunk t = tickets [64 t, 64 t + 64)): the super-tile's pixels sorted by the ray count the
+// last launch measured for them (pixelCost, ticket order under the map as it is), most expensive first, and dealt out to the super-tile's own chunks 64 at a time; pixelCost is
+// permuted along, so that it stays in ticket order under the NEW map.  side: 2 / 4 / 8.
+constexpr unsigned kRegroupMaxSide = 8;
+// classes: {0, -, -} = sort by the ray count itself; {t1, t2, t3} = by cost class (<= t1, <= t2, <= t3, beyond), pixels of a class in tile order
+hipError_t launchRegroupTickets(unsigned short* pixelCost, unsigned* ticketMap, unsigned tilesPerRow, unsigned tileRows, unsigned side, const unsigned classes[3], hipStream_t stream);
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream);  // inverse transforms of general entities, on device
 hipError_t launchCombine(const RtowCombineParams& p, const float* inColor, const float* inNormal, const float* inAlbedo,
                          float* outColor, float* outNormal, float* outAlbedo, hipStream_t stream);
@@ -234,6 +244,9 @@ hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsig
 // accum[row] += src_0[row] ... += src_{groups-1}[row] (group order) for rows first, first + step, ...; src_g = ownPartial (frame layout) for g == own, else packed rows at recv + g * regionFloats
 hipError_t launchFoldRows(float* accum, const float* ownPartial, const float* recv, size_t regionFloats, unsigned rowFloats, unsigned rows, unsigned first, unsigned step,
                           unsigned groups, unsigned own, hipStream_t stream);
+
+// rtowProbeNearestHit (rtow_probe.hip): one ray walked on the host through the scene's host image (derived entity transforms included); false = miss
+bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const float origin[3], const float direction[3], float time, float* distance, int* entity);
 
 // same-XCD hand-over litmus of the chained launches (rtow_kernels.hip): pairs of workgroups that ran on one XCD, stale dwords seen, waits that timed out
 hipError_t runXcdCoherenceLitmus(int cuCount, hipStream_t stream, unsigned* outPairs, unsigned* outStale, unsigned* outTimeouts);

@@ -210,6 +210,65 @@ __global__ void __launch_bounds__(1024) build_chunk_order_kernel(const unsigned*
     for (unsigned i = t; i < n; i += 1024) order[atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)(chunk_key(cost, n, i, byMax) * scale)], 1u)] = i;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Which pixels share a wave (SampleKernelArgs.ticketMap).  A chunk's 64 tickets go to the 64 lanes of one wave; numbered in tiles they are an 8 x 8 block of the image - but a tile on
+// a sphere's edge holds sky pixels (one ray per sample), ground pixels and glass pixels, whose lanes wait for each other's stages.  The reference hands pixels out in no
+// defined order (Schedule(W * H, 1), UNITY/Raytracer.cs:730), so the numbering is free: per super-tile of side x side tiles this kernel sorts the super-tile's pixels by the ray
+// count the last launch measured for them - most expensive first; equal counts (sky: exactly one ray per sample) keep their tile order - and deals them out to the super-tile's own
+// chunks 64 at a time.  A super-tile's accumulator lines stay with the few CUs that take its chunks.  One workgroup per super-tile, bitonic sort in LDS of
+// (cost + 1) << 32 | owned-pixel number (0 = padding).  In place: ticketMap and pixelCost (permuted along, so that it stays in ticket order under the new map).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) init_ticket_map_kernel(unsigned* __restrict__ map, unsigned n)
+{
+    const unsigned i = blockIdx.x * 1024u + threadIdx.x;
+    if (i < n) map[i] = i;
+}
+__global__ void __launch_bounds__(1024) regroup_tickets_kernel(unsigned short* __restrict__ pixelCost, unsigned* __restrict__ ticketMap, unsigned tilesPerRow, unsigned tileRows, unsigned side,
+                                                              unsigned t1, unsigned t2, unsigned t3)
+{
+    extern __shared__ unsigned long long regroupKeys[];
+    const unsigned perRow = (tilesPerRow + side - 1u) / side;
+    const unsigned sty = blockIdx.x / perRow, stx = blockIdx.x - sty * perRow;
+    const unsigned tx0 = stx * side, ty0 = sty * side;
+    const unsigned w = tilesPerRow - tx0 < side ? tilesPerRow - tx0 : side, h = tileRows - ty0 < side ? tileRows - ty0 : side;
+    const unsigned n = w * h * 64u;
+    unsigned N = 64u;
+    while (N < n) N <<= 1;
+    auto ticketOf = [&](unsigned e) { const unsigned k = e >> 6, ky = k / w, kx = k - ky * w; return ((ty0 + ky) * tilesPerRow + tx0 + kx) * 64u + (e & 63u); };
+    for (unsigned e = threadIdx.x; e < N; e += 1024u) {
+        unsigned long long key = 0ull;
+        if (e < n) {
+            const unsigned t = ticketOf(e);
+            const unsigned cost = pixelCost[t];
+            // key = primary << 48 | owned-pixel number << 16 | cost: the primary key is the ray count itself (t1 == 0) or its class (cost classes t1 < t2 < t3: sky only / ... ),
+            // equal primaries keep their tile order, the ray count travels along
+            const unsigned primary = t1 == 0u ? cost + 1u : 1u + (cost > t1 ? 1u : 0u) + (cost > t2 ? 1u : 0u) + (cost > t3 ? 1u : 0u);
+            key = ((unsigned long long)(primary > 0xffffu ? 0xffffu : primary) << 48) | ((unsigned long long)ticketMap[t] << 16) | (unsigned long long)cost;
+        }
+        regroupKeys[e] = key;
+    }
+    __syncthreads();
+    for (unsigned k = 2u; k <= N; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0u; j >>= 1) {
+            for (unsigned e = threadIdx.x; e < N; e += 1024u) {
+                const unsigned p = e ^ j;
+                if (p > e) {
+                    const unsigned long long a = regroupKeys[e], b = regroupKeys[p];
+                    const bool descending = (e & k) == 0u;                       // the whole array ends up descending: padding (0) last
+                    if (descending ? a < b : a > b) { regroupKeys[e] = b; regroupKeys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (unsigned e = threadIdx.x; e < n; e += 1024u) {
+        const unsigned long long key = regroupKeys[e];
+        const unsigned t = ticketOf(e);
+        ticketMap[t] = (unsigned)(key >> 16);
+        pixelCost[t] = (unsigned short)(key & 0xffffull);
+    }
+}
+
 // Derived per-entity transform data for SCENE_KIND_GENERAL, on the device: InverseTransform = inverse(OriginTransform)
 // (RT/Entity.cs:51-52; math.inverse(RigidTransform): invRot = inverse(rot), invTranslation = mul(invRot, -pos);
 // math.inverse(quaternion q) = rcp(dot(q, q)) * q * float4(-1, -1, -1, 1)).
@@ -752,6 +811,22 @@ hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost
     return hipGetLastError();
 }
 
+hipError_t launchInitTicketMap(unsigned* ticketMap, unsigned count, hipStream_t stream)
+{
+    if (count == 0u) return hipSuccess;
+    hipLaunchKernelGGL(init_ticket_map_kernel, dim3((count + 1023u) / 1024u), dim3(1024), 0, stream, ticketMap, count);
+    return hipGetLastError();
+}
+hipError_t launchRegroupTickets(unsigned short* pixelCost, unsigned* ticketMap, unsigned tilesPerRow, unsigned tileRows, unsigned side, const unsigned classes[3], hipStream_t stream)
+{
+    if (tilesPerRow == 0u || tileRows == 0u) return hipSuccess;
+    if (side < 2u || side > kRegroupMaxSide) return hipErrorInvalidValue;
+    const unsigned blocks = ((tilesPerRow + side - 1u) / side) * ((tileRows + side - 1u) / side);
+    unsigned N = 64u;
+    while (N < side * side * 64u) N <<= 1;
+    hipLaunchKernelGGL(regroup_tickets_kernel, dim3(blocks), dim3(1024), (size_t)N * sizeof(unsigned long long), stream, pixelCost, ticketMap, tilesPerRow, tileRows, side, classes[0], classes[1], classes[2]);
+    return hipGetLastError();
+}
 hipError_t launchPrepareEntities(uint8_t* blob, const SceneLayout& layout, hipStream_t stream)
 {
     if (layout.sceneKind < SCENE_KIND_GENERAL) return hipSuccess;

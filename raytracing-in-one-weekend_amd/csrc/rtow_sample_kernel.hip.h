@@ -67,14 +67,16 @@ namespace {
 // small float3 helpers; each spells out the reference's evaluation order
 // ------------------------------------------------------------------------------------------------------------
 struct V3 { float x, y, z; };
+// (the helpers marked __host__ __device__ below - vectors, um_min / um_max, scene access, sphere_at, sphere_hit, general_hit - are also what rtowProbeNearestHit walks its one
+// ray with on the host: rtow_probe.hip; the host pass evaluates the same expressions with the IEEE operations the device's short forms stand for)
 
-__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 v3(const RtowFloat3& a) { return v3(a.x, a.y, a.z); }
-__device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ V3 scale(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__host__ __device__ __forceinline__ V3 v3(const RtowFloat3& a) { return v3(a.x, a.y, a.z); }
+__host__ __device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__host__ __device__ __forceinline__ V3 scale(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__host__ __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // math.normalize(v) = rsqrt(dot(v, v)) * v with rsqrt(x) = 1 / sqrt(x)
 __device__ __forceinline__ V3 normalize(V3 v) { const float r = RTOW_RCP(RTOW_SQRT(dot(v, v))); return scale(r, v); }
 // math.reflect(i, n) = i - 2f * n * dot(i, n)
@@ -84,8 +86,8 @@ __device__ __forceinline__ V3 reflect(V3 i, V3 n)
     return v3(i.x - (2.0f * n.x) * d, i.y - (2.0f * n.y) * d, i.z - (2.0f * n.z) * d);
 }
 // math.min / math.max return the FIRST operand when the second is NaN
-__device__ __forceinline__ float um_min(float x, float y) { return (y != y || x < y) ? x : y; }
-__device__ __forceinline__ float um_max(float x, float y) { return (y != y || x > y) ? x : y; }
+__host__ __device__ __forceinline__ float um_min(float x, float y) { return (y != y || x < y) ? x : y; }
+__host__ __device__ __forceinline__ float um_max(float x, float y) { return (y != y || x > y) ? x : y; }
 __device__ __forceinline__ float um_saturate(float x) { return um_max(0.0f, um_min(1.0f, x)); }
 
 constexpr float kPi = 3.14159265f; // math.PI
@@ -605,7 +607,7 @@ struct SceneRefs {
 };
 
 template <bool ALL_LDS>
-__device__ __forceinline__ void load_node(const SceneRefs& sc, const SceneLayout& L, int idx, float4& q0, float4& q1, float4& q2, int& c0, int& c1)
+__host__ __device__ __forceinline__ void load_node(const SceneRefs& sc, const SceneLayout& L, int idx, float4& q0, float4& q1, float4& q2, int& c0, int& c1)
 {
     const uint32_t off = L.nodeOffset + (uint32_t)idx * 64u;
     const uint8_t* base = (ALL_LDS || (uint32_t)idx < sc.ldsNodeCount) ? sc.lds : sc.glob;
@@ -619,14 +621,14 @@ __device__ __forceinline__ void load_node(const SceneRefs& sc, const SceneLayout
 }
 
 template <bool ALL_LDS>
-__device__ __forceinline__ const uint8_t* section(const SceneRefs& sc, uint32_t offset)
+__host__ __device__ __forceinline__ const uint8_t* section(const SceneRefs& sc, uint32_t offset)
 {
     return (ALL_LDS ? sc.lds : sc.glob) + offset;
 }
 
 // centre of primitive `i` at ray time `time` (Entity.TransformAtTime, RT/Entity.cs:124-127) and its signed radius
 template <bool ALL_LDS, bool HAS_MOTION>
-__device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout& L, int i, float time, V3& c, float& radius)
+__host__ __device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout& L, int i, float time, V3& c, float& radius)
 {
     const float4 s = *reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.sphereOffset) + (uint32_t)i * 16u);
     c = v3(s.x, s.y, s.z);
@@ -635,7 +637,7 @@ __device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout
         const uint8_t* mp = section<ALL_LDS>(sc, L.motionOffset) + (uint32_t)i * 32u;
         const float4 m0 = *reinterpret_cast<const float4*>(mp);      // dx dy dz t0
         const float2 m1 = *reinterpret_cast<const float2*>(mp + 16); // t1 moving
-        if (__float_as_int(m1.y) != 0) {
+        if (__builtin_bit_cast(int, m1.y) != 0) {
             // clamp(unlerp(t0, t1, t), 0, 1); when every moving entity shares one TimeRange (L.commonTimeRange) `time` already IS that value:
             // the sample's ray time goes through the expression once, in REGEN, instead of once per sphere test (same operands, same result)
             const float f = L.commonTimeRange ? time : um_max(0.0f, um_min(1.0f, (time - m0.w) / (m1.x - m0.w)));
@@ -645,7 +647,7 @@ __device__ __forceinline__ void sphere_at(const SceneRefs& sc, const SceneLayout
 }
 
 // (p.x / d, p.y / d, p.z / d): three IEEE divisions by one divisor (a sphere's outward normal, r.GetPoint(t) / radius, RT/HitTests.cs:56)
-__device__ __forceinline__ V3 div3(V3 p, float d)
+__host__ __device__ __forceinline__ V3 div3(V3 p, float d)
 {
 #if RTOW_EXACT_DIV3
     V3 q;
@@ -657,7 +659,7 @@ __device__ __forceinline__ V3 div3(V3 p, float d)
 }
 
 // HitTests.Hit(Sphere) (RT/HitTests.cs:23-60) in entity space (oc = origin - centre), tMin = 0, tMax = +inf
-__device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, float& tOut)
+__host__ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, float& tOut)
 {
     const float b = dot(oc, d);
     const float c = dot(oc, oc) - radius * radius;
@@ -682,7 +684,7 @@ __device__ __forceinline__ bool sphere_hit(V3 oc, V3 d, float a, float radius, f
 }
 
 // the same test with an arbitrary tMin (strict: t > tMin), RT/HitTests.cs:40,49
-__device__ __forceinline__ bool sphere_hit_tmin(V3 oc, V3 d, float a, float radius, float tMin, float& tOut)
+__host__ __device__ __forceinline__ bool sphere_hit_tmin(V3 oc, V3 d, float a, float radius, float tMin, float& tOut)
 {
     const float b = dot(oc, d);
     const float c = dot(oc, oc) - radius * radius;
@@ -706,22 +708,22 @@ __device__ __forceinline__ bool sphere_hit_tmin(V3 oc, V3 d, float a, float radi
 // ------------------------------------------------------------------------------------------------------------
 // general entities (SCENE_KIND_GENERAL): Rect / Box / Triangle and rotated or moving transforms, RT/Entity.cs:58-127
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__host__ __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 // math.mul(quaternion q, float3 v): t = 2 * cross(q.xyz, v); v + q.w * t + cross(q.xyz, t)
-__device__ __forceinline__ V3 rotate(float4 q, V3 v)
+__host__ __device__ __forceinline__ V3 rotate(float4 q, V3 v)
 {
     const V3 qv = v3(q.x, q.y, q.z);
     const V3 t = scale(2.0f, cross(qv, v));
     const V3 c = cross(qv, t);
     return v3(v.x + q.w * t.x + c.x, v.y + q.w * t.y + c.y, v.z + q.w * t.z + c.z);
 }
-__device__ __forceinline__ float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); }
+__host__ __device__ __forceinline__ float um_sign(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); }
 
 // Entity.HitInternal + HitContent for primitive `i` (RT/Entity.cs:74-122) with tMax = +inf (tMin = 0 except for the exit-hit
 // probe of volume hulls, JOBS/SampleBatchJob.cs:465).
 // Returns the distance, the entity-space normal and the rotation that takes it to world space.
 template <bool ALL_LDS, bool TRIANGLES_ONLY = false>
-__device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time, float tMin,
+__host__ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayout& L, int i, unsigned type, V3 ro, V3 rd, float time, float tMin,
                                             float& tOut, V3& nLocal, float4& rot, float2* texCoord = nullptr)
 {
     const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)i * 128u);
@@ -759,7 +761,7 @@ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const SceneLayo
     rot = p[0];
     const float4 invRot = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
     V3 invT = v3(q4.y, q4.z, q4.w);
-    if (__float_as_int(q2.w) != 0) {
+    if (__builtin_bit_cast(int, q2.w) != 0) {
         // TransformAtTime (RT/Entity.cs:124-127) and its inverse (:87-88): invTranslation = mul(invRot, -pos(t))
         const float f = um_max(0.0f, um_min(1.0f, (time - q3.w) / (q4.x - q3.w)));
         const V3 pt = v3(q2.x + q3.x * f, q2.y + q3.y * f, q2.z + q3.z * f);
@@ -1447,6 +1449,10 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     newBatch = chained ? (ticket >> kChainShift) : 0u;
                     if (chained) ticket &= kChainTicketMask;
                     if (PER_SAMPLE) { unitGroup = ticket % C.groupsPerPixel; ticket = ticket / C.groupsPerPixel; }   // unit = (owned pixel, sample group)
+                    // which pixel a ticket stands for: by default the ticket's place in its 8 x 8 tile; with a map, the pixels of a super-tile of tiles sorted by the ray count
+                    // of the previous launch and dealt out 64 at a time (SampleKernelArgs.ticketMap), so that a wave's lanes hold pixels of like cost.  `tick` stays the ticket:
+                    // the chunk's hand-over counter and the cost map are per ticket
+                    else if (!(REDO_CAPABLE && redo)) { const unsigned* const map = C.ticketMap; if (map && ticket < C.tiledPixels) ticket = map[ticket]; }
                     int ownedRow;
                     owned_pixel_xy(ticket, (unsigned)C.width, C.tilesPerRow, C.tiledPixels, cx, ownedRow);   // a chunk's 64 tickets: an 8 x 8 tile of the owned pixels (rtow_kernels.h), or a strip
                     cy = C.sliceOffset + ownedRow * C.sliceDivider;      // rows with row % SliceDivider == SliceOffset (:69-70)

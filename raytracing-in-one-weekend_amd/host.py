@@ -173,6 +173,14 @@ class Context:
         check(load().rtowGetSceneInfo(self.handle, C.byref(info)), "rtowGetSceneInfo")
         return info
 
+    def hit_world(self, origin, direction, time=0.0):
+        """Raytracer.HitWorld (UNITY/Raytracer.cs:1353; the auto-focus probe of ScheduleSample, :608-609) through rtowProbeNearestHit:
+        (hit, distance, entity index) - `if hit: focusDistance = distance`."""
+        d, e = C.c_float(), C.c_int32()
+        o3, d3 = abi.Float3(*[float(x) for x in origin]), abi.Float3(*[float(x) for x in direction])
+        check(load().rtowProbeNearestHit(self.handle, C.byref(o3), C.byref(d3), float(time), C.byref(d), C.byref(e)), "rtowProbeNearestHit")
+        return e.value >= 0, d.value, e.value
+
     def synchronize(self):
         check(load().rtowSynchronize(self.handle), "rtowSynchronize")
 

@@ -57,6 +57,7 @@ def load():
     lib.rtowSampleBatchGroupDevice.argtypes = [vp, C.c_int32, C.POINTER(abi.SampleParams), AB, AB, C.POINTER(vp), vp, vp]
     lib.rtowSampleBatchChain.argtypes = [vp, C.c_int32, C.POINTER(abi.SampleParams), AB, AB, C.POINTER(vp), vp]
     lib.rtowGetLastSampleKernelMs.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.rtowProbeNearestHit.argtypes = [vp, C.POINTER(abi.Float3), C.POINTER(abi.Float3), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     lib.rtowReduceMetricsDevice.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, vp, C.POINTER(abi.Metrics)]
     lib.rtowCombineDevice.argtypes = [vp, C.POINTER(abi.CombineParams), vp, vp, vp, vp, vp, vp, vp]
     lib.rtowFinalizeDevice.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]

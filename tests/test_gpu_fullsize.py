@@ -148,10 +148,14 @@ def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, name):
     variants = {"second launch": _device_render(rt, gpu_context, p, w * h, 4)}   # chunk order now comes from the first launch's cost map
     for what, kw in (("no camera-ray lists", dict(flags=a.CONTEXT_NO_CAMERA_RAY_LISTS)), ("row-order tickets", dict(flags=a.CONTEXT_NO_CHUNK_ORDER)),
                      ("every stage at once", dict(scheduler_tune=(1, 1, 1, 1, 1, 1, 1, 1, 16))),
-                     ("heavy thresholds, 5-visit walk slices", dict(scheduler_tune=(32, 64, 16, 16, 16, 1, 1, 1, 5)))):
+                     ("heavy thresholds, 5-visit walk slices", dict(scheduler_tune=(32, 64, 16, 16, 16, 1, 1, 1, 5))),
+                     ("pixels regrouped in 16 x 16 super-tiles", dict(scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 2, 0))),
+                     ("pixels regrouped in 64 x 64 super-tiles", dict(scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 8, 0))),
+                     ("tiles as they are", dict(scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 1, 0)))):
         with rt.Context(0, **kw) as ctx:
             ctx.upload_scene(desc)
             variants[what] = _device_render(rt, ctx, p, w * h, 4)
+            if "regrouped" in what: variants[what + ", map re-sorted from the launch's own ray counts"] = _device_render(rt, ctx, p, w * h, 4)
     for what, r in variants.items():
         for k in ("color", "normal", "albedo", "scw", "diag"):
             assert np.array_equal(base[k].view(np.uint32), r[k].view(np.uint32)), (name, what, k)
