@@ -30,7 +30,7 @@
 // 4K / 1024 spp / 16 bounces 9 464 against 8 851 (+6.9 %).  The general-entity kinds keep REGEN 1/4, walk 3/4, HIT and SKY at once (kGeneralTune):
 // on the 250 k-triangle mesh HIT from 1/2 loses 6 % (1 732 against 1 840), SKY from 1/2 3 %.
 #ifndef RTOW_DEFAULT_REGROUP_SIDE
-#define RTOW_DEFAULT_REGROUP_SIDE 4     // pixels regrouped by cost inside super-tiles of 4 x 4 tiles = 32 x 32 pixels (launchSample; regroup_tickets_kernel)
+#define RTOW_DEFAULT_REGROUP_SIDE 1     // 1 = the 8 x 8 tiles as they are; n >= 2: pixels regrouped by cost inside super-tiles of n x n tiles (launchSample; regroup_tickets_kernel)
 #endif
 #ifndef RTOW_DEFAULT_TUNE
 #define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 3, 1, 16
