@@ -94,6 +94,38 @@ def main():
         d["lds_busy_fraction"] = c["SQ_LDS_IDX_ACTIVE"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256)
     if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:
         d["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    # what the wave cycles that wait for an instruction wait for (collect.sh passes sq4 / sqc / sq5)
+    if "SQ_WAVE_CYCLES" in c:
+        wc = c["SQ_WAVE_CYCLES"]
+        for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC"):
+            if k in c:
+                d[k.lower() + "_per_wave_cycle"] = c[k] / wc
+    if "SQC_ICACHE_REQ" in c and c["SQC_ICACHE_REQ"] > 0:
+        d["icache_hit_rate"] = c.get("SQC_ICACHE_HITS", 0.0) / c["SQC_ICACHE_REQ"]
+        d["icache_misses_per_launch"] = c.get("SQC_ICACHE_MISSES", 0.0)
+    if "SQC_DCACHE_REQ" in c and c["SQC_DCACHE_REQ"] > 0:
+        d["scalar_cache_hit_rate"] = c.get("SQC_DCACHE_HITS", 0.0) / c["SQC_DCACHE_REQ"]
+    if "SQ_IFETCH" in c and "SQ_IFETCH_LEVEL" in c and c["SQ_IFETCH"] > 0:
+        d["ifetch_average_latency_cycles"] = c["SQ_IFETCH_LEVEL"] / c["SQ_IFETCH"]
+        if "SQ_INSTS_VALU" in c:
+            d["ifetches_per_valu_inst"] = c["SQ_IFETCH"] / c["SQ_INSTS_VALU"]
+    for lvl, cnt in (("SQ_INST_LEVEL_LDS", "SQ_INSTS_LDS"), ("SQ_INST_LEVEL_VMEM", "SQ_INSTS_VMEM"), ("SQ_INST_LEVEL_SMEM", "SQ_INSTS_SMEM")):
+        if lvl in c and cnt in c and c[cnt] > 0:
+            d[cnt.lower().replace("sq_insts_", "") + "_average_latency_cycles"] = c[lvl] / c[cnt]
+    if "SQ_INSTS_SALU" in c and "SQ_INSTS_VALU" in c:
+        d["salu_per_valu_inst"] = c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"]
+        d["lds_per_valu_inst"] = c.get("SQ_INSTS_LDS", 0.0) / c["SQ_INSTS_VALU"]
+    if "SQ_INSTS_BRANCH" in c and "SQ_INSTS_VALU" in c:
+        d["branches_per_valu_inst"] = c["SQ_INSTS_BRANCH"] / c["SQ_INSTS_VALU"]
+    # L2 side (collect.sh with L2=1): requests, hit rate, and the reads that went out to memory (32 B / 64 B / 128 B requests)
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+        d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        d["l2_requests_per_launch"] = c.get("TCC_REQ_sum", c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "TCC_EA0_RDREQ_sum" in c:
+        r32 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        d["l2_memory_read_bytes_estimate"] = r32 * 32 + (c["TCC_EA0_RDREQ_sum"] - r32) * 64
+    if "TCP_TCC_READ_REQ_sum" in c:
+        d["l1_to_l2_read_requests_per_launch"] = c["TCP_TCC_READ_REQ_sum"]
     summary["derived"] = d
     bl = os.path.join(SRC, "bench_line.json")
     if os.path.exists(bl) and os.path.getsize(bl):
