@@ -52,17 +52,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def measured_hbm_traffic():
-    """HBM bytes PER BATCH of the sample kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
+def measured_hbm_traffic(workload="c2"):
+    """HBM bytes PER BATCH of the sample kernel from the newest committed rocprofv3 PMC summary of THIS workload (profiles/rNN[x]_pmc_summary.json for the
+    headline C2 command, profiles/rNN[x]_<workload>_pmc_summary.json - c4, c5, mesh ... - for the others; profiles/collect.sh + summarize.py:
     FETCH_SIZE and WRITE_SIZE from separate --pmc passes of this same bench command, KiB -> bytes, read side doubled as
     MI355X_MICROARCH.md prescribes for gfx950; the profiled launch held `batches_per_launch` batches).  PMC counters cannot be
     collected from inside the timed run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    import re
+    pattern = re.compile(r"^r\d\d[a-z]*_pmc_summary\.json$" if workload == "c2" else r"^r\d\d[a-z]*_%s_pmc_summary\.json$" % re.escape(workload or "-"))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")) if pattern.match(os.path.basename(f)))
     for f in reversed(files):
         try:
             d = json.load(open(f))
-            keys = ("valu_issue_utilisation", "valu_lane_utilisation", "simd_cycles_per_valu_inst", "valu_pipe_busy_estimate", "lds_busy_fraction")
+            keys = ("valu_issue_utilisation", "valu_lane_utilisation", "simd_cycles_per_valu_inst", "valu_pipe_busy_estimate", "lds_busy_fraction", "l2_hit_rate", "l2_memory_read_bytes_estimate",
+                    "icache_hit_rate")
             secondary = {k: round(float(d["derived"][k]), 4) for k in keys if k in d["derived"]}
             if "valu_issue_utilisation" in secondary and "valu_lane_utilisation" in secondary:
                 # what actually bounds the kernel: VALU instructions issued per SIMD cycle against the peak rate x lanes doing useful work in them
@@ -247,6 +251,8 @@ def main():
     ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default: on one GPU the steps split into equal chains of at most 16, on several 1 (one gather per batch)")
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
     ap.add_argument("--context-flags", type=int, default=0, help="development: RtowContextOptions.flags (e.g. 1 = exact-tie kernels always)")
+    ap.add_argument("--only-leg", choices=("group_fold", "host_default_chain", "host_default_group", "host_default_adaptive"), default=None,
+                    help="profiling aid: run only this secondary measurement (--steps batches, --chain per launch) and print its block")
     ap.add_argument("--post-only", default=None, metavar="WxH", help="profiling aid: run only the post-pass measurement at this frame size and print its block (profiles/collect.sh)")
     ap.add_argument("--partition", choices=("hybrid", "tiles", "batches"), default="hybrid", help="which N > 1 partition `value` reports (the other is reported beside it): hybrid = tiles x batches "
                     "behind the C ABI (the reference stream's scalable split), tiles = rows only (north_star's), batches = hybrid with one tile")
@@ -505,6 +511,127 @@ def main():
         return {"value": round(float(n) * t_spp * steps / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms_per_step": round(sum(kms) / steps, 3),
                 "mrays_per_s": round(rays_last * steps / dt / 1e6, 1), "steps": steps, "batches_per_launch": per_launch}
 
+    def adaptive_batches(steps, warm=4, t_depth=32, t_range=(1, 50), t_stride=16):
+        """The reference host AS COMMITTED (Assets/Prefabs/Raytracer.prefab:383-391: samplesPerBatchRange {1, 50}, traceDepth 32; FULL_DIAGNOSTICS records): every batch takes
+        between 1 and 50 samples PER PIXEL, decided per pixel from its accumulated sample-count weight against the extrema of the frame (JOBS/SampleBatchJob.cs:118-126), and
+        the extrema come from the ReduceMetricsJob of the batch that completed last (UNITY/Raytracer.cs:527-543) - with two batches in flight (:586-596), of batch i - 2.
+        Plain rtowSampleBatchDevice launches accumulating in place, each followed by rtowReduceMetricsDeviceAsync into a pinned record; the host waits for record i - 2
+        before it enqueues batch i, exactly the dependency the reference host has.  Samples are counted like the reference counts them (TotalSamples = sum of color.w)."""
+        acc = mg.accum_views(torch.zeros(mg.ACCUM_FLOATS * n, device=dev), n)
+        ba = abi.AccumBuffers(*[t.data_ptr() for t in acc])
+        dg = torch.zeros(n * (t_stride // 4), device=dev)
+        records = torch.zeros((steps + warm, 16), dtype=torch.int32).pin_memory()          # one 64-byte slot per batch, RtowMetrics (40 bytes) at its start
+        events = [torch.cuda.Event() for _ in range(steps + warm)]
+        basep = rt.scenes.make_params(scene, W, H, spp=t_range[0], spp_max=t_range[1], trace_depth=t_depth, diagnostics_stride=t_stride, focus=focus)
+        extrema = (0.0, 0.0)                                                                # the host's field before any batch has completed
+        kms, spans = [], []
+
+        def record_of(i):
+            return abi.Metrics.from_buffer_copy(records[i].numpy().tobytes()[:C.sizeof(abi.Metrics)])
+
+        def go(first, count):
+            nonlocal extrema
+            for i in range(first, first + count):
+                if i >= 2:
+                    events[i - 2].synchronize()                                             # the batch before the one in flight has completed: its metrics are the host's
+                    r = record_of(i - 2)
+                    extrema = (float(r.sampleCountWeightExtrema.x), float(r.sampleCountWeightExtrema.y))
+                p = abi.SampleParams.from_buffer_copy(basep)
+                p.seed = i + 1
+                p.sampleCountWeightExtrema = abi.Float2(*extrema)
+                rt.lib.check(lib.rtowSampleBatchDevice(ctx.handle, C.byref(p), C.byref(ba), C.byref(ba), dg.data_ptr(), stream.cuda_stream, None), "rtowSampleBatchDevice")
+                rt.lib.check(lib.rtowReduceMetricsDeviceAsync(ctx.handle, n, dg.data_ptr(), t_stride, acc[0].data_ptr(), acc[3].data_ptr(), stream.cuda_stream, records[i].data_ptr()),
+                             "rtowReduceMetricsDeviceAsync")
+                events[i].record(stream)
+
+        go(0, warm)
+        torch.cuda.synchronize(dev)
+        before = record_of(warm - 1)
+        t0 = time.perf_counter()
+        go(warm, steps)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ctx.batch_status()
+        after = record_of(warm + steps - 1)
+        samples = int(after.totalSamples64) - int(before.totalSamples64)
+        rays = sum(int(record_of(i).totalRayCount64) for i in range(warm, warm + steps))
+        per_batch = [int(record_of(i).totalSamples64) - int(record_of(i - 1).totalSamples64) for i in range(warm, warm + steps)]
+        return {"value": round(samples / dt / 1e6, 2), "unit": "Msamples/s (successful samples, as the reference's TotalSamples counts them)", "ms_per_step": round(dt / steps * 1e3, 3),
+                "mrays_per_s": round(rays / dt / 1e6, 1), "steps": steps, "batches_per_launch": 1, "samples_per_pixel_per_batch_mean": round(samples / steps / n, 2),
+                "samples_per_pixel_per_batch_min_max": [round(min(per_batch) / n, 2), round(max(per_batch) / n, 2)],
+                "sample_count_weight_extrema_last": [float(after.sampleCountWeightExtrema.x), float(after.sampleCountWeightExtrema.y)],
+                "samples_per_pixel_extrema_last": [int(after.sampleCountExtrema[0]), int(after.sampleCountExtrema[1])]}
+
+    def partition_self_check(partition):
+        """N > 1: BEFORE anything is timed, the chosen partition renders a 64 x 36 frame over the transport the timed run will use, and rank 0 checks the colour frame it
+        ends up with (a) bit for bit against the same sub-batches rendered by rank 0 ALONE and folded in the same order, and (b) within north_star's 1e-4 per channel of the mean of
+        the reference's sequential accumulation of those sub-batches.  (a) proves that N ranks really took part and that the exchange / gather deliver every row;
+        (b) that the image the scaling line is quoted for is the reference's image up to float association.  Fails the run, loudly, otherwise."""
+        nonlocal W, H, n, spp
+        import numpy as np
+        keep = (W, H, n, spp)
+        steps_c = 2
+        W, H = 64, 36
+        n = W * H
+        hybrid_c = partition in ("hybrid", "batches")
+        tiles_t = 1 if partition == "batches" else (args.tiles or mg.default_tiles(world, keep[3]))
+        spp = 4 * (world // tiles_t) if hybrid_c else 4                   # every seed group gets 4 samples
+        try:
+            mm = measure(partition, "reference", 1, steps_c, 0)
+            got = mm["last"][0].view(n, 4).cpu().numpy().copy() if rank == 0 else None
+            result = None
+            if rank == 0:
+                def render(params, src):
+                    bufs = [torch.zeros(n * c, device=dev) if src is None else src[k].clone() for k, c in enumerate((4, 3, 3, 1))]
+                    b = abi.AccumBuffers(*[t.data_ptr() for t in bufs])
+                    rt.lib.check(lib.rtowSampleBatchDevice(ctx.handle, C.byref(params), C.byref(b), C.byref(b), None, stream.cuda_stream, None), "rtowSampleBatchDevice")
+                    torch.cuda.synchronize(dev)
+                    return bufs
+                fold = np.zeros((n, 4), np.float32)
+                seq = None
+                rows = np.arange(n) // W
+                for step in range(1, steps_c + 1):
+                    for r in range(world):
+                        if hybrid_c:
+                            pl = rt.Context.hybrid_plan(world, r, tiles_t, spp, step)
+                            p = rt.scenes.make_params(scene, W, H, spp=int(pl.samples), trace_depth=depth, seed=int(pl.seed), slice_offset=int(pl.sliceOffset), slice_divider=int(pl.sliceDivider), focus=focus)
+                            own = rows % int(pl.sliceDivider) == int(pl.sliceOffset)
+                        else:
+                            p = rt.scenes.make_params(scene, W, H, spp=spp, trace_depth=depth, seed=step, slice_offset=r, slice_divider=world, focus=focus)
+                            own = rows % world == r
+                        part = render(p, None)[0].view(n, 4).cpu().numpy()
+                        fold[own] = fold[own] + part[own]                   # group order (ranks of a tile ascend with their group), float32 like fold_rows_kernel
+                        seq = render(p, seq)                                # the reference's way: every batch on top of its predecessor's sums
+                seqc = seq[0].view(n, 4).cpu().numpy()
+                same = bool(np.array_equal(got.view(np.uint32), fold.view(np.uint32)))
+                mean_a = got[:, :3] / np.maximum(got[:, 3:4], 1)
+                mean_s = seqc[:, :3] / np.maximum(seqc[:, 3:4], 1)
+                counts = bool(np.array_equal(got[:, 3], seqc[:, 3]))
+                result = {"frame": "%dx%d, %d steps, %d samples per step" % (W, H, steps_c, spp), "bit_identical_to_the_same_sub_batches_on_one_gpu": same,
+                          "success_counts_equal_the_sequential_accumulation": counts, "max_abs_mean_colour_difference_to_the_sequential_accumulation": float(np.abs(mean_a - mean_s).max()),
+                          "transport": "RCCL behind the C ABI" if (have_comm and not shared_gpu) else "stand-in transport (debug)" if have_comm else "torch.distributed"}
+                if not (same and counts and result["max_abs_mean_colour_difference_to_the_sequential_accumulation"] <= 1e-4):
+                    raise SystemExit("bench.py --gpus %d: the %s partition's frame is not the frame of its sub-batches: %s" % (world, partition, json.dumps(result)))
+            return result
+        finally:
+            W, H, n, spp = keep
+            ctx.synchronize()
+
+    self_check = partition_self_check(args.partition) if world > 1 else None
+
+    if args.only_leg:
+        # profiling / A-B aid (profiles/collect.sh, profiles/r05_runs): ONE of the secondary measurements as the whole run
+        per = args.chain
+        leg = {"group_fold": lambda: timed_batches("group_fold", depth, spp, 4, args.steps, per),
+               "host_default_chain": lambda: timed_batches("chain", 32, 50, 16, args.steps, per),
+               "host_default_group": lambda: timed_batches("group_fold", 32, 50, 16, args.steps, per),
+               "host_default_adaptive": lambda: adaptive_batches(args.steps)}[args.only_leg]()
+        tuned = ctx.scene_info()
+        print(json.dumps({"only_leg": args.only_leg, "scene": args.scene, "width": W, "height": H, "config": {"batches_per_launch": leg.get("batches_per_launch"), "scheduler_tune": [int(x) for x in tuned.schedulerTune],
+                                                                                                  "threshold_set": int(tuned.thresholdSet), "context_flags": args.context_flags}, **leg}), flush=True)
+        ctx.close()
+        return
+
     main_partition = args.partition if world > 1 else "single"
     m = measure(args.partition, args.rng, args.chain, args.steps, args.warmup)
     hybrid = m["hybrid"]
@@ -534,9 +661,12 @@ def main():
                 # (Assets/Prefabs/Raytracer.prefab:383-391), same scene and frame
                 hd_steps = 2 * args.chain
                 extras["host_default"] = {
-                    "config": "16-byte FULL_DIAGNOSTICS records, traceDepth 32, 50 samples per batch (the reference host's committed defines and prefab), %s %dx%d" % (args.scene, W, H),
+                    "config": "16-byte FULL_DIAGNOSTICS records, traceDepth 32 (the reference host's committed defines and prefab), %s %dx%d; `chain` / `group_fold`: every pixel takes the 50 samples that are "
+                              "the UPPER end of the prefab's samplesPerBatchRange {1, 50}; `adaptive`: the range as committed, per-pixel counts" % (args.scene, W, H),
                     "chain": timed_batches("chain", 32, 50, 16, hd_steps, args.chain),
                     "group_fold": timed_batches("group_fold", 32, 50, 16, hd_steps, args.chain),
+                    "adaptive": dict(adaptive_batches(hd_steps), note="the schedule the committed host actually runs: sampleCountRange (1, 50) decided per pixel from the sample-count weights, extrema fed back from the "
+                                                                      "metrics of batch i - 2 (rtowReduceMetricsDeviceAsync), plain launches with two in flight, traceDepth 32, FULL_DIAGNOSTICS records"),
                     "note": "a chain is bound by its slowest pixel's batches in a row (cover scene at depth 32: 6 429 sequential path segments per 256 samples of one pixel, ~13 us each; "
                             "profiles/r04g_ray_count_stats.txt), a group by the slowest pixel-batch: DESIGN.md 4.1"}
             # the drop-in form of INTEGRATION.md: rtowSampleBatch on the host's own (pinned, registered) accumulation arrays
@@ -589,7 +719,9 @@ def main():
         alg_bytes = int(owned_pixels * 92 * steps_per_launch) + int(info.sceneBytesDevice)
         launch_ms = avg_kernel_ms * steps_per_launch
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src, secondary = measured_hbm_traffic() if world == 1 else (None, None, {})
+        # which committed profile speaks for this workload: the headline command's, or the one collected for this config / scene (profiles/collect.sh <tag>_<workload> ...)
+        wkey = ("c%d" % args.config) if not overridden else (args.scene if overridden == ["scene"] and args.config == 2 else None)
+        traffic, traffic_src, secondary = measured_hbm_traffic(wkey) if (world == 1 and wkey) else (None, None, {})
         profiled_bpl = None
         if traffic is not None:
             try:
@@ -624,6 +756,12 @@ def main():
                               "(rtowGatherRowsDevice); the reference's successive batches (UNITY/Raytracer.cs:656-661,798-802) run concurrently" % (m["tiles"], m["groups"], rank_spp, spp, m["steps_per_launch"])
                               if hybrid else "tiles: row-interleaved slices (SliceDivider=%d), one RCCL gather of colour rows per batch behind the C ABI (rtowGatherRowsDevice)" % world),
                 "tiles": m["tiles"] if world > 1 else None, "seed_groups": m["groups"] if world > 1 else None,
+                "rccl_ranks": (world if (have_comm and not shared_gpu) else 0) if world > 1 else None,
+                "collectives_per_step": None if world == 1 else (2 if hybrid else 1),
+                "image": None if world == 1 else ("per step %d sub-batches of %d of the %d samples, Seeds (step - 1) * %d + 1 ... step * %d, each rendered from zeroed accumulators and folded in group order: the reference's "
+                                                  "samples under another association of the float sums - bit-identical to the same sub-batches on one GPU, within 1e-4 of the sequential accumulation (self_check)"
+                                                  % (m["groups"], rank_spp, spp, m["groups"], m["groups"]) if hybrid else "the single-GPU frame, bit for bit: every rank renders its rows of the one batch (Seed = step)"),
+                "self_check": self_check,
                 "gather": None if world == 1 else ("rtowGatherRowsDevice (DEBUG: the tests' stand-in transport instead of RCCL, ranks share one GPU)" if (have_comm and shared_gpu) else "rtowGatherRowsDevice (RCCL behind the C ABI)" if have_comm else "torch.distributed (debug: ranks share one GPU)" if shared_gpu else "torch.distributed (the C-ABI communicator was not available)"),
                 "batches_per_launch": m["steps_per_launch"],
                 "launches": m["launches"],

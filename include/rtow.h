@@ -185,7 +185,10 @@ typedef struct RtowSceneInfo {
     uint64_t hitSpillBytes;         /* bytes of HBM this scene reserves for hit lists beyond the 24 entries a lane holds itself (scenes with
                                        ProbabilisticVolume materials, exact-tie kernels): 16 B x 1024 lanes x CUs x (list capacity - 24) entries,
                                        0 where no ray can need it.  Grow-only per context; RtowContextOptions.hitListCapacity sizes it */
-    int32_t hitListCapacity;        /* most surfaces one ray may meet in this scene before the batch reports RTOW_ERROR_CAPACITY (0: only the nearest hit is kept) */
+    int32_t hitListCapacity;        /* most surfaces one ray may meet in this scene before the batch reports RTOW_ERROR_CAPACITY (0: only the nearest hit is kept; for sphere scenes
+                                       whose rare nearest-hit ties are settled by the fix-up pass: the capacity of that pass's lists).  A launch also reports RTOW_ERROR_CAPACITY - final,
+                                       this value unchanged - when it marks more than 2^20 pixel-batches for the fix-up pass: a scene of coinciding spheres that should run with
+                                       RTOW_CONTEXT_EXACT_TIES_ALWAYS */
     int32_t wideCodes;              /* 1: more than 65 535 entities or tree nodes - the kernels that keep 32-bit candidate / stack codes run (tree read from HBM) */
     int32_t thresholdSet;           /* stage thresholds in use for this scene: -1 the built-in ones of its kernel kind (nothing measured yet - the probes of a measurement may be in
                                        flight -, too few samples asked for so far, tuning off, or RtowContextOptions.schedulerTune given); 0 / 1 / 2 the sphere family / the general family /
@@ -525,10 +528,15 @@ typedef struct RtowCommId { char bytes[128]; } RtowCommId;        /* ncclUniqueI
 RTOW_API int rtowCommSetLibraryPath(const char* path);
 typedef enum RtowGatherMask {
     RTOW_GATHER_COLOR = 1, RTOW_GATHER_NORMAL = 2, RTOW_GATHER_ALBEDO = 4, RTOW_GATHER_SAMPLE_COUNT_WEIGHT = 8, RTOW_GATHER_ALL = 15,
-    RTOW_GATHER_NO_BATCH_WAIT = 16   /* rtowGatherRowsDevice / rtowExchangeAccumDevice normally start after the context's most recent sample batch, whatever
+    RTOW_GATHER_NO_BATCH_WAIT = 16,  /* rtowGatherRowsDevice / rtowExchangeAccumDevice normally start after the context's most recent sample batch, whatever
                                       * stream that batch was given (its rows are what travels).  With this bit the call is ordered by `stream` alone: for rows
                                       * that do not come out of that batch - the output of rtowExchangeAccumDevice on the same stream, or a partial result
                                       * whose batch the caller has already ordered before `stream` itself - while the NEXT batch is already enqueued */
+    RTOW_GATHER_LOOPBACK = 32        /* rtowGatherRowsDevice on a communicator of ONE rank (rtowCommInit(ctx, id, 0, 1)): send the rows to itself THROUGH the transport - pack,
+                                      * ncclSend + ncclRecv to / from rank 0 in one group, scatter - instead of copying them.  A deployment check: on a box with a single GPU
+                                      * (RCCL refuses two ranks on one device) it runs the loaded library's ncclGetUniqueId / ncclCommInitRank / ncclGroupStart / ncclSend /
+                                      * ncclRecv / ncclGroupEnd / ncclCommDestroy with this library's own argument conventions (the 128-byte id by value, ncclFloat32, counts in
+                                      * elements, the caller's stream).  Ignored by communicators of more than one rank */
 } RtowGatherMask;
 RTOW_API int rtowCommGetUniqueId(RtowCommId* outId);
 RTOW_API int rtowCommInit(RtowContext context, const RtowCommId* id, int32_t rank, int32_t worldSize);

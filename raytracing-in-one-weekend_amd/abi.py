@@ -137,7 +137,7 @@ LogCallback = C.CFUNCTYPE(None, C.c_int32, C.c_char_p, C.c_char_p, C.c_void_p)
 # RtowContextFlags
 CONTEXT_EXACT_TIES_ALWAYS, CONTEXT_EXACT_TIES_NEVER, CONTEXT_REFERENCE_DIAGNOSTICS, CONTEXT_NO_CAMERA_RAY_LISTS, CONTEXT_NO_CHUNK_ORDER, CONTEXT_FORCE_WIDE_CODES, CONTEXT_NO_THRESHOLD_TUNING, CONTEXT_NO_CHAIN_FUSION = 1, 2, 4, 8, 16, 32, 64, 128
 # RtowGatherMask
-GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_ALL, GATHER_NO_BATCH_WAIT = 1, 2, 4, 8, 15, 16
+GATHER_COLOR, GATHER_NORMAL, GATHER_ALBEDO, GATHER_SAMPLE_COUNT_WEIGHT, GATHER_ALL, GATHER_NO_BATCH_WAIT, GATHER_LOOPBACK = 1, 2, 4, 8, 15, 16, 32
 
 
 class ContextOptions(C.Structure):

@@ -303,7 +303,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.ldsNodeCount = ctx->ldsNodeCount;
     a.workCounter = ctx->dWorkCounter;
     a.cancelFlag = useCancelFlag ? ctx->hCancel : nullptr;
-    a.overflowFlag = const_cast<uint32_t*>(ctx->hCancel) + 1;
+    a.overflowFlag = const_cast<uint32_t*>(ctx->hCancel) + 1;      // [1]: a ray beyond the hit-list capacity (grows: takeOverflow); [2]: more tied pixel-batches than the fix-up list holds (final)
     a.width = (int)p->size.x;
     a.height = (int)p->size.y;
     a.totalWork = (uint32_t)ownedRows(p) * (uint32_t)a.width;
@@ -626,8 +626,10 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             // ~0.05 ms at 1920 x 1080 against a batch's tens of milliseconds)
             static const size_t comps[4] = {4, 3, 3, 1};
             float* at = ctx->dTieInputs;
+            const size_t rows = (size_t)ownedRows(p);                // the rows this launch writes (row % SliceDivider == SliceOffset), at their places in the frame
             for (int k = 0; k < 4; k++) {
-                HIP_TRY(ctx, hipMemcpyAsync(at, redoIn[k], framePixels * comps[k] * sizeof(float), hipMemcpyDeviceToDevice, stream), RTOW_ERROR_LAUNCH_FAILURE);
+                const size_t rowBytes = (size_t)a.width * comps[k] * sizeof(float), first = (size_t)a.sliceOffset * rowBytes, pitch = (size_t)a.sliceDivider * rowBytes;
+                HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t*)at + first, pitch, (const uint8_t*)redoIn[k] + first, pitch, rowBytes, rows, hipMemcpyDeviceToDevice, stream), RTOW_ERROR_LAUNCH_FAILURE);
                 redoIn[k] = at;
                 at += framePixels * comps[k];
             }
@@ -641,7 +643,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         // the fix-up: marked pixels -> list -> the exact-tie kernel of the same kind over the list (almost always empty: that kernel then leaves before it stages the scene).
         // A chain's pixel is listed once and carried through all its batches; a group's once per batch.
         const size_t framePixels = (size_t)a.width * (size_t)a.height;
-        HIP_TRY(ctx, launchCollectTiedPixels(ctx->dTieBits, (unsigned)((framePixels + 31u) / 32u), ctx->dTieRedo, kTieRedoCapacity, a.chainIndependent ? a.chainCount : 1u, a.overflowFlag, stream),
+        HIP_TRY(ctx, launchCollectTiedPixels(ctx->dTieBits, (unsigned)((framePixels + 31u) / 32u), ctx->dTieRedo, kTieRedoCapacity, a.chainIndependent ? a.chainCount : 1u, a.overflowFlag + 1, stream),
                 RTOW_ERROR_LAUNCH_FAILURE);
         SampleKernelArgs r = a;
         r.layout.exactTies = 1u;
@@ -735,6 +737,15 @@ bool growHitList(RtowContext ctx)
 // (rtowSampleBatch, a cancellable rtowSampleBatchDevice, rtowGetBatchStatus, rtowSynchronize).
 int takeOverflow(RtowContext ctx)
 {
+    if (ctx->hCancel[2] != 0u) {
+        // not a hit list: a launch marked more pixel-batches for the tie fix-up pass than its list holds (kTieRedoCapacity = 2^20; a scene of coinciding spheres that
+        // did not go to the exact-tie kernels).  Growing the hit lists would not help and running the batch again would overflow again: the error is final
+        ctx->hCancel[2] = 0u;
+        ctx->hCancel[1] = 0u;
+        ctx->overflowGrew = false;
+        logf(ctx, 2, "rtow", "more than %u pixel-batches of one launch met nearest-hit ties: results of this batch are invalid (use RTOW_CONTEXT_EXACT_TIES_ALWAYS for this scene)", kTieRedoCapacity);
+        return RTOW_ERROR_CAPACITY;
+    }
     if (ctx->hCancel[1] == 0u) return RTOW_SUCCESS;
     ctx->hCancel[1] = 0u;
     const bool volumes = ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
@@ -755,6 +766,7 @@ int waitWithCancel(RtowContext ctx, const volatile uint8_t* cancel)
         if (q != hipErrorNotReady) {
             logf(ctx, 2, "hip", "sample kernel failed: %s", hipGetErrorString(q));
             ctx->hCancel[1] = 0u;
+            ctx->hCancel[2] = 0u;
             return RTOW_ERROR_LAUNCH_FAILURE;
         }
         if (cancel && *cancel && !cancelled) {
@@ -766,6 +778,7 @@ int waitWithCancel(RtowContext ctx, const volatile uint8_t* cancel)
     if (cancel && *cancel) cancelled = true;
     if (cancelled) {
         ctx->hCancel[1] = 0u;          // the cancelled batch's outputs are discarded; its overflow must not be blamed on the next batch
+        ctx->hCancel[2] = 0u;
         return RTOW_ERROR_CANCELLED;
     }
     return takeOverflow(ctx);
@@ -886,6 +899,8 @@ int enqueueChain(RtowContext ctx, int count, const RtowSampleParams* params, con
     }
     const uint64_t paddedPixels = ((uint64_t)ownedRows(&params[0]) * (uint64_t)(int)params[0].size.x + 63u) & ~63ull;
     if (paddedPixels >= (1ull << 27)) fusable = false;
+    // (the tie fix-up list names FRAME pixels beside the batch number, batch << 27 | pixel: a sliced launch of a frame of 2^27 pixels or more runs batch by batch)
+    if ((uint64_t)(int)params[0].size.x * (uint64_t)(int)params[0].size.y >= (1ull << 27)) fusable = false;
     // one launch is one kernel variant, and the variant follows the record format (launchByDiag: 16-byte FULL_DIAGNOSTICS records need the
     // counters compiled in): a chain in which only SOME batches carry a diagnostics buffer runs batch by batch, each with its own variant
     if (diagnostics) {
@@ -985,17 +1000,25 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     ctx->hCancel = (volatile uint32_t*)pinned;
     ctx->hCancel[0] = 0u;
     ctx->hCancel[1] = 0u;
+    ctx->hCancel[2] = 0u;
     logf(ctx, 4, "rtow", "context on device %d (%s, %d CUs)", ordinal, prop.gcnArchName, ctx->cuCount);
     // chained launches hand accumulators over inside an XCD with plain stores + sc1 loads: measured on THIS device before it is relied on
     if (ctx->flags & RTOW_CONTEXT_NO_CHAIN_FUSION) {
         ctx->chainFusion = false;
     } else {
+        // stale > 0: the hand-over is unsafe on this device.  timeouts > 0 with nothing stale: inconclusive - the litmus needs its 2 x CU workgroups resident at the same time,
+        // which a device shared with other work may not grant within its bounded waits - so it runs once more before chains are given up (RtowSceneInfo does not say so; the log does)
         unsigned pairs = 0, stale = 0, timeouts = 0;
-        const hipError_t le = runXcdCoherenceLitmus(ctx->cuCount, ctx->stream, &pairs, &stale, &timeouts);
+        hipError_t le = hipSuccess;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            le = runXcdCoherenceLitmus(ctx->cuCount, ctx->stream, &pairs, &stale, &timeouts);
+            if (le != hipSuccess || stale != 0 || (pairs > 0 && timeouts == 0)) break;
+            logf(ctx, 3, "rtow", "same-XCD hand-over litmus inconclusive (%u pairs, %u timeouts): %s", pairs, timeouts, attempt == 0 ? "once more" : "giving up");
+        }
         ctx->chainFusion = le == hipSuccess && pairs > 0 && stale == 0 && timeouts == 0;
         if (le != hipSuccess) (void)hipGetLastError();
         logf(ctx, ctx->chainFusion ? 4 : 3, "rtow", "same-XCD hand-over litmus: %u pairs, %u stale dwords, %u timeouts%s", pairs, stale, timeouts,
-             ctx->chainFusion ? "" : " - chained batches will run one launch per batch");
+             ctx->chainFusion ? "" : stale ? " - unsafe here: chained batches will run one launch per batch" : " - inconclusive: chained batches will run one launch per batch");
     }
     *outContext = ctx;
     return RTOW_SUCCESS;
@@ -1257,7 +1280,11 @@ RTOW_API int rtowGetSceneInfo(RtowContext ctx, RtowSceneInfo* info)
     info->sceneBytesDevice = ctx->scene.layout.totalBytes;
     info->hitSpillBytes = (uint64_t)ctx->hitSpillEntries * (uint64_t)ctx->cuCount * (uint64_t)kBlockThreads * sizeof(uint4);
     const bool keepsLists = ctx->scene.layout.exactTies || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES || ctx->scene.layout.sceneKind == SCENE_KIND_VOLUMES_TEXTURED;
-    info->hitListCapacity = keepsLists ? (int32_t)(ctx->hitSpillEntries + (uint32_t)kLocalHitEntries) : 0;
+    // sphere scenes under the rank rule keep no lists in the fast kernel, but their tie fix-up launch (the exact-tie kernel over the marked pixels) does: its capacity is what a
+    // RTOW_ERROR_CAPACITY of such a scene has just doubled (growHitList), and what a device-resident caller compares across the error
+    const bool tieWatch = ctx->scene.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION && !ctx->scene.layout.exactTies && ctx->scene.entityCount > 16 && !(ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER);
+    info->hitListCapacity = keepsLists ? (int32_t)(ctx->hitSpillEntries + (uint32_t)kLocalHitEntries)
+                                       : tieWatch ? (int32_t)std::min<uint64_t>((uint64_t)ctx->scene.entityCount, listCapacity(ctx, false)) : 0;
     info->wideCodes = ctx->wideCodes ? 1 : 0;
     info->thresholdSet = ctx->tunedScene == ctx->sceneSerial ? ctx->tunedCandidate : -1;
     for (int k = 0; k < 9; k++) info->schedulerTune[k] = ctx->tune[k];
@@ -1329,6 +1356,7 @@ RTOW_API int rtowSampleBatchGroupDevice(RtowContext ctx, int32_t count, const Rt
     }
     const uint64_t paddedPixels = ((uint64_t)ownedRows(&params[0]) * (uint64_t)(int)params[0].size.x + 63u) & ~63ull;
     if (paddedPixels >= (1ull << 27)) fusable = false;
+    if ((uint64_t)(int)params[0].size.x * (uint64_t)(int)params[0].size.y >= (1ull << 27)) fusable = false;      // tie fix-up entries: batch << 27 | FRAME pixel (enqueueChain)
     if (diagnostics) {
         int withDiag = 0;
         for (int b = 0; b < count; b++) withDiag += diagnostics[b] != nullptr ? 1 : 0;
@@ -1704,11 +1732,13 @@ RTOW_API int rtowCommDestroy(RtowContext ctx)
 RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height, int32_t sliceDivider, const RtowAccumBuffers* mine,
                                   const RtowAccumBuffers* frame, int32_t what, int32_t root, void* stream)
 {
-    if (!ctx || !mine || width <= 0 || height <= 0 || sliceDivider < 1 || (what & ~(RTOW_GATHER_ALL | RTOW_GATHER_NO_BATCH_WAIT)) || !(what & RTOW_GATHER_ALL)) return RTOW_ERROR_INVALID_VALUE;
+    if (!ctx || !mine || width <= 0 || height <= 0 || sliceDivider < 1 || (what & ~(RTOW_GATHER_ALL | RTOW_GATHER_NO_BATCH_WAIT | RTOW_GATHER_LOOPBACK)) || !(what & RTOW_GATHER_ALL)) return RTOW_ERROR_INVALID_VALUE;
     const bool waitForBatch = !(what & RTOW_GATHER_NO_BATCH_WAIT);
+    const bool wantLoopback = (what & RTOW_GATHER_LOOPBACK) != 0;
     what &= RTOW_GATHER_ALL;
     std::lock_guard<std::mutex> lock(ctx->mu);
     const int world = ctx->comm ? ctx->commWorld : 1, rank = ctx->comm ? ctx->commRank : 0;
+    const bool loopback = wantLoopback && ctx->comm && world == 1;      // one rank sending its rows to itself through the transport (RTOW_GATHER_LOOPBACK)
     if (sliceDivider != world || root < 0 || root >= world) return RTOW_ERROR_INVALID_VALUE;   // rank g owns the rows of slice g: one slice per rank
     if (rank == root && !frame) return RTOW_ERROR_INVALID_VALUE;
     HIP_TRY(ctx, hipSetDevice(ctx->device), RTOW_ERROR_NO_DEVICE);
@@ -1727,6 +1757,46 @@ RTOW_API int rtowGatherRowsDevice(RtowContext ctx, int32_t width, int32_t height
         }
     auto packedFloats = [&](int r) { return (size_t)rowsOwnedBy(r, world, height) * (size_t)width * floatsPerPixel; };
 
+    if (loopback) {
+        // the whole transport path of a peer AND of the root, against itself: pack -> {ncclSend, ncclRecv} to / from rank 0 in one group -> scatter
+        RcclApi* api = rccl();
+        if (!api) return RTOW_ERROR_UNSUPPORTED;
+        if (ctx->haveGatherDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evGatherDone, 0), RTOW_ERROR_LAUNCH_FAILURE);
+        const size_t need = packedFloats(0);
+        if (need > ctx->gatherSendFloats || need > ctx->gatherRecvFloats) {
+            HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
+            if (ctx->dGatherSend) (void)hipFree(ctx->dGatherSend);
+            if (ctx->dGatherRecv) (void)hipFree(ctx->dGatherRecv);
+            ctx->dGatherSend = ctx->dGatherRecv = nullptr; ctx->gatherSendFloats = ctx->gatherRecvFloats = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dGatherSend, need * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->gatherSendFloats = need;
+            HIP_TRY(ctx, hipMalloc(&ctx->dGatherRecv, need * 4u), RTOW_ERROR_MEMORY_ALLOCATION);
+            ctx->gatherRecvFloats = need;
+        }
+        size_t at = 0;
+        for (int b = 0; b < 4; b++)
+            if (what & (1 << b)) {
+                HIP_TRY(ctx, launchCopyRows(mineBuf[b], ctx->dGatherSend + at, (unsigned)(width * kComponents[b]), (unsigned)height, 0u, 1u, false, s), RTOW_ERROR_LAUNCH_FAILURE);
+                at += (size_t)height * width * kComponents[b];
+            }
+        RCCL_TRY(ctx, api, api->GroupStart());
+        int posted = api->Send(ctx->dGatherSend, need, kRcclFloat32, 0, ctx->comm, s);
+        if (posted == 0) posted = api->Recv(ctx->dGatherRecv, need, kRcclFloat32, 0, ctx->comm, s);
+        const int closed = api->GroupEnd();
+        if (posted != 0 || closed != 0) {
+            logf(ctx, 2, "rccl", "loop-back gather failed: ncclSend / ncclRecv %s, ncclGroupEnd %s", api->GetErrorString(posted), api->GetErrorString(closed));
+            return RTOW_ERROR_LAUNCH_FAILURE;
+        }
+        at = 0;
+        for (int b = 0; b < 4; b++)
+            if (what & (1 << b)) {
+                HIP_TRY(ctx, launchCopyRows(frameBuf[b], ctx->dGatherRecv + at, (unsigned)(width * kComponents[b]), (unsigned)height, 0u, 1u, true, s), RTOW_ERROR_LAUNCH_FAILURE);
+                at += (size_t)height * width * kComponents[b];
+            }
+        HIP_TRY(ctx, hipEventRecord(ctx->evGatherDone, s), RTOW_ERROR_LAUNCH_FAILURE);
+        ctx->haveGatherDone = true;
+        return RTOW_SUCCESS;
+    }
     if (world == 1 || rank == root) {
         // the root's own rows: already in place when frame == mine, else copied row by row on the device
         const unsigned rows = rowsOwnedBy(rank, world, height);

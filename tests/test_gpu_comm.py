@@ -390,3 +390,63 @@ def test_hybrid_plan_and_single_rank_exchange(rt, gpu_context):
     assert np.array_equal(got[1], dst[1]) and np.array_equal(got[2], dst[2])
     for b in part + acc:
         b.free()
+
+
+REAL_RCCL_SCRIPT = r"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+rt = importlib.import_module("raytracing-in-one-weekend_amd")
+a = rt.abi
+log = []
+ctx = rt.Context(0, log=lambda lvl, tag, msg, ud: log.append("%s: %s" % (tag.decode(), msg.decode())), log_level=4)
+uid = rt.Context.comm_unique_id()                         # ncclGetUniqueId of the REAL library (nothing was given to rtowCommSetLibraryPath)
+assert len(uid) == 128 and not uid.startswith(b"fake_rccl_")
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps, "the process did not map librccl.so"
+assert "fake_rccl" not in maps
+ctx.comm_init(uid, 0, 1)                                  # ncclCommInitRank(&comm, 1, id /* by value */, 0)
+w, h = 96, 54
+n = w * h
+rng = np.random.default_rng(4)
+src = [rng.random((n, c)).astype(np.float32) for c in (4, 3, 3, 1)]
+mine = [rt.DeviceBuffer(ctx).upload(x) for x in src]
+frame = [rt.DeviceBuffer(ctx, n * c * 4) for c in (4, 3, 3, 1)]
+lib = rt.lib.load()
+for f in frame:
+    assert lib.rtowDeviceMemset(ctx.handle, f.handle, 0xFF, f.nbytes) == 0
+bm, bf = a.AccumBuffers(*[b.ptr for b in mine]), a.AccumBuffers(*[b.ptr for b in frame])
+for rep in range(3):                                      # pack -> ncclGroupStart, ncclSend(self), ncclRecv(self), ncclGroupEnd -> scatter, three times over the same staging
+    ctx.gather_rows(w, h, 1, bm, bf, what=a.GATHER_ALL | a.GATHER_LOOPBACK)
+ctx.synchronize()
+for k, (f, c) in enumerate(zip(frame, (4, 3, 3, 1))):
+    assert np.array_equal(f.download(np.float32, (n, c)).view(np.uint32), src[k].view(np.uint32)), k
+# a masked loop-back of freshly rendered rows, ordered behind the batch that wrote them (the default wait)
+scene = rt.scenes.cover_scene()
+ctx.upload_scene(scene.desc())
+p = rt.scenes.make_params(scene, w, h, spp=2, trace_depth=8)
+bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for c in (4, 3, 3, 1)]
+job = rt.SampleBatchJob(ctx, p)
+job.InputColor, job.InputNormal, job.InputAlbedo, job.InputSampleCountWeight = bufs
+job.OutputColor, job.OutputNormal, job.OutputAlbedo, job.OutputSampleCountWeight = bufs
+handle = job.Schedule()
+out = rt.DeviceBuffer(ctx, n * 16).zero()
+ctx.gather_rows(w, h, 1, a.AccumBuffers(*[b.ptr for b in bufs]), a.AccumBuffers(out.ptr, None, None, None), what=a.GATHER_COLOR | a.GATHER_LOOPBACK)
+assert handle.Complete() == 0
+ctx.synchronize()
+col = bufs[0].download(np.float32, (n, 4))
+assert col[:, 3].sum() > 0 and np.array_equal(out.download(np.float32, (n, 4)).view(np.uint32), col.view(np.uint32))
+ctx.comm_destroy()                                        # ncclCommDestroy
+ctx.close()
+print("real rccl loop-back ok")
+"""
+
+
+def test_real_rccl_loopback_on_one_gpu(rt):
+    """the REAL librccl.so, on the one GPU this box has.  RCCL refuses two ranks on one device, so every multi-rank test above runs
+    over the stand-in transport; this one makes a world of ONE rank and has it send its rows to itself through the library (RTOW_GATHER_LOOPBACK): the dlopen,
+    the by-value 128-byte id, ncclFloat32 = 7, counts in elements, the grouped send / receive on the caller's stream and the destroy are the very calls and the very
+    function pointers (RcclApi, csrc/rtow_api.hip) the 8-GPU gather uses.  In a process of its own: the transport is chosen once per process."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-c", REAL_RCCL_SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0 and "real rccl loop-back ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
