@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default: on one GPU the steps split into equal chains of at most 16, on several 1 (one gather per batch)")
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
     ap.add_argument("--context-flags", type=int, default=0, help="development: RtowContextOptions.flags (e.g. 1 = exact-tie kernels always)")
-    ap.add_argument("--only-leg", choices=("group_fold", "host_default_chain", "host_default_group", "host_default_adaptive"), default=None,
+    ap.add_argument("--only-leg", choices=("group_fold", "host_default_chain", "host_default_group", "host_default_adaptive", "plain_two_in_flight"), default=None,
                     help="profiling aid: run only this secondary measurement (--steps batches, --chain per launch) and print its block")
     ap.add_argument("--post-only", default=None, metavar="WxH", help="profiling aid: run only the post-pass measurement at this frame size and print its block (profiles/collect.sh)")
     ap.add_argument("--partition", choices=("hybrid", "tiles", "batches"), default="hybrid", help="which N > 1 partition `value` reports (the other is reported beside it): hybrid = tiles x batches "
@@ -625,7 +625,8 @@ def main():
         leg = {"group_fold": lambda: timed_batches("group_fold", depth, spp, 4, args.steps, per),
                "host_default_chain": lambda: timed_batches("chain", 32, 50, 16, args.steps, per),
                "host_default_group": lambda: timed_batches("group_fold", 32, 50, 16, args.steps, per),
-               "host_default_adaptive": lambda: adaptive_batches(args.steps)}[args.only_leg]()
+               "host_default_adaptive": lambda: adaptive_batches(args.steps),
+               "plain_two_in_flight": lambda: adaptive_batches(args.steps, warm=2, t_depth=depth, t_range=(spp, spp), t_stride=4)}[args.only_leg]()
         tuned = ctx.scene_info()
         print(json.dumps({"only_leg": args.only_leg, "scene": args.scene, "width": W, "height": H, "config": {"batches_per_launch": leg.get("batches_per_launch"), "scheduler_tune": [int(x) for x in tuned.schedulerTune],
                                                                                                   "threshold_set": int(tuned.thresholdSet), "context_flags": args.context_flags}, **leg}), flush=True)
@@ -652,6 +653,13 @@ def main():
                 extras["chain2"] = {"value": round(float(n) * spp * steps2 / m2["elapsed"] / 1e6, 2), "ms_per_step": round(m2["elapsed"] / steps2 * 1e3, 3), "kernel_ms_per_step": round(m2["kernel_ms_per_step"], 3),
                                     "batches_per_launch": 2, "steps": steps2,
                                     "note": "two batches per launch (rtowSampleBatchChainDevice, count = 2): what a host with the reference's queue depth of two gets (UNITY/Raytracer.cs:586-593); INTEGRATION.md 3 shows the edit that queues more"}
+            # the UNMODIFIED host's call sequence on the device API: per batch rtowSampleBatchDevice, then the metrics reduction that reads that batch's outputs
+            # (ScheduleSample enqueues SampleBatchJob -> RecordTimeJob -> ReduceMetricsJob, UNITY/Raytracer.cs:729-754), asynchronously, two batches in flight (:586-596)
+            extras["plain_two_in_flight"] = dict(adaptive_batches(args.steps, warm=2, t_depth=depth, t_range=(spp, spp), t_stride=4),
+                                                 note="one launch per batch + rtowReduceMetricsDeviceAsync after each, the host two batches ahead of the device at most: what the reference host's own call order gets "
+                                                      "from the device-resident API without the queue-depth edit.  Between any two of its batches a consumer of the first one's outputs is enqueued (the metrics the "
+                                                      "NEXT batches' adaptive sample counts are decided from), so a library that deferred a launch to fuse it with the next call would have to flush it at once - or change "
+                                                      "what that reduction sees (DESIGN.md 8)")
             if args.chain > 1:
                 extras["group_fold"] = dict(timed_batches("group_fold", depth, spp, 4, args.steps, args.chain),
                                             note="the same steps as batch groups (rtowSampleBatchGroupDevice: every batch from zeroed inputs into its own partial sums, one launch per group) "

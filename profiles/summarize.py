@@ -106,12 +106,12 @@ def main():
     if "SQC_DCACHE_REQ" in c and c["SQC_DCACHE_REQ"] > 0:
         d["scalar_cache_hit_rate"] = c.get("SQC_DCACHE_HITS", 0.0) / c["SQC_DCACHE_REQ"]
     if "SQ_IFETCH" in c and "SQ_IFETCH_LEVEL" in c and c["SQ_IFETCH"] > 0:
-        d["ifetch_average_latency_cycles"] = c["SQ_IFETCH_LEVEL"] / c["SQ_IFETCH"]
+        d["ifetch_level_per_fetch_uncalibrated"] = c["SQ_IFETCH_LEVEL"] / c["SQ_IFETCH"]      # (the LEVEL counters are sampled occupancies: ratios compare runs, they are not cycles)
         if "SQ_INSTS_VALU" in c:
             d["ifetches_per_valu_inst"] = c["SQ_IFETCH"] / c["SQ_INSTS_VALU"]
     for lvl, cnt in (("SQ_INST_LEVEL_LDS", "SQ_INSTS_LDS"), ("SQ_INST_LEVEL_VMEM", "SQ_INSTS_VMEM"), ("SQ_INST_LEVEL_SMEM", "SQ_INSTS_SMEM")):
         if lvl in c and cnt in c and c[cnt] > 0:
-            d[cnt.lower().replace("sq_insts_", "") + "_average_latency_cycles"] = c[lvl] / c[cnt]
+            d[cnt.lower().replace("sq_insts_", "") + "_level_per_instruction_uncalibrated"] = c[lvl] / c[cnt]
     if "SQ_INSTS_SALU" in c and "SQ_INSTS_VALU" in c:
         d["salu_per_valu_inst"] = c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"]
         d["lds_per_valu_inst"] = c.get("SQ_INSTS_LDS", 0.0) / c["SQ_INSTS_VALU"]

@@ -2218,6 +2218,9 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
         if constexpr (TIES) { if (!fullDiag && args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
         return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
     } else {
+        // (16-word history variants for depth 17 .. 32 - the reference host's own default traceDepth - were built again in round 5 and measured under group launches, the
+        // adaptive schedule and single launches: 2 - 10 % SLOWER than the generic 32-word kernels everywhere (the eight register pairs are demoted to scratch behind their
+        // select chains at 128 VGPRs: profiles/r05e_history16_variants.json); removed again)
         if (fullDiag) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
         if constexpr (!TIES || kTiesWithShortHistory<KIND>) if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
         if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
