@@ -92,7 +92,9 @@ struct RtowContext_t {
     uint32_t chunkCapacity = 0;
     bool orderValid = false;
     int orderW = 0, orderH = 0, orderOff = 0, orderDiv = 0;
-    volatile uint32_t* hCancel = nullptr; // pinned, device-visible
+    volatile uint32_t* hCancel = nullptr; // pinned, device-visible: [0] cancel, [1] hit-list overflow, [2] tie-list overflow; the metrics record of rtowReduceMetricsDevice at byte 64
+    volatile RtowMetrics* hMetricsRecord = nullptr;
+    RtowMetrics* dMetricsRecord = nullptr;
     // RTOW_RNG_PER_SAMPLE: one 64-byte record per (owned pixel, sample group) unit
     float* dUnitRecords = nullptr;
     size_t unitRecordCapacity = 0;
@@ -995,9 +997,13 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     ok = ok && hipMalloc(&ctx->dByteThresholds, kByteThresholdTableBytes) == hipSuccess;
     ok = ok && launchBuildByteThresholds(ctx->dByteThresholds, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
     void* pinned = nullptr;
-    ok = ok && hipHostMalloc(&pinned, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-    if (!ok) { rtowDestroyContext(ctx); return RTOW_ERROR_MEMORY_ALLOCATION; }
+    ok = ok && hipHostMalloc(&pinned, 256, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    void* pinnedDevice = nullptr;
+    ok = ok && hipHostGetDevicePointer(&pinnedDevice, pinned, 0) == hipSuccess;
+    if (!ok) { if (pinned) (void)hipHostFree(pinned); rtowDestroyContext(ctx); return RTOW_ERROR_MEMORY_ALLOCATION; }
     ctx->hCancel = (volatile uint32_t*)pinned;
+    ctx->hMetricsRecord = (volatile RtowMetrics*)((uint8_t*)pinned + 64);         // where the blocking metrics reduction has its record written by the device
+    ctx->dMetricsRecord = (RtowMetrics*)((uint8_t*)pinnedDevice + 64);
     ctx->hCancel[0] = 0u;
     ctx->hCancel[1] = 0u;
     ctx->hCancel[2] = 0u;
@@ -1576,25 +1582,11 @@ RTOW_API int rtowReduceMetricsDevice(RtowContext ctx, int32_t pixelCount, const 
     if (ctx->haveMetricsDone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->evMetricsDone, 0), RTOW_ERROR_LAUNCH_FAILURE);      // an asynchronous reduction may still be folding the partials
     HIP_TRY(ctx, launchReduceMetrics(pixelCount, (const uint8_t*)diagnostics, diagnosticsStride, color, sampleCountWeight, ctx->dPartials, s),
             RTOW_ERROR_LAUNCH_FAILURE);
-    std::vector<MetricsPartial> parts(kMetricsBlocks);
-    HIP_TRY(ctx, hipMemcpyAsync(parts.data(), ctx->dPartials, sizeof(MetricsPartial) * kMetricsBlocks, hipMemcpyDeviceToHost, s), RTOW_ERROR_LAUNCH_FAILURE);
+    // the per-block partials are folded on the device and the 40-byte record lands in pinned host memory by the time the stream is idle: no 8 KB copy of the partials, no
+    // DMA of its own (round 4 copied and folded them on the host: 44.6 us per call at 1920 x 1080 against 18.6 us of kernels)
+    HIP_TRY(ctx, launchFoldMetrics(ctx->dPartials, ctx->dMetricsRecord, s), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipStreamSynchronize(s), RTOW_ERROR_LAUNCH_FAILURE);
-    long long rays = 0, samples = 0;
-    float minW = INFINITY, maxW = -INFINITY, minS = INFINITY, maxS = -INFINITY;
-    auto fmin1 = [](float x, float y) { return (y != y || x < y) ? x : y; };
-    auto fmax1 = [](float x, float y) { return (y != y || x > y) ? x : y; };
-    for (const MetricsPartial& p : parts) {
-        rays += p.rays; samples += p.samples;
-        minW = fmin1(minW, p.minW); maxW = fmax1(maxW, p.maxW);
-        minS = fmin1(minS, p.minS); maxS = fmax1(maxS, p.maxS);
-    }
-    outMetrics->totalRayCount = (int32_t)(uint32_t)(uint64_t)rays;   // the reference accumulates in int32 (wraps)
-    outMetrics->totalSamples = (int32_t)(uint32_t)(uint64_t)samples;
-    outMetrics->sampleCountWeightExtrema = RtowFloat2{minW, maxW};
-    outMetrics->sampleCountExtrema[0] = (int32_t)minS;
-    outMetrics->sampleCountExtrema[1] = (int32_t)maxS;
-    outMetrics->totalRayCount64 = rays;
-    outMetrics->totalSamples64 = samples;
+    memcpy(outMetrics, (const void*)ctx->hMetricsRecord, sizeof(RtowMetrics));
     return RTOW_SUCCESS;
 }
 
