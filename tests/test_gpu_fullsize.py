@@ -242,7 +242,7 @@ def test_threshold_probes_do_not_block_and_do_not_report_overflow(rt):
         t = time.perf_counter()
         rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")     # probes (10 launches) + a 60 ms batch are enqueued ...
         dt = time.perf_counter() - t
-        assert dt < 0.02, dt                                                 # ... and the call does not wait for any of it
+        assert dt < 0.045, dt                                                # ... and the call does not wait for any of it (~75 ms of device work; the bound leaves room for a host that runs three other test workers)
         ctx.synchronize()
         assert ctx.scene_info().thresholdSet >= 0
 
