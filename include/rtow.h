@@ -193,7 +193,7 @@ typedef struct RtowSceneInfo {
     int32_t thresholdSet;           /* stage thresholds in use for this scene: -1 the built-in ones of its kernel kind (nothing measured yet - the probes of a measurement may be in
                                        flight -, too few samples asked for so far, tuning off, or RtowContextOptions.schedulerTune given); 0 / 1 / 2 the sphere family / the general family /
                                        the general family with REGEN and SKY from 1/8, as measured (or as measured earlier for a like scene); 3 / 4 / 5 the same with the volume stage waiting too */
-    int32_t schedulerTune[9];       /* the values themselves (REGEN TRAV TEST HIT SKY VOL | hand-over count | - | walk slice), as RtowContextOptions.schedulerTune would set them */
+    int32_t schedulerTune[9];       /* the values themselves (REGEN TRAV TEST HIT SKY VOL | hand-over count | pixel regrouping | walk slice), as RtowContextOptions.schedulerTune would set them */
 } RtowSceneInfo;
 
 /* ---- the operator's parameter block: SampleBatchJob's public fields (JOBS/SampleBatchJob.cs:23-51) ---- */
@@ -330,8 +330,13 @@ typedef struct RtowContextOptions {
     int32_t ldsSceneBudgetBytes;    /* development: cap on the bytes of scene image staged into LDS (0 = all that fits); smaller scenes then run
                                      * through the kernels that read the tree from HBM */
     int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL; values below 1 mean 1 = any lane), the number of
-                                     * candidates at which a box walk hands over to the exact tests (1 .. 7; 0 = the built-in 3), one unused value, and the box-walk slice (node visits
-                                     * per trip; 0 = the built-in value of the scene); all zero = everything built in, thresholds measured per scene */
+                                     * candidates at which a box walk hands over to the exact tests (1 .. 7; 0 = the built-in 3), the pixel regrouping (below), and the box-walk slice (node visits
+                                     * per trip; 0 = the built-in value of the scene); all zero = everything built in, thresholds measured per scene.
+                                     * [7], the pixel regrouping, is a knob of its own (setting it says nothing about the thresholds): 0 / 1 = a wave's 64 tickets are an 8 x 8 tile of the
+                                     * image (the default); n + 16 * mode with n = 2 / 4 / 8: inside super-tiles of n x n tiles the pixels are sorted by the ray count of the previous launch
+                                     * (mode 0), or by class only - sky / not sky (mode 1), four classes of rays per sample (mode 2) - keeping their tile order inside a class, and dealt out 64 at
+                                     * a time; re-sorted behind every launch.  Scheduling only, like everything here: results do not change (the reference hands pixels out in no defined order,
+                                     * UNITY/Raytracer.cs:730).  Measured 0 ... -5 %: off by default */
     int32_t hitListCapacity;        /* most surfaces one ray may meet where every hit of a ray is kept (scenes with ProbabilisticVolume materials, and
                                      * the exact-tie procedure): the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71);
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per
