@@ -56,10 +56,10 @@ def _scene(rt, kind):
 # (trace depth -> history width 4 / 8 / 32, noise, rng policy); the texture-driven noise sources only exist with history width 32
 def _modes(abi):
     out = []
-    for depth in (5, 12, 20):                     # 20: the 16-word history of the sphere kinds (depth 17 .. 32), the 32-word one elsewhere
+    for depth in (5, 12, 20):
         out.append((depth, abi.NOISE_WHITE, abi.RNG_REFERENCE))
         out.append((depth, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE))
-    out.append((40, abi.NOISE_WHITE, abi.RNG_REFERENCE))      # beyond 32: the generic 32-word history in every kind
+    out.append((40, abi.NOISE_WHITE, abi.RNG_REFERENCE))      # a path deeper than 32 segments through the generic 32-word history (64 is the limit)
     out.append((5, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE_XOROSHIRO))
     out.append((12, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE_XOROSHIRO))
     out.append((6, abi.NOISE_BLUE, abi.RNG_REFERENCE))
