@@ -332,11 +332,13 @@ typedef struct RtowContextOptions {
     int32_t schedulerTune[9];       /* development: stage thresholds in 64ths of the live lanes (REGEN TRAV TEST HIT SKY VOL; values below 1 mean 1 = any lane), the number of
                                      * candidates at which a box walk hands over to the exact tests (1 .. 7; 0 = the built-in 3), the pixel regrouping (below), and the box-walk slice (node visits
                                      * per trip; 0 = the built-in value of the scene); all zero = everything built in, thresholds measured per scene.
-                                     * [7], the pixel regrouping, is a knob of its own (setting it says nothing about the thresholds): 0 / 1 = a wave's 64 tickets are an 8 x 8 tile of the
-                                     * image (the default); n + 16 * mode with n = 2 / 4 / 8: inside super-tiles of n x n tiles the pixels are sorted by the ray count of the previous launch
-                                     * (mode 0), or by class only - sky / not sky (mode 1), four classes of rays per sample (mode 2) - keeping their tile order inside a class, and dealt out 64 at
-                                     * a time; re-sorted behind every launch.  Scheduling only, like everything here: results do not change (the reference hands pixels out in no defined order,
-                                     * UNITY/Raytracer.cs:730).  Measured 0 ... -5 %: off by default */
+                                     * [7], which pixel a ticket stands for, is a knob of its own (setting it says nothing about the thresholds): 0 = the default (3); 1 = a wave's 64 tickets are
+                                     * an 8 x 8 tile of the image in row order; 3 = the same tile, its tickets ordered most expensive pixel first by the ray counts of the previous launch
+                                     * (a wave's lanes take a chunk's tickets one by one as they finish their previous pixels, so a chunk's expensive pixel should not be its last ticket:
+                                     * +0.7 ... 1.3 %); n + 16 * mode with n = 2 / 4 / 8: inside super-tiles of n x n tiles the pixels are sorted by ray count (mode 0), or by class only -
+                                     * sky / not sky (mode 1), four classes of rays per sample (mode 2) - keeping their tile order inside a class, and dealt out 64 at a time (0 ... -5 %:
+                                     * measured, not used).  Re-sorted behind every launch.  Scheduling only, like everything here: results do not change (the reference hands
+                                     * pixels out in no defined order, UNITY/Raytracer.cs:730) */
     int32_t hitListCapacity;        /* most surfaces one ray may meet where every hit of a ray is kept (scenes with ProbabilisticVolume materials, and
                                      * the exact-tie procedure): the reference's hitRecordBuffer grows on the heap (UTIL/HybridCollections.cs:65-71);
                                      * here a lane holds 24 hits itself and longer lists continue in device memory, 16 bytes x 262 144 lanes per

@@ -30,7 +30,10 @@
 // 4K / 1024 spp / 16 bounces 9 464 against 8 851 (+6.9 %).  The general-entity kinds keep REGEN 1/4, walk 3/4, HIT and SKY at once (kGeneralTune):
 // on the 250 k-triangle mesh HIT from 1/2 loses 6 % (1 732 against 1 840), SKY from 1/2 3 %.
 #ifndef RTOW_DEFAULT_REGROUP_SIDE
-#define RTOW_DEFAULT_REGROUP_SIDE 1     // 1 = the 8 x 8 tiles as they are; n >= 2: pixels regrouped by cost inside super-tiles of n x n tiles (launchSample; regroup_tickets_kernel)
+// RtowContextOptions.schedulerTune[7], which pixel a ticket stands for: 1 = its place in its 8 x 8 tile; 3 = the tiles as they are, each tile's tickets most expensive pixel first
+// (order_tile_tickets_kernel: +0.7 % on the headline, +0.9 % as plain launches, +1.3 % as groups, same box, three alternating runs - profiles/r05a_pixel_regrouping.json);
+// 2 / 4 / 8 (+ 16 x mode): pixels regrouped by cost or class inside super-tiles of that many tiles (0 ... -5 %: measured, not used)
+#define RTOW_DEFAULT_REGROUP_SIDE 3
 #endif
 #ifndef RTOW_DEFAULT_TUNE
 #define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 3, 1, 16
@@ -152,7 +155,7 @@ struct RtowContext_t {
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
     int tune[9] = {RTOW_DEFAULT_TUNE};
     bool userTune = false;                // RtowContextOptions.schedulerTune was given: no per-scene adjustment
-    int regroupSide = RTOW_DEFAULT_REGROUP_SIDE;   // RtowContextOptions.schedulerTune[7]: super-tile side (in 8 x 8 tiles) of the pixel regrouping, 1 = off
+    int regroupSide = RTOW_DEFAULT_REGROUP_SIDE;   // RtowContextOptions.schedulerTune[7] (see RTOW_DEFAULT_REGROUP_SIDE)
     bool userSliceDefault = false;        // ... with a zero walk slice: the per-scene built-in value
     bool chainFusion = true;              // the same-XCD hand-over litmus passed on this device (rtowCreateContext): chains may run as one launch
     uint64_t tunedScene = ~0ull;          // sceneSerial whose thresholds were measured (tuneThresholds)
@@ -470,13 +473,16 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     const bool wantOrder = a.chunkCount >= (uint32_t)(4 * ctx->cuCount) && !(ctx->flags & RTOW_CONTEXT_NO_CHUNK_ORDER);   // tiny frames: not worth it
     // ---- and which pixels share a chunk (a wave): the pixels of a super-tile of regroupSide x regroupSide tiles sorted by the ray counts of the previous launch and dealt out
     // 64 at a time (regroup_tickets_kernel), re-sorted behind every launch like the order.  Reference stream only (per-sample units are alike by construction).
-    const unsigned regroupSide = (ctx->regroupSide & 15) >= 2 ? std::min<unsigned>((unsigned)(ctx->regroupSide & 15), kRegroupMaxSide) : 0u;
+    // schedulerTune[7]: 1 = no map; 3 = the tiles as they are, each tile's tickets most expensive first (regroupSide 1 below); 2 / 4 / 8 (+ 16 x mode) = super-tiles of that many tiles
+    const unsigned knob = (unsigned)(ctx->regroupSide & 15);
+    const unsigned regroupSide = knob == 3u ? 1u : (knob == 2u || knob == 4u || knob == 8u) ? knob : 0u;
     // (development: schedulerTune[7] = side + 16 * mode; mode 0 sorts by the ray count itself, 1 by sky / not sky, 2 by four classes of rays per sample - pixels of a class in tile order)
     const unsigned regroupMode = (unsigned)ctx->regroupSide >> 4;
     auto regroupClasses = [&](unsigned floorCost, unsigned out[3]) {
+        if (regroupSide == 1u) { out[0] = regroupMode == 0u ? 0u : (2u << regroupMode); out[1] = out[2] = 0u; return; }      // tile order: levels of the tile's cost range (mode 1 / 2 / 3: 4 / 8 / 16), 0 = by the ray count itself
         out[0] = regroupMode == 0u ? 0u : floorCost; out[1] = regroupMode >= 2u ? (floorCost * 11u) / 4u : 0xffffffffu; out[2] = regroupMode >= 2u ? floorCost * 4u : 0xffffffffu;
     };
-    const bool wantMap = wantOrder && regroupSide >= 2u && a.tiledPixels != 0u && !a.unitRecords;
+    const bool wantMap = wantOrder && regroupSide >= 1u && a.tiledPixels != 0u && !a.unitRecords;
     const unsigned tileRows = a.tilesPerRow ? a.tiledPixels / (64u * a.tilesPerRow) : 0u;
     if (wantOrder) {
         if (a.chunkCount > ctx->chunkCapacity) {

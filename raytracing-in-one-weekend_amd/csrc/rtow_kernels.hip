@@ -269,6 +269,36 @@ __global__ void __launch_bounds__(1024) regroup_tickets_kernel(unsigned short* _
     }
 }
 
+// The same map with the tiles left as they are: only the ORDER of a tile's 64 tickets changes - most expensive pixel first.  A wave's lanes take the tickets of its chunk one by one
+// as they finish their previous pixels (the first tickets go within microseconds, the last ones when the slowest lanes of the previous chunk are done, a pixel-time later), so a chunk's
+// expensive pixel that happens to be its 60th ticket starts tens of milliseconds after the chunk was handed out - and ends the launch.  The wave still traces the same 64 neighbours.
+// One wave per tile: 64 keys (cost + 1) << 32 | owned-pixel number, bitonic sort through cross-lane moves, descending.
+__global__ void __launch_bounds__(256) order_tile_tickets_kernel(unsigned short* __restrict__ pixelCost, unsigned* __restrict__ ticketMap, unsigned tiles, unsigned levels)
+{
+    const unsigned tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (tile >= tiles) return;
+    const unsigned t = tile * 64u + lane;
+    const unsigned cost = pixelCost[t], pixel = ticketMap[t];
+    // primary key: the ray count itself (levels == 0), or its level among `levels` equal parts of the tile's range [0, max] - pixels of one level keep the order they had, so
+    // that a tile of like pixels (all sky; a patch of ground) is still taken row by row and its accumulator lines are touched once, and only the pixels that stand out move to the front
+    unsigned top = cost;
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)top, off, 64); top = o > top ? o : top; }
+    const unsigned primary = levels ? (cost * levels) / (top + 1u) : cost;
+    unsigned key = (primary << 12) | ((63u - lane) << 6) | lane;                 // descending: higher level first, then the earlier place; the low six bits say where the element came from
+    for (unsigned k = 2u; k <= 64u; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0u; j >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)key, (int)j, 64);
+            const bool upper = (lane & j) != 0u;                                 // this lane holds the later element of the pair
+            const bool descending = (lane & k) == 0u;
+            const bool keepLarger = descending != upper;                         // the earlier place of a descending run keeps the larger key
+            key = keepLarger ? (key > other ? key : other) : (key < other ? key : other);
+        }
+    }
+    const int from = (int)(key & 63u);
+    ticketMap[t] = (unsigned)__shfl((int)pixel, from, 64);
+    pixelCost[t] = (unsigned short)__shfl((int)cost, from, 64);
+}
+
 // Derived per-entity transform data for SCENE_KIND_GENERAL, on the device: InverseTransform = inverse(OriginTransform)
 // (RT/Entity.cs:51-52; math.inverse(RigidTransform): invRot = inverse(rot), invTranslation = mul(invRot, -pos);
 // math.inverse(quaternion q) = rcp(dot(q, q)) * q * float4(-1, -1, -1, 1)).
@@ -820,6 +850,11 @@ hipError_t launchInitTicketMap(unsigned* ticketMap, unsigned count, hipStream_t 
 hipError_t launchRegroupTickets(unsigned short* pixelCost, unsigned* ticketMap, unsigned tilesPerRow, unsigned tileRows, unsigned side, const unsigned classes[3], hipStream_t stream)
 {
     if (tilesPerRow == 0u || tileRows == 0u) return hipSuccess;
+    if (side == 1u) {                                                            // the tiles as they are, their tickets most expensive first
+        const unsigned tiles = tilesPerRow * tileRows;
+        hipLaunchKernelGGL(order_tile_tickets_kernel, dim3((tiles + 3u) / 4u), dim3(256), 0, stream, pixelCost, ticketMap, tiles, classes[0]);      // classes[0]: levels (0 = by the ray count itself)
+        return hipGetLastError();
+    }
     if (side < 2u || side > kRegroupMaxSide) return hipErrorInvalidValue;
     const unsigned blocks = ((tilesPerRow + side - 1u) / side) * ((tileRows + side - 1u) / side);
     unsigned N = 64u;

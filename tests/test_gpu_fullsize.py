@@ -151,7 +151,7 @@ def test_full_frames_do_not_depend_on_the_schedule(rt, gpu_context, name):
                      ("heavy thresholds, 5-visit walk slices", dict(scheduler_tune=(32, 64, 16, 16, 16, 1, 1, 1, 5))),
                      ("pixels regrouped in 16 x 16 super-tiles", dict(scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 2, 0))),
                      ("pixels regrouped in 64 x 64 super-tiles", dict(scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 8, 0))),
-                     ("tiles as they are", dict(scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 1, 0)))):
+                     ("tiles in row order (the default orders a tile's tickets most expensive first)", dict(scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 1, 0)))):
         with rt.Context(0, **kw) as ctx:
             ctx.upload_scene(desc)
             variants[what] = _device_render(rt, ctx, p, w * h, 4)

@@ -42,7 +42,7 @@ def _same(a, b, what):
 FRAMES = [("cover", 520, 264, 3, 8, 0, 1), ("cover", 528, 262, 2, 8, 0, 1), ("moving", 776, 344, 2, 6, 1, 3), ("mixed", 520, 264, 2, 6, 0, 1)]
 
 
-@pytest.mark.parametrize("side", [2, 4, 8])
+@pytest.mark.parametrize("side", [2, 3, 4, 8])      # 3: the tiles as they are, each tile's tickets most expensive first
 @pytest.mark.parametrize("name,w,h,spp,depth,off,div", FRAMES)
 def test_regrouped_frames_equal_the_oracle_launch_after_launch(rt, oracle, name, w, h, spp, depth, off, div, side):
     S = rt.scenes
@@ -66,7 +66,7 @@ def test_regrouped_frames_equal_the_oracle_launch_after_launch(rt, oracle, name,
             assert np.array_equal(gpu["diag"][owned, 0], ref["diag"][owned, 0])
 
 
-@pytest.mark.parametrize("side", [2, 8])
+@pytest.mark.parametrize("side", [2, 3, 8])
 def test_regrouped_chains_and_groups_equal_the_separate_batches(rt, side):
     """Chains hand a chunk's pixels from batch to batch through per-chunk counters (per TICKET chunk: the map only says which pixels those are); groups hand out
     (chunk, batch) pairs.  Both against the same batches as separate launches of a context that keeps the tiles as they are."""
