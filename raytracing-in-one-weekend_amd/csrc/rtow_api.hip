@@ -673,7 +673,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, stream), RTOW_ERROR_LAUNCH_FAILURE);
     // refresh the order for the next batch from what this one measured (same stream, after the timed kernel)
     if (wantMap) { unsigned cls[3]; regroupClasses(std::max(1u, a.sampleCountMin), cls); HIP_TRY(ctx, launchRegroupTickets(ctx->dPixelCost, ctx->dTicketMap, a.tilesPerRow, tileRows, regroupSide, cls, stream), RTOW_ERROR_LAUNCH_FAILURE); }
-    if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
+    // (development: schedulerTune[7] + 64 orders the chunks by their TOTAL ray count instead of by their most expensive pixel)
+    if (wantOrder) HIP_TRY(ctx, launchBuildChunkOrder(ctx->dPixelCost, ctx->dChunkCost, a.chunkCount, ctx->dChunkOrder, (ctx->regroupSide & 64) ? 0 : 1, stream), RTOW_ERROR_LAUNCH_FAILURE);
     HIP_TRY(ctx, hipEventRecord(ctx->evBatchDone, stream), RTOW_ERROR_LAUNCH_FAILURE);
     ctx->haveBatchDone = true;
     ctx->haveTiming = true;
