@@ -42,6 +42,9 @@
 #ifndef RTOW_EXACT_MATH
 #define RTOW_EXACT_MATH 1
 #endif
+#ifndef RTOW_SPLIT_NODE_LOADS
+#define RTOW_SPLIT_NODE_LOADS 1   // 0: A/B build with one flat load per node quad (the base chosen per lane) in the kernels whose tree does not fit LDS
+#endif
 #ifndef RTOW_TIE_WATCH
 #define RTOW_TIE_WATCH 1      // 0: A/B build without the nearest-hit tie watch of the sphere kinds
 #endif
@@ -606,10 +609,39 @@ struct SceneRefs {
     uint32_t ldsNodeCount;
 };
 
-template <bool ALL_LDS>
+template <bool ALL_LDS, bool SPLIT = false>
 __host__ __device__ __forceinline__ void load_node(const SceneRefs& sc, const SceneLayout& L, int idx, float4& q0, float4& q1, float4& q2, int& c0, int& c1)
 {
     const uint32_t off = L.nodeOffset + (uint32_t)idx * 64u;
+#if defined(__HIP_DEVICE_COMPILE__) && RTOW_SPLIT_NODE_LOADS
+    if (!ALL_LDS && SPLIT) {
+        // A tree that does not fit LDS keeps its first ldsNodeCount nodes (the top levels) there; the blob in memory holds every node.  Selecting the BASE per lane makes
+        // every node load a flat_load (address-space check per lane, both memory counters, seven instructions to build the generic pointer), and a wave waits for its
+        // slowest lane anyway: so the wave reads from LDS when ALL its walking lanes are in the top levels and through L1 / L2 otherwise - ds_read or global_load
+        // (scalar base + 32-bit offset), never flat.  (Per-lane branches - ds_read under one EXEC mask, global_load under the other - make the compiler wait for the
+        // first group before it issues the second: both write the same registers.)  SPLIT = the walk of the kernels with 16-bit codes: 10 000 spheres +0.6 %, same box,
+        // three alternating runs each, every run above the other side's best.  The wide-code kernels keep the flat loads: their trees' lower levels miss L1 and L2, and
+        // the lanes in the top levels are better off in LDS whatever the others do (250 882 triangles: -5 % with the split; profiles/r05q_node_loads.json).
+        typedef __attribute__((address_space(3))) const uint8_t* LdsBytes;
+        typedef __attribute__((address_space(1))) const uint8_t* GlobalBytes;
+        if (__ballot((uint32_t)idx >= sc.ldsNodeCount) == 0ull) {      // wave-uniform: every lane that walks right now is in the top levels
+            LdsBytes b = (LdsBytes)sc.lds + off;
+            q0 = *(__attribute__((address_space(3))) const float4*)(b);
+            q1 = *(__attribute__((address_space(3))) const float4*)(b + 16);
+            q2 = *(__attribute__((address_space(3))) const float4*)(b + 32);
+            const int4 c = *(__attribute__((address_space(3))) const int4*)(b + 48);      // (the whole fourth quad: as two dwords the compiler hoists one of them behind the branch - as a flat load)
+            c0 = c.x; c1 = c.y;
+        } else {
+            GlobalBytes b = (GlobalBytes)sc.glob + off;
+            q0 = *(__attribute__((address_space(1))) const float4*)(b);
+            q1 = *(__attribute__((address_space(1))) const float4*)(b + 16);
+            q2 = *(__attribute__((address_space(1))) const float4*)(b + 32);
+            const int4 c = *(__attribute__((address_space(1))) const int4*)(b + 48);
+            c0 = c.x; c1 = c.y;
+        }
+        return;
+    }
+#endif
     const uint8_t* base = (ALL_LDS || (uint32_t)idx < sc.ldsNodeCount) ? sc.lds : sc.glob;
     const float4* p = reinterpret_cast<const float4*>(base + off);
     q0 = p[0];
@@ -1061,6 +1093,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // Sphere kinds only: the general-entity, textured and volume kernels spill already, and two more list registers cost them more than the lists bring
     // (image-textured spheres -13 %, mixed primitives -1.7 % with eight nodes: gpurun_out/r04am); their lists stay at four nodes (the first uint2 of the pixel's record).
     constexpr bool LONG_LISTS = !WIDE && (KIND & 7) <= SCENE_KIND_SPHERES_MOTION;
+    constexpr bool SPLIT_NODES = !ALL_LDS && !WIDE;      // node loads as ds_read / global_load behind a wave-uniform branch instead of flat loads (load_node)
     using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
     constexpr int kStackBytesT = (int)geo_stack_bytes(GEO);
 
@@ -1564,7 +1597,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             if (node == (WIDE ? 0xffffffffu : 0xffffu)) break;
                             float4 q0, q1, q2;
                             int c0, c1;
-                            load_node<ALL_LDS>(sc, L, (int)node, q0, q1, q2, c0, c1);
+                            load_node<ALL_LDS, SPLIT_NODES>(sc, L, (int)node, q0, q1, q2, c0, c1);
                             const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
                             const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
                             const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
@@ -1619,7 +1652,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     STAT_LANES(4);
                     float4 q0, q1, q2;
                     int c0, c1;
-                    load_node<ALL_LDS>(sc, L, cur, q0, q1, q2, c0, c1);
+                    load_node<ALL_LDS, SPLIT_NODES>(sc, L, cur, q0, q1, q2, c0, c1);
                     const int spm1 = sp > 0 ? sp - 1 : 0;
                     const int popped = (int)stack[spm1 * BT];
                     // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
@@ -1678,7 +1711,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             if (node == 0xffffu) break;
                             float4 q0, q1, q2;
                             int c0, c1;
-                            load_node<ALL_LDS>(sc, L, (int)node, q0, q1, q2, c0, c1);
+                            load_node<ALL_LDS, SPLIT_NODES>(sc, L, (int)node, q0, q1, q2, c0, c1);
                             const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
                             const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
                             const f2 tlz = (f2{q1.x, q1.y} - oz) * invz, thz = (f2{q2.z, q2.w} - oz) * invz;
@@ -2016,7 +2049,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             while (bcur >= 0) {                                              // FindHitCandidates(backwardsRay): no pruning
                                 float4 q0, q1, q2;
                                 int c0, c1;
-                                load_node<ALL_LDS>(sc, L, bcur, q0, q1, q2, c0, c1);
+                                load_node<ALL_LDS, SPLIT_NODES>(sc, L, bcur, q0, q1, q2, c0, c1);
                                 const float t0x = (q0.x - ro.x) * binv.x, t1x = (q1.z - ro.x) * binv.x, u0x = (q0.y - ro.x) * binv.x, u1x = (q1.w - ro.x) * binv.x;
                                 const float t0y = (q0.z - ro.y) * binv.y, t1y = (q2.x - ro.y) * binv.y, u0y = (q0.w - ro.y) * binv.y, u1y = (q2.y - ro.y) * binv.y;
                                 const float t0z = (q1.x - ro.z) * binv.z, t1z = (q2.z - ro.z) * binv.z, u0z = (q1.y - ro.z) * binv.z, u1z = (q2.w - ro.z) * binv.z;
