@@ -23,7 +23,7 @@ constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThread
 constexpr int kStackBytesWide = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 4; // 32-bit entries: scenes beyond 65 535 entities / tree nodes
 constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: first slot empty, second not - "no list, walk the tree"
 constexpr unsigned kSampleGroup = 16;   // RTOW_RNG_PER_SAMPLE: samples per work unit (part of that policy's definition: partial sums are per group)
-constexpr int kQueueBytes = 256;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B)
+constexpr int kQueueBytes = 384;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B), then 128 bytes of launch constants (view, sky, frame size: RTOW_LDS_VIEW)
 constexpr int kMaxChain = 16;      // successive batches one launch can run (rtowSampleBatchChainDevice)
 constexpr int kLocalHitEntries = 24;                // entries of a ray's hit list a lane holds itself; longer lists continue in SampleKernelArgs.hitSpill
 constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0, scenes with volumes (long lists are their normal case)

@@ -45,6 +45,12 @@
 #ifndef RTOW_SPLIT_NODE_LOADS
 #define RTOW_SPLIT_NODE_LOADS 1   // 0: A/B build with one flat load per node quad (the base chosen per lane) in the kernels whose tree does not fit LDS
 #endif
+#ifndef RTOW_LDS_VIEW
+#define RTOW_LDS_VIEW 2           // bit 0 / bit 1 = the kernels with / without the scene in LDS read the view's and the sky's launch constants from an LDS copy (see REGEN)
+#endif
+#ifndef RTOW_COLD_VIEW
+#define RTOW_COLD_VIEW 1          // 0: A/B build in which every kernel holds the view's and the sky's launch constants in scalar registers through every stage
+#endif
 #ifndef RTOW_TIE_WATCH
 #define RTOW_TIE_WATCH 1      // 0: A/B build without the nearest-hit tie watch of the sphere kinds
 #endif
@@ -356,8 +362,18 @@ __device__ __forceinline__ float smith_g1(V3 w, V3 n, float alpha /* = Roughness
 // Cubemap.Sample (RT/Texture.cs:171-210): the face is the first axis whose |component| is the largest (x before y before z), the
 // texel min((int2)((uv + 1) * halfFaceSize), faceSizeMinusOne) of that face, point sampled; RGBA half or byte channels.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ V3 cubemap_sample(const SampleKernelArgs& A, V3 d)
+__device__ __forceinline__ V3 cubemap_sample(const SampleKernelArgs& hotArgs, V3 d)
 {
+    // the cubemap's nine launch constants are read where they are used - through a laundered pointer to the kernarg segment, like the pixel boundary's (REGEN) - instead of
+    // living in scalar registers (or, spilled, in VGPR lanes and scratch) through every stage of every launch, most of which have a gradient sky
+#if defined(__HIP_DEVICE_COMPILE__)
+    const SampleKernelArgs* coldArgs = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // the struct is the kernel's only argument
+    asm volatile("" : "+s"(coldArgs));
+    const SampleKernelArgs& A = *coldArgs;
+#else
+    const SampleKernelArgs& A = hotArgs;                                                                   // host pass of the HIP compiler: never executed
+#endif
+    (void)hotArgs;
     if (!A.cubemapData) return v3(0, 0, 0);
     const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
     const float m = um_max(um_max(um_max(ax, ay), az), 0.0f);                  // cmax(float4(abs(vector), 0))
@@ -1093,6 +1109,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // Sphere kinds only: the general-entity, textured and volume kernels spill already, and two more list registers cost them more than the lists bring
     // (image-textured spheres -13 %, mixed primitives -1.7 % with eight nodes: gpurun_out/r04am); their lists stay at four nodes (the first uint2 of the pixel's record).
     constexpr bool LONG_LISTS = !WIDE && (KIND & 7) <= SCENE_KIND_SPHERES_MOTION;
+    constexpr bool LDS_VIEW = (RTOW_LDS_VIEW & (ALL_LDS ? 1 : 2)) != 0;   // ... or read from an LDS copy (bit 0: kernels with the scene in LDS, bit 1: the others)
+    constexpr bool COLD_VIEW __attribute__((unused)) = RTOW_COLD_VIEW && !ALL_LDS && !LDS_VIEW;    // the view's and the sky's launch constants are read on use instead of held in scalar registers (REGEN)
     constexpr bool SPLIT_NODES = !ALL_LDS && !WIDE;      // node loads as ds_read / global_load behind a wave-uniform branch instead of flat loads (load_node)
     using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
     constexpr int kStackBytesT = (int)geo_stack_bytes(GEO);
@@ -1107,6 +1125,18 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytesT) + (tid >> 6) * 4;
     uint8_t* const ldsScene = smem + kStackBytesT + kQueueBytes;
     if ((tid & 63) == 0) { waveQueue[0] = 0; waveQueue[1] = 0; waveQueue[2] = 0; waveQueue[3] = 0; }
+    // launch constants only REGEN and SKY read (view: 22 floats, sky: 7 dwords, frame size: 2 floats), parked in LDS behind the wave queues (RTOW_LDS_VIEW)
+    float* const ldsConst = reinterpret_cast<float*>(smem + kStackBytesT + 256);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LDS_VIEW && tid < 31) {
+        // copied dword by dword from the kernarg segment (a struct assignment from the by-value argument goes through a private copy)
+        const uint8_t* const ka = (const uint8_t*)__builtin_amdgcn_kernarg_segment_ptr();
+        const size_t from = tid < 22 ? __builtin_offsetof(SampleKernelArgs, view) + 4u * (size_t)tid
+                          : tid < 29 ? __builtin_offsetof(SampleKernelArgs, environment) + 4u * (size_t)(tid - 22)
+                                     : __builtin_offsetof(SampleKernelArgs, sizeX) + 4u * (size_t)(tid - 29);
+        ldsConst[tid] = *reinterpret_cast<const float*>(ka + from);
+    }
+#endif
     {
         const uint4* src = reinterpret_cast<const uint4*>(A.sceneBlob);
         uint4* dst = reinterpret_cast<uint4*>(ldsScene);
@@ -1549,15 +1579,29 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 }
                 if (st == ST_REGEN) {
                     // ---- camera ray (:134-135, RT/View.cs:38-48) ----
-                    const V3 viewRight = v3(A.view.right), viewUp = v3(A.view.up);
-                    const V3 viewLLC = v3(A.view.lowerLeftCorner), viewH = v3(A.view.horizontal), viewV = v3(A.view.vertical);
-                    const float lensRadius = A.view.lensRadius;
+                    // The view's nineteen constants, the frame size and (SKY) the sky's seven live in scalar registers through every stage if nothing is done - a kernel has 102
+                    // and spills the rest into VGPR lanes, read back with v_readlane in the walk and the exact tests (25 - 33 spilled before).  Three places were measured, same
+                    // box, three alternating runs each (profiles/r05x_launch_constants.json): registers; read on use through a laundered pointer to the kernarg segment (COLD_VIEW:
+                    // one scalar-cache round trip per REGEN / SKY run); read on use from a 128-byte LDS copy behind the wave queues (LDS_VIEW).  Kernels whose tree does not fit
+                    // LDS - their waves wait for memory anyway - gain from both: 10 000 spheres +1.2 % (kernarg) / +2.0 % (LDS), 250 882 triangles +2.2 / +2.4 %: they read the LDS
+                    // copy.  Kernels with the scene in LDS LOSE with both (cover -1.1 / -1.7 %, depth 32 groups -2.8 %: their REGEN and SKY runs are short and the round trip
+                    // shows): they keep the registers.  (The cubemap's nine constants are read on use in every kernel: cubemap_sample.)
+                    const SampleKernelArgs* viewArgs = &A;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (COLD_VIEW) { viewArgs = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(viewArgs)); }
+#endif
+                    const SampleKernelArgs& VA = *viewArgs;
+                    const RtowView& VW = LDS_VIEW ? *reinterpret_cast<const RtowView*>(ldsConst) : VA.view;
+                    const float frameX = LDS_VIEW ? ldsConst[29] : VA.sizeX, frameY = LDS_VIEW ? ldsConst[30] : VA.sizeY;
+                    const V3 viewRight = v3(VW.right), viewUp = v3(VW.up);
+                    const V3 viewLLC = v3(VW.lowerLeftCorner), viewH = v3(VW.horizontal), viewV = v3(VW.vertical);
+                    const float lensRadius = VW.lensRadius;
                     float jx = 0.5f, jy = 0.5f;
                     const NoiseSite at{&A, (unsigned)cx, (unsigned)cy};
                     if (PER_SAMPLE) rng.begin_sample(at, (unsigned)pix, smp);
                     if (A.subPixelJitter) rng.next2(at, jx, jy);
-                    const float u = ((float)cx + jx) / A.sizeX;
-                    const float v = ((float)cy + jy) / A.sizeY;
+                    const float u = ((float)cx + jx) / frameX;
+                    const float v = ((float)cy + jy) / frameY;
                     float rdx = 0, rdy = 0;
                     if (lensRadius != 0) {
                         float dx, dy;
@@ -1566,7 +1610,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         rdy = lensRadius * dy;
                     }
                     const V3 offset = v3(viewRight.x * rdx + viewUp.x * rdy, viewRight.y * rdx + viewUp.y * rdy, viewRight.z * rdx + viewUp.z * rdy);
-                    ro = add(v3(A.view.origin), offset);
+                    ro = add(v3(VW.origin), offset);
                     rd = normalize(v3(viewLLC.x - offset.x + u * viewH.x + v * viewV.x,
                                       viewLLC.y - offset.y + u * viewH.y + v * viewV.y,
                                       viewLLC.z - offset.z + u * viewH.z + v * viewV.z));
@@ -2152,11 +2196,17 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
             if (st == ST_SKY) {
                 DBG_TRACE(2, 0xffff, 0.0f);
                 V3 sky = v3(0, 0, 0);
-                if (A.environment.skyType == RTOW_SKY_GRADIENT) {
+                const SampleKernelArgs* skyArgs = &A;                      // the sky's seven constants: read on use in the kernels that read the view's so (REGEN)
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (COLD_VIEW) { skyArgs = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(skyArgs)); }
+#endif
+                const SampleKernelArgs& EA = *skyArgs;
+                const RtowEnvironment& ENV = LDS_VIEW ? *reinterpret_cast<const RtowEnvironment*>(ldsConst + 22) : EA.environment;
+                if (ENV.skyType == RTOW_SKY_GRADIENT) {
                     const float s = 0.5f * (rd.y + 1);
-                    const V3 b = v3(A.environment.skyBottomColor), tp = v3(A.environment.skyTopColor);
+                    const V3 b = v3(ENV.skyBottomColor), tp = v3(ENV.skyTopColor);
                     sky = v3(b.x + s * (tp.x - b.x), b.y + s * (tp.y - b.y), b.z + s * (tp.z - b.z));
-                } else if (A.environment.skyType == RTOW_SKY_CUBEMAP) {
+                } else if (ENV.skyType == RTOW_SKY_CUBEMAP) {
                     sky = cubemap_sample(A, rd);
                 }
                 // randomEventsLocalAcc += rng.RandomEvents / pow(2, depth) (:363): RandomEvents is 0 here unless a ProbabilisticHit
