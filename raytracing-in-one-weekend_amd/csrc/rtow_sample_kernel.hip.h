@@ -645,14 +645,18 @@ __host__ __device__ __forceinline__ void load_node(const SceneRefs& sc, const Sc
             q0 = *(__attribute__((address_space(3))) const float4*)(b);
             q1 = *(__attribute__((address_space(3))) const float4*)(b + 16);
             q2 = *(__attribute__((address_space(3))) const float4*)(b + 32);
-            const int4 c = *(__attribute__((address_space(3))) const int4*)(b + 48);      // (the whole fourth quad: as two dwords the compiler hoists one of them behind the branch - as a flat load)
+            // the two child codes through an asm statement (with its own wait: the compiler's wait-count bookkeeping does not see into it): as an ordinary load the
+            // compiler sinks one of the two dwords behind the branch - as a flat load through a phi of both pointers, one more memory instruction per node visit
+            typedef int i2 __attribute__((ext_vector_type(2)));
+            i2 c;
+            asm volatile("ds_read_b64 %0, %1 offset:48\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"((unsigned)(uintptr_t)b) : "memory");
             c0 = c.x; c1 = c.y;
         } else {
             GlobalBytes b = (GlobalBytes)sc.glob + off;
             q0 = *(__attribute__((address_space(1))) const float4*)(b);
             q1 = *(__attribute__((address_space(1))) const float4*)(b + 16);
             q2 = *(__attribute__((address_space(1))) const float4*)(b + 32);
-            const int4 c = *(__attribute__((address_space(1))) const int4*)(b + 48);
+            const int2 c = *(__attribute__((address_space(1))) const int2*)(b + 48);
             c0 = c.x; c1 = c.y;
         }
         return;
