@@ -29,6 +29,10 @@
 // cover 9 417 against 8 685 Msamples/s (+8.4 %), 10 000 spheres 7 513 against 7 042 (+6.7 %), moving + defocus 6 306 against 5 958 (+5.8 %),
 // 4K / 1024 spp / 16 bounces 9 464 against 8 851 (+6.9 %).  The general-entity kinds keep REGEN 1/4, walk 3/4, HIT and SKY at once (kGeneralTune):
 // on the 250 k-triangle mesh HIT from 1/2 loses 6 % (1 732 against 1 840), SKY from 1/2 3 %.
+#ifndef RTOW_GROUP_SLOT_BLOCK
+#define RTOW_GROUP_SLOT_BLOCK 4     // (chunk, batch) slots a wave reserves at a time in a batch group (SampleKernelArgs.slotBlock): groups + fold 9 978 -> 10 160 Msamples/s at 4, 10 118 at 2
+#endif
+static constexpr unsigned kGroupSlotBlock = RTOW_GROUP_SLOT_BLOCK;
 #ifndef RTOW_DEFAULT_REGROUP_SIDE
 // RtowContextOptions.schedulerTune[7], which pixel a ticket stands for: 1 = its place in its 8 x 8 tile; 3 = the tiles as they are, each tile's tickets most expensive pixel first
 // (order_tile_tickets_kernel: +0.7 % on the headline, +0.9 % as plain launches, +1.3 % as groups, same box, three alternating runs - profiles/r05a_pixel_regrouping.json);
@@ -319,6 +323,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.seed = chain ? chain->seeds[0] : p->seed;
     a.chainCount = chain ? (uint32_t)chain->count : 1u;
     a.chainIndependent = (chain && chain->outs) ? 1 : 0;
+    a.groupRecip = (uint32_t)((1ull << 32) / (a.chainCount ? a.chainCount : 1u) + 1ull);      // slot / chainCount = (slot * groupRecip) >> 32 for every slot of a launch (chunkCount * chainCount <= 2^25)
     if (chain) {
         if (diag == nullptr && chain->diags) diag = chain->diags[0];
         a.diagnostics = (uint8_t*)diag;
@@ -477,7 +482,9 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     const unsigned knob = (unsigned)(ctx->regroupSide & 15);
     const unsigned regroupSide = knob == 3u ? 1u : (knob == 2u || knob == 4u || knob == 8u) ? knob : 0u;
     // (development: schedulerTune[7] = side + 16 * mode; mode 0 sorts by the ray count itself, 1 by sky / not sky, 2 by four classes of rays per sample - pixels of a class in tile order)
-    const unsigned regroupMode = (unsigned)ctx->regroupSide >> 4;
+    const unsigned regroupMode = ((unsigned)ctx->regroupSide >> 4) & 3u;
+    // batch groups: (chunk, batch) slots a wave reserves at a time (schedulerTune[7] bits 8 .. 11 override the default for A/B runs)
+    a.slotBlock = (((unsigned)ctx->regroupSide >> 8) & 15u) ? (((unsigned)ctx->regroupSide >> 8) & 15u) : kGroupSlotBlock;
     auto regroupClasses = [&](unsigned floorCost, unsigned out[3]) {
         if (regroupSide == 1u) { out[0] = regroupMode == 0u ? 0u : (2u << regroupMode); out[1] = out[2] = 0u; return; }      // tile order: levels of the tile's cost range (mode 1 / 2 / 3: 4 / 8 / 16), 0 = by the ray count itself
         out[0] = regroupMode == 0u ? 0u : floorCost; out[1] = regroupMode >= 2u ? (floorCost * 11u) / 4u : 0xffffffffu; out[2] = regroupMode >= 2u ? floorCost * 4u : 0xffffffffu;

@@ -106,6 +106,7 @@ struct SampleKernelArgs {
     const unsigned int* ticketMap;        // [tiledPixels] ticket -> owned-pixel number (owned_pixel_xy's argument): which pixels share a chunk, i.e. a wave (regroup_tickets_kernel: the pixels of a
                                           // super-tile of tiles sorted by ray count and dealt out 64 at a time); a permutation inside every super-tile; null = the tiles themselves
     uint32_t chunkCount;
+    uint32_t slotBlock, groupRecip;       // batch groups: (chunk, batch) slots a wave reserves at a time (>= 1: it then works through the batches of one tile, and the neighbours in the cost order, one after the other) and 2^32 / chainCount + 1 (slot -> chunk by a multiply)
     const uint2* pixelCandidates;         // [2 x width * height] = one uint4 per pixel (8 x 16-bit node codes, or 4 x 32-bit): camera-ray candidate list of every owned pixel (primary_candidates_kernel), null = walk every ray;
                                           // wideCodes: uint4 records (4 x 32-bit node indices) behind the same pointer
     int32_t probeOnly;                    // > 0: probe - this many samples per pixel, nothing stored but pixelCost (1: the cost probe; 4: the threshold-tuning probes)

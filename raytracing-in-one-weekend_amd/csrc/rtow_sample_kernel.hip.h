@@ -1443,6 +1443,21 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                 }
                                 continue;
                             }
+                            if (grouped) {
+                                // a batch group: the queue holds (chunk, batch) slots, every batch of the most expensive chunk first - no batch waits for another.  A wave reserves
+                                // slotBlock slots at a time and its tickets are slot << 6 | pixel of the chunk: the range below spans the slots, and a lane finds chunk and batch from
+                                // its ticket (below) - so the pixels a wave holds next to each other are the same tile's under other seeds, or its neighbours' in the cost order:
+                                // like work (profiles/r05x_launch_constants.json "queue slots": +1.4 ... 1.8 % on groups; chains and plain launches keep one chunk per pull)
+                                if (lane == leader) {
+                                    bool cancelled = false;
+                                    if (C.cancelFlag) cancelled = *C.cancelFlag != 0u;
+                                    const unsigned slots = C.chunkCount * C.chainCount;
+                                    const unsigned first = cancelled ? 0xffffffffu : atomicAdd(C.workCounter, C.slotBlock);
+                                    if (first >= slots) { waveQueue[0] = 0xffffffffu; waveQueue[1] = 0xffffffffu; }
+                                    else { waveQueue[2] = 0u; waveQueue[0] = first << 6; waveQueue[1] = (first + C.slotBlock < slots ? first + C.slotBlock : slots) << 6; }
+                                }
+                                continue;
+                            }
                             if (lane == leader) {
                                 bool cancelled = false;
                                 if (C.cancelFlag) cancelled = *C.cancelFlag != 0u;
@@ -1451,12 +1466,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                 unsigned slot = cancelled ? 0xffffffffu : atomicAdd(C.workCounter, 1u);
                                 unsigned b = 0u, chunk = 0u;
                                 bool exhausted = slot >= C.chunkCount, notReady = false;
-                                if (grouped) {
-                                    // a batch group: the queue holds (chunk, batch) pairs, every batch of the most expensive chunk first - no batch waits for another
-                                    exhausted = cancelled || slot >= C.chunkCount * C.chainCount;
-                                    b = slot % C.chainCount;
-                                    slot = slot / C.chainCount;
-                                }
                                 if (!exhausted) chunk = C.chunkOrder ? C.chunkOrder[slot] : slot;
                                 if (chained && !grouped && !cancelled) {
                                     // Batch 0 of every chunk comes from the one device-wide queue above; the XCD whose wave takes it owns the chunk for
@@ -1489,7 +1498,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                 else {
                                     const unsigned base = chunk * 64u;
                                     const unsigned last = (C.totalWork - base < 64u) ? C.totalWork : base + 64u;
-                                    waveQueue[2] = grouped ? 0u : b * (last - base); // pixels of this chunk that must be stored before batch b may read them (a group's batches read the inputs)
+                                    waveQueue[2] = b * (last - base);               // pixels of this chunk that must be stored before batch b may read them
                                     waveQueue[3] = chunk;
                                     waveQueue[0] = base | (b << kChainShift);
                                     waveQueue[1] = last | (b << kChainShift);
@@ -1512,6 +1521,15 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     }
                     if (ticket == 0xffffffffu) { st = parked ? ST_IDLE : ST_DEAD; break; }
                     if (REDO_CAPABLE) { if (redo) ticket = C.tieRedo[4u + ticket]; }          // the listed entry: batch << 27 | FRAME pixel index (a chain's pixels are listed with batch 0 and carried through)
+                    if (grouped && !redo) {
+                        // a group's ticket = slot << 6 | pixel of the chunk, slot = place in the order * chainCount + batch (see above)
+                        const unsigned slot = ticket >> 6;
+                        const unsigned place = __umulhi(slot, C.groupRecip);            // slot / chainCount
+                        const unsigned chunk = C.chunkOrder ? C.chunkOrder[place] : place;
+                        ticket = (chunk << 6) | (ticket & 63u);
+                        if (ticket >= C.totalWork) { pix = -1; nsamp = 0; smp = 0; continue; }      // the last chunk's tail: no pixel behind this ticket - ask again
+                        ticket |= (slot - place * C.chainCount) << kChainShift;
+                    }
                     tick = ticket;
                     newBatch = chained ? (ticket >> kChainShift) : 0u;
                     if (chained) ticket &= kChainTicketMask;
