@@ -1114,7 +1114,6 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // (image-textured spheres -13 %, mixed primitives -1.7 % with eight nodes: gpurun_out/r04am); their lists stay at four nodes (the first uint2 of the pixel's record).
     constexpr bool LONG_LISTS = !WIDE && (KIND & 7) <= SCENE_KIND_SPHERES_MOTION;
     constexpr bool LDS_VIEW = (RTOW_LDS_VIEW & (ALL_LDS ? 1 : 2)) != 0;   // ... or read from an LDS copy (bit 0: kernels with the scene in LDS, bit 1: the others)
-    constexpr bool LDS_SKY = LDS_VIEW || ((RTOW_LDS_VIEW & 4) != 0 && ALL_LDS);      // (development, bit 2: only the sky's seven constants from the LDS copy in the kernels with the scene in LDS)
     constexpr bool COLD_VIEW __attribute__((unused)) = RTOW_COLD_VIEW && !ALL_LDS && !LDS_VIEW;    // the view's and the sky's launch constants are read on use instead of held in scalar registers (REGEN)
     constexpr bool SPLIT_NODES = !ALL_LDS && !WIDE;      // node loads as ds_read / global_load behind a wave-uniform branch instead of flat loads (load_node)
     using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
@@ -1133,7 +1132,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // launch constants only REGEN and SKY read (view: 22 floats, sky: 7 dwords, frame size: 2 floats), parked in LDS behind the wave queues (RTOW_LDS_VIEW)
     float* const ldsConst = reinterpret_cast<float*>(smem + kStackBytesT + 256);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if ((LDS_VIEW || LDS_SKY) && tid < 31) {
+    if (LDS_VIEW && tid < 31) {
         // copied dword by dword from the kernarg segment (a struct assignment from the by-value argument goes through a private copy)
         const uint8_t* const ka = (const uint8_t*)__builtin_amdgcn_kernarg_segment_ptr();
         const size_t from = tid < 22 ? __builtin_offsetof(SampleKernelArgs, view) + 4u * (size_t)tid
@@ -2224,7 +2223,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 if (COLD_VIEW) { skyArgs = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(skyArgs)); }
 #endif
                 const SampleKernelArgs& EA = *skyArgs;
-                const RtowEnvironment& ENV = LDS_SKY ? *reinterpret_cast<const RtowEnvironment*>(ldsConst + 22) : EA.environment;
+                const RtowEnvironment& ENV = LDS_VIEW ? *reinterpret_cast<const RtowEnvironment*>(ldsConst + 22) : EA.environment;
                 if (ENV.skyType == RTOW_SKY_GRADIENT) {
                     const float s = 0.5f * (rd.y + 1);
                     const V3 b = v3(ENV.skyBottomColor), tp = v3(ENV.skyTopColor);
