@@ -154,3 +154,22 @@ def test_group_can_be_cancelled(rt, gpu_context):
     assert rc == rt.abi.RTOW_ERROR_CANCELLED and dt < 0.4, (rc, dt)                  # 4 x 512 spp at 1080p would take 0.9 s (the bound leaves room for a GPU shared with other test processes)
     for b in src + [x for o in outs for x in o]:
         b.free()
+
+
+@pytest.mark.parametrize("slots", [1, 2, 4, 7, 15])
+@pytest.mark.parametrize("w,h,count,divider,offset", [(520, 264, 5, 1, 0), (100, 37, 3, 3, 1), (1032, 520, 10, 1, 0)])
+def test_slot_tickets_any_number_of_slots_per_pull(rt, w, h, count, divider, offset, slots):
+    """A group's tickets are slot << 6 | pixel of the chunk; a wave reserves `slots` (chunk, batch) slots with one atomic (schedulerTune[7] + 256 x slots; 4 built in) and finds chunk
+    and batch from the ticket.  Whatever the number - also one that does not divide the slot count, with a last chunk that is not full (100 x 37 sliced in three: 1 300 owned pixels)
+    and with more chunks than the order needs (1 032 x 520: 8 385 chunks, the cost-ordered hand-out is on) - the group equals the batches launched separately, bit for bit."""
+    scene = rt.scenes.cover_scene()
+    n = w * h
+    plist = [rt.scenes.make_params(scene, w, h, spp=2, trace_depth=8, seed=900 + 7 * k, slice_offset=offset, slice_divider=divider) for k in range(count)]
+    ins = _inputs(n, 9)
+    fill = {k: np.full((n, c), -3.0, np.float32) for k, c in KEYS}
+    with rt.Context(0, scheduler_tune=(0, 0, 0, 0, 0, 0, 0, 3 + 256 * slots, 0)) as ctx:
+        ctx.upload_scene(scene.desc())
+        sep = _separate(rt, ctx, plist, ins, n, 4, fill)
+        for _ in range(2):                                        # second launch: order and ticket maps come from the first one's ray counts
+            grp = _grouped(rt, ctx, plist, ins, n, 4, fill)
+            _same(grp, sep, (w, h, count, slots))
