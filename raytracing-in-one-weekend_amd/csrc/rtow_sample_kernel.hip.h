@@ -45,6 +45,9 @@
 #ifndef RTOW_SPLIT_NODE_LOADS
 #define RTOW_SPLIT_NODE_LOADS 1   // 0: A/B build with one flat load per node quad (the base chosen per lane) in the kernels whose tree does not fit LDS
 #endif
+#ifndef RTOW_WHOLE_MATERIAL
+#define RTOW_WHOLE_MATERIAL 1     // 0: A/B build in which the kernels beyond LDS load a hit's material record piece by piece where it is used (HIT)
+#endif
 #ifndef RTOW_LDS_VIEW
 #define RTOW_LDS_VIEW 2           // bit 0 / bit 1 = the kernels with / without the scene in LDS read the view's and the sky's launch constants from an LDS copy (see REGEN)
 #endif
@@ -1937,8 +1940,25 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     N = normalize(nLocal);                                                    // RT/Entity.cs:65
                 }
                 const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + matIdx * 64u;
-                const float4 m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
-                const float4 m1 = *reinterpret_cast<const float4*>(mp + 16);  // emission.yz type metallic
+                // A material record that comes through L1 / L2 is fetched WHOLE here, four quads in flight at once: left to the compiler the second half is loaded dword by dword
+                // inside the class bodies that use it - up to three more dependent round trips per hit (roughness for the shared hemisphere pass, then the general / dielectric
+                // constants) - because that is where the values are used (RTOW_WHOLE_MATERIAL=0: A/B build without it)
+                constexpr bool WHOLE_MATERIAL = RTOW_WHOLE_MATERIAL && !ALL_LDS && !TEXTURED;
+                float4 m0, m1, m2whole = make_float4(0, 0, 0, 0), m3whole = make_float4(0, 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (WHOLE_MATERIAL) {
+                    fvec4 w0, w1, w2, w3;
+                    const unsigned recordOffset = L.materialOffset + matIdx * 64u;
+                    asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:16\n\tglobal_load_dwordx4 %2, %4, %5 offset:32\n\tglobal_load_dwordx4 %3, %4, %5 offset:48\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(recordOffset), "s"(sc.glob) : "memory");
+                    m0 = make_float4(w0.x, w0.y, w0.z, w0.w); m1 = make_float4(w1.x, w1.y, w1.z, w1.w);
+                    m2whole = make_float4(w2.x, w2.y, w2.z, w2.w); m3whole = make_float4(w3.x, w3.y, w3.z, w3.w);
+                } else
+#endif
+                {
+                    m0 = *reinterpret_cast<const float4*>(mp);       // albedo.xyz emission.x
+                    m1 = *reinterpret_cast<const float4*>(mp + 16);  // emission.yz type metallic
+                }
                 V3 reflectance = v3(m0.x, m0.y, m0.z);
                 V3 emission = v3(m0.w, m1.x, m1.y);
                 float metallicHit = m1.w;
@@ -1987,7 +2007,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 if (kSharedHemisphere) {
                     bool want = cls == MAT_CLASS_LAMBERT;
                     if (cls == MAT_CLASS_LAMBERT) rng.skip_cosine_hemisphere(at);                       // the unused rough-normal draw (see below)
-                    if (cls == MAT_CLASS_GENERAL) want = *reinterpret_cast<const float*>(mp + 44) > 0;  // roughness > 0
+                    if (cls == MAT_CLASS_GENERAL) want = (WHOLE_MATERIAL ? m2whole.w : *reinterpret_cast<const float*>(mp + 44)) > 0;  // roughness > 0
                     if (want) hemi = rng.cosine_hemisphere(at, N);
                 }
                 if (VOLUMES && cls == MAT_CLASS_VOLUME) {
@@ -2005,8 +2025,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     randomEvents += 1.0f;                          // 0 + 0 + 1 * 0 + 1 * 1 on top of whatever was pending
                 } else if (cls == MAT_CLASS_GENERAL) {                                        // RT/Material.cs:75-119
                     STAT_ADD(11, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(12);
-                    const float4 m2 = TEXTURED ? m2hit : *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags roughness
-                    const float4 m3 = TEXTURED ? m3hit : *reinterpret_cast<const float4*>(mp + 48);  // alpha ior r0 1/ior
+                    const float4 m2 = TEXTURED ? m2hit : WHOLE_MATERIAL ? m2whole : *reinterpret_cast<const float4*>(mp + 32);  // glossiness parameter flags roughness
+                    const float4 m3 = TEXTURED ? m3hit : WHOLE_MATERIAL ? m3whole : *reinterpret_cast<const float4*>(mp + 48);  // alpha ior r0 1/ior
                     const float metallic = TEXTURED ? metallicHit : m1.w;
                     const float glossiness = m2.x;
                     const float roughness = m2.w;                                 // pow(1 - glossiness, 2)
@@ -2035,8 +2055,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     randomEvents += roughness * (reflectionChance + (1 - reflectionChance) * metallic);
                     randomEvents += (1 - reflectionChance) * (1 - metallic);
                 } else {                                                                      // Dielectric, RT/Material.cs:121-161
-                    const float4 m2 = TEXTURED ? m2hit : *reinterpret_cast<const float4*>(mp + 32);
-                    const float4 m3 = TEXTURED ? m3hit : *reinterpret_cast<const float4*>(mp + 48);
+                    const float4 m2 = TEXTURED ? m2hit : WHOLE_MATERIAL ? m2whole : *reinterpret_cast<const float4*>(mp + 32);
+                    const float4 m3 = TEXTURED ? m3hit : WHOLE_MATERIAL ? m3whole : *reinterpret_cast<const float4*>(mp + 48);
                     STAT_ADD(13, (threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) ? 1 : 0); STAT_LANES(14);
                     perfectSpecular = true;
                     const float ior = m2.y;
