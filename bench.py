@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (plain batches, host-buffer form, other partitions)")
     ap.add_argument("--chain", type=int, default=None, help="batches per launch (rtowSampleBatchChainDevice); default: on one GPU the steps split into equal chains of at most 16, on several 1 (one gather per batch)")
+    ap.add_argument("--prewarm", type=float, default=2.0, help="seconds of untimed launches of the timed kind in front of the W warmup steps of the main measurement (clocks / power state of a fresh box; 0 = none)")
     ap.add_argument("--tune", default=None, help="development: RtowContextOptions.schedulerTune as 9 comma-separated integers")
     ap.add_argument("--context-flags", type=int, default=0, help="development: RtowContextOptions.flags (e.g. 1 = exact-tie kernels always)")
     ap.add_argument("--only-leg", choices=("group_fold", "host_default_chain", "host_default_group", "host_default_adaptive", "plain_two_in_flight"), default=None,
@@ -362,7 +363,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def measure(partition, rng, chain, steps, warmup):
+    def measure(partition, rng, chain, steps, warmup, prewarm_s=0.0):
         """Time `steps` batches (after `warmup` untimed ones) under one partition / RNG policy / chain length; max over ranks.
         Returns wall seconds, mean kernel ms per step, and the buffers of the last batch (for the ray / success statistics)."""
         hybrid = world > 1 and partition in ("hybrid", "batches")
@@ -453,6 +454,17 @@ def main():
                     kernel_ms.append(ctx.last_sample_kernel_ms())  # HIP events on the launch stream (synchronises); one launch = c steps
                 i += c
 
+        if prewarm_s > 0:
+            # a fresh box runs its first seconds of sustained load 2 - 4 % slower (clocks, power state: profiles/r05_runs/repeatability.json); launches of the same kind as
+            # the timed ones, untimed and before the W warmup steps, until the GPU has been busy for prewarm_s - then the accumulators are zeroed again
+            tw = time.perf_counter()
+            k = 0
+            while time.perf_counter() - tw < prewarm_s:
+                run(1000 + k, max(chain, group if hybrid else 1), False)
+                torch.cuda.synchronize(dev)
+                k += max(chain, 1)
+            for key in ("ping_flat", "pong_flat"):
+                state[key].zero_()
         run(0, warmup, False)
         barrier()
         t0 = time.perf_counter()
@@ -634,7 +646,7 @@ def main():
         return
 
     main_partition = args.partition if world > 1 else "single"
-    m = measure(args.partition, args.rng, args.chain, args.steps, args.warmup)
+    m = measure(args.partition, args.rng, args.chain, args.steps, args.warmup, prewarm_s=args.prewarm)
     hybrid = m["hybrid"]
 
     def summary(mm):
@@ -746,6 +758,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_s": args.prewarm,
             "ms_per_step": round(ms_per_step, 3),
             "batches_per_launch": m["steps_per_launch"],   # `value` is measured with this many successive batches fused into one launch (1 = plain batches)
             "launches": m["launches"],
