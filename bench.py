@@ -459,10 +459,12 @@ def main():
             # the timed ones, untimed and before the W warmup steps, until the GPU has been busy for prewarm_s - then the accumulators are zeroed again
             tw = time.perf_counter()
             k = 0
-            while time.perf_counter() - tw < prewarm_s:
-                run(1000 + k, max(chain, group if hybrid else 1), False)
+            per = max(chain, group if hybrid else 1)
+            # (several ranks: the launches carry collectives, so every rank makes the same number of them - 20 steps per second asked for - instead of watching its own clock)
+            while (time.perf_counter() - tw < prewarm_s) if world == 1 else (k < int(20 * prewarm_s)):
+                run(1000 + k, per, False)
                 torch.cuda.synchronize(dev)
-                k += max(chain, 1)
+                k += per
             for key in ("ping_flat", "pong_flat"):
                 state[key].zero_()
         run(0, warmup, False)
