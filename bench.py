@@ -617,11 +617,13 @@ def main():
                         fold[own] = fold[own] + part[own]                   # group order (ranks of a tile ascend with their group), float32 like fold_rows_kernel
                         seq = render(p, seq)                                # the reference's way: every batch on top of its predecessor's sums
                 seqc = seq[0].view(n, 4).cpu().numpy()
-                same = bool(np.array_equal(got.view(np.uint32), fold.view(np.uint32)))
+                # hybrid: the fold of the sub-batches in group order; tiles: the reference's own sequential accumulation of the batches, which a tile partition reproduces bit for bit
+                same = bool(np.array_equal(got.view(np.uint32), (fold if hybrid_c else seqc).view(np.uint32)))
                 mean_a = got[:, :3] / np.maximum(got[:, 3:4], 1)
                 mean_s = seqc[:, :3] / np.maximum(seqc[:, 3:4], 1)
                 counts = bool(np.array_equal(got[:, 3], seqc[:, 3]))
                 result = {"frame": "%dx%d, %d steps, %d samples per step" % (W, H, steps_c, spp), "bit_identical_to_the_same_sub_batches_on_one_gpu": same,
+                          "compared_with": "the same sub-batches rendered by rank 0 alone from zeroed accumulators and folded in group order" if hybrid_c else "the same batches accumulated one after the other by rank 0 alone (the single-GPU frame)",
                           "success_counts_equal_the_sequential_accumulation": counts, "max_abs_mean_colour_difference_to_the_sequential_accumulation": float(np.abs(mean_a - mean_s).max()),
                           "transport": "RCCL behind the C ABI" if (have_comm and not shared_gpu) else "stand-in transport (debug)" if have_comm else "torch.distributed"}
                 if not (same and counts and result["max_abs_mean_colour_difference_to_the_sequential_accumulation"] <= 1e-4):
@@ -631,7 +633,12 @@ def main():
             W, H, n, spp = keep
             ctx.synchronize()
 
-    self_check = partition_self_check(args.partition) if world > 1 else None
+    # N > 1: both partitions check themselves before anything is timed - the one `value` is quoted for, and the other, reported beside it as a first-class block
+    self_checks = {}
+    if world > 1:
+        for part in ("tiles", "hybrid") if args.partition != "batches" else ("tiles", "batches"):
+            self_checks[part] = partition_self_check(part)
+    self_check = self_checks.get(args.partition)
 
     if args.only_leg:
         # profiling / A-B aid (profiles/collect.sh, profiles/r05_runs): ONE of the secondary measurements as the whole run
@@ -722,7 +729,17 @@ def main():
             ctx.unregister_host_buffers()
         else:
             other = "hybrid" if args.partition == "tiles" else "tiles"
-            extras["partitions"] = {args.partition: summary(m), other: summary(measure(other, args.rng, 1, args.steps, 1))}
+            measured = {args.partition: m, other: measure(other, args.rng, 1, args.steps, 1)}
+            extras["partitions"] = {k: summary(v) for k, v in measured.items()}
+            # north_star's partition and the one that scales, each as a block of its own: value, time per step, ranks RCCL connected, collectives per step, what the image is, self-check
+            ranks_connected = world if (have_comm and not shared_gpu) else 0
+            for k, v in measured.items():
+                is_tiles = k == "tiles"
+                extras[k] = dict(summary(v), unit="Msamples/s", n_gpus=world, rccl_ranks=ranks_connected, collectives_per_step=1 if is_tiles else 2,
+                                 partition=("row-interleaved slices (SliceDivider = %d, JOBS/SampleBatchJob.cs:69-70), ONE gather of colour rows per sample batch (rtowGatherRowsDevice)" % world) if is_tiles else
+                                           ("%d row slices x %d seed groups (rtowHybridPlan): grouped send / receive exchange + ordered fold (rtowExchangeAccumDevice), then the tile gather" % (v["tiles"], v["groups"])),
+                                 image="the single-GPU frame, bit for bit" if is_tiles else "the reference's samples under another association of the float sums: bit-identical to the same sub-batches on one GPU, within 1e-4 of the sequential accumulation",
+                                 batches_per_launch=v["steps_per_launch"], is_value=(k == args.partition), self_check=self_checks.get(k))
             if args.rng == "reference":
                 extras["partitions"]["tiles, RTOW_RNG_PER_SAMPLE (not the reference stream)"] = summary(measure("tiles", "per-sample", 1, args.steps, 1))
 

@@ -39,6 +39,9 @@ static constexpr unsigned kGroupSlotBlock = RTOW_GROUP_SLOT_BLOCK;
 // 2 / 4 / 8 (+ 16 x mode): pixels regrouped by cost or class inside super-tiles of that many tiles (0 ... -5 %: measured, not used)
 #define RTOW_DEFAULT_REGROUP_SIDE 3
 #endif
+#ifndef RTOW_PIXEL_GATE
+#define RTOW_PIXEL_GATE 1     // lanes of a wave that must want a pixel boundary before the boundary block runs (1 = at once; the kernel's A.tune[7]); measured: see HISTORY.md round 6
+#endif
 #ifndef RTOW_DEFAULT_TUNE
 #define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 3, 1, 16
 #endif
@@ -84,6 +87,7 @@ struct RtowContext_t {
     uint8_t* dScene = nullptr;
     size_t dSceneCapacity = 0;
     uint32_t ldsSceneBytes = 0, ldsNodeCount = 0;
+    LdsPlan ldsPlan{};                    // of launches whose variant keeps its whole path history in registers (trace depth <= 16); the others plan per launch (launchSample)
 
     // work distribution / cancellation
     unsigned int* dWorkCounter = nullptr;
@@ -115,6 +119,7 @@ struct RtowContext_t {
     uint32_t hitSpillCapacity = 0;        // entries per lane the allocation holds
     uint32_t hitListCapacity = 0;         // RtowContextOptions.hitListCapacity (0 = default)
     uint32_t grownListCapacity = 0;       // hitListCapacity == 0 only: what the capacity has grown to after batches that met longer lists (growHitList); kept across scenes
+    bool triWatchOff = false;             // this all-triangle scene ties too often for the tie watch (a watched launch marked thousands of pixels, or more than the list holds): exact-tie kernels from now on
     bool overflowGrew = false;            // the last reported overflow enlarged the capacity: the same batch, issued again, has room
     // Image-texture blob of the current scene (CompiledScene.texBlob), HBM only
     uint8_t* dTexBlob = nullptr;
@@ -190,6 +195,7 @@ struct RtowContext_t {
     bool haveMetricsDone = false;
 
     std::mutex mu;
+    std::mutex sceneMu;      // guards the HOST image of the scene (scene.blob / layout / entityOfPrim, haveScene) between rtowUploadScene and rtowProbeNearestHit; taken after mu, never the other way round
 };
 
 namespace {
@@ -297,6 +303,8 @@ bool finishThresholdTuning(RtowContext ctx, bool wait)
 }
 
 uint64_t listCapacity(const RtowContext_t* ctx, bool volumes);    // (defined with growHitList below)
+inline bool triangleKind(uint32_t kind) { return kind == SCENE_KIND_TRIANGLES || kind == SCENE_KIND_TRIANGLES_TEXTURED; }
+constexpr unsigned kTieWatchBusy = 4096;   // a watched launch of an all-triangle scene that lists more pixel-batches than this (8 workgroups render them) sends the scene to the exact-tie kernels
 
 int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuffers* in, const RtowAccumBuffers* out, void* diag,
                  hipStream_t stream, bool useCancelFlag, const ChainSpec* chain = nullptr)
@@ -310,6 +318,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.layout = ctx->scene.layout;
     a.ldsSceneBytes = ctx->ldsSceneBytes;
     a.ldsNodeCount = ctx->ldsNodeCount;
+    a.ldsStackRows = ctx->ldsPlan.stackRows; a.ldsHistOffset = 0u; a.ldsFrontBytes = ctx->ldsPlan.frontBytes;      // (launches of the generic variants plan again below: their history rows)
     a.workCounter = ctx->dWorkCounter;
     a.cancelFlag = useCancelFlag ? ctx->hCancel : nullptr;
     a.overflowFlag = const_cast<uint32_t*>(ctx->hCancel) + 1;      // [1]: a ray beyond the hit-list capacity (grows: takeOverflow); [2]: more tied pixel-batches than the fix-up list holds (final)
@@ -323,7 +332,9 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.seed = chain ? chain->seeds[0] : p->seed;
     a.chainCount = chain ? (uint32_t)chain->count : 1u;
     a.chainIndependent = (chain && chain->outs) ? 1 : 0;
-    a.groupRecip = (uint32_t)((1ull << 32) / (a.chainCount ? a.chainCount : 1u) + 1ull);      // slot / chainCount = (slot * groupRecip) >> 32 for every slot of a launch (chunkCount * chainCount <= 2^25)
+    // slot / chainCount = (slot * groupRecip) >> 32 for every slot of a launch (chunkCount * chainCount <= 2^25); a count of one has no 32-bit reciprocal (2^32 + 1 would truncate
+    // to 1): 2^32 - 1 is exact for slots below 2^32 - and groups of one batch are plain launches anyway (rtowSampleBatchGroupDevice)
+    a.groupRecip = a.chainCount <= 1u ? 0xffffffffu : (uint32_t)((1ull << 32) / a.chainCount + 1ull);
     if (chain) {
         if (diag == nullptr && chain->diags) diag = chain->diags[0];
         a.diagnostics = (uint8_t*)diag;
@@ -364,9 +375,27 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.cubemapFaceStride = ctx->cubemap.pixelStride * ctx->cubemap.faceWidth * ctx->cubemap.faceHeight;         // :168
     a.cubemapChannelType = ctx->cubemap.channelType;
 
+    {
+        // The variants for paths deeper than 16 (and the generic ones: 16-byte records, texture-driven noise, the per-sample policies beyond depth 8) keep the path-history codes
+        // beyond the first eight in LDS rows: this launch's LDS is planned with them, and the scene image takes what is left (a scene that no longer fits whole keeps the top of
+        // its tree there and reads the rest through L2, like any scene beyond LDS)
+        const bool fullDiag = a.diagnostics && a.diagnosticsStride >= 16;
+        const bool perSample = p->rngPolicy != RTOW_RNG_REFERENCE;
+        int hw = historyWords(a.noiseColor, perSample, ctx->wideCodes, ctx->scene.layout.exactTies != 0, fullDiag, a.traceDepth);
+        // (an all-triangle scene under the tie watch launches its rank-rule kernels first and its exact-tie kernels on the marked pixels, with the one plan: the wider of the two)
+        if (ctx->scene.layout.exactTies) hw = std::max(hw, historyWords(a.noiseColor, perSample, ctx->wideCodes, false, fullDiag, a.traceDepth));
+        if (hw == 32 && a.traceDepth > kHistoryInRegisters) {
+            const LdsPlan plan = planLds(ctx->wideCodes, ctx->scene.layout, (uint32_t)(a.traceDepth - kHistoryInRegisters), ctx->ldsSceneBudget);
+            if (plan.frontBytes + (uint32_t)kQueueBytes + (uint32_t)sizeof(GpuNode) > (uint32_t)kLdsBytesMax) return RTOW_ERROR_CAPACITY;      // (trace depth <= 64 and 24 tree levels always fit)
+            a.ldsStackRows = plan.stackRows; a.ldsHistOffset = plan.histOffset; a.ldsFrontBytes = plan.frontBytes;
+            a.ldsSceneBytes = plan.sceneBytes; a.ldsNodeCount = plan.nodeCount;
+        }
+    }
     // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice (RtowContextOptions.schedulerTune overrides)
     for (int i = 0; i < 8; i++) a.tune[i] = ctx->tune[i] < 1 ? 1 : ctx->tune[i];
     a.travSlice = ctx->tune[8] < 1 ? 1 : ctx->tune[8];
+    const int pixelGate = (ctx->regroupSide >> 12) & 15 ? (ctx->regroupSide >> 12) & 15 : RTOW_PIXEL_GATE;      // lanes that wait for company at a pixel boundary (kernel: A.tune[7]); schedulerTune[7] bits 12 .. 15
+    a.tune[7] = pixelGate;
     const uint32_t ownedPixels = a.totalWork;
     if (ownedPixels == 0) {
         // a slice that owns no row (SliceOffset >= height): Execute returns for every index (JOBS/SampleBatchJob.cs:69-70) - nothing is
@@ -400,8 +429,14 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     }
     // ---- nearest-hit ties under the rank rule: sphere kinds of more than 16 entities, reference stream - a pixel that meets two different spheres at
     // bit-identical distance at a nearest hit is listed instead of stored, and the exact-tie kernel of the same kind renders the list in a second, tiny launch
-    const bool tieWatch = ctx->scene.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION && !ctx->scene.layout.exactTies && ctx->scene.entityCount > 16 &&
-                          !(ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER) && p->rngPolicy == RTOW_RNG_REFERENCE;
+    // All-triangle scenes whose exact-tie kernels were chosen for their size alone (no triangle twice: SceneLayout.tieWatchOk) are watched too: the rank-rule kernels trace the
+    // frame, the exact-tie kernels the marked pixels - unless the scene has shown that it ties often (triWatchOff: the flag below, or a list that overflowed)
+    if (ctx->hCancel[3] != 0u) { ctx->hCancel[3] = 0u; if (triangleKind(ctx->scene.layout.sceneKind)) { ctx->triWatchOff = true; logf(ctx, 3, "rtow", "this scene's nearest hits tie often: exact-tie kernels from now on"); } }
+    const bool sphereWatch = ctx->scene.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION && !ctx->scene.layout.exactTies && ctx->scene.entityCount > 16;
+    const bool triWatch = triangleKind(ctx->scene.layout.sceneKind) && ctx->scene.layout.exactTies && ctx->scene.layout.tieWatchOk && !ctx->triWatchOff &&
+                          !(ctx->flags & RTOW_CONTEXT_EXACT_TIES_ALWAYS);
+    const bool tieWatch = (sphereWatch || triWatch) && !(ctx->flags & RTOW_CONTEXT_EXACT_TIES_NEVER) && p->rngPolicy == RTOW_RNG_REFERENCE;
+    if (tieWatch && triWatch) a.layout.exactTies = 0u;               // this launch goes through the rank-rule kernels of the kind; the fix-up launch below sets the bit again
     // in place: an output buffer that is also the input buffer (a chain's later batches always read the outputs, but they read what THIS launch stored: only batch 0's inputs count)
     const bool inPlace = in->color == out->color || in->normal == out->normal || in->albedo == out->albedo || in->sampleCountWeight == out->sampleCountWeight;
     if (tieWatch) {
@@ -541,9 +576,9 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         // ---- stage thresholds: measured once per scene on this batch's own kernel, frame and view (see kTuneProbeSamples) ----
         // Never waited for: the probes are enqueued in front of a batch, timed with events, and a LATER call that finds the last event complete reads them
         // and switches the thresholds (scheduling only: no result depends on when that happens).  Until then the kernel kind's built-in values run.
-        for (int k = 0; k < 8; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
+        for (int k = 0; k < 7; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
         if (ctx->tunePending && ctx->tunePendingScene == ctx->sceneSerial && finishThresholdTuning(ctx, /*wait*/ false))
-            for (int k = 0; k < 8; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
+            for (int k = 0; k < 7; k++) a.tune[k] = ctx->tune[k] < 1 ? 1 : ctx->tune[k];
         ctx->sppSinceUpload += (uint64_t)a.chainCount * (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
         hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;                   // a stream that is being captured into a graph cannot carry the event pairs: no measurement then
         if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
@@ -569,12 +604,12 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             probe.chainCount = 1;
             probe.chainIndependent = 0;
             // one untimed probe first: clocks, L2 and the instruction cache are warm before the first timed one
-            for (int k = 0; k < 8; k++) probe.tune[k] = kSets[0][k];
+            for (int k = 0; k < 7; k++) probe.tune[k] = kSets[0][k];
             if (ok) ok = hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream) == hipSuccess && launchSampleBatch(probe, blocks, stream) == hipSuccess;
             if (ok) ok = hipEventRecord(ctx->tuneEvents[0], stream) == hipSuccess;
             for (int l = 0; ok && l < launches; l++) {
                 const int c = l % candidates;
-                for (int k = 0; k < 8; k++) probe.tune[k] = kSets[c % kFamilies][k];
+                for (int k = 0; k < 7; k++) probe.tune[k] = kSets[c % kFamilies][k];
                 if (c >= kFamilies) probe.tune[5] = 32;
                 ok = hipMemsetAsync(ctx->dWorkCounter, 0, sizeof(unsigned int), stream) == hipSuccess && launchSampleBatch(probe, blocks, stream) == hipSuccess &&
                      hipEventRecord(ctx->tuneEvents[(size_t)l + 1], stream) == hipSuccess;
@@ -658,7 +693,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         // the fix-up: marked pixels -> list -> the exact-tie kernel of the same kind over the list (almost always empty: that kernel then leaves before it stages the scene).
         // A chain's pixel is listed once and carried through all its batches; a group's once per batch.
         const size_t framePixels = (size_t)a.width * (size_t)a.height;
-        HIP_TRY(ctx, launchCollectTiedPixels(ctx->dTieBits, (unsigned)((framePixels + 31u) / 32u), ctx->dTieRedo, kTieRedoCapacity, a.chainIndependent ? a.chainCount : 1u, a.overflowFlag + 1, stream),
+        HIP_TRY(ctx, launchCollectTiedPixels(ctx->dTieBits, (unsigned)((framePixels + 31u) / 32u), ctx->dTieRedo, kTieRedoCapacity, a.chainIndependent ? a.chainCount : 1u, a.overflowFlag + 1,
+                                             triWatch ? kTieWatchBusy : 0xffffffffu, stream),
                 RTOW_ERROR_LAUNCH_FAILURE);
         SampleKernelArgs r = a;
         r.layout.exactTies = 1u;
@@ -758,6 +794,14 @@ int takeOverflow(RtowContext ctx)
         // did not go to the exact-tie kernels).  Growing the hit lists would not help and running the batch again would overflow again: the error is final
         ctx->hCancel[2] = 0u;
         ctx->hCancel[1] = 0u;
+        if (ctx->haveScene && triangleKind(ctx->scene.layout.sceneKind) && !ctx->triWatchOff) {
+            // an all-triangle scene that ties over whole regions (coplanar layers): its exact-tie kernels need no list - the batch, issued again, runs on them
+            ctx->triWatchOff = true;
+            ctx->hCancel[3] = 0u;
+            ctx->overflowGrew = true;
+            logf(ctx, 3, "rtow", "more than %u pixel-batches of one launch met nearest-hit ties: results of this batch are invalid; the scene runs on the exact-tie kernels from now on", kTieRedoCapacity);
+            return RTOW_ERROR_CAPACITY;
+        }
         ctx->overflowGrew = false;
         logf(ctx, 2, "rtow", "more than %u pixel-batches of one launch met nearest-hit ties: results of this batch are invalid (use RTOW_CONTEXT_EXACT_TIES_ALWAYS for this scene)", kTieRedoCapacity);
         return RTOW_ERROR_CAPACITY;
@@ -991,7 +1035,20 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
         ctx->hitListCapacity = (uint32_t)options->hitListCapacity;
         bool anyTune = false;
         for (int i = 0; i < 9; i++) anyTune = anyTune || (i != 7 && options->schedulerTune[i] != 0);
-        if (options->schedulerTune[7] > 0) ctx->regroupSide = options->schedulerTune[7];     // its own knob: says nothing about the thresholds
+        if (options->schedulerTune[7] > 0) {                                                  // its own knob: says nothing about the thresholds
+            // packed: side (low nibble: 1 none, 3 a tile's tickets most expensive first, 2 / 4 / 8 super-tiles) + 16 x mode (0 .. 3) + 64 x chunk order by total + 256 x queue slots per pull
+            // + 4096 x lanes that wait for company at a pixel boundary.
+            // A low nibble of 0 (only the upper fields given) keeps the default side; any other value would silently switch the ticket map off
+            int v = options->schedulerTune[7];
+            if ((v & 15) == 0) v |= RTOW_DEFAULT_REGROUP_SIDE & 15;
+            const int side = v & 15;
+            if (!(side == 1 || side == 2 || side == 3 || side == 4 || side == 8) || v >= (1 << 16)) {
+                logf(ctx, 2, "rtow", "schedulerTune[7] = %d: the low four bits must be 1, 2, 3, 4 or 8 (or 0 for the default)", options->schedulerTune[7]);
+                delete ctx;
+                return RTOW_ERROR_INVALID_VALUE;
+            }
+            ctx->regroupSide = v;
+        }
         if (anyTune) {
             // stage thresholds below 1 mean "any lane" (1); a zero hand-over count or walk slice means "the built-in value" (3; per scene at upload), as in API v6
             for (int i = 0; i < 9; i++) ctx->tune[i] = options->schedulerTune[i] < 1 ? 1 : options->schedulerTune[i];
@@ -1021,6 +1078,7 @@ RTOW_API int rtowCreateContext(const RtowContextOptions* options, RtowContext* o
     ctx->hCancel[0] = 0u;
     ctx->hCancel[1] = 0u;
     ctx->hCancel[2] = 0u;
+    ctx->hCancel[3] = 0u;          // [3]: a watched launch of an all-triangle scene listed thousands of tied pixels (read at the next launch: triWatchOff)
     logf(ctx, 4, "rtow", "context on device %d (%s, %d CUs)", ordinal, prop.gcnArchName, ctx->cuCount);
     // chained launches hand accumulators over inside an XCD with plain stores + sc1 loads: measured on THIS device before it is relied on
     if (ctx->flags & RTOW_CONTEXT_NO_CHAIN_FUSION) {
@@ -1170,20 +1228,15 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     } else if (ctx->userSliceDefault) {
         ctx->tune[8] = compiled.layout.nodeCount > 65535u ? 24 : 16;
     }
+    std::lock_guard<std::mutex> sceneLock(ctx->sceneMu);          // rtowProbeNearestHit reads the host image under this lock only
     ctx->scene = std::move(compiled);
-    uint32_t budget = (uint32_t)(kLdsBytesMax - (wide ? kStackBytesWide : kStackBytes) - kQueueBytes);
-    if (ctx->ldsSceneBudget >= sizeof(GpuNode) && ctx->ldsSceneBudget < budget) budget = ctx->ldsSceneBudget;   // development aid: small scenes through the tree-in-HBM kernels
-    if (ctx->scene.layout.totalBytes <= budget && !wide) {
-        ctx->ldsSceneBytes = ctx->scene.layout.totalBytes;
-        ctx->ldsNodeCount = ctx->scene.layout.nodeCount;
-    } else {
-        // too large for LDS: stage the top of the (breadth-first) node array, read the rest through L2
-        uint32_t nodes = budget / (uint32_t)sizeof(GpuNode);
-        if (nodes > ctx->scene.layout.nodeCount) nodes = ctx->scene.layout.nodeCount;
-        ctx->ldsNodeCount = nodes;
-        ctx->ldsSceneBytes = nodes * (uint32_t)sizeof(GpuNode);
-    }
+    // LDS of a launch: a traversal-stack row per inner level of THIS tree, then the scene image - whole, or the top of the node array (planLds, rtow_kernels.h)
+    ctx->ldsPlan = planLds(wide, ctx->scene.layout, 0u, ctx->ldsSceneBudget);
+    ctx->ldsSceneBytes = ctx->ldsPlan.sceneBytes;
+    ctx->ldsNodeCount = ctx->ldsPlan.nodeCount;
     ctx->haveScene = true;
+    ctx->triWatchOff = false;
+    ctx->hCancel[3] = 0u;
     ctx->sceneSerial++;
     ctx->orderValid = false;
     dropThresholdTuning(ctx);                                   // (the device is idle: rtowUploadScene synchronised it above)
@@ -1563,12 +1616,14 @@ RTOW_API int rtowUnregisterHostBuffer(RtowContext ctx, void* pointer)
 RTOW_API int rtowProbeNearestHit(RtowContext ctx, const RtowFloat3* origin, const RtowFloat3* direction, float time, float* distance, int32_t* entityIndex)
 {
     if (!ctx || !origin || !direction) return RTOW_ERROR_INVALID_VALUE;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    // the host image of the scene has a lock of its own (held here and while rtowUploadScene swaps the image in): the blocking entry points hold ctx->mu for a whole
+    // batch, and a probe from another thread must not wait for them
+    std::lock_guard<std::mutex> lock(ctx->sceneMu);
     if (!ctx->haveScene) return RTOW_ERROR_NO_SCENE;
     const float o[3] = {origin->x, origin->y, origin->z}, d[3] = {direction->x, direction->y, direction->z};
     float t = 0.0f;
     int prim = -1;
-    (void)probeNearestHitHost(ctx->scene.blob.data(), ctx->scene.layout, o, d, time, &t, &prim);      // no device work: batches in flight are neither waited for nor disturbed
+    (void)probeNearestHitHost(ctx->scene.blob.data(), ctx->scene.layout, ctx->scene.entityOfPrim.empty() ? nullptr : ctx->scene.entityOfPrim.data(), o, d, time, &t, &prim);      // no device work: batches in flight are neither waited for nor disturbed
     if (distance) *distance = t;
     if (entityIndex) *entityIndex = prim;
     return RTOW_SUCCESS;

@@ -452,6 +452,17 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     }
     cullBoxes = guardBoxes;   // from here on: leaf-child boxes of the GPU tree and the backwards probe's guard
 
+    // All-triangle scenes without volumes (SCENE_KIND_TRIANGLES / _TEXTURED) number their primitives in this tree's leaf order and get the compact GpuTriHot / GpuTriCold records
+    // (rtow_scene.h): the candidates of neighbouring leaves then sit next to each other in memory.  Results-neutral: a primitive number never leaves the library
+    // (the probe maps it back), and ties are decided by rank[] - the place in the REFERENCE tree's leaf order - which is permuted along.
+    bool allTriangles = general;
+    for (int i = 0; i < n && allTriangles; i++) allTriangles = desc->entities[i].type == RTOW_ENTITY_TRIANGLE;
+    const bool triKind = allTriangles && !hasVolumes;
+    std::vector<int> placeOf;                // entity -> place in leaf order (triKind only)
+    auto leafPlace = [&](int entity) { return triKind && !placeOf.empty() ? placeOf[entity] : entity; };
+    std::vector<uint32_t> ranksInLeafOrder(triKind ? n : 0);
+    out->entityOfPrim.clear();
+
     // ---- SAH build, then breadth-first renumbering ----
     std::vector<int> idx(n);
     std::iota(idx.begin(), idx.end(), 0);
@@ -472,6 +483,10 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         b.nodes.reserve(n);
         const int root = b.build(idx, 0, n, maxDepth, 0, &rootBox);
         depthSeen = b.maxDepthSeen;
+        if (triKind) {                       // build() partitions idx in place: what is left is the leaves from left to right
+            placeOf.resize(n);
+            for (int k = 0; k < n; k++) placeOf[idx[k]] = k;
+        }
         // Numbering.  The first kBreadthFirstNodes nodes are numbered breadth-first - "the first K nodes" must be the top levels, because a scene
         // that does not fit LDS stages a prefix of the node array (at most (160 KB - 64 KB) / 64 B = 1 535 nodes) - and every subtree hanging
         // below that front is numbered depth-first (pre-order): a ray that has descended into a subtree keeps reading nodes that lie next to
@@ -513,14 +528,27 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
                     for (int a = 0; a < 3; a++) { cb[c].lo[a] = e[a]; cb[c].hi[a] = e[4 + a]; }
                 }
             setBoxes(g, cb[0], cb[1]);
-            g.child0 = t.child[0] >= 0 ? newIndex[t.child[0]] : t.child[0];
-            g.child1 = t.child[1] >= 0 ? newIndex[t.child[1]] : t.child[1];
+            g.child0 = t.child[0] >= 0 ? newIndex[t.child[0]] : ~leafPlace(~t.child[0]);
+            g.child1 = t.child[1] >= 0 ? newIndex[t.child[1]] : ~leafPlace(~t.child[1]);
             gnodes[i] = g;
         }
     }
+    if (triKind && n > 1) {
+        // every per-entity array follows the entities into leaf order; entityOfPrim takes a primitive number back to the host's entity index (rtowProbeNearestHit)
+        auto permute = [&](auto& v, size_t per) {
+            if (v.empty()) return;
+            auto w = v;
+            for (int i = 0; i < n; i++) std::copy(w.begin() + (size_t)i * per, w.begin() + (size_t)(i + 1) * per, v.begin() + (size_t)placeOf[i] * per);
+        };
+        permute(spheres, 1); permute(motion, 1); permute(prims, 1); permute(cullBoxes, 8); permute(matIndex, 1);
+        std::vector<uint32_t> r = ranks;
+        for (int i = 0; i < n; i++) ranksInLeafOrder[placeOf[i]] = r[i];
+        out->entityOfPrim.assign(n, 0);
+        for (int i = 0; i < n; i++) out->entityOfPrim[placeOf[i]] = i;
+    }
     {
         // section offsets are 32-bit: the whole image must stay below 4 GiB
-        const uint64_t bytes = (uint64_t)gnodes.size() * sizeof(GpuNode) + (uint64_t)n * (sizeof(GpuSphere) + (hasMotion ? sizeof(GpuMotion) : 0) + (general ? sizeof(GpuPrim) : 0) + (hasVolumes ? 32u : 0u) + 8u) +
+        const uint64_t bytes = (uint64_t)gnodes.size() * sizeof(GpuNode) + (uint64_t)n * (sizeof(GpuSphere) + (hasMotion ? sizeof(GpuMotion) : 0) + (general ? sizeof(GpuPrim) : 0) + (hasVolumes ? 32u : 0u) + (triKind ? sizeof(GpuTriHot) + sizeof(GpuTriCold) : 0) + 8u) +
                                (uint64_t)mats.size() * sizeof(GpuMaterial) + 256u;
         if (bytes >= 0xfff00000ull) {
             *err = "scene image exceeds 4 GiB";
@@ -549,8 +577,6 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
         if (same && !first) { L.commonTimeRange = 1u; memcpy(&L.commonT0, &t0, 4); memcpy(&L.commonT1, &t1, 4); }
     }
     L.motionOffset = off; if (hasMotion) off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuMotion));
-    bool allTriangles = general;
-    for (int i = 0; i < n && allTriangles; i++) allTriangles = desc->entities[i].type == RTOW_ENTITY_TRIANGLE;
     L.sceneKind = hasVolumes ? (hasImageTextures ? SCENE_KIND_VOLUMES_TEXTURED : SCENE_KIND_VOLUMES) : hasImageTextures ? (allTriangles ? SCENE_KIND_TRIANGLES_TEXTURED : SCENE_KIND_TEXTURED) : allTriangles ? SCENE_KIND_TRIANGLES
                   : general ? SCENE_KIND_GENERAL : hasMotion ? SCENE_KIND_SPHERES_MOTION : SCENE_KIND_SPHERES;
     // Does the scene hold the same primitive twice (same geometry, any material)?  Two such surfaces coincide everywhere - the same float
@@ -560,6 +586,25 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     // per ray.  Volume scenes resolve every tie in their hit list anyway.
     L.exactTies = 0u;
     if (!hasVolumes && (general || hasImageTextures) && n > 16) L.exactTies = 1u;      // see below; decided first so that a million-triangle mesh skips the duplicate scan
+    if (triKind && L.exactTies) {
+        // An all-triangle scene may run on the rank-rule kernels with the tie watch (the exact-tie kernels then render only the marked pixels) unless it holds the same
+        // triangle twice - coinciding surfaces tie over whole image regions.  Triangles are tested in world space on `Data` alone (RT/Entity.cs:91-93, RT/HitTests.cs:116-139): 64-bit
+        // hashes of those nine floats (-0 folded into +0), sorted; equal hashes count as duplicates without a second look (a collision only costs speed: the scene keeps
+        // the exact-tie kernels).
+        std::vector<uint64_t> h(n);
+        for (int i = 0; i < n; i++) {
+            const float* f = reinterpret_cast<const float*>(&desc->triangles[desc->entities[i].contentIndex]);
+            uint64_t x = 0x9E3779B97F4A7C15ull;
+            for (int k = 0; k < 9; k++) {
+                const float v = f[k] + 0.0f;
+                uint32_t w; memcpy(&w, &v, 4);
+                x ^= w; x *= 0xff51afd7ed558ccdull; x ^= x >> 29;
+            }
+            h[i] = x;
+        }
+        std::sort(h.begin(), h.end());
+        L.tieWatchOk = std::adjacent_find(h.begin(), h.end()) == h.end() ? 1u : 0u;
+    }
     if (!hasVolumes && !L.exactTies) {
         std::vector<std::array<uint32_t, 38>> keys(n);
         for (int i = 0; i < n; i++) {
@@ -590,6 +635,12 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     L.cullOffset = off; if (hasVolumes) off = align16(off + (uint32_t)n * 32u);
     L.rankOffset = off; off = align16(off + (uint32_t)n * 4u);
     L.matIndexOffset = off; off = align16(off + (uint32_t)n * 4u);
+    if (triKind) {
+        off = (off + 127u) & ~127u;              // records never straddle a 64-byte memory sector they need not
+        L.triHotOffset = off; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuTriHot));
+        off = (off + 127u) & ~127u;
+        L.triColdOffset = off; off = align16(off + (uint32_t)n * (uint32_t)sizeof(GpuTriCold));
+    }
     L.materialOffset = off; L.materialCount = (uint32_t)mats.size(); off = align16(off + L.materialCount * (uint32_t)sizeof(GpuMaterial));
     L.totalBytes = off;
     L.bvhDepth = (uint32_t)depthSeen;
@@ -600,7 +651,17 @@ int compileScene(const RtowSceneDesc* desc, int maxDepth, CompiledScene* out, st
     if (hasMotion) memcpy(out->blob.data() + L.motionOffset, motion.data(), motion.size() * sizeof(GpuMotion));
     if (general) memcpy(out->blob.data() + L.primOffset, prims.data(), prims.size() * sizeof(GpuPrim));
     if (hasVolumes) memcpy(out->blob.data() + L.cullOffset, cullBoxes.data(), cullBoxes.size() * 4u);
-    memcpy(out->blob.data() + L.rankOffset, ranks.data(), ranks.size() * 4u);
+    memcpy(out->blob.data() + L.rankOffset, triKind && n > 1 ? ranksInLeafOrder.data() : ranks.data(), ranks.size() * 4u);
+    if (triKind) {
+        GpuTriHot* hot = reinterpret_cast<GpuTriHot*>(out->blob.data() + L.triHotOffset);
+        GpuTriCold* cold = reinterpret_cast<GpuTriCold*>(out->blob.data() + L.triColdOffset);
+        for (int i = 0; i < n; i++) {
+            const float* q = prims[i].q;             // RtowTriangle verbatim: Data (e0 e1 v0), Normals, TextureCoordinates; q[24..27] = rotation
+            memcpy(hot[i].e0, q, 9 * sizeof(float));
+            memcpy(cold[i].n0, q + 9, 9 * sizeof(float));
+            memcpy(cold[i].rot, q + 24, 4 * sizeof(float));
+        }
+    }
     memcpy(out->blob.data() + L.matIndexOffset, matIndex.data(), matIndex.size() * 4u);
     memcpy(out->blob.data() + L.materialOffset, mats.data(), mats.size() * sizeof(GpuMaterial));
     out->layout = L;

@@ -24,6 +24,7 @@ struct CompiledScene {
     TexLayout texLayout{};
     std::vector<uint8_t> refTree; // the reference's own tree (rtow_reforder.h RefTreeNode[], node 0 = root): uploaded only for RTOW_CONTEXT_REFERENCE_DIAGNOSTICS
     int refTreeDepth = 0;         // its depth bound (the host's MaxBvhDepth)
+    std::vector<int32_t> entityOfPrim; // all-triangle scenes number their primitives in leaf order: primitive -> the host's entity index (empty: the same number)
 };
 
 // Returns an RtowResult; *err describes failures.

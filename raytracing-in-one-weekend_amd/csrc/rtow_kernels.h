@@ -19,11 +19,61 @@ constexpr int kLdsBytesMax = 160 * 1024;
 #define RTOW_TRAV_SLICE 8   // box-walk node visits per scheduler trip
 #endif
 constexpr int kCandCapacity = 8;   // per-lane list of leaf candidates awaiting their exact test (flushed when full)
-constexpr int kStackBytes = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 2; // 16-bit entries, [level][lane] (the default geometry; rtow_sample_kernel.hip.h: geo_stack_bytes)
-constexpr int kStackBytesWide = (RTOW_STACK_CAPACITY + kCandCapacity) * kBlockThreads * 4; // 32-bit entries: scenes beyond 65 535 entities / tree nodes
+constexpr int kQueueBytes = 384;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B), then 128 bytes of launch constants (view, sky, frame size: RTOW_LDS_VIEW)
+constexpr int kHistoryInRegisters = 8;   // path-history codes (one per surface hit of a path) every variant keeps in registers; the variants for deeper paths keep the rest in LDS rows
+
+// LDS of one workgroup of the sample kernel, front to back.  Every size is decided per launch (round 6; rounds 1 - 5 reserved 24 stack rows whatever the tree):
+//   [candidates: 8 rows][traversal stack: one row per inner level of THIS scene's tree]      rows of 1024 codes (2 bytes; 4 with wide codes) - one per-lane base, row offsets are immediates
+//   [wide codes only: the 256-byte dump row of the walk's prefetches]
+//   [path history: traceDepth - 8 rows of 1024 16-bit codes]                                 only the variants for paths deeper than 16 (and the generic ones): the codes of depth >= 8
+//   [wave queues 256 B][launch constants 128 B]
+//   [scene image: the whole blob, or the top of the node array]
+// The cover scene's tree is 11 levels deep: 26 KB come back, which is where the reference host's committed traceDepth 32 keeps its path history (48 KB) - rounds 1 - 5 kept it in a
+// 448-byte private segment per lane, cleared per sample: 186 GB of HBM writes per 10-batch launch (profiles/r05_hostdefault_pmc_summary.json).
+struct LdsPlan {
+    uint32_t stackRows;      // >= 1
+    uint32_t histOffset;     // byte offset of the history rows (0: none)
+    uint32_t histRows;
+    uint32_t frontBytes;     // everything in front of the wave queues
+    uint32_t sceneBytes;     // bytes of the blob staged behind the queues
+    uint32_t nodeCount;      // nodes [0, nodeCount) are LDS resident
+    bool allLds;
+};
+inline LdsPlan planLds(bool wide, const SceneLayout& L, uint32_t histRows, uint32_t budgetOverride)
+{
+    LdsPlan p{};
+    const uint32_t codeBytes = wide ? 4u : 2u;
+    p.stackRows = L.bvhDepth < 1u ? 1u : L.bvhDepth;
+    uint32_t front = ((uint32_t)kCandCapacity + p.stackRows) * (uint32_t)kBlockThreads * codeBytes + (wide ? 256u : 0u);
+    p.histRows = histRows;
+    p.histOffset = histRows ? front : 0u;
+    front += histRows * (uint32_t)kBlockThreads * 2u;
+    p.frontBytes = front;
+    uint32_t budget = front + (uint32_t)kQueueBytes < (uint32_t)kLdsBytesMax ? (uint32_t)kLdsBytesMax - front - (uint32_t)kQueueBytes : 0u;
+    if (budgetOverride >= sizeof(GpuNode) && budgetOverride < budget) budget = budgetOverride;      // development aid: small scenes through the tree-in-HBM kernels
+    if (L.totalBytes <= budget && !wide) {
+        p.sceneBytes = L.totalBytes; p.nodeCount = L.nodeCount; p.allLds = true;
+    } else {
+        // too large for LDS: stage the top of the (breadth-first) node array, read the rest through L2
+        uint32_t nodes = budget / (uint32_t)sizeof(GpuNode);
+        if (nodes > L.nodeCount) nodes = L.nodeCount;
+        p.nodeCount = nodes; p.sceneBytes = nodes * (uint32_t)sizeof(GpuNode); p.allLds = false;
+    }
+    return p;
+}
+// History words of the variant that serves a launch (launchByDiagGeo, rtow_sample_kernel.hip.h): 4 / 8 = every code in registers (trace depth <= 8 / <= 16), 32 = the generic
+// variants, whose codes beyond kHistoryInRegisters live in LDS rows - the host sizes the launch's LDS from this (rtow_api.hip)
+inline int historyWords(int noiseColor, bool perSample, bool wide, bool ties, bool fullDiag, int traceDepth)
+{
+    if (noiseColor != RTOW_NOISE_WHITE) return 32;
+    if (perSample) return (!ties && !wide && !fullDiag && traceDepth <= 8) ? 4 : 32;
+    if (fullDiag) return 32;
+    if (traceDepth <= 8) return 4;
+    if (traceDepth <= 16 && (!wide || ties)) return 8;
+    return 32;
+}
 constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: first slot empty, second not - "no list, walk the tree"
 constexpr unsigned kSampleGroup = 16;   // RTOW_RNG_PER_SAMPLE: samples per work unit (part of that policy's definition: partial sums are per group)
-constexpr int kQueueBytes = 384;   // per-wave pixel-ticket chunk {next, end, needDone, chunk} (16 waves x 16 B), then 128 bytes of launch constants (view, sky, frame size: RTOW_LDS_VIEW)
 constexpr int kMaxChain = 16;      // successive batches one launch can run (rtowSampleBatchChainDevice)
 constexpr int kLocalHitEntries = 24;                // entries of a ray's hit list a lane holds itself; longer lists continue in SampleKernelArgs.hitSpill
 constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0, scenes with volumes (long lists are their normal case)
@@ -98,6 +148,7 @@ struct SampleKernelArgs {
     SceneLayout layout;
     uint32_t ldsSceneBytes;  // bytes of the blob staged into LDS (whole blob, or a node prefix)
     uint32_t ldsNodeCount;   // nodes [0, ldsNodeCount) are LDS resident
+    uint32_t ldsStackRows, ldsHistOffset, ldsFrontBytes;   // this launch's LDS plan (LdsPlan above): traversal-stack rows, where the path-history rows start (0: none), where the wave queues start
 
     // work distribution
     unsigned int* workCounter;            // zeroed before the launch; counts 64-pixel ticket chunks
@@ -240,14 +291,14 @@ hipError_t launchCombineFinalize(const RtowCombineParams& p, const float* inColo
 hipError_t launchAddAccum(size_t pixels, float* const dst[4], const float* const src[4], hipStream_t stream);
 // rows first, first + step, ... (`rows` of them, `rowFloats` floats each) of a full-frame buffer -> / <- one contiguous block
 // bits of tieBits -> entries of tieRedo (one per marked pixel; `batches` per pixel, batch index in bits 27.., for a batch group)
-hipError_t launchCollectTiedPixels(const unsigned* tieBits, unsigned words, unsigned* tieRedo, unsigned capacity, unsigned batches, uint32_t* overflowFlag, hipStream_t stream);
+hipError_t launchCollectTiedPixels(const unsigned* tieBits, unsigned words, unsigned* tieRedo, unsigned capacity, unsigned batches, uint32_t* overflowFlag, unsigned busyAt, hipStream_t stream);
 hipError_t launchCopyRows(float* frame, float* packed, unsigned rowFloats, unsigned rows, unsigned first, unsigned step, bool toFrame, hipStream_t stream);
 // accum[row] += src_0[row] ... += src_{groups-1}[row] (group order) for rows first, first + step, ...; src_g = ownPartial (frame layout) for g == own, else packed rows at recv + g * regionFloats
 hipError_t launchFoldRows(float* accum, const float* ownPartial, const float* recv, size_t regionFloats, unsigned rowFloats, unsigned rows, unsigned first, unsigned step,
                           unsigned groups, unsigned own, hipStream_t stream);
 
 // rtowProbeNearestHit (rtow_probe.hip): one ray walked on the host through the scene's host image (derived entity transforms included); false = miss
-bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const float origin[3], const float direction[3], float time, float* distance, int* entity);
+bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const int32_t* entityOfPrim, const float origin[3], const float direction[3], float time, float* distance, int* entity);
 
 // same-XCD hand-over litmus of the chained launches (rtow_kernels.hip): pairs of workgroups that ran on one XCD, stale dwords seen, waits that timed out
 hipError_t runXcdCoherenceLitmus(int cuCount, hipStream_t stream, unsigned* outPairs, unsigned* outStale, unsigned* outTimeouts);

@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(1024) regroup_tickets_kernel(unsigned short* _
             // key = primary << 48 | owned-pixel number << 16 | cost: the primary key is the ray count itself (t1 == 0) or its class (cost classes t1 < t2 < t3: sky only / ... ),
             // equal primaries keep their tile order, the ray count travels along
             const unsigned primary = t1 == 0u ? cost + 1u : 1u + (cost > t1 ? 1u : 0u) + (cost > t2 ? 1u : 0u) + (cost > t3 ? 1u : 0u);
-            key = ((unsigned long long)(primary > 0xffffu ? 0xffffu : primary) << 48) | ((unsigned long long)ticketMap[t] << 16) | (unsigned long long)cost;
+            // (the sort is descending: the pixel number goes in complemented, so that equal primaries come out in ASCENDING pixel order - their tile order)
+            key = ((unsigned long long)(primary > 0xffffu ? 0xffffu : primary) << 48) | ((unsigned long long)(0xffffffffu - ticketMap[t]) << 16) | (unsigned long long)cost;
         }
         regroupKeys[e] = key;
     }
@@ -264,7 +265,7 @@ __global__ void __launch_bounds__(1024) regroup_tickets_kernel(unsigned short* _
     for (unsigned e = threadIdx.x; e < n; e += 1024u) {
         const unsigned long long key = regroupKeys[e];
         const unsigned t = ticketOf(e);
-        ticketMap[t] = (unsigned)(key >> 16);
+        ticketMap[t] = 0xffffffffu - (unsigned)(key >> 16);
         pixelCost[t] = (unsigned short)(key & 0xffffull);
     }
 }
@@ -651,7 +652,7 @@ __global__ void __launch_bounds__(64) xcd_coherence_litmus_kernel(unsigned* stat
 
 // the tie watch's bitmap -> the fix-up launch's list (rtow_kernels.h: SampleKernelArgs.tieRedo); almost always all zero
 __global__ void __launch_bounds__(256) collect_tied_pixels_kernel(const unsigned* __restrict__ bits, unsigned words, unsigned* __restrict__ redo, unsigned capacity, unsigned batches,
-                                                                  uint32_t* overflowFlag)
+                                                                  uint32_t* overflowFlag, unsigned busyAt)
 {
     const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= words) return;
@@ -660,6 +661,7 @@ __global__ void __launch_bounds__(256) collect_tied_pixels_kernel(const unsigned
         const unsigned b = (unsigned)__builtin_ctz(v);
         v &= v - 1u;
         const unsigned k = atomicAdd(redo, batches);
+        if (k + batches > busyAt) overflowFlag[1] = 1u;           // correct, but many: the host sends an all-triangle scene that ties this often to its exact-tie kernels (rtow_api.hip kTieWatchBusy)
         for (unsigned q = 0; q < batches; q++) {
             if (k + q < capacity) redo[4u + k + q] = (q << 27) | (w * 32u + b);
             else *overflowFlag = 1u;                              // more tied pixel-batches than the list holds: RTOW_ERROR_CAPACITY on the host side
@@ -669,9 +671,9 @@ __global__ void __launch_bounds__(256) collect_tied_pixels_kernel(const unsigned
 
 } // namespace
 
-hipError_t launchCollectTiedPixels(const unsigned* tieBits, unsigned words, unsigned* tieRedo, unsigned capacity, unsigned batches, uint32_t* overflowFlag, hipStream_t stream)
+hipError_t launchCollectTiedPixels(const unsigned* tieBits, unsigned words, unsigned* tieRedo, unsigned capacity, unsigned batches, uint32_t* overflowFlag, unsigned busyAt, hipStream_t stream)
 {
-    hipLaunchKernelGGL(collect_tied_pixels_kernel, dim3((words + 255u) / 256u), dim3(256), 0, stream, tieBits, words, tieRedo, capacity, batches, overflowFlag);
+    hipLaunchKernelGGL(collect_tied_pixels_kernel, dim3((words + 255u) / 256u), dim3(256), 0, stream, tieBits, words, tieRedo, capacity, batches, overflowFlag, busyAt);
     return hipGetLastError();
 }
 

@@ -19,6 +19,8 @@
 // subtree on such a tie - the host only reads the distance.
 #include "rtow_sample_kernel.hip.h"
 
+#include <vector>
+
 namespace rtow {
 
 namespace {
@@ -44,7 +46,7 @@ void walk(const uint8_t* blob, const SceneLayout& L, V3 ro, V3 rd, float time, f
     const bool twoChildren = L.sphereCount > 1u;
     float best = __builtin_inff();
     int prim = -1;
-    int stack[RTOW_STACK_CAPACITY + 2];
+    std::vector<int> stack((size_t)L.bvhDepth + 2u);      // one entry per inner level of the tree that was built (never more pending far children than that)
     int sp = 0, cur = 0;
     while (cur >= 0) {
         float4 q0, q1, q2;
@@ -85,7 +87,8 @@ void walk(const uint8_t* blob, const SceneLayout& L, V3 ro, V3 rd, float time, f
         }
         if (inner == 2) {
             const int far = entry[1] < entry[0] ? 0 : 1;                       // near child first
-            if (sp < RTOW_STACK_CAPACITY + 2) stack[sp++] = next[far];
+            if ((size_t)sp == stack.size()) stack.resize(stack.size() * 2);      // (cannot happen for a tree within its own depth bound; never drop a subtree silently)
+            stack[sp++] = next[far];
             cur = next[1 - far];
         } else if (inner == 1) {
             cur = next[0];
@@ -99,8 +102,9 @@ void walk(const uint8_t* blob, const SceneLayout& L, V3 ro, V3 rd, float time, f
 
 } // namespace
 
-// blob: the HOST image of the scene, derived entity transforms included (rtowUploadScene copies them back).  Returns false on a miss.
-bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const float origin[3], const float direction[3], float time, float* distance, int* entity)
+// blob: the HOST image of the scene, derived entity transforms included (rtowUploadScene copies them back).  entityOfPrim: CompiledScene.entityOfPrim (all-triangle scenes
+// number their primitives in leaf order) or null.  Returns false on a miss.
+bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const int32_t* entityOfPrim, const float origin[3], const float direction[3], float time, float* distance, int* entity)
 {
     const V3 ro = v3(origin[0], origin[1], origin[2]), rd = v3(direction[0], direction[1], direction[2]);
     float t = __builtin_inff();
@@ -109,7 +113,7 @@ bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const float 
     else if (L.sceneKind == SCENE_KIND_SPHERES_MOTION) walk<SCENE_KIND_SPHERES_MOTION>(blob, L, ro, rd, time, t, prim);
     else walk<SCENE_KIND_GENERAL>(blob, L, ro, rd, time, t, prim);
     *distance = t;
-    *entity = prim;
+    *entity = prim >= 0 && entityOfPrim ? entityOfPrim[prim] : prim;
     return prim >= 0;
 }
 

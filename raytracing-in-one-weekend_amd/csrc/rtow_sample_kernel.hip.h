@@ -54,6 +54,14 @@
 #ifndef RTOW_COLD_VIEW
 #define RTOW_COLD_VIEW 1          // 0: A/B build in which every kernel holds the view's and the sky's launch constants in scalar registers through every stage
 #endif
+#ifndef RTOW_TRI_HOT
+#define RTOW_TRI_HOT 1        // 0: A/B build in which the all-triangle kinds test and shade from the 128-byte GpuPrim records (the compact GpuTriHot / GpuTriCold records are still uploaded)
+#endif
+#ifndef RTOW_PREFETCH
+#define RTOW_PREFETCH 0       // A/B builds, wide-code kernels: bit 0 = the far child's node is requested when it is pushed, bit 1 = a triangle's compact record when it is listed.
+                              // Measured on the 250 882-triangle mesh, same box (profiles/r06a_mesh_layout_prefetch_watch.json): 2 178 Msamples/s without, 2 090 with bit 0, 1 990 with
+                              // bit 1, 1 910 with both - every extra vector-memory request costs: the kernel is bound by its request path (one request per lane and node quad), not by latency alone
+#endif
 #ifndef RTOW_TIE_WATCH
 #define RTOW_TIE_WATCH 1      // 0: A/B build without the nearest-hit tie watch of the sphere kinds
 #endif
@@ -862,7 +870,60 @@ __host__ __device__ __forceinline__ bool general_hit(const SceneRefs& sc, const 
     return true;
 }
 
+// HitTests.Hit(Triangle) (RT/HitTests.cs:115-150) on the compact record of an all-triangle scene (GpuTriHot, rtow_scene.h): the same expressions as general_hit's triangle
+// branch on the same operands, up to the distance; the barycentric (u, v) are handed back instead of the blended normal, which only the ray's nearest hit needs (tri_normal_cold)
+template <bool ALL_LDS>
+__host__ __device__ __forceinline__ bool tri_hit_hot(const SceneRefs& sc, const SceneLayout& L, int i, V3 ro, V3 rd, float tMin, float& tOut, float& uOut, float& vOut)
+{
+    const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.triHotOffset) + (uint32_t)i * (uint32_t)sizeof(GpuTriHot));
+    const float4 a0 = p[0], a1 = p[1];
+    const float a2x = *reinterpret_cast<const float*>(p + 2);
+    const V3 e0 = v3(a0.x, a0.y, a0.z), e1 = v3(a0.w, a1.x, a1.y), v0 = v3(a1.z, a1.w, a2x);
+    const V3 pvec = cross(rd, e0);
+    const float det = dot(e1, pvec);
+    if (det == 0) return false;
+    const float invDet = RTOW_RCP(det);
+    const V3 tvec = sub(ro, v0);
+    const float u = dot(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    const V3 qvec = cross(tvec, e1);
+    const float v = dot(rd, qvec) * invDet;
+    if (v < 0 || u + v > 1) return false;
+    const float dist = dot(e0, qvec) * invDet;
+    if (dist < tMin || dist > __builtin_inff()) return false;
+    tOut = dist;
+    uOut = u;
+    vOut = v;
+    return true;
+}
+// the rest of that test for the hit that won: mul(tri.Normals, barycentricCoords) (RT/HitTests.cs:140-146) from the GpuTriCold record, and the entity's rotation
+template <bool ALL_LDS>
+__host__ __device__ __forceinline__ V3 tri_normal_cold(const SceneRefs& sc, const SceneLayout& L, int i, float u, float v, float4& rot)
+{
+    const float4* p = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.triColdOffset) + (uint32_t)i * (uint32_t)sizeof(GpuTriCold));
+    const float4 c0 = p[0], c1 = p[1];
+    const float c2x = *reinterpret_cast<const float*>(p + 2);
+    rot = p[3];
+    const float b0 = 1 - u - v;
+    const V3 n0 = v3(c0.x, c0.y, c0.z), n1 = v3(c0.w, c1.x, c1.y), n2 = v3(c1.z, c1.w, c2x);
+    return v3(n0.x * b0 + n1.x * u + n2.x * v, n0.y * b0 + n1.y * u + n2.y * v, n0.z * b0 + n1.z * u + n2.z * v);
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+// A request that brings one memory sector into the caches and lands in no register: a global -> LDS load of one dword per lane into a 256-byte dump row of the workgroup
+// (nothing reads it).  The walk of a tree that lives in HBM is a chain of dependent misses (profiles/r05_mesh_pmc_summary.json: 62 % of wave cycles in s_waitcnt, 5.7 L2
+// misses per ray); what is known ahead of its use - the far child that was just pushed, the triangle that was just listed - is asked for at once and arrives while the
+// near subtree is walked.  M0 (the LDS destination) is saved and restored around the instruction.
+__device__ __forceinline__ void prefetch_sector(const uint8_t* base, uint32_t byteOffset, uint32_t ldsDump)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(byteOffset), "s"(base), "s"(ldsDump) : "memory");
+#else
+    (void)base; (void)byteOffset; (void)ldsDump;
+#endif
+}
 
 // Raw VALU min/max (IEEE mode: a NaN operand yields the other operand).  __builtin_fminf/fmaxf would first canonicalise
 // both inputs (v_max_f32 x, x), which doubles the instruction count of the slab test for nothing.
@@ -896,36 +957,56 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 // tail -> head (:384-396); the codes are re-expanded at the fold, which reproduces the fold order bit for bit.
 // Depth <= 8 and <= 16 keep the codes in named 64-bit registers (an indexed array would be demoted to scratch).
 // ------------------------------------------------------------------------------------------------------------
+// Deeper paths (HW = 32: the generic variants, trace depth up to 64): the first kHistoryInRegisters codes in registers like the others, the rest in LDS - rows of 1024
+// 16-bit codes behind the traversal stack, [depth - 8][lane] (LdsPlan, rtow_kernels.h).  Rounds 1 - 5 kept 32 words per lane in a private segment and cleared them per sample
+// (the reference host's committed traceDepth 32: 186 GB of HBM writes per 10-batch launch); a path rarely gets that deep (2.5 segments on average), so the rows cost a few
+// ds_write_b16 per thousand hits, and nothing is cleared: a row entry is written before the fold reads it.
+struct HistRows { unsigned short* lane; };     // this lane's entry of row 0 (null where the variant keeps every code in registers)
 template <int HW> struct Hist {
     unsigned w[HW];
     __device__ __forceinline__ void clear() { for (int i = 0; i < HW; i++) w[i] = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code) { w[depth >> 1] |= code << ((unsigned)(depth & 1) * 16u); }
-    __device__ __forceinline__ unsigned get(int depth) const { return (w[depth >> 1] >> ((unsigned)(depth & 1) * 16u)) & 0xffffu; }
+    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows&) { w[depth >> 1] |= code << ((unsigned)(depth & 1) * 16u); }
+    __device__ __forceinline__ unsigned get(int depth, const HistRows&) const { return (w[depth >> 1] >> ((unsigned)(depth & 1) * 16u)) & 0xffffu; }
 };
 template <> struct Hist<4> {
     unsigned long long a, b;
     __device__ __forceinline__ void clear() { a = 0; b = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code)
+    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows&)
     {
         const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
         if (depth < 4) a |= v; else b |= v;
     }
-    __device__ __forceinline__ unsigned get(int depth) const { return (unsigned)((depth < 4 ? a : b) >> ((unsigned)(depth & 3) * 16u)) & 0xffffu; }
+    __device__ __forceinline__ unsigned get(int depth, const HistRows&) const { return (unsigned)((depth < 4 ? a : b) >> ((unsigned)(depth & 3) * 16u)) & 0xffffu; }
 };
 template <> struct Hist<8> {
     unsigned long long a, b, c, d;
     __device__ __forceinline__ void clear() { a = 0; b = 0; c = 0; d = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code)
+    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows&)
     {
         const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
         const int q = depth >> 2;
         if (q == 0) a |= v; else if (q == 1) b |= v; else if (q == 2) c |= v; else d |= v;
     }
-    __device__ __forceinline__ unsigned get(int depth) const
+    __device__ __forceinline__ unsigned get(int depth, const HistRows&) const
     {
         const int q = depth >> 2;
         const unsigned long long v = q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
         return (unsigned)(v >> ((unsigned)(depth & 3) * 16u)) & 0xffffu;
+    }
+};
+template <> struct Hist<32> {
+    Hist<4> head;
+    static_assert(kHistoryInRegisters == 8, "Hist<4> holds the register-resident part");
+    __device__ __forceinline__ void clear() { head.clear(); }
+    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows& rows)
+    {
+        if (depth < kHistoryInRegisters) head.set(depth, code, rows);
+        else rows.lane[(depth - kHistoryInRegisters) * kBlockThreads] = (unsigned short)code;
+    }
+    __device__ __forceinline__ unsigned get(int depth, const HistRows& rows) const
+    {
+        if (depth < kHistoryInRegisters) return head.get(depth, rows);
+        return rows.lane[(depth - kHistoryInRegisters) * kBlockThreads];
     }
 };
 
@@ -1035,7 +1116,8 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
                 constexpr bool TRI = KIND == SCENE_KIND_TRIANGLES || KIND == SCENE_KIND_TRIANGLES_TEXTURED;
                 const unsigned type = TRI ? (unsigned)RTOW_ENTITY_TRIANGLE : *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
                 V3 nl; float4 rq;
-                ok = general_hit<ALL_LDS, TRI>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq);
+                if (TRI && RTOW_TRI_HOT) { float uu, vv; ok = tri_hit_hot<ALL_LDS>(sc, L, i, ro, rd, 0.0f, t, uu, vv); }
+                else ok = general_hit<ALL_LDS, TRI>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq);
             } else {
                 V3 c; float r;
                 sphere_at<ALL_LDS, KIND == SCENE_KIND_SPHERES_MOTION>(sc, L, i, rtime, c, r);
@@ -1098,11 +1180,13 @@ __device__ __noinline__ __attribute__((unused)) float2 reference_counts(const ui
 // nodes; the tree is then read from HBM).
 constexpr int kGeoWide = 4;
 constexpr int geo_block_threads(int) { return kBlockThreads; }
-constexpr size_t geo_stack_bytes(int geo) { return (size_t)(RTOW_STACK_CAPACITY + kCandCapacity) * (size_t)geo_block_threads(geo) * ((geo & kGeoWide) ? 4u : 2u); }
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
+// DIAG: 0 = RayCount only; 1 = the FULL_DIAGNOSTICS counters of this library's own walk; 2 = those, or - when the launch carries the reference's tree
+// (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS) - the reference's counts through reference_counts, whose 64-entry stack is a private segment the other variants do without
+template <bool ALL_LDS, int KIND, int HW, int DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
 __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(const SampleKernelArgs A)
 {
+    constexpr bool FULL_DIAG = DIAG != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = (int)threadIdx.x;
     constexpr int BT = geo_block_threads(GEO);
@@ -1120,20 +1204,23 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool COLD_VIEW __attribute__((unused)) = RTOW_COLD_VIEW && !ALL_LDS && !LDS_VIEW;    // the view's and the sky's launch constants are read on use instead of held in scalar registers (REGEN)
     constexpr bool SPLIT_NODES = !ALL_LDS && !WIDE;      // node loads as ds_read / global_load behind a wave-uniform branch instead of flat loads (load_node)
     using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
-    constexpr int kStackBytesT = (int)geo_stack_bytes(GEO);
+    const uint32_t ldsFront = A.ldsFrontBytes;          // this launch's LDS plan (LdsPlan, rtow_kernels.h): where the wave queues start
 
     // ---- stage the scene image into LDS: coalesced 16 B per lane ----
     // [level][lane] uint16 arrays; within a wave lane l sits at 2*(l&31) + (l>>5), so the 32 lanes the LDS services together
     // touch 32 different dwords (= banks) whatever level each of them is at
     // (32-bit codes: one dword per lane, the natural order already is conflict free)
-    Code* const stack = reinterpret_cast<Code*>(smem) + (WIDE ? tid : (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1));
-    Code* const cand = stack + RTOW_STACK_CAPACITY * BT;                                       // [slot][lane] leaf candidates
+    const int swizzled = (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
+    Code* const cand = reinterpret_cast<Code*>(smem) + (WIDE ? tid : swizzled);                // [slot][lane] leaf candidates: the first kCandCapacity rows
+    Code* const stack = cand + kCandCapacity * BT;                                             // [level][lane]: A.ldsStackRows rows, one per inner level of this scene's tree
+    HistRows histRows;
+    histRows.lane = HW == 32 ? reinterpret_cast<unsigned short*>(smem + A.ldsHistOffset) + swizzled : nullptr;
     // {next, end} ticket chunk of this wave; chains: {.., needDone, chunk} = the chunk may only be handed out once chunkDone[chunk] >= needDone
-    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + kStackBytesT) + (tid >> 6) * 4;
-    uint8_t* const ldsScene = smem + kStackBytesT + kQueueBytes;
+    volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + ldsFront) + (tid >> 6) * 4;
+    uint8_t* const ldsScene = smem + ldsFront + kQueueBytes;
     if ((tid & 63) == 0) { waveQueue[0] = 0; waveQueue[1] = 0; waveQueue[2] = 0; waveQueue[3] = 0; }
     // launch constants only REGEN and SKY read (view: 22 floats, sky: 7 dwords, frame size: 2 floats), parked in LDS behind the wave queues (RTOW_LDS_VIEW)
-    float* const ldsConst = reinterpret_cast<float*>(smem + kStackBytesT + 256);
+    float* const ldsConst = reinterpret_cast<float*>(smem + ldsFront + 256);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (LDS_VIEW && tid < 31) {
         // copied dword by dword from the kernarg segment (a struct assignment from the by-value argument goes through a private copy)
@@ -1158,7 +1245,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     sc.ldsNodeCount = A.ldsNodeCount;
     const SceneLayout L = A.layout;
     const int traceDepth = A.traceDepth;
-    const bool refDiag = FULL_DIAG && A.refTree != nullptr;   // BoundsHitCount / CandidateCount count the reference's tree (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS)
+    const bool refDiag = DIAG == 2 && A.refTree != nullptr;   // BoundsHitCount / CandidateCount count the reference's tree (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS)
     const bool chained = A.chainCount > 1u;      // several successive batches in this launch (wave-uniform): coherent accumulator accesses, per-chunk hand-off
     // a one-entity scene has a root whose second child is a placeholder; its (inverted) box cannot be told from a real one by the
     // symmetric slab test, so it is masked explicitly (wave-uniform, costs one scalar AND per node visit)
@@ -1173,8 +1260,13 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool TEXTURED = BASE == SCENE_KIND_TEXTURED || BASE == SCENE_KIND_VOLUMES_TEXTURED || BASE == SCENE_KIND_TRIANGLES_TEXTURED; // Image textures present: albedo / emission / metallic / glossiness are per hit
     // Sphere kinds under the rank rule: a nearest hit shared by two DIFFERENT spheres is exact for rays of at most 16 hits only, so such a pixel is
     // not stored but handed to the exact-tie kernel of the same kind, which runs a second, tiny launch over the listed pixels (redo)
-    constexpr bool TIE_WATCH = RTOW_TIE_WATCH && !GENERAL && !EXACT_TIES && !PER_SAMPLE;
-    constexpr bool REDO_CAPABLE = !GENERAL && EXACT_TIES && !PER_SAMPLE;
+    // All-triangle scenes (round 6) are watched the same way: their exact-tie kernels carry the resolver's hit lists in scratch and spill twenty registers on top (the
+    // 250 882-triangle mesh ran on them: 896 bytes of private segment per lane), and a mesh only ties where a ray meets a shared edge to the last bit - the rank-rule
+    // kernel (119 registers, no scratch) traces the frame, the exact-tie kernel the handful of marked pixels.  Scenes that hold the same triangle twice tie everywhere
+    // and keep the exact-tie kernels (SceneLayout.tieWatchOk, rtow_bvh.cpp); so does a scene whose first watched launch marks more than a few thousand pixels (rtow_api.hip).
+    constexpr bool TRI_KIND = BASE == SCENE_KIND_TRIANGLES || BASE == SCENE_KIND_TRIANGLES_TEXTURED;
+    constexpr bool TIE_WATCH = RTOW_TIE_WATCH && (!GENERAL || TRI_KIND) && !EXACT_TIES && !PER_SAMPLE;
+    constexpr bool REDO_CAPABLE = (!GENERAL || TRI_KIND) && EXACT_TIES && !PER_SAMPLE;
     // (whether a launch watches / fixes up, and whether its batches are a group, are launch constants read from the kernarg segment where they are used - at pixel
     // boundaries and in the rare fallback store - not values that live in registers through every stage: the kernel sits at the edge of its register file)
 
@@ -1219,6 +1311,10 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     bool insideHit = false;          // the chosen "hit" is a scattering event inside the volume
     float hitTmin = 0;               // tMin of the test that produced the chosen hit (exit hits use entry + 0.001)
     constexpr bool TRIANGLES_ONLY = BASE == SCENE_KIND_TRIANGLES || BASE == SCENE_KIND_TRIANGLES_TEXTURED;   // every entity is a triangle: no type dispatch, no transform code
+    constexpr bool TRI_HOT = TRIANGLES_ONLY && RTOW_TRI_HOT;                                                    // ... tested from the compact GpuTriHot records; keptNormal.x / .y then carry the winner's (u, v)
+    constexpr bool PREFETCH_FAR = WIDE && !ALL_LDS && (RTOW_PREFETCH & 1) != 0;
+    constexpr bool PREFETCH_TRI = WIDE && !ALL_LDS && TRI_HOT && (RTOW_PREFETCH & 2) != 0;
+    const uint32_t ldsDump __attribute__((unused)) = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + ((uint32_t)kCandCapacity + A.ldsStackRows) * (uint32_t)BT * 4u);
     constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL || BASE == SCENE_KIND_TRIANGLES;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
     V3 keptNormal = v3(0, 0, 0);
 
@@ -1233,7 +1329,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         // the sky the path ended in, else the default 0 (a path cut off at TraceDepth that only met perfect mirrors / glass)
         V3 sampleAlbedo = ok ? skyColor : v3(0, 0, 0);
         if (firstNs >= 0) {
-            const unsigned code = hist.get(firstNs);
+            const unsigned code = hist.get(firstNs, histRows);
             const bool white = (code & 0x8000u) != 0;
             if (TEXTURED) {
                 const V3 refl = white ? v3(1, 1, 1) : v3(texHist[firstNs * 6 + 0], texHist[firstNs * 6 + 1], texHist[firstNs * 6 + 2]);
@@ -1279,7 +1375,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         tieAtBest = false;
         nHits = 0;
         st = ST_TRAV;
-        if (FULL_DIAG) { if (refDiag) { const float2 rc = reference_counts(A.refTree, ro, rd); boundsHits += rc.x; candidates += rc.y; } }   // FindHitCandidates(ray, ...) of this segment (:186)
+        if (DIAG == 2) { if (refDiag) { const float2 rc = reference_counts(A.refTree, ro, rd); boundsHits += rc.x; candidates += rc.y; } }   // FindHitCandidates(ray, ...) of this segment (:186)
     };
     // traversal finished: classify the result
     auto classify = [&]() {
@@ -1310,12 +1406,21 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         const int live = (int)__popcll(__ballot(st != ST_DEAD && st != ST_IDLE));
         auto need = [&](int k) { const int t = (live * A.tune[k] + 63) >> 6; return t < 1 ? 1 : t; };
         bool ran = false;
-        if ((int)__popcll(__ballot(st == ST_REGEN)) >= (force == ST_REGEN ? 1 : need(0))) {
+        // Pixel boundaries in company (round 6).  A lane that has finished its pixel (unit) runs two to three hundred instructions - stores, ticket, loads, seed, sample count - that
+        // nothing else in its wave takes part in: 1.2 lanes on average (profiles/r05_runs/run_r05u.sh), and the wave issues every one of them.  With A.tune[7] = K > 1 such a lane
+        // waits in ST_REGEN until K of the wave's live lanes want a boundary (or nothing else can run): the block then runs once for K lanes.  Scheduling only.
+        bool regenReady = st == ST_REGEN;
+        if (A.tune[7] > 1) {
+            const int wantPixel = (int)__popcll(__ballot(st == ST_REGEN && smp >= nsamp));
+            const int company = live < A.tune[7] ? live : A.tune[7];
+            if (wantPixel < company && force != ST_REGEN) regenReady = st == ST_REGEN && smp < nsamp;
+        }
+        if ((int)__popcll(__ballot(regenReady)) >= (force == ST_REGEN ? 1 : need(0))) {
             ran = true;
             STAGE_MARK(0);
             // ================= next sample of this pixel, or next pixel =================
             STAT_ADD(1, 1);
-            if (st == ST_REGEN) {
+            if (regenReady) {
                 STAT_LANES(2);
                 while (smp >= nsamp) {
                     // Pixel boundaries are rare (one per `spp` samples) and touch two dozen launch constants nothing else needs - buffer pointers,
@@ -1743,10 +1848,20 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     nc += leaf0 ? 1 : 0;
                     cand[nc * BT] = (Code)~c1;
                     nc += leaf1 ? 1 : 0;
+                    if (PREFETCH_TRI) {
+                        // the listed triangle's record is on its way while the walk goes on; both leaves of one parent are neighbours in leaf order
+                        if (leaf0) prefetch_sector(sc.glob, L.triHotOffset + (uint32_t)~c0 * (uint32_t)sizeof(GpuTriHot), ldsDump);
+                        if (leaf1) prefetch_sector(sc.glob, L.triHotOffset + (uint32_t)~c1 * (uint32_t)sizeof(GpuTriHot), ldsDump);
+                    }
                     const bool in0 = hit0 && c0 >= 0;
                     const bool in1 = hit1 && c1 >= 0;
                     const bool both = in0 && in1;
                     const bool swap = tmin1 < tmin0;                         // near child first
+                    if (PREFETCH_FAR) {
+                        // every pushed node is visited later (nothing is dropped at the pop): ask for it now
+                        const uint32_t farNode = (uint32_t)(swap ? c0 : c1);
+                        if (both && farNode >= sc.ldsNodeCount) prefetch_sector(sc.glob, L.nodeOffset + farNode * 64u, ldsDump);
+                    }
                     stack[sp * BT] = (Code)(swap ? c0 : c1);
                     const int next = both ? (swap ? c1 : c0) : (in0 ? c0 : c1);
                     const bool any = in0 || in1;
@@ -1828,8 +1943,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         }
                     } else if (GENERAL) {
                         const unsigned type = TRIANGLES_ONLY ? (unsigned)RTOW_ENTITY_TRIANGLE : *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)i * 4u) >> kPrimTypeShift;
-                        float t; V3 nl; float4 rq;
-                        if (general_hit<ALL_LDS, TRIANGLES_ONLY>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq)) {
+                        float t; V3 nl = v3(0, 0, 0); float4 rq;
+                        if (TRI_HOT ? tri_hit_hot<ALL_LDS>(sc, L, i, ro, rd, 0.0f, t, nl.x, nl.y) : general_hit<ALL_LDS, TRIANGLES_ONLY>(sc, L, i, type, ro, rd, rtime, 0.0f, t, nl, rq)) {
                             // two surfaces at the bit-identical distance: the reference's sorted hit list starts with the one that
                             // comes first in its tree's leaf order (rtow_reforder.h)
                             const unsigned* rank = reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.rankOffset));
@@ -1838,12 +1953,25 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             // conditions so that a lane winning BY THE TIE RULE took nl.x but kept the old normal's y and z: 1 pixel of the 1080p mesh
                             // frame with a 1-ulp wrong normal AOV, 4 097 pixels of the coplanar frame shaded off the wrong twin.
                             const bool tie = t == best && prim >= 0;
+                            if (TIE_WATCH) {
+                                // the watch of the all-triangle kinds (see TIE_WATCH above): same mark as the sphere kinds' below
+                                if (tie) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                    const SampleKernelArgs* rareArgs = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                                    asm volatile("" : "+s"(rareArgs));
+#else
+                                    const SampleKernelArgs* rareArgs = &A;
+#endif
+                                    unsigned* const bits = rareArgs->tieBits;
+                                    if (bits) atomicOr(bits + ((unsigned)pix >> 5), 1u << ((unsigned)pix & 31u));
+                                }
+                            }
                             const unsigned rankHeld = tie ? rank[prim] : 0u;
                             const bool take = t < best || (tie && rank[i] < rankHeld);
                             if (EXACT_TIES) tieAtBest = tie ? true : (t < best ? false : tieAtBest);
                             best = take ? t : best;
                             prim = take ? i : prim;
-                            if (KEEP_NORMAL) { keptNormal.x = take ? nl.x : keptNormal.x; keptNormal.y = take ? nl.y : keptNormal.y; keptNormal.z = take ? nl.z : keptNormal.z; }
+                            if (KEEP_NORMAL) { keptNormal.x = take ? nl.x : keptNormal.x; keptNormal.y = take ? nl.y : keptNormal.y; if (!TRI_HOT) keptNormal.z = take ? nl.z : keptNormal.z; }
                         }
                     } else {
                         V3 c; float r, t;
@@ -1903,7 +2031,8 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         if (KEEP_NORMAL) {
                             const unsigned type = TRIANGLES_ONLY ? (unsigned)RTOW_ENTITY_TRIANGLE : *reinterpret_cast<const unsigned*>(section<ALL_LDS>(sc, L.matIndexOffset) + (uint32_t)prim * 4u) >> kPrimTypeShift;
                             float t2; float4 rq;
-                            (void)general_hit<ALL_LDS, TRIANGLES_ONLY>(sc, L, prim, type, ro, rd, rtime, 0.0f, t2, keptNormal, rq);
+                            if (TRI_HOT) (void)tri_hit_hot<ALL_LDS>(sc, L, prim, ro, rd, 0.0f, t2, keptNormal.x, keptNormal.y);
+                            else (void)general_hit<ALL_LDS, TRIANGLES_ONLY>(sc, L, prim, type, ro, rd, rtime, 0.0f, t2, keptNormal, rq);
                         }
                     }
                 }
@@ -1922,7 +2051,12 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     cls = MAT_CLASS_VOLUME;
                 } else if (GENERAL) {
                     // re-run the winning primitive's test for its entity-space normal, then rotate it out (RT/Entity.cs:62-66)
-                    if (KEEP_NORMAL) {
+                    if (KEEP_NORMAL && TRI_HOT) {
+                        // TEST kept this hit's barycentric (u, v): the normal blend and the rotation come from the winner's GpuTriCold record
+                        float4 rq;
+                        const V3 nLocal = tri_normal_cold<ALL_LDS>(sc, L, prim, keptNormal.x, keptNormal.y, rq);
+                        N = normalize(rotate(rq, nLocal));
+                    } else if (KEEP_NORMAL) {
                         // TEST kept the entity-space normal of this very hit; only the rotation is fetched again (GpuPrim: [6] for triangles, else [0])
                         const float4* pp = reinterpret_cast<const float4*>(section<ALL_LDS>(sc, L.primOffset) + (uint32_t)prim * 128u);
                         const float4 rq = pp[(TRIANGLES_ONLY || (mi >> kPrimTypeShift) == RTOW_ENTITY_TRIANGLE) ? 6 : 0];
@@ -2091,7 +2225,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     randomEvents += roughness;
                 }
 
-                hist.set(depth, (white ? 0x8000u : 0u) | matIdx);                             // :311,330 (re-expanded at the fold)
+                hist.set(depth, (white ? 0x8000u : 0u) | matIdx, histRows);                             // :311,330 (re-expanded at the fold)
                 if (depth == 0) sampleNormal = N;                                             // :313-314
                 if (firstNs < 0 && !perfectSpecular) {                                        // :316-328: sampleAlbedo = emission + reflectance of THIS hit (see endSample)
                     sampleNormal = N;
@@ -2124,7 +2258,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             if (c & 0x40000000u) break;                                   // entry hit, early out
                             // exit hit before an entry hit: throw a ray backwards; inside iff it meets the inner side of a volume hull
                             const V3 bd = neg(rd);
-                            if (FULL_DIAG) { if (refDiag) { const float2 rc = reference_counts(A.refTree, ro, bd); boundsHits += rc.x; candidates += rc.y; } }   // FindHitCandidates(backwardsRay, ...) counts too (:495)
+                            if (DIAG == 2) { if (refDiag) { const float2 rc = reference_counts(A.refTree, ro, bd); boundsHits += rc.x; candidates += rc.y; } }   // FindHitCandidates(backwardsRay, ...) counts too (:495)
                             V3 einv = v3(RTOW_RCP(bd.x), RTOW_RCP(bd.y), RTOW_RCP(bd.z));                    // math.rcp + "convert NaN to INFINITY" (:409-412)
                             if (einv.x != einv.x) einv.x = __builtin_inff();
                             if (einv.y != einv.y) einv.y = __builtin_inff();
@@ -2258,7 +2392,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
 
                 V3 col = sky; // 0 * 1 + sky
                 for (int i = depth - 1; i >= 0; i--) {
-                    const unsigned code = hist.get(i);
+                    const unsigned code = hist.get(i, histRows);
                     const uint8_t* mp = section<ALL_LDS>(sc, L.materialOffset) + (code & 0x7fffu) * 64u;
                     const float4 m0 = *reinterpret_cast<const float4*>(mp);
                     const float2 m1 = *reinterpret_cast<const float2*>(mp + 16);
@@ -2300,11 +2434,13 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     }
 }
 
-template <bool ALL_LDS, int KIND, int HW, bool FULL_DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
+template <bool ALL_LDS, int KIND, int HW, int DIAG, int NOISE, bool PER_SAMPLE, int GEO = 0>
 hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
-    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE, PER_SAMPLE, GEO>;
-    const size_t ldsBytes = geo_stack_bytes(GEO) + (size_t)kQueueBytes + args.ldsSceneBytes;
+    auto k = sample_batch_kernel<ALL_LDS, KIND, HW, DIAG, NOISE, PER_SAMPLE, GEO>;
+    const size_t ldsBytes = (size_t)args.ldsFrontBytes + (size_t)kQueueBytes + args.ldsSceneBytes;
+    // the launch's LDS plan must be the plan of THIS variant: history rows where the codes beyond the registers go, a stack row per level of the tree
+    if (args.ldsStackRows < 1u || ldsBytes > (size_t)kLdsBytesMax || (HW == 32 && args.traceDepth > kHistoryInRegisters && args.ldsHistOffset == 0u)) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(numBlocks), dim3(geo_block_threads(GEO)), ldsBytes, stream, args);
@@ -2332,25 +2468,27 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
     constexpr bool TIES = (KIND & kExactTiesBit) != 0;
     constexpr bool WIDE = (GEO & kGeoWide) != 0;
     const bool fullDiag = args.diagnostics && args.diagnosticsStride >= 16;
-    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_BLUE, false, GEO>(args, numBlocks, stream);
-    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false, GEO>(args, numBlocks, stream);
+    // (which history width serves the launch is historyWords' decision - rtow_kernels.h - because the host sizes the launch's LDS from it)
+    const int hw = historyWords(args.noiseColor, args.unitRecords != nullptr, WIDE, TIES, fullDiag, args.traceDepth);
+    if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_BLUE, false, GEO>(args, numBlocks, stream);
+    if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false, GEO>(args, numBlocks, stream);
     if (args.unitRecords) {      // RTOW_RNG_PER_SAMPLE
-        if constexpr (!TIES && !WIDE) if (!fullDiag && args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
-        return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
+        if constexpr (!TIES && !WIDE) if (hw == 4) return launchVariant<ALL_LDS, KIND, 4, 0, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
+        return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
     }
+    if (hw == 4) return launchVariant<ALL_LDS, KIND, 4, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
     if constexpr (WIDE) {
-        if constexpr (!TIES || kTiesWithShortHistory<KIND>) { if (!fullDiag && args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
-        if constexpr (TIES) { if (!fullDiag && args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
-        return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+        if constexpr (TIES) { if (hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
     } else {
         // (16-word history variants for depth 17 .. 32 - the reference host's own default traceDepth - were built again in round 5 and measured under group launches, the
-        // adaptive schedule and single launches: 2 - 10 % SLOWER than the generic 32-word kernels everywhere (the eight register pairs are demoted to scratch behind their
-        // select chains at 128 VGPRs: profiles/r05e_history16_variants.json); removed again)
-        if (fullDiag) return launchVariant<ALL_LDS, KIND, 32, true, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
-        if constexpr (!TIES || kTiesWithShortHistory<KIND>) if (args.traceDepth <= 8) return launchVariant<ALL_LDS, KIND, 4, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
-        if (args.traceDepth <= 16) return launchVariant<ALL_LDS, KIND, 8, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
-        return launchVariant<ALL_LDS, KIND, 32, false, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+        // adaptive schedule and single launches: 2 - 10 % SLOWER than the generic 32-word kernels everywhere (profiles/r05e_history16_variants.json); removed again.  Round 6:
+        // the generic kernels keep the codes beyond depth 8 in LDS rows instead of a private segment)
+        if (hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+        if (!fullDiag) return launchVariant<ALL_LDS, KIND, 32, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
     }
+    // FULL_DIAGNOSTICS records (and every deeper wide-code launch): the counters of this library's own walk, or - a variant of its own, with a private segment - the reference's
+    if (args.refTree) return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+    return launchVariant<ALL_LDS, KIND, 32, 1, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
 }
 
 template <int KIND>

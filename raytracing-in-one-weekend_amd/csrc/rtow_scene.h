@@ -107,6 +107,27 @@ struct GpuPrim {
 };
 static_assert(sizeof(GpuPrim) == 128, "GpuPrim must be 128 bytes");
 
+// All-triangle scenes (SCENE_KIND_TRIANGLES*: what the reference's live host produces, one entity per mesh triangle, UNITY/Raytracer.cs:1193-1198) number their
+// entities in the LEAF ORDER of this library's tree and carry, next to the GpuPrim records, two compact ones:
+//   GpuTriHot   what the exact test reads for EVERY candidate: the two edges and the first vertex (RT/EntityTypes/Triangle.cs:8-12 `Data`), one 64-byte memory sector
+//               per triangle, siblings of a leaf parent next to each other - a quarter-million-triangle mesh keeps 16 MB of these hot instead of 32 MB of GpuPrim
+//   GpuTriCold  what only the WINNER needs, in HIT: the three vertex normals and the entity's rotation (the barycentric blend of RT/HitTests.cs:140-146 runs there, on
+//               the (u, v) the test kept - the same float program on the same operands)
+// Texture coordinates stay in the GpuPrim record (textured meshes re-run the winner's test on it in HIT, as before).
+#ifndef RTOW_TRI_HOT_BYTES
+#define RTOW_TRI_HOT_BYTES 64
+#endif
+struct GpuTriHot {
+    float e0[3], e1[3], v0[3];                       // q0 = (e0.xyz e1.x)  q1 = (e1.yz v0.xy)  q2 = (v0.z - - -)
+    float pad[RTOW_TRI_HOT_BYTES / 4 - 9];
+};
+struct GpuTriCold {
+    float n0[3], n1[3], n2[3];                       // q0 = (n0.xyz n1.x)  q1 = (n1.yz n2.xy)  q2 = (n2.z - - -)
+    float pad[3];
+    float rot[4];                                    // q3
+};
+static_assert(sizeof(GpuTriHot) == RTOW_TRI_HOT_BYTES && (RTOW_TRI_HOT_BYTES == 48 || RTOW_TRI_HOT_BYTES == 64) && sizeof(GpuTriCold) == 64, "triangle records");
+
 enum : uint32_t {
     SCENE_KIND_SPHERES = 0,        // identity-rotation static spheres: GpuSphere only
     SCENE_KIND_SPHERES_MOTION = 1, // identity-rotation spheres, some moving: GpuSphere + GpuMotion
@@ -141,7 +162,9 @@ struct SceneLayout {
     uint32_t rankOffset;                    // uint32 per entity when sceneKind >= SCENE_KIND_GENERAL: place in the reference tree's leaf order (rtow_reforder.h)
     uint32_t commonTimeRange;               // 1: every moving entity has the same TimeRange (the generated scenes: (0, 1)); then the kernel evaluates
     float commonT0, commonT1;               //    clamp(unlerp(t0, t1, ray.Time), 0, 1) (RT/Entity.cs:124-127) once per sample instead of once per sphere test
-    uint32_t pad[3];
+    uint32_t triHotOffset, triColdOffset;   // GpuTriHot[sphereCount], GpuTriCold[sphereCount] when sceneKind == SCENE_KIND_TRIANGLES / _TEXTURED (entities in leaf order), else 0
+    uint32_t tieWatchOk;                    // all-triangle scenes: no two entities are the same triangle, so nearest-hit ties are rare events (shared edges) and the rank-rule kernels may
+                                            // trace the frame with the tie watch on, the exact-tie kernels only the marked pixels; 0: exact-tie kernels for every pixel
 };
 
 } // namespace rtow

@@ -583,6 +583,33 @@ def _quad(s, p00, p10, p11, p01, material, uv0=(0.0, 0.0), uv1=(1.0, 1.0)):
     s.add_triangle(p00, p11, p01, material, uvs=((u0, v0), (u1, v1), (u0, v1)))
 
 
+def triangle_layers_scene(layers=20, duplicate=False):
+    """An all-triangle scene (what the reference's live host produces) built to tie: `layers` parallel walls of two triangles each across the whole view, so that
+    a ray has more than 16 hits, and in front of them two DIFFERENT triangles that meet every ray through the smaller one at bit-identical distance: the second is the
+    first scaled by two about their common first vertex (Data = {2 e0, 2 e1, v0}: the determinant and the numerator of HitTests.Hit(Triangle) both pick up an exact factor
+    of four, RT/HitTests.cs:116-139), in another material - a tie that only the reference's whole hit-list procedure settles.
+    `duplicate`: the same front triangle twice on top (the scene then keeps the exact-tie kernels for every pixel: SceneLayout.tieWatchOk = 0)."""
+    s = Scene("triangle_layers_dup" if duplicate else "triangle_layers")
+    mats = [lambertian((0.8, 0.25, 0.2)), metal((0.9, 0.9, 0.9), 0.0), dielectric(1.5), standard((0.05, 0.05, 0.05), 0.0, 0.0, emission=(2.0, 1.6, 1.1)),
+            lambertian((0.15, 0.65, 0.25)), metal((0.8, 0.6, 0.2), 0.3), dielectric(1.33)]
+    order = [int(k) for k in np.random.default_rng(29).permutation(layers)]               # not in depth order
+    for k in order:
+        z = -0.25 * (k + 1)
+        m = mats[(2 + k * 3) % len(mats)]
+        if k % 2: _quad(s, (-6, -4, z), (6, -4, z), (6, 4, z), (-6, 4, z), m)
+        else:
+            s.add_triangle((-6, -4, z), (6, -4, z), (-6, 4, z), m)
+            s.add_triangle((6, -4, z), (6, 4, z), (-6, 4, z), m)
+    # the tied pair: v1 = (-4, -3, 0), small = v1 + {(4, 0, 0), (0, 3.5, 0)}, large = v1 + {(8, 0, 0), (0, 7, 0)}; and a second pair mirrored about the view axis
+    s.add_triangle((-4.0, -3.0, 0.0), (0.0, -3.0, 0.0), (-4.0, 0.5, 0.0), mats[0])
+    s.add_triangle((-4.0, -3.0, 0.0), (4.0, -3.0, 0.0), (-4.0, 4.0, 0.0), mats[3])
+    s.add_triangle((4.0, 3.0, 0.0), (0.0, 3.0, 0.0), (4.0, -0.5, 0.0), mats[1])
+    s.add_triangle((4.0, 3.0, 0.0), (-4.0, 3.0, 0.0), (4.0, -4.0, 0.0), mats[4])
+    if duplicate: s.add_triangle((-4.0, -3.0, 0.0), (0.0, -3.0, 0.0), (-4.0, 0.5, 0.0), mats[5])
+    s.camera = {"position": [0.3, 0.2, 7.0], "target": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "vfov": 40.0, "aperture": 0.0}
+    return s
+
+
 def textured_scene(triangles_only=False):
     """Triangle meshes with Image textures on every texture slot (albedo, emission, glossiness, metallic; Standard and Dielectric),
     a constant-scalar texture, a null image pointer, and image-textured spheres / rects (whose texture coordinates are always 0).

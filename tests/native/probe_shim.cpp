@@ -8,7 +8,7 @@
 #include "../../raytracing-in-one-weekend_amd/csrc/rtow_bvh.h"
 
 namespace rtow {
-bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const float origin[3], const float direction[3], float time, float* distance, int* entity);
+bool probeNearestHitHost(const uint8_t* blob, const SceneLayout& L, const int32_t* entityOfPrim, const float origin[3], const float direction[3], float time, float* distance, int* entity);
 }
 
 static rtow::CompiledScene g_scene;
@@ -22,5 +22,5 @@ extern "C" int shim_probe_compile(const RtowSceneDesc* desc)
 
 extern "C" int shim_probe(const float* origin, const float* direction, float time, float* distance, int* entity)
 {
-    return rtow::probeNearestHitHost(g_scene.blob.data(), g_scene.layout, origin, direction, time, distance, entity) ? 1 : 0;
+    return rtow::probeNearestHitHost(g_scene.blob.data(), g_scene.layout, g_scene.entityOfPrim.empty() ? nullptr : g_scene.entityOfPrim.data(), origin, direction, time, distance, entity) ? 1 : 0;
 }

@@ -226,6 +226,15 @@ def test_bench_with_two_ranks_runs_end_to_end_through_the_c_abi_gather(rt):
     parts = out["partitions"]
     assert set(parts) >= {"tiles", "hybrid"} and all(v["value"] > 0 for v in parts.values())
     assert abs(parts["hybrid"]["value"] - out["value"]) < 1e-6 * max(out["value"], 1.0)       # `value` is the reference-stream partition that scales
+    # both partitions as first-class blocks, each with its own figures and its own self-check (north_star's tile partition: one gather per batch, the single-GPU frame bit for bit)
+    for k, collectives in (("tiles", 1), ("hybrid", 2)):
+        b = out[k]
+        assert b["value"] > 0 and b["ms_per_step"] > 0 and b["n_gpus"] == 2 and b["collectives_per_step"] == collectives, b
+        assert b["is_value"] == (k == "hybrid")
+        chk = b["self_check"]
+        assert chk["bit_identical_to_the_same_sub_batches_on_one_gpu"] and chk["success_counts_equal_the_sequential_accumulation"], chk
+        assert chk["max_abs_mean_colour_difference_to_the_sequential_accumulation"] <= 1e-4
+    assert out["tiles"]["self_check"]["max_abs_mean_colour_difference_to_the_sequential_accumulation"] == 0.0      # tiles: the very frame
 
 
 # ---------------------------------------------------------------------------------------------------

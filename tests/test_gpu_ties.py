@@ -166,3 +166,74 @@ def test_tie_lists_longer_than_the_default_capacity_grow(rt, oracle, flags):
         assert np.array_equal(r["diag"][:, 0], wdiag[0][:, 0])
         if flags:
             assert ctx.scene_info().hitListCapacity == 142
+
+
+# ---- round 6: all-triangle scenes are watched the same way (the reference's live host makes one entity per mesh triangle, UNITY/Raytracer.cs:1193-1198) ----
+TW, TH = 96, 64
+
+
+def _triangle_frames(rt, oracle, scene, flags, mode, seeds=(31, 32, 33), spp=3, depth=6):
+    n = TW * TH
+    desc = scene.desc()
+    plist = [rt.scenes.make_params(scene, TW, TH, spp=spp, trace_depth=depth, seed=s, diagnostics_stride=4) for s in seeds]
+    start = _start(n, 5)
+    with rt.Context(0, flags=flags) as ctx:
+        ctx.upload_scene(desc)
+        if mode == "plain":
+            acc = {k: v.copy() for k, v in start.items()}
+            for p in plist:
+                r = rt.sample_batch_host(ctx, p, acc)
+                acc = {k: r[k] for k, _ in KEYS}
+            got = [acc]
+            want = [_oracle_batches(oracle, scene, plist, start)[0]]
+        elif mode == "chain":
+            bufs = [rt.DeviceBuffer(ctx).upload(start[k]) for k, _ in KEYS]
+            rt.lib.check(rt.sample_batch_chain_device(ctx, plist, bufs, bufs), "rtowSampleBatchChainDevice")
+            ctx.synchronize()
+            got = [{k: b.download(np.float32, (n, c)) for (k, c), b in zip(KEYS, bufs)}]
+            want = [_oracle_batches(oracle, scene, plist, start)[0]]
+        else:
+            src = [rt.DeviceBuffer(ctx).upload(start[k]) for k, _ in KEYS]
+            outs = [[rt.DeviceBuffer(ctx, n * c * 4).zero() for _, c in KEYS] for _ in plist]
+            rt.lib.check(rt.sample_batch_group_device(ctx, plist, src, outs), "rtowSampleBatchGroupDevice")
+            ctx.synchronize()
+            got = [{key: b.download(np.float32, (n, c)) for (key, c), b in zip(KEYS, outs[k])} for k in range(len(plist))]
+            want = [_oracle_batches(oracle, scene, [p], start)[0] for p in plist]
+        ctx.batch_status()
+    return sum(_differs(g, w) for g, w in zip(got, want))
+
+
+@pytest.mark.parametrize("mode", ["plain", "chain", "group"])
+def test_watched_triangle_scenes_equal_the_oracle(rt, oracle, mode):
+    """Walls of triangles, 23 hits per ray, two different pairs of triangles in the nearest plane: by default the rank-rule triangle kernels trace the frame and the
+    exact-tie kernels only the pixels that met a tie (tieWatchOk: no triangle twice); with every pixel on the exact-tie kernels (RTOW_CONTEXT_EXACT_TIES_ALWAYS) the
+    same frames; with the rank rule alone (RTOW_CONTEXT_EXACT_TIES_NEVER) the scene must differ somewhere - or it does not exercise the fix-up."""
+    scene = rt.scenes.triangle_layers_scene()
+    assert _triangle_frames(rt, oracle, scene, 0, mode) == 0
+    assert _triangle_frames(rt, oracle, scene, rt.abi.CONTEXT_EXACT_TIES_ALWAYS, mode) == 0
+    if mode == "plain":
+        assert _triangle_frames(rt, oracle, scene, rt.abi.CONTEXT_EXACT_TIES_NEVER, mode) > 0, "the rank rule alone agreed with the reference's sort: the test has lost its teeth"
+
+
+def test_a_triangle_scene_with_the_same_triangle_twice_keeps_the_exact_kernels(rt, oracle):
+    """Coinciding triangles tie over whole regions: no watch (SceneLayout.tieWatchOk = 0), every pixel through the exact-tie kernels, as before round 6."""
+    assert _triangle_frames(rt, oracle, rt.scenes.triangle_layers_scene(duplicate=True), 0, "plain") == 0
+
+
+def test_a_triangle_scene_that_ties_often_moves_to_the_exact_kernels(rt, oracle):
+    """The first watched launch of a frame in which thousands of pixels tie (more than 8 workgroups should render: kTieWatchBusy) is still correct, and sends the
+    scene to its exact-tie kernels for the launches after it; frames equal the oracle before and after."""
+    scene = rt.scenes.triangle_layers_scene()
+    w, h = 320, 200
+    n = w * h
+    desc = scene.desc()
+    plist = [rt.scenes.make_params(scene, w, h, spp=1, trace_depth=3, seed=s, diagnostics_stride=4) for s in (41, 42, 43)]
+    start = {k: np.zeros((n, c) if c > 1 else (n,), np.float32) for k, c in KEYS}
+    want, _ = _oracle_batches(oracle, scene, plist, start)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(desc)
+        acc = {k: v.copy() for k, v in start.items()}
+        for p in plist:
+            r = rt.sample_batch_host(ctx, p, acc)
+            acc = {k: r[k] for k, _ in KEYS}
+    assert _differs(acc, want) == 0

@@ -67,8 +67,8 @@ def _bodies(asm):
 
 
 def _variant(name):
-    """template arguments of sample_batch_kernel<ALL_LDS, KIND, HW, FULL_DIAG, NOISE, PER_SAMPLE, GEO> out of the mangled name"""
-    m = re.search(r"sample_batch_kernelILb([01])ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])ELi(\d+)EE", name)
+    """template arguments of sample_batch_kernel<ALL_LDS, KIND, HW, DIAG, NOISE, PER_SAMPLE, GEO> out of the mangled name"""
+    m = re.search(r"sample_batch_kernelILb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)EE", name)
     assert m, name
     return tuple(int(x) for x in m.groups())
 
@@ -89,7 +89,7 @@ def test_hot_variants_stay_spill_free(compiled, unit, kind):
     remarks, asm = compiled[unit]
     usage = _usage(remarks)
     bodies = _bodies(asm)
-    hot = 0
+    hot = deep = 0
     for name, u in usage.items():
         if "sample_batch_kernel" not in name:
             continue
@@ -104,7 +104,16 @@ def test_hot_variants_stay_spill_free(compiled, unit, kind):
             # not one scratch instruction and no private segment in any of them (round 5: the cubemap's constants are read on use - until then 36 / 68 bytes were reserved)
             assert u["scratch"] == 0, (name, u)
             assert not [l for l in bodies[name] if l.startswith("scratch_")], name
+        if hw == 32 and full_diag in (0, 1) and noise == 0 and not per_sample:
+            # the generic reference-stream kernels: depth 17 .. 64, and - DIAG 1 - the 16-byte FULL_DIAGNOSTICS records = the reference host's COMMITTED configuration (traceDepth 32,
+            # Assets/Prefabs/Raytracer.prefab:383-395; ProjectSettings.asset:590).  Round 6: their path history beyond depth 8 lives in LDS rows, the reference-tree counter walk in a
+            # variant of its own (DIAG 2) - no private segment (rounds 1 - 5: 448 bytes per lane, 186 GB of HBM writes per 10-batch launch), no spilled VGPR
+            deep += 1
+            # (the moving-sphere kind with its scene in LDS keeps 36 bytes of dead spill slots - nine of the view's constants, never touched: not one scratch instruction)
+            assert u["vgpr_spill"] == 0 and u["scratch"] <= (36 if kind == 1 and all_lds else 0), (name, u)
+            assert not [l for l in bodies[name] if l.startswith("scratch_")], name
     assert hot == 4, hot                                     # 2 history widths x (LDS | HBM)
+    assert deep == 5, deep                                   # DIAG 1: LDS, HBM, HBM with wide codes; DIAG 0: LDS, HBM (wide codes serve every deeper launch from DIAG 1: launchByDiagGeo)
     headline = [u for n, u in usage.items() if "sample_batch_kernel" in n and _variant(n) == (1, kind, 4, 0, 0, 0, 0)]
     assert len(headline) == 1 and headline[0]["vgprs"] <= 128, headline      # (the allocator takes all 128 since round 5 - no spill, no scratch; 124 / 127 before)
 
