@@ -39,6 +39,9 @@ static constexpr unsigned kGroupSlotBlock = RTOW_GROUP_SLOT_BLOCK;
 // 2 / 4 / 8 (+ 16 x mode): pixels regrouped by cost or class inside super-tiles of that many tiles (0 ... -5 %: measured, not used)
 #define RTOW_DEFAULT_REGROUP_SIDE 3
 #endif
+#ifndef RTOW_PACKED_STACK
+#define RTOW_PACKED_STACK 1   // 0: A/B build in which every wide-code scene keeps 32-bit stack rows
+#endif
 #ifndef RTOW_PIXEL_GATE
 #define RTOW_PIXEL_GATE 1     // lanes of a wave that must want a pixel boundary before the boundary block runs (1 = at once; the kernel's A.tune[7]); measured: see HISTORY.md round 6
 #endif
@@ -159,6 +162,7 @@ struct RtowContext_t {
     uint32_t redoSpillEntries = 0;
 
     // RtowContextOptions: behaviour switches and development knobs (nothing is read from the environment)
+    bool packedStack = false;             // ... and of those the all-triangle scenes of up to 262 144 nodes: 16 + 2-bit stack entries (kGeoPacked)
     bool wideCodes = false;               // current scene: more than 65 535 entities or tree nodes (32-bit candidate / stack codes, tree read from HBM)
     uint32_t flags = 0;
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
@@ -385,7 +389,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         // (an all-triangle scene under the tie watch launches its rank-rule kernels first and its exact-tie kernels on the marked pixels, with the one plan: the wider of the two)
         if (ctx->scene.layout.exactTies) hw = std::max(hw, historyWords(a.noiseColor, perSample, ctx->wideCodes, false, fullDiag, a.traceDepth));
         if (hw == 32 && a.traceDepth > kHistoryInRegisters) {
-            const LdsPlan plan = planLds(ctx->wideCodes, ctx->scene.layout, (uint32_t)(a.traceDepth - kHistoryInRegisters), ctx->ldsSceneBudget);
+            const LdsPlan plan = planLds(ctx->wideCodes, ctx->packedStack, ctx->scene.layout, (uint32_t)(a.traceDepth - kHistoryInRegisters), ctx->ldsSceneBudget);
             if (plan.frontBytes + (uint32_t)kQueueBytes + (uint32_t)sizeof(GpuNode) > (uint32_t)kLdsBytesMax) return RTOW_ERROR_CAPACITY;      // (trace depth <= 64 and 24 tree levels always fit)
             a.ldsStackRows = plan.stackRows; a.ldsHistOffset = plan.histOffset; a.ldsFrontBytes = plan.frontBytes;
             a.ldsSceneBytes = plan.sceneBytes; a.ldsNodeCount = plan.nodeCount;
@@ -394,7 +398,11 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice (RtowContextOptions.schedulerTune overrides)
     for (int i = 0; i < 8; i++) a.tune[i] = ctx->tune[i] < 1 ? 1 : ctx->tune[i];
     a.travSlice = ctx->tune[8] < 1 ? 1 : ctx->tune[8];
-    const int pixelGate = (ctx->regroupSide >> 12) & 15 ? (ctx->regroupSide >> 12) & 15 : RTOW_PIXEL_GATE;      // lanes that wait for company at a pixel boundary (kernel: A.tune[7]); schedulerTune[7] bits 12 .. 15
+    // Lanes that wait for company at a pixel boundary (kernel: A.tune[7]; schedulerTune[7] bits 12 .. 15 override).  Measured (profiles/r06d_pixel_boundaries_in_company.json):
+    // worth it only where boundaries are frequent - the reference host's 50 samples per batch: groups +2.5 % with 3 - 4 lanes, the per-sample policies' 16-sample units +1.6 % -
+    // and a loss of 1 - 3 % where a pixel takes hundreds of samples (the wait costs more than the shared instructions save): so by the samples a unit of work takes
+    const unsigned unitSamples = p->rngPolicy != RTOW_RNG_REFERENCE ? kSampleGroup : (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
+    const int pixelGate = (ctx->regroupSide >> 12) & 15 ? (ctx->regroupSide >> 12) & 15 : (unitSamples <= 64u && a.sampleCountMin == a.sampleCountMax ? 4 : RTOW_PIXEL_GATE);
     a.tune[7] = pixelGate;
     const uint32_t ownedPixels = a.totalWork;
     if (ownedPixels == 0) {
@@ -470,7 +478,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
 
     // ---- launch geometry: one persistent 1024-lane workgroup per CU (four waves per SIMD).  Smaller workgroups for launches that own about one pixel
     // per resident lane were built, measured and removed: results never depended on it.
-    a.wideCodes = ctx->wideCodes ? 1 : 0;
+    a.wideCodes = ctx->wideCodes ? (ctx->packedStack ? 2 : 1) : 0;
     a.blockThreads = kBlockThreads;
     int blocks = (int)((a.totalWork + (uint32_t)a.blockThreads - 1) / (uint32_t)a.blockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
@@ -1215,6 +1223,9 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     // every scene kind has kernels with 32-bit codes (volume kinds included: a triangle-mesh scene with one fog volume among the meshes)
     const bool wide = compiled.entityCount > 65535 || compiled.layout.nodeCount > 65535u || (ctx->flags & RTOW_CONTEXT_FORCE_WIDE_CODES) != 0;
     ctx->wideCodes = wide;
+    // all-triangle scenes of up to 262 144 tree nodes (the meshes the reference's live host makes, UNITY/Raytracer.cs:1193-1198): stack entries of 16 + 2 bits, so that twice the
+    // tree top fits LDS next to the stack rows (kGeoPacked)
+    ctx->packedStack = RTOW_PACKED_STACK && wide && triangleKind(compiled.layout.sceneKind) && compiled.layout.nodeCount <= (1u << 18);
     if (!ctx->userTune) {
         // Box-walk slice (node visits per trip).  16 for trees whose nodes come from LDS or L2 (with the hand-over at 3 candidates: cover 12 / 16 / 20
         // visits 9.34 / 9.48 / 9.23 Gsamples/s; 10 000 spheres, tree partly in LDS, 16 / 20 / 24: 8.00 / 7.81 / 7.45).  A tree of hundreds of
@@ -1231,7 +1242,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     std::lock_guard<std::mutex> sceneLock(ctx->sceneMu);          // rtowProbeNearestHit reads the host image under this lock only
     ctx->scene = std::move(compiled);
     // LDS of a launch: a traversal-stack row per inner level of THIS tree, then the scene image - whole, or the top of the node array (planLds, rtow_kernels.h)
-    ctx->ldsPlan = planLds(wide, ctx->scene.layout, 0u, ctx->ldsSceneBudget);
+    ctx->ldsPlan = planLds(wide, ctx->packedStack, ctx->scene.layout, 0u, ctx->ldsSceneBudget);
     ctx->ldsSceneBytes = ctx->ldsPlan.sceneBytes;
     ctx->ldsNodeCount = ctx->ldsPlan.nodeCount;
     ctx->haveScene = true;

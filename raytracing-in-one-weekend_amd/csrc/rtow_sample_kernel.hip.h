@@ -62,6 +62,9 @@
                               // Measured on the 250 882-triangle mesh, same box (profiles/r06a_mesh_layout_prefetch_watch.json): 2 178 Msamples/s without, 2 090 with bit 0, 1 990 with
                               // bit 1, 1 910 with both - every extra vector-memory request costs: the kernel is bound by its request path (one request per lane and node quad), not by latency alone
 #endif
+#ifndef RTOW_PINHOLE
+#define RTOW_PINHOLE 1        // 0: A/B build without the pinhole twins (kGeoPinhole)
+#endif
 #ifndef RTOW_TIE_WATCH
 #define RTOW_TIE_WATCH 1      // 0: A/B build without the nearest-hit tie watch of the sphere kinds
 #endif
@@ -1077,10 +1080,11 @@ enum : int {
 // that one ray: every hit of the ray (the walk again, not pruned, same box tests), in leaf order, through the same sort; element 0 wins.
 // A real call: it is rare, and its list lives in scratch.
 // ------------------------------------------------------------------------------------------------------------
-template <bool ALL_LDS, int KIND, typename Code, int BT>
+template <bool ALL_LDS, int KIND, typename Code, int BT, bool PACKED = false>
 __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs sc, const SceneLayout* layoutInKernarg, V3 ro, V3 rd, float rtime, Code* stack,
                                                                        uint32_t* overflowFlag, HitSpill spill)
 {
+    unsigned long long stackHi = 0ull;      // PACKED: bits 16, 17 of the entry at level k in bits 2k, 2k + 1 (see the kernel's stackPut / stackGet)
     // The scene layout is read through a pointer into the kernarg segment, the scene references travel by value: taking the address of the kernel's
     // own copies for a by-reference parameter forced those copies - 25 dwords every stage reads - into scratch for the whole kernel (the exact-tie
     // variants ran 7 - 17 % behind their rank-rule twins "whether the call is taken or not": most of it was this).
@@ -1128,9 +1132,13 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
             else *overflowFlag = 1u;                                                                       // more hits than the context's hitListCapacity: RTOW_ERROR_CAPACITY on the host side
         }
         const bool in0 = hit0 && c0 >= 0, in1 = hit1 && c1 >= 0;
-        if (in0 && in1) { stack[sp * BT] = (Code)c1; sp++; cur = c0; }
+        if (in0 && in1) {
+            stack[sp * BT] = (Code)c1;
+            if (PACKED) stackHi = (stackHi & ~(3ull << (2 * sp))) | ((unsigned long long)(((unsigned)c1 >> 16) & 3u) << (2 * sp));
+            sp++; cur = c0;
+        }
         else if (in0 || in1) cur = in0 ? c0 : c1;
-        else if (sp > 0) { sp--; cur = (int)stack[sp * BT]; }
+        else if (sp > 0) { sp--; cur = (int)((unsigned)stack[sp * BT] | (PACKED ? ((unsigned)(stackHi >> (2 * sp)) & 3u) << 16 : 0u)); }
         else cur = -1;
     }
     if (n == 0) return -1;
@@ -1179,6 +1187,13 @@ __device__ __noinline__ __attribute__((unused)) float2 reference_counts(const ui
 // loses 2.6 x - and removed in round 4); bit 2 = 32-bit traversal-stack / candidate codes (scenes of more than 65 535 entities or tree
 // nodes; the tree is then read from HBM).
 constexpr int kGeoWide = 4;
+// bit 3 = pinhole camera (RtowView.lensRadius == 0: the book-cover, 4K and 10 000-sphere configurations, LEGACY/Final Scene (Book 1).asset:15-18): the lens draw, the lens offset and
+// the view's `right` / `up` are not compiled in - six launch constants fewer in the scalar registers of kernels that spill two dozen of them into VGPR lanes.  Only the reference-stream
+// variants that keep their whole path history in registers have the twin (launchByDiagGeo).
+constexpr int kGeoPinhole = 8;
+// bit 4 (with bit 2) = packed traversal stack: scenes of up to 262 144 tree nodes keep a stack entry as a 16-bit row entry + two bits in a per-lane register pair, so that the stack
+// rows take 2 bytes per lane and level instead of 4 and the top of the tree that fits LDS next to them nearly doubles (the all-triangle kinds: the meshes the reference's live host makes)
+constexpr int kGeoPacked = 16;
 constexpr int geo_block_threads(int) { return kBlockThreads; }
 
 // DIAG: 0 = RayCount only; 1 = the FULL_DIAGNOSTICS counters of this library's own walk; 2 = those, or - when the launch carries the reference's tree
@@ -1193,6 +1208,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // the tie fix-up launch (SampleKernelArgs.redoMode) has nothing to do almost always: it leaves before it stages the scene
     if (A.redoMode) { if (__hip_atomic_load(A.tieRedo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return; }
     constexpr bool WIDE = (GEO & kGeoWide) != 0;
+    constexpr bool PINHOLE = (GEO & kGeoPinhole) != 0;
     // Camera-ray lists hold up to eight leaf-parent nodes with 16-bit codes (one uint4 per pixel, four registers), four with 32-bit codes.  Four covered 95.6 % of the
     // cover scene's pixels (pinhole camera), 93.6 % of the 10 000 spheres', 56.7 % with moving spheres and a lens; eight cover 100 / 99.9 / 88.5 %.  The pixels beyond four
     // are sphere edges in tiles of sky - the minority lanes whose walks wait longest for their stage (profiles/r04n): cover scene +1.1 % (10 batches per launch), +6.6 % as
@@ -1203,7 +1219,10 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool LDS_VIEW = (RTOW_LDS_VIEW & (ALL_LDS ? 1 : 2)) != 0;   // ... or read from an LDS copy (bit 0: kernels with the scene in LDS, bit 1: the others)
     constexpr bool COLD_VIEW __attribute__((unused)) = RTOW_COLD_VIEW && !ALL_LDS && !LDS_VIEW;    // the view's and the sky's launch constants are read on use instead of held in scalar registers (REGEN)
     constexpr bool SPLIT_NODES = !ALL_LDS && !WIDE;      // node loads as ds_read / global_load behind a wave-uniform branch instead of flat loads (load_node)
-    using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
+    constexpr bool PACKED = (GEO & kGeoPacked) != 0;
+    static_assert(!PACKED || WIDE, "the packed stack is a flavour of the wide-code kernels");
+    using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;                 // candidate codes
+    using StackCode = typename std::conditional<WIDE && !PACKED, unsigned, unsigned short>::type;  // traversal-stack row entries
     const uint32_t ldsFront = A.ldsFrontBytes;          // this launch's LDS plan (LdsPlan, rtow_kernels.h): where the wave queues start
 
     // ---- stage the scene image into LDS: coalesced 16 B per lane ----
@@ -1212,7 +1231,18 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // (32-bit codes: one dword per lane, the natural order already is conflict free)
     const int swizzled = (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
     Code* const cand = reinterpret_cast<Code*>(smem) + (WIDE ? tid : swizzled);                // [slot][lane] leaf candidates: the first kCandCapacity rows
-    Code* const stack = cand + kCandCapacity * BT;                                             // [level][lane]: A.ldsStackRows rows, one per inner level of this scene's tree
+    // [level][lane]: A.ldsStackRows rows, one per inner level of this scene's tree, behind the candidate rows
+    StackCode* const stack = reinterpret_cast<StackCode*>(smem + (size_t)kCandCapacity * BT * sizeof(Code)) + ((WIDE && !PACKED) ? tid : swizzled);
+    unsigned long long stackHi = 0ull;       // PACKED: bits 16, 17 of the entry at level k in bits 2k, 2k + 1 (24 levels: 48 bits)
+    auto stackPut = [&](int level, int v) {
+        stack[level * BT] = (StackCode)v;
+        if (PACKED) { const unsigned sh = 2u * (unsigned)level; stackHi = (stackHi & ~(3ull << sh)) | ((unsigned long long)(((unsigned)v >> 16) & 3u) << sh); }
+    };
+    auto stackGet = [&](int level) {
+        unsigned v = stack[level * BT];
+        if (PACKED) v |= ((unsigned)(stackHi >> (2u * (unsigned)level)) & 3u) << 16;
+        return (int)v;
+    };
     HistRows histRows;
     histRows.lane = HW == 32 ? reinterpret_cast<unsigned short*>(smem + A.ldsHistOffset) + swizzled : nullptr;
     // {next, end} ticket chunk of this wave; chains: {.., needDone, chunk} = the chunk may only be handed out once chunkDone[chunk] >= needDone
@@ -1314,7 +1344,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool TRI_HOT = TRIANGLES_ONLY && RTOW_TRI_HOT;                                                    // ... tested from the compact GpuTriHot records; keptNormal.x / .y then carry the winner's (u, v)
     constexpr bool PREFETCH_FAR = WIDE && !ALL_LDS && (RTOW_PREFETCH & 1) != 0;
     constexpr bool PREFETCH_TRI = WIDE && !ALL_LDS && TRI_HOT && (RTOW_PREFETCH & 2) != 0;
-    const uint32_t ldsDump __attribute__((unused)) = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + ((uint32_t)kCandCapacity + A.ldsStackRows) * (uint32_t)BT * 4u);
+    const uint32_t ldsDump __attribute__((unused)) = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + ((uint32_t)kCandCapacity * (uint32_t)sizeof(Code) + A.ldsStackRows * (uint32_t)sizeof(StackCode)) * (uint32_t)BT);
     constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL || BASE == SCENE_KIND_TRIANGLES;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
     V3 keptNormal = v3(0, 0, 0);
 
@@ -1409,8 +1439,11 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         // Pixel boundaries in company (round 6).  A lane that has finished its pixel (unit) runs two to three hundred instructions - stores, ticket, loads, seed, sample count - that
         // nothing else in its wave takes part in: 1.2 lanes on average (profiles/r05_runs/run_r05u.sh), and the wave issues every one of them.  With A.tune[7] = K > 1 such a lane
         // waits in ST_REGEN until K of the wave's live lanes want a boundary (or nothing else can run): the block then runs once for K lanes.  Scheduling only.
+        // Only the variants whose workloads have frequent boundaries carry the code (the generic ones: the reference host's 50 samples per batch at depth 32; the per-sample
+        // policies' 16-sample units): its mere presence brought the moving-sphere headline kernel's 36-byte private segment back.
+        constexpr bool PIXEL_COMPANY = HW == 32 || PER_SAMPLE;
         bool regenReady = st == ST_REGEN;
-        if (A.tune[7] > 1) {
+        if (PIXEL_COMPANY && A.tune[7] > 1) {
             const int wantPixel = (int)__popcll(__ballot(st == ST_REGEN && smp >= nsamp));
             const int company = live < A.tune[7] ? live : A.tune[7];
             if (wantPixel < company && force != ST_REGEN) regenReady = st == ST_REGEN && smp < nsamp;
@@ -1723,9 +1756,9 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     const SampleKernelArgs& VA = *viewArgs;
                     const RtowView& VW = LDS_VIEW ? *reinterpret_cast<const RtowView*>(ldsConst) : VA.view;
                     const float frameX = LDS_VIEW ? ldsConst[29] : VA.sizeX, frameY = LDS_VIEW ? ldsConst[30] : VA.sizeY;
-                    const V3 viewRight = v3(VW.right), viewUp = v3(VW.up);
+                    const V3 viewRight = PINHOLE ? v3(0, 0, 0) : v3(VW.right), viewUp = PINHOLE ? v3(0, 0, 0) : v3(VW.up);
                     const V3 viewLLC = v3(VW.lowerLeftCorner), viewH = v3(VW.horizontal), viewV = v3(VW.vertical);
-                    const float lensRadius = VW.lensRadius;
+                    const float lensRadius = PINHOLE ? 0.0f : VW.lensRadius;
                     float jx = 0.5f, jy = 0.5f;
                     const NoiseSite at{&A, (unsigned)cx, (unsigned)cy};
                     if (PER_SAMPLE) rng.begin_sample(at, (unsigned)pix, smp);
@@ -1828,7 +1861,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     int c0, c1;
                     load_node<ALL_LDS, SPLIT_NODES>(sc, L, cur, q0, q1, q2, c0, c1);
                     const int spm1 = sp > 0 ? sp - 1 : 0;
-                    const int popped = (int)stack[spm1 * BT];
+                    const int popped = stackGet(spm1);
                     // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
                     const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
                     const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
@@ -1862,7 +1895,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         const uint32_t farNode = (uint32_t)(swap ? c0 : c1);
                         if (both && farNode >= sc.ldsNodeCount) prefetch_sector(sc.glob, L.nodeOffset + farNode * 64u, ldsDump);
                     }
-                    stack[sp * BT] = (Code)(swap ? c0 : c1);
+                    stackPut(sp, swap ? c0 : c1);
                     const int next = both ? (swap ? c1 : c0) : (in0 ? c0 : c1);
                     const bool any = in0 || in1;
                     cur = any ? next : (sp > 0 ? popped : -1);
@@ -2025,7 +2058,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
 #else
                     const SampleKernelArgs* argsInKernarg = &A;                                                           // host pass of the HIP compiler: never executed
 #endif
-                    const int winner = resolve_nearest_tie<ALL_LDS, BASE, Code, BT>(sc, &argsInKernarg->layout, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
+                    const int winner = resolve_nearest_tie<ALL_LDS, BASE, StackCode, BT, PACKED>(sc, &argsInKernarg->layout, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
                     if (winner >= 0 && winner != prim) {
                         prim = winner;
                         if (KEEP_NORMAL) {
@@ -2296,9 +2329,9 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                     if (general_hit<ALL_LDS>(sc, L, ~cc, mw >> kPrimTypeShift, ro, bd, rtime, 0.0f, t, nl, rq) && dot(normalize(rotate(rq, nl)), bd) > 0) insideVolume = true;
                                 }
                                 const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
-                                if (in0 && in1) { stack[bsp * BT] = (Code)c1; bsp++; bcur = c0; }
+                                if (in0 && in1) { stackPut(bsp, c1); bsp++; bcur = c0; }
                                 else if (in0 || in1) bcur = in0 ? c0 : c1;
-                                else if (bsp > 0) { bsp--; bcur = (int)stack[bsp * BT]; }
+                                else if (bsp > 0) { bsp--; bcur = stackGet(bsp); }
                                 else bcur = -1;
                             }
                             if (insideVolume) { curVol = (int)(matOf(c) & 0xffffu); break; }
@@ -2476,6 +2509,19 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
         if constexpr (!TIES && !WIDE) if (hw == 4) return launchVariant<ALL_LDS, KIND, 4, 0, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
         return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_WHITE, true, GEO>(args, numBlocks, stream);
     }
+    // pinhole twins (kGeoPinhole) of the sphere kinds' register-history variants: what the benchmark configurations with aperture 0 run
+    // Only the kernels whose tree is beyond LDS have the twin: 10 000 spheres +0.9 % (118 VGPRs, nothing spilled); with the scene in LDS the twin spills 13 SGPRs instead of 25
+    // but four VGPRs into a 12-byte private segment, and runs exactly as fast as the general variant (profiles/r06e_pinhole_relax_alllambert.json)
+    constexpr bool HAS_PINHOLE_TWIN = RTOW_PINHOLE && !ALL_LDS && !WIDE && (KIND & 7) == SCENE_KIND_SPHERES;
+    // (with a lens radius of 0 the reference still adds right * 0 + up * 0 - a zero of either sign - to the origin and subtracts it from the lower left corner: that leaves every
+    // NON-ZERO component as it is, and only those; a view with a component that is exactly zero keeps the general variant, whose zeros carry the reference's signs)
+    const RtowView& vw = args.view;
+    const bool pinhole = vw.lensRadius == 0.0f && vw.origin.x != 0.0f && vw.origin.y != 0.0f && vw.origin.z != 0.0f &&
+                         vw.lowerLeftCorner.x != 0.0f && vw.lowerLeftCorner.y != 0.0f && vw.lowerLeftCorner.z != 0.0f;
+    if constexpr (HAS_PINHOLE_TWIN) {
+        if (pinhole && hw == 4) return launchVariant<ALL_LDS, KIND, 4, 0, RTOW_NOISE_WHITE, false, GEO | kGeoPinhole>(args, numBlocks, stream);
+        if (pinhole && hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO | kGeoPinhole>(args, numBlocks, stream);
+    }
     if (hw == 4) return launchVariant<ALL_LDS, KIND, 4, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
     if constexpr (WIDE) {
         if constexpr (TIES) { if (hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
@@ -2498,6 +2544,10 @@ template <bool ALL_LDS, int KIND>
 hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
     if constexpr (!ALL_LDS && kind_has_wide_codes<KIND>()) {
+        if constexpr ((KIND & 7) == SCENE_KIND_TRIANGLES || (KIND & 7) == SCENE_KIND_TRIANGLES_TEXTURED) {
+            if (args.wideCodes == 2) return launchByDiagGeo<false, KIND, kGeoWide | kGeoPacked>(args, numBlocks, stream);      // up to 262 144 nodes: 16 + 2-bit stack entries
+        }
+        if (args.wideCodes == 2) return hipErrorInvalidValue;
         if (args.wideCodes) return launchByDiagGeo<false, KIND, kGeoWide>(args, numBlocks, stream);
     }
     if (args.wideCodes) return hipErrorInvalidValue;                                    // refused at upload (rtow_api.hip): never reached

@@ -112,7 +112,7 @@ def test_hot_variants_stay_spill_free(compiled, unit, kind):
             # (the moving-sphere kind with its scene in LDS keeps 36 bytes of dead spill slots - nine of the view's constants, never touched: not one scratch instruction)
             assert u["vgpr_spill"] == 0 and u["scratch"] <= (36 if kind == 1 and all_lds else 0), (name, u)
             assert not [l for l in bodies[name] if l.startswith("scratch_")], name
-    assert hot == 4, hot                                     # 2 history widths x (LDS | HBM)
+    assert hot == (6 if kind == 0 else 4), hot               # 2 history widths x (LDS | HBM), + the pinhole twins of the static-sphere kernels whose tree is beyond LDS (GEO bit 3)
     assert deep == 5, deep                                   # DIAG 1: LDS, HBM, HBM with wide codes; DIAG 0: LDS, HBM (wide codes serve every deeper launch from DIAG 1: launchByDiagGeo)
     headline = [u for n, u in usage.items() if "sample_batch_kernel" in n and _variant(n) == (1, kind, 4, 0, 0, 0, 0)]
     assert len(headline) == 1 and headline[0]["vgprs"] <= 128, headline      # (the allocator takes all 128 since round 5 - no spill, no scratch; 124 / 127 before)
