@@ -681,6 +681,14 @@ def main():
                                                       "from the device-resident API without the queue-depth edit.  Between any two of its batches a consumer of the first one's outputs is enqueued (the metrics the "
                                                       "NEXT batches' adaptive sample counts are decided from), so a library that deferred a launch to fuse it with the next call would have to flush it at once - or change "
                                                       "what that reduction sees (DESIGN.md 8)")
+            if args.rng == "reference":
+                # north_star's lane-per-pixel-sample shape as far as it is built: RTOW_RNG_PER_SAMPLE (one xorshift32 generator per SAMPLE, work units of 16 samples, partial sums folded in
+                # group order) and its xoroshiro64** twin - another image by construction (not the reference's stream), bit-exact against the oracle's same policy; plain launches
+                for key, pol in (("per_sample", "per-sample"), ("per_sample_xoroshiro", "per-sample-xoroshiro")):
+                    mp = measure("tiles", pol, 1, max(4, args.steps // 2), 2)
+                    extras[key] = {"value": round(float(n) * spp * max(4, args.steps // 2) / mp["elapsed"] / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(mp["elapsed"] / max(4, args.steps // 2) * 1e3, 3),
+                                   "kernel_ms_per_step": round(mp["kernel_ms_per_step"], 3), "batches_per_launch": 1,
+                                   "note": "NOT the reference stream: one generator per sample (rngPolicy %d), units of 16 samples, unit records folded by fold_unit_records; one launch + fold per batch" % (1 if pol == "per-sample" else 2)}
             if args.chain > 1:
                 extras["group_fold"] = dict(timed_batches("group_fold", depth, spp, 4, args.steps, args.chain),
                                             note="the same steps as batch groups (rtowSampleBatchGroupDevice: every batch from zeroed inputs into its own partial sums, one launch per group) "

@@ -39,9 +39,6 @@ static constexpr unsigned kGroupSlotBlock = RTOW_GROUP_SLOT_BLOCK;
 // 2 / 4 / 8 (+ 16 x mode): pixels regrouped by cost or class inside super-tiles of that many tiles (0 ... -5 %: measured, not used)
 #define RTOW_DEFAULT_REGROUP_SIDE 3
 #endif
-#ifndef RTOW_PACKED_STACK
-#define RTOW_PACKED_STACK 1   // 0: A/B build in which every wide-code scene keeps 32-bit stack rows
-#endif
 #ifndef RTOW_PIXEL_GATE
 #define RTOW_PIXEL_GATE 1     // lanes of a wave that must want a pixel boundary before the boundary block runs (1 = at once; the kernel's A.tune[7]); measured: see HISTORY.md round 6
 #endif
@@ -162,7 +159,6 @@ struct RtowContext_t {
     uint32_t redoSpillEntries = 0;
 
     // RtowContextOptions: behaviour switches and development knobs (nothing is read from the environment)
-    bool packedStack = false;             // ... and of those the all-triangle scenes of up to 262 144 nodes: 16 + 2-bit stack entries (kGeoPacked)
     bool wideCodes = false;               // current scene: more than 65 535 entities or tree nodes (32-bit candidate / stack codes, tree read from HBM)
     uint32_t flags = 0;
     uint32_t ldsSceneBudget = 0;          // 0 = everything that fits
@@ -389,7 +385,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         // (an all-triangle scene under the tie watch launches its rank-rule kernels first and its exact-tie kernels on the marked pixels, with the one plan: the wider of the two)
         if (ctx->scene.layout.exactTies) hw = std::max(hw, historyWords(a.noiseColor, perSample, ctx->wideCodes, false, fullDiag, a.traceDepth));
         if (hw == 32 && a.traceDepth > kHistoryInRegisters) {
-            const LdsPlan plan = planLds(ctx->wideCodes, ctx->packedStack, ctx->scene.layout, (uint32_t)(a.traceDepth - kHistoryInRegisters), ctx->ldsSceneBudget);
+            const LdsPlan plan = planLds(ctx->wideCodes, ctx->scene.layout, (uint32_t)(a.traceDepth - kHistoryInRegisters), ctx->ldsSceneBudget);
             if (plan.frontBytes + (uint32_t)kQueueBytes + (uint32_t)sizeof(GpuNode) > (uint32_t)kLdsBytesMax) return RTOW_ERROR_CAPACITY;      // (trace depth <= 64 and 24 tree levels always fit)
             a.ldsStackRows = plan.stackRows; a.ldsHistOffset = plan.histOffset; a.ldsFrontBytes = plan.frontBytes;
             a.ldsSceneBytes = plan.sceneBytes; a.ldsNodeCount = plan.nodeCount;
@@ -478,7 +474,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
 
     // ---- launch geometry: one persistent 1024-lane workgroup per CU (four waves per SIMD).  Smaller workgroups for launches that own about one pixel
     // per resident lane were built, measured and removed: results never depended on it.
-    a.wideCodes = ctx->wideCodes ? (ctx->packedStack ? 2 : 1) : 0;
+    a.wideCodes = ctx->wideCodes ? 1 : 0;
     a.blockThreads = kBlockThreads;
     int blocks = (int)((a.totalWork + (uint32_t)a.blockThreads - 1) / (uint32_t)a.blockThreads);
     if (blocks > ctx->cuCount) blocks = ctx->cuCount; // persistent: one workgroup per CU
@@ -1223,9 +1219,6 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     // every scene kind has kernels with 32-bit codes (volume kinds included: a triangle-mesh scene with one fog volume among the meshes)
     const bool wide = compiled.entityCount > 65535 || compiled.layout.nodeCount > 65535u || (ctx->flags & RTOW_CONTEXT_FORCE_WIDE_CODES) != 0;
     ctx->wideCodes = wide;
-    // all-triangle scenes of up to 262 144 tree nodes (the meshes the reference's live host makes, UNITY/Raytracer.cs:1193-1198): stack entries of 16 + 2 bits, so that twice the
-    // tree top fits LDS next to the stack rows (kGeoPacked)
-    ctx->packedStack = RTOW_PACKED_STACK && wide && triangleKind(compiled.layout.sceneKind) && compiled.layout.nodeCount <= (1u << 18);
     if (!ctx->userTune) {
         // Box-walk slice (node visits per trip).  16 for trees whose nodes come from LDS or L2 (with the hand-over at 3 candidates: cover 12 / 16 / 20
         // visits 9.34 / 9.48 / 9.23 Gsamples/s; 10 000 spheres, tree partly in LDS, 16 / 20 / 24: 8.00 / 7.81 / 7.45).  A tree of hundreds of
@@ -1242,7 +1235,7 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
     std::lock_guard<std::mutex> sceneLock(ctx->sceneMu);          // rtowProbeNearestHit reads the host image under this lock only
     ctx->scene = std::move(compiled);
     // LDS of a launch: a traversal-stack row per inner level of THIS tree, then the scene image - whole, or the top of the node array (planLds, rtow_kernels.h)
-    ctx->ldsPlan = planLds(wide, ctx->packedStack, ctx->scene.layout, 0u, ctx->ldsSceneBudget);
+    ctx->ldsPlan = planLds(wide, ctx->scene.layout, 0u, ctx->ldsSceneBudget);
     ctx->ldsSceneBytes = ctx->ldsPlan.sceneBytes;
     ctx->ldsNodeCount = ctx->ldsPlan.nodeCount;
     ctx->haveScene = true;

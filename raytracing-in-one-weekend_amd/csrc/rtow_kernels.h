@@ -39,13 +39,12 @@ struct LdsPlan {
     uint32_t nodeCount;      // nodes [0, nodeCount) are LDS resident
     bool allLds;
 };
-// (packedStack: wide codes whose stack rows hold 16 bits per entry, the two bits above them in a register pair - kGeoPacked, rtow_sample_kernel.hip.h)
-inline LdsPlan planLds(bool wide, bool packedStack, const SceneLayout& L, uint32_t histRows, uint32_t budgetOverride)
+inline LdsPlan planLds(bool wide, const SceneLayout& L, uint32_t histRows, uint32_t budgetOverride)
 {
     LdsPlan p{};
-    const uint32_t codeBytes = wide ? 4u : 2u, stackBytes = (wide && !packedStack) ? 4u : 2u;
+    const uint32_t codeBytes = wide ? 4u : 2u;
     p.stackRows = L.bvhDepth < 1u ? 1u : L.bvhDepth;
-    uint32_t front = ((uint32_t)kCandCapacity * codeBytes + p.stackRows * stackBytes) * (uint32_t)kBlockThreads + (wide ? 256u : 0u);
+    uint32_t front = ((uint32_t)kCandCapacity + p.stackRows) * (uint32_t)kBlockThreads * codeBytes + (wide ? 256u : 0u);
     p.histRows = histRows;
     p.histOffset = histRows ? front : 0u;
     front += histRows * (uint32_t)kBlockThreads * 2u;
@@ -237,7 +236,7 @@ struct SampleKernelArgs {
     // launch geometry (rtow_sample_kernel.hip.h, GEO): lanes per workgroup of THIS launch (1024) and whether candidate / stack codes are 32 bits
     // wide (scenes beyond 65 535 entities or tree nodes)
     int32_t blockThreads;
-    int32_t wideCodes;                    // 0: 16-bit codes; 1: 32-bit candidate / stack / camera-list codes; 2: 32-bit codes with the packed 16 + 2-bit stack (kGeoPacked)
+    int32_t wideCodes;
 
     // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice
     int32_t tune[8];

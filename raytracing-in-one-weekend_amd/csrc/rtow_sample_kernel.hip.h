@@ -1080,11 +1080,10 @@ enum : int {
 // that one ray: every hit of the ray (the walk again, not pruned, same box tests), in leaf order, through the same sort; element 0 wins.
 // A real call: it is rare, and its list lives in scratch.
 // ------------------------------------------------------------------------------------------------------------
-template <bool ALL_LDS, int KIND, typename Code, int BT, bool PACKED = false>
+template <bool ALL_LDS, int KIND, typename Code, int BT>
 __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const SceneRefs sc, const SceneLayout* layoutInKernarg, V3 ro, V3 rd, float rtime, Code* stack,
                                                                        uint32_t* overflowFlag, HitSpill spill)
 {
-    unsigned long long stackHi = 0ull;      // PACKED: bits 16, 17 of the entry at level k in bits 2k, 2k + 1 (see the kernel's stackPut / stackGet)
     // The scene layout is read through a pointer into the kernarg segment, the scene references travel by value: taking the address of the kernel's
     // own copies for a by-reference parameter forced those copies - 25 dwords every stage reads - into scratch for the whole kernel (the exact-tie
     // variants ran 7 - 17 % behind their rank-rule twins "whether the call is taken or not": most of it was this).
@@ -1132,13 +1131,9 @@ __device__ __noinline__ __attribute__((unused)) int resolve_nearest_tie(const Sc
             else *overflowFlag = 1u;                                                                       // more hits than the context's hitListCapacity: RTOW_ERROR_CAPACITY on the host side
         }
         const bool in0 = hit0 && c0 >= 0, in1 = hit1 && c1 >= 0;
-        if (in0 && in1) {
-            stack[sp * BT] = (Code)c1;
-            if (PACKED) stackHi = (stackHi & ~(3ull << (2 * sp))) | ((unsigned long long)(((unsigned)c1 >> 16) & 3u) << (2 * sp));
-            sp++; cur = c0;
-        }
+        if (in0 && in1) { stack[sp * BT] = (Code)c1; sp++; cur = c0; }
         else if (in0 || in1) cur = in0 ? c0 : c1;
-        else if (sp > 0) { sp--; cur = (int)((unsigned)stack[sp * BT] | (PACKED ? ((unsigned)(stackHi >> (2 * sp)) & 3u) << 16 : 0u)); }
+        else if (sp > 0) { sp--; cur = (int)stack[sp * BT]; }
         else cur = -1;
     }
     if (n == 0) return -1;
@@ -1191,9 +1186,6 @@ constexpr int kGeoWide = 4;
 // the view's `right` / `up` are not compiled in - six launch constants fewer in the scalar registers of kernels that spill two dozen of them into VGPR lanes.  Only the reference-stream
 // variants that keep their whole path history in registers have the twin (launchByDiagGeo).
 constexpr int kGeoPinhole = 8;
-// bit 4 (with bit 2) = packed traversal stack: scenes of up to 262 144 tree nodes keep a stack entry as a 16-bit row entry + two bits in a per-lane register pair, so that the stack
-// rows take 2 bytes per lane and level instead of 4 and the top of the tree that fits LDS next to them nearly doubles (the all-triangle kinds: the meshes the reference's live host makes)
-constexpr int kGeoPacked = 16;
 constexpr int geo_block_threads(int) { return kBlockThreads; }
 
 // DIAG: 0 = RayCount only; 1 = the FULL_DIAGNOSTICS counters of this library's own walk; 2 = those, or - when the launch carries the reference's tree
@@ -1219,10 +1211,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool LDS_VIEW = (RTOW_LDS_VIEW & (ALL_LDS ? 1 : 2)) != 0;   // ... or read from an LDS copy (bit 0: kernels with the scene in LDS, bit 1: the others)
     constexpr bool COLD_VIEW __attribute__((unused)) = RTOW_COLD_VIEW && !ALL_LDS && !LDS_VIEW;    // the view's and the sky's launch constants are read on use instead of held in scalar registers (REGEN)
     constexpr bool SPLIT_NODES = !ALL_LDS && !WIDE;      // node loads as ds_read / global_load behind a wave-uniform branch instead of flat loads (load_node)
-    constexpr bool PACKED = (GEO & kGeoPacked) != 0;
-    static_assert(!PACKED || WIDE, "the packed stack is a flavour of the wide-code kernels");
-    using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;                 // candidate codes
-    using StackCode = typename std::conditional<WIDE && !PACKED, unsigned, unsigned short>::type;  // traversal-stack row entries
+    using Code = typename std::conditional<WIDE, unsigned, unsigned short>::type;
     const uint32_t ldsFront = A.ldsFrontBytes;          // this launch's LDS plan (LdsPlan, rtow_kernels.h): where the wave queues start
 
     // ---- stage the scene image into LDS: coalesced 16 B per lane ----
@@ -1231,18 +1220,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // (32-bit codes: one dword per lane, the natural order already is conflict free)
     const int swizzled = (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
     Code* const cand = reinterpret_cast<Code*>(smem) + (WIDE ? tid : swizzled);                // [slot][lane] leaf candidates: the first kCandCapacity rows
-    // [level][lane]: A.ldsStackRows rows, one per inner level of this scene's tree, behind the candidate rows
-    StackCode* const stack = reinterpret_cast<StackCode*>(smem + (size_t)kCandCapacity * BT * sizeof(Code)) + ((WIDE && !PACKED) ? tid : swizzled);
-    unsigned long long stackHi = 0ull;       // PACKED: bits 16, 17 of the entry at level k in bits 2k, 2k + 1 (24 levels: 48 bits)
-    auto stackPut = [&](int level, int v) {
-        stack[level * BT] = (StackCode)v;
-        if (PACKED) { const unsigned sh = 2u * (unsigned)level; stackHi = (stackHi & ~(3ull << sh)) | ((unsigned long long)(((unsigned)v >> 16) & 3u) << sh); }
-    };
-    auto stackGet = [&](int level) {
-        unsigned v = stack[level * BT];
-        if (PACKED) v |= ((unsigned)(stackHi >> (2u * (unsigned)level)) & 3u) << 16;
-        return (int)v;
-    };
+    Code* const stack = cand + kCandCapacity * BT;                                             // [level][lane]: A.ldsStackRows rows, one per inner level of this scene's tree
     HistRows histRows;
     histRows.lane = HW == 32 ? reinterpret_cast<unsigned short*>(smem + A.ldsHistOffset) + swizzled : nullptr;
     // {next, end} ticket chunk of this wave; chains: {.., needDone, chunk} = the chunk may only be handed out once chunkDone[chunk] >= needDone
@@ -1344,7 +1322,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     constexpr bool TRI_HOT = TRIANGLES_ONLY && RTOW_TRI_HOT;                                                    // ... tested from the compact GpuTriHot records; keptNormal.x / .y then carry the winner's (u, v)
     constexpr bool PREFETCH_FAR = WIDE && !ALL_LDS && (RTOW_PREFETCH & 1) != 0;
     constexpr bool PREFETCH_TRI = WIDE && !ALL_LDS && TRI_HOT && (RTOW_PREFETCH & 2) != 0;
-    const uint32_t ldsDump __attribute__((unused)) = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + ((uint32_t)kCandCapacity * (uint32_t)sizeof(Code) + A.ldsStackRows * (uint32_t)sizeof(StackCode)) * (uint32_t)BT);
+    const uint32_t ldsDump __attribute__((unused)) = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + ((uint32_t)kCandCapacity + A.ldsStackRows) * (uint32_t)BT * 4u);
     constexpr bool KEEP_NORMAL = BASE == SCENE_KIND_GENERAL || BASE == SCENE_KIND_TRIANGLES;   // the winning test's entity-space normal travels from TEST to HIT (else HIT re-runs the test)
     V3 keptNormal = v3(0, 0, 0);
 
@@ -1861,7 +1839,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                     int c0, c1;
                     load_node<ALL_LDS, SPLIT_NODES>(sc, L, cur, q0, q1, q2, c0, c1);
                     const int spm1 = sp > 0 ? sp - 1 : 0;
-                    const int popped = stackGet(spm1);
+                    const int popped = (int)stack[spm1 * BT];
                     // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z): pairs = (child0, child1)
                     const f2 tlx = (f2{q0.x, q0.y} - ox) * invx, thx = (f2{q1.z, q1.w} - ox) * invx;
                     const f2 tly = (f2{q0.z, q0.w} - oy) * invy, thy = (f2{q2.x, q2.y} - oy) * invy;
@@ -1895,7 +1873,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                         const uint32_t farNode = (uint32_t)(swap ? c0 : c1);
                         if (both && farNode >= sc.ldsNodeCount) prefetch_sector(sc.glob, L.nodeOffset + farNode * 64u, ldsDump);
                     }
-                    stackPut(sp, swap ? c0 : c1);
+                    stack[sp * BT] = (Code)(swap ? c0 : c1);
                     const int next = both ? (swap ? c1 : c0) : (in0 ? c0 : c1);
                     const bool any = in0 || in1;
                     cur = any ? next : (sp > 0 ? popped : -1);
@@ -2058,7 +2036,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
 #else
                     const SampleKernelArgs* argsInKernarg = &A;                                                           // host pass of the HIP compiler: never executed
 #endif
-                    const int winner = resolve_nearest_tie<ALL_LDS, BASE, StackCode, BT, PACKED>(sc, &argsInKernarg->layout, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
+                    const int winner = resolve_nearest_tie<ALL_LDS, BASE, Code, BT>(sc, &argsInKernarg->layout, ro, rd, rtime, stack, A.overflowFlag, hit_spill_of(A));
                     if (winner >= 0 && winner != prim) {
                         prim = winner;
                         if (KEEP_NORMAL) {
@@ -2329,9 +2307,9 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                                     if (general_hit<ALL_LDS>(sc, L, ~cc, mw >> kPrimTypeShift, ro, bd, rtime, 0.0f, t, nl, rq) && dot(normalize(rotate(rq, nl)), bd) > 0) insideVolume = true;
                                 }
                                 const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
-                                if (in0 && in1) { stackPut(bsp, c1); bsp++; bcur = c0; }
+                                if (in0 && in1) { stack[bsp * BT] = (Code)c1; bsp++; bcur = c0; }
                                 else if (in0 || in1) bcur = in0 ? c0 : c1;
-                                else if (bsp > 0) { bsp--; bcur = stackGet(bsp); }
+                                else if (bsp > 0) { bsp--; bcur = (int)stack[bsp * BT]; }
                                 else bcur = -1;
                             }
                             if (insideVolume) { curVol = (int)(matOf(c) & 0xffffu); break; }
@@ -2544,10 +2522,6 @@ template <bool ALL_LDS, int KIND>
 hipError_t launchByDiag(const SampleKernelArgs& args, int numBlocks, hipStream_t stream)
 {
     if constexpr (!ALL_LDS && kind_has_wide_codes<KIND>()) {
-        if constexpr ((KIND & 7) == SCENE_KIND_TRIANGLES || (KIND & 7) == SCENE_KIND_TRIANGLES_TEXTURED) {
-            if (args.wideCodes == 2) return launchByDiagGeo<false, KIND, kGeoWide | kGeoPacked>(args, numBlocks, stream);      // up to 262 144 nodes: 16 + 2-bit stack entries
-        }
-        if (args.wideCodes == 2) return hipErrorInvalidValue;
         if (args.wideCodes) return launchByDiagGeo<false, KIND, kGeoWide>(args, numBlocks, stream);
     }
     if (args.wideCodes) return hipErrorInvalidValue;                                    // refused at upload (rtow_api.hip): never reached

@@ -119,6 +119,18 @@ def test_mesh_grid_of_250k_triangles(rt, oracle, gpu_context):
         assert ctx.scene_info().wideCodes == 1 and ctx.scene_info().hitSpillBytes == 0
 
 
+def test_mesh_grid_beyond_262144_nodes(rt, oracle, gpu_context):
+    """A larger grid than the benchmark's: 15 x 15 icospheres + floor = 288 002 entities (18 bits no longer number its nodes), sparse pixels bit for bit against the
+    oracle under the tie watch, with 16-byte records (the generic variant) and under the per-sample policy (the exact-tie kernels)."""
+    scene = rt.scenes.mesh_grid_scene(grid=(15, 15))
+    assert scene.entity_count == 288002
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 6, 8, count=300, seed=31, focus=scene.meta["focus"])
+    info = gpu_context.scene_info()
+    assert info.wideCodes == 1 and info.bvhNodeCount == 288001
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 5, 10, count=200, seed=32, stride=16, focus=scene.meta["focus"])
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 20, 6, count=200, seed=33, focus=scene.meta["focus"], rng_policy=rt.abi.RNG_PER_SAMPLE)
+
+
 def test_mesh_grid_with_fog_volumes_beyond_65535_entities(rt, oracle, gpu_context):
     """One ProbabilisticVolume among the meshes makes a triangle-mesh scene a VOLUME scene (every hit of a ray kept, sorted, containment probe):
     8 x 8 icospheres + floor + a fog ball around one mesh, a haze box across a row and a haze sphere around the camera = 81 925 entities, beyond
