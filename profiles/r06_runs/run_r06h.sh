@@ -1,0 +1,27 @@
+# round 6, GPU call h: the sphere kinds' camera-ray lists in an LDS row instead of four registers (A/B build pcandlds: headline kernel 124 VGPRs instead of 128) against the
+# round's build, same box, three alternating rounds; parity subset on the A/B build first.
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06h; mkdir -p $O
+B=raytracing-in-one-weekend_amd/csrc/build
+RTOW_LIB_PATH=$B/librtow_hip_pcandlds.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_chain.py -q -n 4 > $O/pytest_pcandlds.log 2>&1; tail -3 $O/pytest_pcandlds.log
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2>&1
+for R in 1 2 3; do for V in new pcandlds; do
+  unset RTOW_LIB_PATH; [ $V != new ] && export RTOW_LIB_PATH=$B/librtow_hip_$V.so
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/c2_${V}_$R.json 2> $O/c2_${V}_$R.err
+  python bench.py --steps 10 --warmup 3 --chain 1 --no-cpu-baseline --no-extras > $O/c2plain_${V}_$R.json 2> $O/c2plain_${V}_$R.err
+  python bench.py --only-leg group_fold --chain 10 --steps 20 --no-cpu-baseline > $O/groupfold_${V}_$R.json 2> $O/groupfold_${V}_$R.err
+  python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/c5_${V}_$R.json 2> $O/c5_${V}_$R.err
+  python bench.py --config 3 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/c3_${V}_$R.json 2> $O/c3_${V}_$R.err
+done; done
+unset RTOW_LIB_PATH
+python - <<'PY'
+import json, glob, os, collections
+res = collections.defaultdict(list)
+for f in sorted(glob.glob("gpurun_out/r06h/*_*_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); name = os.path.basename(f).rsplit("_", 1)[0]
+        res[name].append(round(d["value"], 1))
+    except Exception as e:
+        print(f, "FAILED", e)
+for k in sorted(res): print("%-24s %s" % (k, res[k]))
+PY

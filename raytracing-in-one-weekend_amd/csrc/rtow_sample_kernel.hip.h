@@ -1,13 +1,14 @@
 // rtow_sample_kernel.hip.h - the sample-batch megakernel (hand-written gfx950 / CDNA4) and the device helpers shared with the small
-// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_*.hip): the kernel has 144
-// template instantiations and compiling them side by side keeps the build at half a minute.
+// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_*.hip): the kernel has 334
+// template instantiations (240 + 90 with wide codes + 4 pinhole twins) and compiling them side by side keeps the build at a minute and a half.
 //
 // sample_batch_kernel replaces SampleBatchJob.Execute + Sample + FindHitCandidates + FindHits + Entity.Hit +
 // Sphere.Hit + Material.Scatter + View.GetRay + RandomSource (JOBS/SampleBatchJob.cs:59-475, RT/*.cs).
 //
 // Shape of the kernel:
 //  * persistent: one 1024-lane workgroup per CU; the whole scene image (BVH nodes, primitives, materials) is staged once into LDS with
-//    coalesced 16-byte loads, next to a [level][lane] 16-bit traversal stack and an 8-entry candidate list per lane;
+//    coalesced 16-byte loads, behind an 8-entry candidate list per lane and a [level][lane] 16-bit traversal stack with one row per level of the
+//    scene's own tree (LdsPlan, rtow_kernels.h: every LDS size is decided per launch);
 //  * one lane = one PIXEL under the reference RNG policy (the reference seeds its generator once per pixel and runs it through all of
 //    that pixel's samples, JOBS/SampleBatchJob.cs:91,132-157), one lane = one (pixel, 16-sample group) unit under RTOW_RNG_PER_SAMPLE;
 //    pixel tickets are handed to waves in 64-pixel chunks, most expensive chunks first;
@@ -23,8 +24,10 @@
 //    handed out once batch b - 1 of that chunk is stored (per-chunk counters, device-coherent accumulator accesses), so lanes that run out
 //    of one batch's pixels take the next batch's instead of idling through the batch's tail;
 //  * template parameters: ALL_LDS (scene fully LDS resident), KIND (spheres / moving spheres / general entities / volumes / textured /
-//    both), HW (history words: trace depth <= 8 / 16 / 64), FULL_DIAG (the FULL_DIAGNOSTICS counters are kept), NOISE (white / blue / STBN),
-//    PER_SAMPLE; launchByDiag (end of this file) says which of the 144 instantiations serves which batch.
+//    both / triangles / textured triangles, + exact-tie bit), HW (history words: 4 / 8 = every code in registers, trace depth <= 8 / 16; 32 = eight codes in
+//    registers, the rest in LDS rows, trace depth <= 64), DIAG (0 RayCount only / 1 the FULL_DIAGNOSTICS counters of this library's walk / 2 those or the
+//    reference tree's), NOISE (white / blue / STBN), PER_SAMPLE, GEO (bit 2 wide codes, bit 3 pinhole twin); launchByDiagGeo (end of this file) says which
+//    instantiation serves which batch.
 //
 // Numerics: compiled with -ffp-contract=off; every expression below is written in the evaluation order of the C#
 // source (left to right, no fusion), with IEEE division and square root (1 / x and sqrt(x) through the exhaustively checked short forms
@@ -2463,7 +2466,7 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_
 // elsewhere: ONE variant with the full history (32 words) and the counters switched on serves every deeper path, every 16-byte
 // diagnostics record, the texture-driven noise sources and the per-sample policy beyond depth 8 (the counters cost ~2 % there; the record
 // format is chosen at run time from diagnosticsStride).  Scenes that need the exact-tie resolver (kExactTiesBit) are rare: depth <= 16 shares
-// the 8-word variant.  On top of these 144 (tests/test_gpu_variants.py runs every variant on every build):
+// the 8-word variant.  On top of these (tests/test_gpu_variants.py runs every variant on every build):
 //   * wide codes (args.wideCodes, scenes beyond 65 535 entities / nodes; the tree is read from HBM, so ALL_LDS = false only): every scene kind
 //     (a host that ingests triangle meshes produces spheres, general entities, triangles, textured ones - and a volume scene as soon as one fog
 //     volume stands among the meshes), each with and without the exact-tie resolver where the kind has one - as the specialised

@@ -1,7 +1,7 @@
 """GPU: every compiled variant of the sample kernel, one by one.
 
 The kernel is instantiated per (tree in LDS | in HBM) x scene kind x the (history width, diagnostics, noise source, RNG policy) combinations
-`launchByDiag` (end of csrc/rtow_sample_kernel.hip.h) dispatches to - 144 kernels, the spilling ones compiled under heavy register pressure.  During development one of them (VOLUMES, spatio-temporal noise,
+`launchByDiag` (end of csrc/rtow_sample_kernel.hip.h) dispatches to - 334 kernels at the end of round 6, the spilling ones compiled under heavy register pressure.  During development one of them (VOLUMES, spatio-temporal noise,
 short diagnostics) was once MISCOMPILED by hipcc (ROCm 7.2): a VGPR spill store was scheduled in front of the `s_or_b64 exec` of a join
 block, so the lanes that had skipped the region kept a stale spill slot and later reloaded it - their ray-count diagnostic came out 0
 while the colours were right.  Any source change reshuffles the register allocation of all of them, so every build
@@ -148,3 +148,52 @@ def test_wide_code_variants(rt, oracle, kind):
                  (5, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE, 4), (12, abi.NOISE_WHITE, abi.RNG_PER_SAMPLE_XOROSHIRO, 16), (6, abi.NOISE_BLUE, abi.RNG_REFERENCE, 4),
                  (6, abi.NOISE_SPATIOTEMPORAL_BLUE, abi.RNG_REFERENCE, 16)]
         _compare_modes(rt, oracle, ctx, scene, desc, modes, (kind, "wide"))
+
+
+@pytest.mark.parametrize("in_lds", [True, False], ids=["lds", "hbm"])
+@pytest.mark.parametrize("kind", KINDS)
+def test_reference_diagnostics_variant_of_every_kind(rt, oracle, kind, in_lds):
+    """Round 6: the walk that counts the REFERENCE's tree (RTOW_CONTEXT_REFERENCE_DIAGNOSTICS, reference_counts with its 64-entry stack) is a variant of its own
+    (DIAG 2); the 16-byte records without the option run on DIAG 1, which has no private segment.  Every kind, tree in LDS and beyond, at a register-history depth
+    and at a depth whose history codes live in LDS rows: all four diagnostics columns and every output against the oracle, which walks that very tree."""
+    scene = _scene(rt, kind)
+    desc = scene.desc()
+    w, h = 40, 24
+    osc = oracle.OracleScene(desc)
+    try:
+        with rt.Context(0, flags=rt.abi.CONTEXT_REFERENCE_DIAGNOSTICS, lds_scene_budget=0 if in_lds else 1024) as ctx:
+            ctx.upload_scene(desc)
+            for depth in (5, 20):
+                p = rt.scenes.make_params(scene, w, h, spp=3, trace_depth=depth, seed=78, diagnostics_stride=16)
+                gpu = rt.sample_batch_host(ctx, p)
+                ref = osc.sample_batch(p)
+                for k in ("color", "normal", "albedo", "scw"):
+                    assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (kind, in_lds, depth, k)
+                for col, what in enumerate(("RayCount", "BoundsHitCount", "CandidateCount", "SampleCountWeight")):
+                    assert np.array_equal(gpu["diag"][:, col].view(np.uint32), ref["diag"][:, col].view(np.uint32)), (kind, in_lds, depth, what)
+    finally:
+        osc.close()
+
+
+def test_lens_and_pinhole_variants_beyond_lds(rt, oracle):
+    """Static spheres whose tree is beyond LDS have a pinhole twin (GEO bit 3: lens code and the view's right / up not compiled in) - taken when the lens radius is 0 and
+    no component of the view's origin or lower left corner is exactly zero.  The same scene with a lens, without one, and without one from a camera ON a coordinate plane
+    (the general variant must serve it: its zero offset carries the reference's sign) against the oracle, at both register-history depths."""
+    S = rt.scenes
+    scene = S.cover_scene(60, 600)
+    desc = scene.desc()
+    osc = oracle.OracleScene(desc)
+    try:
+        with rt.Context(0, lds_scene_budget=1024) as ctx:
+            ctx.upload_scene(desc)
+            assert not ctx.scene_info().sceneInLds
+            for camera in ({"aperture": 0.0}, {"aperture": 0.08}, {"aperture": 0.0, "position": [0.0, 2.0, -4.0]}, {"aperture": 0.0, "position": [9.0, 0.0, 3.0]}):
+                scene.camera = dict(scene.camera, **camera)
+                for depth in (6, 14):
+                    p = S.make_params(scene, 64, 36, spp=4, trace_depth=depth, seed=5)
+                    gpu = rt.sample_batch_host(ctx, p)
+                    ref = osc.sample_batch(p)
+                    for k in ("color", "normal", "albedo", "scw"):
+                        assert np.array_equal(gpu[k].view(np.uint32), ref[k].view(np.uint32)), (camera, depth, k)
+    finally:
+        osc.close()
