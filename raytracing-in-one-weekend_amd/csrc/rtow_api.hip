@@ -396,9 +396,10 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.travSlice = ctx->tune[8] < 1 ? 1 : ctx->tune[8];
     // Lanes that wait for company at a pixel boundary (kernel: A.tune[7]; schedulerTune[7] bits 12 .. 15 override).  Measured (profiles/r06d_pixel_boundaries_in_company.json):
     // worth it only where boundaries are frequent - the reference host's 50 samples per batch: groups +2.5 % with 3 - 4 lanes, the per-sample policies' 16-sample units +1.6 % -
-    // and a loss of 1 - 3 % where a pixel takes hundreds of samples (the wait costs more than the shared instructions save): so by the samples a unit of work takes
+    // (the adaptive {1, 50} schedule +0.5 ... 1 %) and a loss of 1 - 3 % where a pixel takes hundreds of samples (the wait costs more than the shared instructions save):
+    // so by the samples a unit of work takes at most
     const unsigned unitSamples = p->rngPolicy != RTOW_RNG_REFERENCE ? kSampleGroup : (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
-    const int pixelGate = (ctx->regroupSide >> 12) & 15 ? (ctx->regroupSide >> 12) & 15 : (unitSamples <= 64u && a.sampleCountMin == a.sampleCountMax ? 4 : RTOW_PIXEL_GATE);
+    const int pixelGate = (ctx->regroupSide >> 12) & 15 ? (ctx->regroupSide >> 12) & 15 : (unitSamples <= 64u ? 4 : RTOW_PIXEL_GATE);
     a.tune[7] = pixelGate;
     const uint32_t ownedPixels = a.totalWork;
     if (ownedPixels == 0) {

@@ -52,7 +52,11 @@ def main():
              ("cover, tiny frame", S.cover_scene, 160, 90, 64, 8, 16, {}),
              # round 3: chains through the wide-code kernels (tree in HBM, 32-bit codes) and the mesh that needs them
              ("cover, wide codes", S.cover_scene, 1920, 1080, 16, 8, 8, {"_context": dict(flags=rt.abi.CONTEXT_FORCE_WIDE_CODES)}),
-             ("mesh grid 250k", S.mesh_grid_scene, 1280, 720, 2, 8, 4, {"_focus_from_meta": True})]
+             ("mesh grid 250k", S.mesh_grid_scene, 1280, 720, 2, 8, 4, {"_focus_from_meta": True}),
+             # round 6: chains through the variants whose path history lives in LDS rows, and through the tie watch of the all-triangle kinds
+             ("cover depth 32", S.cover_scene, 1920, 1080, 16, 32, 10, {}),
+             ("moving depth 24", S.moving_scene, 1280, 720, 16, 24, 10, {}),
+             ("triangle layers (tie watch)", S.triangle_layers_scene, 960, 640, 4, 10, 8, {})]
     main_ctx = rt.Context(0)
     bad_total = 0
     for name, make, w, h, spp, depth, count, kw in cases:

@@ -47,6 +47,14 @@ def main():
         ("mixed wide codes", S.mixed_scene, 1280, 720, 8, 8, {"_context": dict(flags=abi.CONTEXT_FORCE_WIDE_CODES)}),
         ("moving wide codes", S.moving_scene, 1280, 720, 8, 8, {"_context": dict(flags=abi.CONTEXT_FORCE_WIDE_CODES)}),
         ("mesh grid 250k", S.mesh_grid_scene, 1280, 720, 3, 8, {"_focus_from_meta": True}),
+        # round 6: path history in LDS rows (depth 32, both record formats; depth 48), the tie watch of the all-triangle kinds, the reference-diagnostics variant
+        ("cover depth 32", S.cover_scene, 1920, 1080, 24, 32, {}),
+        ("cover depth 32 records", S.cover_scene, 1920, 1080, 24, 32, {"diagnostics_stride": 16}),
+        ("moving depth 48 records", S.moving_scene, 1280, 720, 16, 48, {"diagnostics_stride": 16}),
+        ("stress 6000 depth 24", lambda: S.stress_scene(count=6000, max_tentatives=40000), 1280, 720, 12, 24, {}),
+        ("triangle layers", S.triangle_layers_scene, 960, 640, 12, 10, {}),
+        ("mesh depth 20 records", S.mesh_scene, 1280, 720, 8, 20, {"diagnostics_stride": 16}),
+        ("cover reference counters", S.cover_scene, 1280, 720, 8, 20, {"diagnostics_stride": 16, "_context": dict(flags=abi.CONTEXT_REFERENCE_DIAGNOSTICS)}),
     ]
     main_ctx = rt.Context(0)
     main_ctx.upload_blue_noise(noise.blue_desc())
