@@ -42,6 +42,12 @@ def main():
             if KERNEL in row["Kernel_Name"]:
                 if "dispatch" not in summary:
                     summary["dispatch"] = {k: row[k] for k in ("Kernel_Name", "Workgroup_Size_X", "Grid_Size_X", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
+                    if "VGPR_Count" in row:
+                        # rocprofv3 prints HALF the allocation.  It decodes the kernel descriptor's granulated VGPR count with a granule of 4 registers; gfx90a and
+                        # later (gfx950 included) allocate wave64 VGPRs in granules of 8.  Checked against -Rpass-analysis=kernel-resource-usage on kernels of known size: the rank-rule
+                        # triangle kernel (116 VGPRs -> 120 allocated) is reported as 60, the 128-VGPR kernels as 64.  Occupancy follows from the allocation: 512 / 128 = 4 waves per SIMD.
+                        summary["dispatch"]["VGPRs_allocated"] = 2 * int(row["VGPR_Count"])
+                        summary["dispatch"]["VGPR_note"] = "VGPR_Count is rocprofv3's figure (descriptor granule taken as 4); gfx950 allocates in granules of 8: allocated = 2 x VGPR_Count"
                 durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
         if durs:
             longest = max(durs)

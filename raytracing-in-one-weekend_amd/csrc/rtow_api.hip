@@ -525,6 +525,14 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     const unsigned regroupMode = ((unsigned)ctx->regroupSide >> 4) & 3u;
     // batch groups: (chunk, batch) slots a wave reserves at a time (schedulerTune[7] bits 8 .. 11 override the default for A/B runs)
     a.slotBlock = (((unsigned)ctx->regroupSide >> 8) & 15u) ? (((unsigned)ctx->regroupSide >> 8) & 15u) : kGroupSlotBlock;
+    if ((((unsigned)ctx->regroupSide >> 8) & 15u) == 0u) {
+        // Reserving several (chunk, batch) slots per pull pays where a wave has dozens of them to work through (a whole frame's group: 79 slots per wave, +1.8 %); a launch that
+        // owns a few slots per wave - the sub-batches of an 8-way row slice: 7.9 - must balance with single slots (profiles/r06j_partitions_c2.json: 10.9 ms per step against the
+        // 7.9 of round 5's single slots)
+        const uint64_t slotsPerWave = (uint64_t)a.chunkCount * a.chainCount / ((uint64_t)blocks * (uint64_t)(kBlockThreads / 64));
+        if (slotsPerWave < 32u) a.slotBlock = 1u;
+        else if (slotsPerWave < 64u && a.slotBlock > 2u) a.slotBlock = 2u;
+    }
     auto regroupClasses = [&](unsigned floorCost, unsigned out[3]) {
         if (regroupSide == 1u) { out[0] = regroupMode == 0u ? 0u : (2u << regroupMode); out[1] = out[2] = 0u; return; }      // tile order: levels of the tile's cost range (mode 1 / 2 / 3: 4 / 8 / 16), 0 = by the ray count itself
         out[0] = regroupMode == 0u ? 0u : floorCost; out[1] = regroupMode >= 2u ? (floorCost * 11u) / 4u : 0xffffffffu; out[2] = regroupMode >= 2u ? floorCost * 4u : 0xffffffffu;
