@@ -87,6 +87,8 @@ struct RtowContext_t {
     uint8_t* dScene = nullptr;
     size_t dSceneCapacity = 0;
     uint32_t ldsSceneBytes = 0, ldsNodeCount = 0;
+    unsigned short* dHistSpill = nullptr; // path-history rows that do not fit LDS (LdsPlan.histSpillRows), [row][workgroup x 1024 + lane]
+    size_t histSpillBytes = 0;
     LdsPlan ldsPlan{};                    // of launches whose variant keeps its whole path history in registers (trace depth <= 16); the others plan per launch (launchSample)
 
     // work distribution / cancellation
@@ -386,9 +388,21 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         if (ctx->scene.layout.exactTies) hw = std::max(hw, historyWords(a.noiseColor, perSample, ctx->wideCodes, false, fullDiag, a.traceDepth));
         if (hw == 32 && a.traceDepth > kHistoryInRegisters) {
             const LdsPlan plan = planLds(ctx->wideCodes, ctx->scene.layout, (uint32_t)(a.traceDepth - kHistoryInRegisters), ctx->ldsSceneBudget);
-            if (plan.frontBytes + (uint32_t)kQueueBytes + (uint32_t)sizeof(GpuNode) > (uint32_t)kLdsBytesMax) return RTOW_ERROR_CAPACITY;      // (trace depth <= 64 and 24 tree levels always fit)
-            a.ldsStackRows = plan.stackRows; a.ldsHistOffset = plan.histOffset; a.ldsFrontBytes = plan.frontBytes;
+            a.ldsStackRows = plan.stackRows; a.ldsHistOffset = plan.histOffset; a.ldsFrontBytes = plan.frontBytes; a.ldsHistRows = plan.histRows;
             a.ldsSceneBytes = plan.sceneBytes; a.ldsNodeCount = plan.nodeCount;
+            if (plan.histSpillRows) {
+                // the rows that do not fit LDS (32-bit stack rows of a deep tree next to a deep trace depth; a scene kept whole in LDS): 2 bytes per lane and row in HBM
+                const size_t stride = (size_t)ctx->cuCount * (size_t)kBlockThreads, need = (size_t)plan.histSpillRows * stride * sizeof(unsigned short);
+                if (need > ctx->histSpillBytes) {
+                    HIP_TRY(ctx, hipDeviceSynchronize(), RTOW_ERROR_LAUNCH_FAILURE);          // a batch in flight may still use the smaller area
+                    if (ctx->dHistSpill) (void)hipFree(ctx->dHistSpill);
+                    ctx->dHistSpill = nullptr;
+                    ctx->histSpillBytes = 0;
+                    HIP_TRY(ctx, hipMalloc(&ctx->dHistSpill, need), RTOW_ERROR_MEMORY_ALLOCATION);
+                    ctx->histSpillBytes = need;
+                }
+                a.histSpill = ctx->dHistSpill; a.histSpillRows = plan.histSpillRows; a.histSpillStride = (uint32_t)stride;
+            }
         }
     }
     // scheduler thresholds (lane population a stage needs before it runs) and box-walk slice (RtowContextOptions.schedulerTune overrides)
@@ -1141,6 +1155,7 @@ RTOW_API int rtowDestroyContext(RtowContext ctx)
     if (ctx->dTieRedo) (void)hipFree(ctx->dTieRedo);
     if (ctx->dTieBits) (void)hipFree(ctx->dTieBits);
     if (ctx->dTieInputs) (void)hipFree(ctx->dTieInputs);
+    if (ctx->dHistSpill) (void)hipFree(ctx->dHistSpill);
     if (ctx->dRedoSpill) (void)hipFree(ctx->dRedoSpill);
     if (ctx->hCancel) (void)hipHostFree((void*)ctx->hCancel);
     if (ctx->dColor) { (void)hipFree(ctx->dColor); (void)hipFree(ctx->dNormal); (void)hipFree(ctx->dAlbedo); (void)hipFree(ctx->dScw); }

@@ -32,26 +32,37 @@ constexpr int kHistoryInRegisters = 8;   // path-history codes (one per surface 
 // 448-byte private segment per lane, cleared per sample: 186 GB of HBM writes per 10-batch launch (profiles/r05_hostdefault_pmc_summary.json).
 struct LdsPlan {
     uint32_t stackRows;      // >= 1
-    uint32_t histOffset;     // byte offset of the history rows (0: none)
-    uint32_t histRows;
+    uint32_t histOffset;     // byte offset of the history rows (0: none in LDS)
+    uint32_t histRows;       // history rows in LDS
+    uint32_t histSpillRows;  // ... and the rest of the rows the launch needs, in HBM (SampleKernelArgs.histSpill)
     uint32_t frontBytes;     // everything in front of the wave queues
     uint32_t sceneBytes;     // bytes of the blob staged behind the queues
     uint32_t nodeCount;      // nodes [0, nodeCount) are LDS resident
     bool allLds;
 };
-inline LdsPlan planLds(bool wide, const SceneLayout& L, uint32_t histRows, uint32_t budgetOverride)
+// histRowsNeeded = traceDepth - kHistoryInRegisters for the variants that keep codes in rows (else 0).  A scene stays whole in LDS only if ALL the rows fit next to it (the
+// scene-in-LDS kernels carry no code for rows elsewhere: it cost them their freedom from a private segment); otherwise the top of the tree is staged - at least 256 nodes - the
+// history gets the rows that fit, and the rest of the rows live in HBM: paths that deep are rare (2.5 segments on average) and rows are only touched beyond depth 8.
+inline LdsPlan planLds(bool wide, const SceneLayout& L, uint32_t histRowsNeeded, uint32_t budgetOverride)
 {
     LdsPlan p{};
-    const uint32_t codeBytes = wide ? 4u : 2u;
+    const uint32_t codeBytes = wide ? 4u : 2u, rowBytes = (uint32_t)kBlockThreads * 2u;
     p.stackRows = L.bvhDepth < 1u ? 1u : L.bvhDepth;
-    uint32_t front = ((uint32_t)kCandCapacity + p.stackRows) * (uint32_t)kBlockThreads * codeBytes + (wide ? 256u : 0u);
-    p.histRows = histRows;
-    p.histOffset = histRows ? front : 0u;
-    front += histRows * (uint32_t)kBlockThreads * 2u;
-    p.frontBytes = front;
-    uint32_t budget = front + (uint32_t)kQueueBytes < (uint32_t)kLdsBytesMax ? (uint32_t)kLdsBytesMax - front - (uint32_t)kQueueBytes : 0u;
-    if (budgetOverride >= sizeof(GpuNode) && budgetOverride < budget) budget = budgetOverride;      // development aid: small scenes through the tree-in-HBM kernels
-    if (L.totalBytes <= budget && !wide) {
+    const uint32_t rowsEnd = ((uint32_t)kCandCapacity + p.stackRows) * (uint32_t)kBlockThreads * codeBytes + (wide ? 256u : 0u);
+    const uint32_t room = (uint32_t)kLdsBytesMax - rowsEnd - (uint32_t)kQueueBytes;           // (8 + 24) x 4 KB + 640 B at most: always positive
+    uint32_t sceneBudget = room;
+    if (budgetOverride >= sizeof(GpuNode) && budgetOverride < sceneBudget) sceneBudget = budgetOverride;      // development aid: small scenes through the tree-in-HBM kernels
+    const bool whole = !wide && L.totalBytes <= sceneBudget && (uint64_t)L.totalBytes + (uint64_t)histRowsNeeded * rowBytes <= (uint64_t)room;
+    const uint32_t keep = whole ? L.totalBytes : (uint32_t)sizeof(GpuNode) * (L.nodeCount < 256u ? (L.nodeCount ? L.nodeCount : 1u) : 256u);   // what the history rows must leave room for
+    const uint32_t keepFits = keep <= sceneBudget ? keep : sceneBudget;
+    uint32_t rowsFit = room > keepFits ? (room - keepFits) / rowBytes : 0u;
+    p.histRows = histRowsNeeded < rowsFit ? histRowsNeeded : rowsFit;
+    p.histSpillRows = histRowsNeeded - p.histRows;
+    p.histOffset = p.histRows ? rowsEnd : 0u;
+    p.frontBytes = rowsEnd + p.histRows * rowBytes;
+    uint32_t budget = (uint32_t)kLdsBytesMax - p.frontBytes - (uint32_t)kQueueBytes;
+    if (budget > sceneBudget) budget = sceneBudget;
+    if (whole) {
         p.sceneBytes = L.totalBytes; p.nodeCount = L.nodeCount; p.allLds = true;
     } else {
         // too large for LDS: stage the top of the (breadth-first) node array, read the rest through L2
@@ -152,6 +163,8 @@ struct SampleKernelArgs {
     uint32_t ldsSceneBytes;  // bytes of the blob staged into LDS (whole blob, or a node prefix)
     uint32_t ldsNodeCount;   // nodes [0, ldsNodeCount) are LDS resident
     uint32_t ldsStackRows, ldsHistOffset, ldsFrontBytes;   // this launch's LDS plan (LdsPlan above): traversal-stack rows, where the path-history rows start (0: none), where the wave queues start
+    uint32_t ldsHistRows, histSpillRows, histSpillStride;  // history rows in LDS; rows beyond them in histSpill ([row][workgroup x 1024 + lane], histSpillStride entries per row)
+    unsigned short* histSpill;                             // null = none
 
     // work distribution
     unsigned int* workCounter;            // zeroed before the launch; counts 64-pixel ticket chunks

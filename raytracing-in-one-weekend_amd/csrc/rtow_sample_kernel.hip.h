@@ -967,33 +967,51 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 // 16-bit codes behind the traversal stack, [depth - 8][lane] (LdsPlan, rtow_kernels.h).  Rounds 1 - 5 kept 32 words per lane in a private segment and cleared them per sample
 // (the reference host's committed traceDepth 32: 186 GB of HBM writes per 10-batch launch); a path rarely gets that deep (2.5 segments on average), so the rows cost a few
 // ds_write_b16 per thousand hits, and nothing is cleared: a row entry is written before the fold reads it.
-struct HistRows { unsigned short* lane; };     // this lane's entry of row 0 (null where the variant keeps every code in registers)
+template <bool SPILL> struct HistRowsT { unsigned short* lane; };     // this lane's entry of row 0 in LDS (null where the variant keeps every code in registers)
+using HistRows = HistRowsT<false>;
+// Rows that do not fit LDS (wide stack rows next to a deep trace depth; a scene that is kept whole in LDS instead) live in HBM, [row][lane] like the LDS rows
+// (SampleKernelArgs.histSpill).  The launch constants are read from the kernarg segment on use (through a laundered pointer, like the pixel boundary's): paths that deep
+// are rare, and nothing of this may sit in a register through the stages.  (Not a call: a call frame would give these variants their private segment back.)
+// SPILL = the variant's launches may have rows in HBM: the kernels whose scene is not whole in LDS (a launch that keeps its scene whole has all its rows in LDS: planLds) -
+// the extra code gave the scene-in-LDS variants their 36-byte private segment back.
+template <bool SPILL>
+__device__ __forceinline__ unsigned short* hist_row_slot(unsigned short* ldsLane, int row)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SPILL) {
+        const SampleKernelArgs* A = (const SampleKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();      // the struct is the kernel's only argument
+        asm volatile("" : "+s"(A));
+        if (row >= (int)A->ldsHistRows) return A->histSpill + (size_t)(row - (int)A->ldsHistRows) * (size_t)A->histSpillStride + (size_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    }
+#endif
+    return ldsLane + row * kBlockThreads;
+}
 template <int HW> struct Hist {
     unsigned w[HW];
     __device__ __forceinline__ void clear() { for (int i = 0; i < HW; i++) w[i] = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows&) { w[depth >> 1] |= code << ((unsigned)(depth & 1) * 16u); }
-    __device__ __forceinline__ unsigned get(int depth, const HistRows&) const { return (w[depth >> 1] >> ((unsigned)(depth & 1) * 16u)) & 0xffffu; }
+    template <class R> __device__ __forceinline__ void set(int depth, unsigned code, const R&) { w[depth >> 1] |= code << ((unsigned)(depth & 1) * 16u); }
+    template <class R> __device__ __forceinline__ unsigned get(int depth, const R&) const { return (w[depth >> 1] >> ((unsigned)(depth & 1) * 16u)) & 0xffffu; }
 };
 template <> struct Hist<4> {
     unsigned long long a, b;
     __device__ __forceinline__ void clear() { a = 0; b = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows&)
+    template <class R> __device__ __forceinline__ void set(int depth, unsigned code, const R&)
     {
         const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
         if (depth < 4) a |= v; else b |= v;
     }
-    __device__ __forceinline__ unsigned get(int depth, const HistRows&) const { return (unsigned)((depth < 4 ? a : b) >> ((unsigned)(depth & 3) * 16u)) & 0xffffu; }
+    template <class R> __device__ __forceinline__ unsigned get(int depth, const R&) const { return (unsigned)((depth < 4 ? a : b) >> ((unsigned)(depth & 3) * 16u)) & 0xffffu; }
 };
 template <> struct Hist<8> {
     unsigned long long a, b, c, d;
     __device__ __forceinline__ void clear() { a = 0; b = 0; c = 0; d = 0; }
-    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows&)
+    template <class R> __device__ __forceinline__ void set(int depth, unsigned code, const R&)
     {
         const unsigned long long v = (unsigned long long)code << ((unsigned)(depth & 3) * 16u);
         const int q = depth >> 2;
         if (q == 0) a |= v; else if (q == 1) b |= v; else if (q == 2) c |= v; else d |= v;
     }
-    __device__ __forceinline__ unsigned get(int depth, const HistRows&) const
+    template <class R> __device__ __forceinline__ unsigned get(int depth, const R&) const
     {
         const int q = depth >> 2;
         const unsigned long long v = q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
@@ -1004,15 +1022,15 @@ template <> struct Hist<32> {
     Hist<4> head;
     static_assert(kHistoryInRegisters == 8, "Hist<4> holds the register-resident part");
     __device__ __forceinline__ void clear() { head.clear(); }
-    __device__ __forceinline__ void set(int depth, unsigned code, const HistRows& rows)
+    template <bool SPILL> __device__ __forceinline__ void set(int depth, unsigned code, const HistRowsT<SPILL>& rows)
     {
         if (depth < kHistoryInRegisters) head.set(depth, code, rows);
-        else rows.lane[(depth - kHistoryInRegisters) * kBlockThreads] = (unsigned short)code;
+        else *hist_row_slot<SPILL>(rows.lane, depth - kHistoryInRegisters) = (unsigned short)code;
     }
-    __device__ __forceinline__ unsigned get(int depth, const HistRows& rows) const
+    template <bool SPILL> __device__ __forceinline__ unsigned get(int depth, const HistRowsT<SPILL>& rows) const
     {
         if (depth < kHistoryInRegisters) return head.get(depth, rows);
-        return rows.lane[(depth - kHistoryInRegisters) * kBlockThreads];
+        return *hist_row_slot<SPILL>(rows.lane, depth - kHistoryInRegisters);
     }
 };
 
@@ -1224,7 +1242,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     const int swizzled = (tid & ~63) + ((tid & 31) << 1) + ((tid >> 5) & 1);
     Code* const cand = reinterpret_cast<Code*>(smem) + (WIDE ? tid : swizzled);                // [slot][lane] leaf candidates: the first kCandCapacity rows
     Code* const stack = cand + kCandCapacity * BT;                                             // [level][lane]: A.ldsStackRows rows, one per inner level of this scene's tree
-    HistRows histRows;
+    HistRowsT<!ALL_LDS> histRows;
     histRows.lane = HW == 32 ? reinterpret_cast<unsigned short*>(smem + A.ldsHistOffset) + swizzled : nullptr;
     // {next, end} ticket chunk of this wave; chains: {.., needDone, chunk} = the chunk may only be handed out once chunkDone[chunk] >= needDone
     volatile unsigned* const waveQueue = reinterpret_cast<volatile unsigned*>(smem + ldsFront) + (tid >> 6) * 4;
@@ -2454,7 +2472,11 @@ hipError_t launchVariant(const SampleKernelArgs& args, int numBlocks, hipStream_
     auto k = sample_batch_kernel<ALL_LDS, KIND, HW, DIAG, NOISE, PER_SAMPLE, GEO>;
     const size_t ldsBytes = (size_t)args.ldsFrontBytes + (size_t)kQueueBytes + args.ldsSceneBytes;
     // the launch's LDS plan must be the plan of THIS variant: history rows where the codes beyond the registers go, a stack row per level of the tree
-    if (args.ldsStackRows < 1u || ldsBytes > (size_t)kLdsBytesMax || (HW == 32 && args.traceDepth > kHistoryInRegisters && args.ldsHistOffset == 0u)) return hipErrorInvalidValue;
+    if (args.ldsStackRows < 1u || ldsBytes > (size_t)kLdsBytesMax) return hipErrorInvalidValue;
+    if (HW == 32 && args.traceDepth > kHistoryInRegisters) {
+        const uint32_t rows = (uint32_t)(args.traceDepth - kHistoryInRegisters);
+        if ((args.ldsHistRows > 0u && args.ldsHistOffset == 0u) || (args.ldsHistRows < rows && (ALL_LDS || !args.histSpill || args.histSpillRows < rows - args.ldsHistRows))) return hipErrorInvalidValue;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(numBlocks), dim3(geo_block_threads(GEO)), ldsBytes, stream, args);

@@ -62,6 +62,15 @@ def test_config2_cover_1080p_256spp(rt, oracle, gpu_context):
     _check_sparse(rt, oracle, gpu_context, rt.scenes.cover_scene(), 1920, 1080, 256, 8, count=600)
 
 
+def test_cover_at_the_deepest_trace_depths(rt, oracle, gpu_context):
+    """Trace depth 64 (the API's limit) and 48: 56 / 40 path-history rows do not fit next to the cover scene, so the launch stages the top of the tree instead of the whole
+    scene and keeps the rows that do not fit in HBM (csrc/rtow_kernels.h planLds); depth 32 - the reference host's committed one - keeps the scene whole."""
+    scene = rt.scenes.cover_scene()
+    for depth, spp, stride in ((64, 6, 16), (48, 6, 4), (32, 8, 16)):
+        _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, spp, depth, count=300, seed=40 + depth, stride=stride)
+    assert gpu_context.scene_info().sceneInLds == 1
+
+
 def test_config3_cover_4k_1024spp_16_bounces(rt, oracle, gpu_context):
     """BASELINE.json configs[2] on one GPU: cover scene 3840x2160, 1024 spp in ONE batch (one generator runs through all 1024 samples of a
     pixel), 16 bounces.  The 8-way tile split of the same config is test_config3_tile_split_slices_equal_the_whole_frame."""
@@ -112,6 +121,10 @@ def test_mesh_grid_of_250k_triangles(rt, oracle, gpu_context):
     assert info.wideCodes == 1 and info.sceneInLds == 0 and info.bvhNodeCount == 250881 and info.entityCount == 250882
     assert info.hitListCapacity == 128 and info.hitSpillBytes > 0 and info.hitSpillBytes % ((128 - 24) * 16 * 1024) == 0      # 104 spill entries x 16 B x 1024 lanes x CUs
     _check_sparse(rt, oracle, gpu_context, scene, 1920, 1080, 20, 12, count=300, seed=10, stride=16, focus=scene.meta["focus"], rng_policy=rt.abi.RNG_PER_SAMPLE)
+    # the reference host's committed trace depth (32) and a deeper one on the mesh it is made for: 29 stack / candidate rows of 4 KB leave room for 13 of the 24 / 32 history
+    # rows next to the top 256 nodes - the rest of the rows live in HBM (LdsPlan.histSpillRows); 16-byte records
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 6, 32, count=250, seed=12, stride=16, focus=scene.meta["focus"])
+    _check_sparse(rt, oracle, gpu_context, scene, 1280, 720, 4, 40, count=200, seed=13, focus=scene.meta["focus"])
     # the rank rule instead of the resolver (RTOW_CONTEXT_EXACT_TIES_NEVER): the other wide kernel family; a smooth closed mesh ties only on shared edges,
     # where both triangles give the same answer up to the leaf order the rank reproduces
     with rt.Context(0, flags=rt.abi.CONTEXT_EXACT_TIES_NEVER) as ctx:

@@ -104,6 +104,18 @@ def geometry_contexts(rt):
 
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("RTOW_FUZZ_SEEDS", "24")))))   # RTOW_FUZZ_SEEDS=1000 for a soak run
 def test_random_scene(rt, oracle, gpu_context, geometry_contexts, seed):
+    _run_seed(rt, oracle, gpu_context, geometry_contexts, seed)
+
+
+@pytest.mark.parametrize("seed", [115, 417, 611, 666, 3, 58])
+def test_heavy_seeds(rt, oracle, gpu_context, geometry_contexts, seed, monkeypatch):
+    """The soak generator (RTOW_FUZZ_HEAVY: up to 120 entities, larger frames) on the seeds whose launches round 6's first LDS plan refused - 32-bit stack rows of a deep
+    tree next to the 32 path-history rows of trace depth 40 had no room, RTOW_ERROR_CAPACITY with hit lists of 6 to 20 entries (profiles/r06_runs/run_r06l.sh) - and two more."""
+    monkeypatch.setenv("RTOW_FUZZ_HEAVY", "1")
+    _run_seed(rt, oracle, gpu_context, geometry_contexts, seed)
+
+
+def _run_seed(rt, oracle, gpu_context, geometry_contexts, seed):
     abi = rt.abi
     # (drawn from a generator of its own so that every seed keeps the scene and parameters it always had)
     extra = np.random.default_rng(77000 + seed)
