@@ -300,9 +300,11 @@ typedef void (*RtowLogCallback)(int32_t level, const char* tag, const char* mess
 typedef enum RtowContextFlags {
     RTOW_CONTEXT_EXACT_TIES_ALWAYS = 1u << 0,      /* settle every nearest-hit tie with the reference's whole procedure (walk again unpruned, sort the hit list like
                                                     * NativeSortExtension.Sort, take [0]) INSIDE the sample kernel in every scene without volumes; default: in scenes that hold the
-                                                    * same primitive twice and in scenes of more than 16 entities that are not all unrotated spheres.  Sphere-only scenes run the
-                                                    * rank-rule kernels (4 % faster) and have the rare pixel that meets two different spheres at bit-identical distance rendered
-                                                    * again by the exact kernel in a fix-up pass after the launch: the same results either way */
+                                                    * same primitive twice and in scenes of more than 16 entities with any rect, box or rotated entity.  Sphere-only scenes and
+                                                    * all-triangle scenes (one entity per mesh triangle: what the live host makes) run the rank-rule kernels and have the rare
+                                                    * pixel that meets two different surfaces at bit-identical distance rendered again by the exact kernel in a fix-up pass after
+                                                    * the launch; a triangle scene that marks thousands of pixels in one launch moves to the exact kernels for
+                                                    * good: the same results either way */
     RTOW_CONTEXT_EXACT_TIES_NEVER = 1u << 1,       /* never (the rank rule everywhere, no fix-up pass: exact for rays of at most 16 hits) */
     RTOW_CONTEXT_REFERENCE_DIAGNOSTICS = 1u << 2,  /* FULL_DIAGNOSTICS records (diagnosticsStride 16): BoundsHitCount / CandidateCount count the REFERENCE's tree -
                                                     * node boxes a ray passes and entities of the leaves it reaches in the tree RebuildBvh would build

@@ -560,7 +560,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
             ctx->dPixelCost = nullptr;
             ctx->dTicketMap = nullptr;
             ctx->chunkCapacity = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dChunkCost, 2 * a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
+            HIP_TRY(ctx, hipMalloc(&ctx->dChunkCost, (2 * (size_t)a.chunkCount + kChunkOrderScratchWords) * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             HIP_TRY(ctx, hipMalloc(&ctx->dChunkOrder, a.chunkCount * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
             HIP_TRY(ctx, hipMalloc(&ctx->dPixelCost, (size_t)a.chunkCount * 64 * sizeof(unsigned short)), RTOW_ERROR_MEMORY_ALLOCATION);
             HIP_TRY(ctx, hipMalloc(&ctx->dTicketMap, (size_t)a.chunkCount * 64 * sizeof(unsigned)), RTOW_ERROR_MEMORY_ALLOCATION);
@@ -1252,9 +1252,10 @@ RTOW_API int rtowUploadScene(RtowContext ctx, const RtowSceneDesc* scene)
         static const int kDefault[9] = {RTOW_DEFAULT_TUNE}, kGeneral[9] = {RTOW_GENERAL_TUNE};
         const int* base = compiled.layout.sceneKind <= SCENE_KIND_SPHERES_MOTION ? kDefault : kGeneral;      // measured per family: see RTOW_DEFAULT_TUNE
         for (int k = 0; k < 9; k++) ctx->tune[k] = base[k];
-        if (compiled.layout.nodeCount > 65535u) ctx->tune[8] = 24;
+        // (round 6: on the rank-rule triangle kernel that traces meshes now, 12 / 16 / 20 / 24 / 32 visits run 2 374 / 2 361 / 2 326 / 2 343 / 2 231 Msamples/s: the 24 of
+        // round 3's exact-tie kernel is no better than the 16 everything else uses, profiles/r06n_mesh_scheduler_sweep.json)
     } else if (ctx->userSliceDefault) {
-        ctx->tune[8] = compiled.layout.nodeCount > 65535u ? 24 : 16;
+        ctx->tune[8] = 16;
     }
     std::lock_guard<std::mutex> sceneLock(ctx->sceneMu);          // rtowProbeNearestHit reads the host image under this lock only
     ctx->scene = std::move(compiled);

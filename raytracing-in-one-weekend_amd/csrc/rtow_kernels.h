@@ -88,6 +88,7 @@ constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: fi
 #define RTOW_SAMPLE_GROUP 16     // (other values: timing builds only - the oracle's restatement of the policy sums groups of 16)
 #endif
 constexpr unsigned kSampleGroup = RTOW_SAMPLE_GROUP;   // RTOW_RNG_PER_SAMPLE: samples per work unit (part of that policy's definition: partial sums are per group)
+constexpr unsigned kChunkOrderScratchWords = 1056;   // behind the 2 x chunkCount words of the chunk-cost array: histogram and maximum of the multi-workgroup chunk order (rtow_kernels.hip)
 constexpr int kMaxChain = 16;      // successive batches one launch can run (rtowSampleBatchChainDevice)
 constexpr int kLocalHitEntries = 24;                // entries of a ray's hit list a lane holds itself; longer lists continue in SampleKernelArgs.hitSpill
 constexpr uint32_t kDefaultHitListCapacity = 1024;  // RtowContextOptions.hitListCapacity == 0, scenes with volumes (long lists are their normal case)

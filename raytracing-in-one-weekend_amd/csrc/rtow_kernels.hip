@@ -19,6 +19,8 @@ __device__ __forceinline__ void store3(float* p, size_t index, V3 v) { F3 o; o.x
 // counts of the previous launch.  Counting sort on a 1024-bucket quantisation of the cost; the order inside a bucket is
 // arbitrary - it only changes which lane renders which pixel, never a result.
 constexpr int kOrderBuckets = 1024;
+constexpr unsigned kOrderSingleBlockChunks = 65536u;      // beyond this many chunks the order is built by several workgroups (order_*_kernel)
+static_assert(kChunkOrderScratchWords >= kOrderBuckets + 1, "histogram + maximum");
 // cost[0..n) = ray count per chunk, cost[n..2n) = ray count of the chunk's most expensive pixel.  byMax: order by the most
 // expensive pixel first (what decides when the last lanes retire), ties by the chunk total; otherwise by the total (used for
 // the 1-sample probe, whose per-pixel counts are too noisy).
@@ -208,6 +210,58 @@ __global__ void __launch_bounds__(1024) build_chunk_order_kernel(const unsigned*
     }
     __syncthreads();
     for (unsigned i = t; i < n; i += 1024) order[atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)(chunk_key(cost, n, i, byMax) * scale)], 1u)] = i;
+}
+
+// The same order over several workgroups, for launches of hundreds of thousands of chunks (the per-sample policies' units at 1080p: 518 400 chunks, 0.67 ms in the one
+// workgroup above = 1.1 % of a batch): maximum, histogram, prefix and scatter as four small launches over a 1 025-word scratch behind the cost array
+// (scratch[0 .. 1023] = histogram / cursors, scratch[1024] = bits of the largest key).  Same buckets, same (unspecified) order inside a bucket.
+__global__ void __launch_bounds__(256) order_max_kernel(const unsigned* __restrict__ cost, unsigned n, int byMax, unsigned* __restrict__ scratch)
+{
+    float m = 1.0f;                                                  // (the single-workgroup kernel starts from 1 too)
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) m = fmaxf(m, chunk_key(cost, n, i, byMax));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63u) == 0) atomicMax(scratch + kOrderBuckets, __float_as_uint(m));
+}
+// (a workgroup counts its 2 048 chunks in LDS and touches every global bucket once: the keys of a launch crowd into a few buckets - per-sample units cost alike - and half a
+// million global atomics on a handful of addresses took longer than the single workgroup they were meant to replace)
+constexpr unsigned kOrderChunksPerBlock = 2048u;
+__global__ void __launch_bounds__(256) order_hist_kernel(const unsigned* __restrict__ cost, unsigned n, int byMax, unsigned* __restrict__ scratch)
+{
+    __shared__ unsigned hist[kOrderBuckets];
+    for (unsigned b = threadIdx.x; b < (unsigned)kOrderBuckets; b += 256u) hist[b] = 0u;
+    __syncthreads();
+    const float scale = (float)(kOrderBuckets - 1) / __uint_as_float(scratch[kOrderBuckets]);
+    const unsigned first = blockIdx.x * kOrderChunksPerBlock, last = first + kOrderChunksPerBlock < n ? first + kOrderChunksPerBlock : n;
+    for (unsigned i = first + threadIdx.x; i < last; i += 256u) atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)(chunk_key(cost, n, i, byMax) * scale)], 1u);
+    __syncthreads();
+    for (unsigned b = threadIdx.x; b < (unsigned)kOrderBuckets; b += 256u) if (hist[b]) atomicAdd(&scratch[b], hist[b]);
+}
+__global__ void __launch_bounds__(1024) order_prefix_kernel(unsigned* __restrict__ scratch)
+{
+    __shared__ unsigned sums[kOrderBuckets];
+    const unsigned t = threadIdx.x, c = scratch[t];
+    sums[t] = c;
+    __syncthreads();
+    for (unsigned d = 1; d < (unsigned)kOrderBuckets; d <<= 1) {      // inclusive scan
+        const unsigned v = t >= d ? sums[t - d] : 0u;
+        __syncthreads();
+        sums[t] += v;
+        __syncthreads();
+    }
+    scratch[t] = sums[t] - c;                                          // exclusive: where bucket t starts
+}
+__global__ void __launch_bounds__(256) order_scatter_kernel(const unsigned* __restrict__ cost, unsigned n, int byMax, unsigned* __restrict__ scratch, unsigned* __restrict__ order)
+{
+    __shared__ unsigned hist[kOrderBuckets];       // this workgroup's count per bucket, then its cursor inside the range it reserved in that bucket
+    for (unsigned b = threadIdx.x; b < (unsigned)kOrderBuckets; b += 256u) hist[b] = 0u;
+    __syncthreads();
+    const float scale = (float)(kOrderBuckets - 1) / __uint_as_float(scratch[kOrderBuckets]);
+    const unsigned first = blockIdx.x * kOrderChunksPerBlock, last = first + kOrderChunksPerBlock < n ? first + kOrderChunksPerBlock : n;
+    for (unsigned i = first + threadIdx.x; i < last; i += 256u) atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)(chunk_key(cost, n, i, byMax) * scale)], 1u);
+    __syncthreads();
+    for (unsigned b = threadIdx.x; b < (unsigned)kOrderBuckets; b += 256u) if (hist[b]) hist[b] = atomicAdd(&scratch[b], hist[b]);      // reserve; hist[b] = where this workgroup's share starts
+    __syncthreads();
+    for (unsigned i = first + threadIdx.x; i < last; i += 256u) order[atomicAdd(&hist[(kOrderBuckets - 1) - (unsigned)(chunk_key(cost, n, i, byMax) * scale)], 1u)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -839,6 +893,17 @@ hipError_t launchPrimaryCandidates(const SampleKernelArgs& args, uint2* out, hip
 hipError_t launchBuildChunkOrder(const unsigned short* pixelCost, unsigned* cost, unsigned chunkCount, unsigned* order, int byMax, hipStream_t stream)
 {
     hipLaunchKernelGGL(reduce_chunk_cost_kernel, dim3((chunkCount + 3u) / 4u), dim3(256), 0, stream, pixelCost, chunkCount, cost);
+    if (chunkCount > kOrderSingleBlockChunks) {
+        unsigned* scratch = cost + 2u * (size_t)chunkCount;            // kChunkOrderScratchWords behind the two cost columns (rtow_api.hip allocates them)
+        const unsigned blocks = (chunkCount + kOrderChunksPerBlock - 1u) / kOrderChunksPerBlock;        // order_hist / order_scatter: one workgroup per 2 048 chunks
+        hipError_t e = hipMemsetAsync(scratch, 0, (size_t)kChunkOrderScratchWords * sizeof(unsigned), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(order_max_kernel, dim3(blocks), dim3(256), 0, stream, cost, chunkCount, byMax, scratch);
+        hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, cost, chunkCount, byMax, scratch);
+        hipLaunchKernelGGL(order_prefix_kernel, dim3(1), dim3(1024), 0, stream, scratch);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, cost, chunkCount, byMax, scratch, order);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(build_chunk_order_kernel, dim3(1), dim3(1024), 0, stream, cost, chunkCount, order, byMax);
     return hipGetLastError();
 }
