@@ -42,6 +42,9 @@ static constexpr unsigned kGroupSlotBlock = RTOW_GROUP_SLOT_BLOCK;
 #ifndef RTOW_PIXEL_GATE
 #define RTOW_PIXEL_GATE 1     // lanes of a wave that must want a pixel boundary before the boundary block runs (1 = at once; the kernel's A.tune[7]); measured: see HISTORY.md round 6
 #endif
+#ifndef RTOW_URGENT_RAYS_PER_SAMPLE
+#define RTOW_URGENT_RAYS_PER_SAMPLE 10.0f   // lanes in a hurry: rays per sample of the batch's (largest) sample count a pixel takes before its lane stops waiting for company (6 ... 14: the same within 1 %)
+#endif
 #ifndef RTOW_DEFAULT_TUNE
 #define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 3, 1, 16
 #endif
@@ -415,6 +418,21 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     const unsigned unitSamples = p->rngPolicy != RTOW_RNG_REFERENCE ? kSampleGroup : (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
     const int pixelGate = (ctx->regroupSide >> 12) & 15 ? (ctx->regroupSide >> 12) & 15 : (unitSamples <= 64u ? 4 : RTOW_PIXEL_GATE);
     a.tune[7] = pixelGate;
+    // Lanes in a hurry (kernel: HURRY; twins of the static-sphere kind's generic reference-stream variants): a pixel that has taken this many rays in the batch stops waiting for
+    // company.  Batch groups run a pixel's batches side by side and keep every wave busy to the end: no bound, and the variants without the code.  Static spheres only: measured at
+    // depth 32, same box (profiles/r06x_lanes_in_a_hurry.json) - cover scene +17 % (adaptive) / +22 % (chains), 10 000 spheres +14.5 %; moving spheres with a lens -1.6 %, the
+    // 250 882-triangle mesh -8.6 % (a stage run for one lane costs the whole wave a memory round trip there).
+    {
+        // (exactly the launches launchByDiagGeo serves from a twin: every other variant reads tune[7] as the pixel gate alone)
+        const bool records16 = a.diagnostics && a.diagnosticsStride >= 16;
+        const bool twin = !a.chainIndependent && a.layout.sceneKind == SCENE_KIND_SPHERES && !a.layout.exactTies && !ctx->wideCodes && p->rngPolicy == RTOW_RNG_REFERENCE &&
+                          a.noiseColor == RTOW_NOISE_WHITE && !(records16 && a.refTree) && historyWords(a.noiseColor, false, false, false, records16, a.traceDepth) == 32;
+        const float urgentRays = twin ? RTOW_URGENT_RAYS_PER_SAMPLE * (float)unitSamples : __builtin_inff();
+        uint32_t bits;
+        memcpy(&bits, &urgentRays, sizeof bits);
+        if (!(urgentRays < __builtin_inff())) bits = 0u;                                  // no bound: the variants without the code (they read tune[7] as the pixel gate alone)
+        a.tune[7] = (int32_t)((bits & 0xffffff00u) | (uint32_t)(pixelGate & 255));
+    }
     const uint32_t ownedPixels = a.totalWork;
     if (ownedPixels == 0) {
         // a slice that owns no row (SliceOffset >= height): Execute returns for every index (JOBS/SampleBatchJob.cs:69-70) - nothing is
@@ -656,6 +674,16 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         }
     }
 
+    {
+        // Plain or chained launches with paths deeper than 16 segments are bound by their slowest pixels (see "lanes in a hurry" above), not by lane occupancy: a static-sphere scene
+        // that is whole in LDS runs them with REGEN from a quarter of the live lanes, HIT from 3/8, and the walk's hand-over at 4 candidates (profiles/r06u_deep_plain_launch_thresholds.json:
+        // +7 ... +10 %; the same values cost batch groups 2.8 %, launches at depth <= 16 1.3 ... 3 %, moving spheres 2 %, and 10 000 spheres - next to the lanes in a hurry - 2 %)
+        static const int kDefault[9] = {RTOW_DEFAULT_TUNE};
+        if (!ctx->userTune && !a.chainIndependent && a.traceDepth > 16 && p->rngPolicy == RTOW_RNG_REFERENCE && a.layout.sceneKind == SCENE_KIND_SPHERES && a.ldsSceneBytes == a.layout.totalBytes &&
+            a.tune[0] == kDefault[0] && a.tune[3] == kDefault[3] && a.tune[6] == kDefault[6]) {
+            a.tune[0] = 16; a.tune[3] = 24; a.tune[6] = 4;
+        }
+    }
     if (a.chainCount > 1u && a.chainIndependent) {
         // a batch group: nothing is handed over between its batches; only the per-batch table (seed, diagnostics, outputs)
         if (!ctx->dChainBatches) HIP_TRY(ctx, hipMalloc(&ctx->dChainBatches, sizeof(ChainBatch) * kMaxChain), RTOW_ERROR_MEMORY_ALLOCATION);
@@ -726,6 +754,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         SampleKernelArgs r = a;
         r.layout.exactTies = 1u;
         r.redoMode = 1;
+        r.tune[7] &= 255;                      // (the exact-tie kernels have no lanes in a hurry: the pixel gate alone)
         r.tieBits = nullptr;
         r.tieRedo = ctx->dTieRedo;
         r.tieRedoCapacity = kTieRedoCapacity;

@@ -252,7 +252,9 @@ struct SampleKernelArgs {
     int32_t blockThreads;
     int32_t wideCodes;
 
-    // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice
+    // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice.  tune[7]: bits 0 .. 7 = lanes of a wave that must want a
+    // pixel boundary before the boundary block runs; bits 8 .. 31 = the float bits (low eight dropped) of the ray count beyond which a pixel's lane stops waiting for company (kernel: HURRY;
+    // 0 = none: the launch runs the variants without that code)
     int32_t tune[8];
     int32_t travSlice;
 };

@@ -1,6 +1,6 @@
 // rtow_sample_kernel.hip.h - the sample-batch megakernel (hand-written gfx950 / CDNA4) and the device helpers shared with the small
-// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_*.hip): the kernel has 334
-// template instantiations (240 + 90 with wide codes + 4 pinhole twins) and compiling them side by side keeps the build at a minute and a half.
+// kernels of rtow_kernels.hip.  Included by one translation unit per scene kind (rtow_sample_*.hip): the kernel has 338
+// template instantiations (240 + 90 with wide codes + 4 pinhole twins + 4 twins with the lanes in a hurry) and compiling them side by side keeps the build at a minute and a half.
 //
 // sample_batch_kernel replaces SampleBatchJob.Execute + Sample + FindHitCandidates + FindHits + Entity.Hit +
 // Sphere.Hit + Material.Scatter + View.GetRay + RandomSource (JOBS/SampleBatchJob.cs:59-475, RT/*.cs).
@@ -26,7 +26,7 @@
 //  * template parameters: ALL_LDS (scene fully LDS resident), KIND (spheres / moving spheres / general entities / volumes / textured /
 //    both / triangles / textured triangles, + exact-tie bit), HW (history words: 4 / 8 = every code in registers, trace depth <= 8 / 16; 32 = eight codes in
 //    registers, the rest in LDS rows, trace depth <= 64), DIAG (0 RayCount only / 1 the FULL_DIAGNOSTICS counters of this library's walk / 2 those or the
-//    reference tree's), NOISE (white / blue / STBN), PER_SAMPLE, GEO (bit 2 wide codes, bit 3 pinhole twin); launchByDiagGeo (end of this file) says which
+//    reference tree's), NOISE (white / blue / STBN), PER_SAMPLE, GEO (bit 2 wide codes, bit 3 pinhole twin, bit 4 lanes in a hurry); launchByDiagGeo (end of this file) says which
 //    instantiation serves which batch.
 //
 // Numerics: compiled with -ffp-contract=off; every expression below is written in the evaluation order of the C#
@@ -59,6 +59,9 @@
 #endif
 #ifndef RTOW_TRI_HOT
 #define RTOW_TRI_HOT 1        // 0: A/B build in which the all-triangle kinds test and shade from the 128-byte GpuPrim records (the compact GpuTriHot / GpuTriCold records are still uploaded)
+#endif
+#ifndef RTOW_URGENT_LANES
+#define RTOW_URGENT_LANES 1   // 0: A/B build without the lanes in a hurry (main loop: HURRY)
 #endif
 #ifndef RTOW_PREFETCH
 #define RTOW_PREFETCH 0       // A/B builds, wide-code kernels: bit 0 = the far child's node is requested when it is pushed, bit 1 = a triangle's compact record when it is listed.
@@ -947,13 +950,14 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm
 #endif
 // (The first build with these instructions exposed a miscompiled tie update in the general-entity kernels - see the TEST stage - which
 // is how that one was found; with the update written as selects every variant equals the oracle with and without them.)
-#define STAGE_PRIO(k) do { if ((RTOW_STAGE_PRIO) != 0) __builtin_amdgcn_s_setprio((short)(((RTOW_STAGE_PRIO) >> (2 * (k))) & 3)); } while (0)
+#define STAGE_PRIO(k) do { if (HURRY && hurry != 0ull) __builtin_amdgcn_s_setprio(3); else if ((RTOW_STAGE_PRIO) != 0) __builtin_amdgcn_s_setprio((short)(((RTOW_STAGE_PRIO) >> (2 * (k))) & 3)); } while (0)
 // instrumentation hooks: empty in the product.  profiles/experiments/instrumentation.patch (applied by profiles/experiments/build.sh to a COPY of this
 // directory, never to the shipped sources) defines them for the stage-statistics build and adds the timing experiments of HISTORY.md.
 #define DBG_TRACE(kind, primv, tv)
 #define STAT_DECL
 #define STAGE_DECL
 #define STAGE_MARK(k) STAGE_PRIO(k)
+#define STAGE_MARK_TOP(k) do { if ((RTOW_STAGE_PRIO) != 0) __builtin_amdgcn_s_setprio((short)(((RTOW_STAGE_PRIO) >> (2 * (k))) & 3)); } while (0)      // (top of a trip: before this trip's lanes in a hurry are known)
 #define STAT_ADD(i, v)
 #define STAT_LANES(i)
 
@@ -1207,6 +1211,9 @@ constexpr int kGeoWide = 4;
 // the view's `right` / `up` are not compiled in - six launch constants fewer in the scalar registers of kernels that spill two dozen of them into VGPR lanes.  Only the reference-stream
 // variants that keep their whole path history in registers have the twin (launchByDiagGeo).
 constexpr int kGeoPinhole = 8;
+// bit 4 = lanes in a hurry (main loop: HURRY): the twins of the static-sphere kind's generic reference-stream variants that plain and chained launches with a bound on a pixel's rays run;
+// batch groups (no bound) keep the variants without the code - its mere presence costs them 2.4 % (profiles/r06x_lanes_in_a_hurry.json)
+constexpr int kGeoHurry = 16;
 constexpr int geo_block_threads(int) { return kBlockThreads; }
 
 // DIAG: 0 = RayCount only; 1 = the FULL_DIAGNOSTICS counters of this library's own walk; 2 = those, or - when the launch carries the reference's tree
@@ -1417,12 +1424,13 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
     // 4 x 32 bit (0xffffffff = empty slot; first slot empty, second not: no list)
     uint4 pcand = make_uint4(WIDE ? 0xffffffffu : kNoPrimaryList, 0u, 0u, 0u);
     int force = -1;
+    constexpr bool HURRY = RTOW_URGENT_LANES && (GEO & kGeoHurry) != 0;      // lanes in a hurry (below): twins of the static-sphere kind's generic reference-stream variants (launchByDiagGeo)
     unsigned trip = 0;          // chained batches only: paces the polls of parked lanes
     STAT_DECL;
     STAGE_DECL;
     for (;;) {
         STAT_ADD(0, 1);
-        STAGE_MARK(7);
+        STAGE_MARK_TOP(7);
         // Stages run in pipeline order; each one only if enough lanes wait in it, so a lane can still advance a whole path segment per
         // trip when the wave is dense, while sparse stages batch up.  A.tune[] holds the thresholds in 64ths of the wave's LIVE lanes
         // (lanes that still have pixels): 1 = "any lane", 48 = three quarters of them.  Depth-0 rays skip the box walk (camera-ray lists),
@@ -1432,8 +1440,23 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         // wave's working lanes would otherwise pay on every trip - and do not count as live: the thresholds below are fractions of the
         // lanes that have work, and a stage that cannot make progress must never keep the others from being forced
         if (chained) { trip++; if ((trip & 7u) == 0u && st == ST_IDLE) st = ST_REGEN; }
-        const int live = (int)__popcll(__ballot(st != ST_DEAD && st != ST_IDLE));
-        auto need = [&](int k) { const int t = (live * A.tune[k] + 63) >> 6; return t < 1 ? 1 : t; };
+        const unsigned long long liveMask = __ballot(st != ST_DEAD && st != ST_IDLE);
+        const int live = (int)__popcll(liveMask);
+        auto need = [&](int sixtyFourths) { const int t = (live * sixtyFourths + 63) >> 6; return t < 1 ? 1 : t; };      // (the threshold itself, not its index: an index that is a
+                                                                                                                       // parameter leaves a dead 32-byte copy of A.tune[] in a private segment)
+        // Lanes in a hurry (round 6).  One generator per pixel and batch: a pixel's samples run in a row on one lane, so a launch is never shorter than its slowest pixel - at the
+        // reference host's trace depth 32 a few dozen pixels take 1 100 rays per 50-sample batch where the mean takes 128 - and as plain or chained launches (each batch waits for
+        // the one before it) the frame waits for them: 16.5 ms per batch where the batch groups need 11.7.  A lane whose pixel has taken more than A.urgentRays rays in this batch
+        // does not wait for company - the stage it waits in runs, whoever else waits there rides along - and its wave issues ahead of the three it shares a SIMD with
+        // (STAGE_PRIO).  Scheduling only; off (+INF) in batch groups, which run a pixel's batches side by side.
+        unsigned long long hurry = 0ull;                                            // the live lanes in a hurry, as of the top of the trip
+        // (the bound shares A.tune[7] with the pixel gate - its float bits above the gate's eight: ray counts are positive floats, whose order is their bit patterns' - because one
+        // more launch constant held through the loop costs the variants beyond LDS their freedom from a private segment, and reading it on use a scalar-memory wait per trip)
+        if (HURRY) hurry = liveMask & __ballot(__float_as_int(rayCount) > (A.tune[7] | 255));
+        auto due = [&](bool waiting, int stage, int sixtyFourths) {
+            const unsigned long long m = __ballot(waiting);
+            return (int)__popcll(m) >= (force == stage ? 1 : need(sixtyFourths)) || (HURRY && (m & hurry) != 0ull);
+        };
         bool ran = false;
         // Pixel boundaries in company (round 6).  A lane that has finished its pixel (unit) runs two to three hundred instructions - stores, ticket, loads, seed, sample count - that
         // nothing else in its wave takes part in: 1.2 lanes on average (profiles/r05_runs/run_r05u.sh), and the wave issues every one of them.  With A.tune[7] = K > 1 such a lane
@@ -1442,12 +1465,13 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         // policies' 16-sample units): its mere presence brought the moving-sphere headline kernel's 36-byte private segment back.
         constexpr bool PIXEL_COMPANY = HW == 32 || PER_SAMPLE;
         bool regenReady = st == ST_REGEN;
-        if (PIXEL_COMPANY && A.tune[7] > 1) {
+        const int pixelGate = HURRY ? A.tune[7] & 255 : A.tune[7];
+        if (PIXEL_COMPANY && pixelGate > 1) {
             const int wantPixel = (int)__popcll(__ballot(st == ST_REGEN && smp >= nsamp));
-            const int company = live < A.tune[7] ? live : A.tune[7];
-            if (wantPixel < company && force != ST_REGEN) regenReady = st == ST_REGEN && smp < nsamp;
+            const int company = live < pixelGate ? live : pixelGate;
+            if (wantPixel < company && force != ST_REGEN) regenReady = st == ST_REGEN && (smp < nsamp || (HURRY && ((hurry >> (tid & 63)) & 1ull) != 0ull));   // (a lane in a hurry stores at once)
         }
-        if ((int)__popcll(__ballot(regenReady)) >= (force == ST_REGEN ? 1 : need(0))) {
+        if (due(regenReady, ST_REGEN, A.tune[0])) {
             ran = true;
             STAGE_MARK(0);
             // ================= next sample of this pixel, or next pixel =================
@@ -1826,7 +1850,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 }
             }
         }
-        if ((int)__popcll(__ballot(st == ST_TRAV)) >= (force == ST_TRAV ? 1 : need(1))) {
+        if (due(st == ST_TRAV, ST_TRAV, A.tune[1])) {
             ran = true;
             STAGE_MARK(1);
             // ================= box walk: FindHitCandidates (JOBS/SampleBatchJob.cs:403-448), resumable =================
@@ -1906,7 +1930,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 }
             }
         }
-        if ((int)__popcll(__ballot(st == ST_TEST)) >= (force == ST_TEST ? 1 : need(2))) {
+        if (due(st == ST_TEST, ST_TEST, A.tune[2])) {
             ran = true;
             STAGE_MARK(2);
             // ================= exact sphere tests: FindHits (JOBS/SampleBatchJob.cs:450-475) =================
@@ -2041,7 +2065,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 else classify();
             }
         }
-        if ((int)__popcll(__ballot(st == ST_HIT)) >= (force == ST_HIT ? 1 : need(3))) {
+        if (due(st == ST_HIT, ST_HIT, A.tune[3])) {
             ran = true;
             STAGE_MARK(3);
             // ================= surface hit: Entity.Hit record + Material.Scatter =================
@@ -2274,7 +2298,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                 else startRay();
             }
         }
-        if (VOLUMES && (int)__popcll(__ballot(st == ST_VOL)) >= (force == ST_VOL ? 1 : need(5))) {
+        if (VOLUMES && due(st == ST_VOL, ST_VOL, A.tune[5])) {
             ran = true;
             STAGE_MARK(5);
             if (st == ST_VOL) {
@@ -2396,7 +2420,7 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
                             [&](int i) { return hit_get(hitT, hitTmin0, hitCode, spill, i).tmin0; });
             }
         }
-        if ((int)__popcll(__ballot(st == ST_SKY)) >= (force == ST_SKY ? 1 : need(4))) {
+        if (due(st == ST_SKY, ST_SKY, A.tune[4])) {
             ran = true;
             STAGE_MARK(4);
             // ================= sky (:341-374), then fold tail -> head (:384-396) =================
@@ -2526,6 +2550,9 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
         if (pinhole && hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO | kGeoPinhole>(args, numBlocks, stream);
     }
     if (hw == 4) return launchVariant<ALL_LDS, KIND, 4, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+    // lanes in a hurry (kGeoHurry): the launch carries a bound on a pixel's rays (plain and chained launches of static-sphere scenes: rtow_api.hip) - the twins of that kind's generic variants
+    constexpr bool HAS_HURRY_TWIN = RTOW_URGENT_LANES && !WIDE && !TIES && (KIND & 7) == SCENE_KIND_SPHERES;
+    const bool hurry = ((uint32_t)args.tune[7] >> 8) != 0u;      // (tune[7] above the pixel gate's eight bits: the bound's float bits, 0 = none)
     if constexpr (WIDE) {
         if constexpr (TIES) { if (hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
     } else {
@@ -2533,10 +2560,12 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
         // adaptive schedule and single launches: 2 - 10 % SLOWER than the generic 32-word kernels everywhere (profiles/r05e_history16_variants.json); removed again.  Round 6:
         // the generic kernels keep the codes beyond depth 8 in LDS rows instead of a private segment)
         if (hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+        if constexpr (HAS_HURRY_TWIN) { if (hurry && !fullDiag) return launchVariant<ALL_LDS, KIND, 32, 0, RTOW_NOISE_WHITE, false, GEO | kGeoHurry>(args, numBlocks, stream); }
         if (!fullDiag) return launchVariant<ALL_LDS, KIND, 32, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
     }
     // FULL_DIAGNOSTICS records (and every deeper wide-code launch): the counters of this library's own walk, or - a variant of its own, with a private segment - the reference's
     if (args.refTree) return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
+    if constexpr (HAS_HURRY_TWIN) { if (hurry) return launchVariant<ALL_LDS, KIND, 32, 1, RTOW_NOISE_WHITE, false, GEO | kGeoHurry>(args, numBlocks, stream); }
     return launchVariant<ALL_LDS, KIND, 32, 1, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
 }
 

@@ -103,6 +103,38 @@ def test_chain_of_slices_and_the_oracle(rt, oracle, gpu_context):
         assert np.array_equal(got[k].reshape(-1).view(np.uint32), ref[k].reshape(-1).view(np.uint32)), k
 
 
+@pytest.mark.parametrize("name,stride", [("cover", 16), ("cover", 4), ("moving", 16)])
+def test_deep_plain_and_chained_launches_with_lanes_in_a_hurry(rt, oracle, gpu_context, name, stride):
+    """The reference host's committed configuration (trace depth 32, 50 samples per batch; 16-byte records or RayCount only) as plain launches, as a chain and as a batch group.
+    At this depth a pixel in a few thousand takes ten times the rays of the mean; plain and chained launches let such a pixel's lane run its stages without waiting for company
+    and use thresholds of their own (csrc/rtow_sample_kernel.hip.h HURRY, csrc/rtow_api.hip) - scheduling only: every form equals the oracle's batches in sequence, and the
+    frame must hold pixels beyond the bound (10 rays per sample of the batch) for the test to mean anything."""
+    ctx = gpu_context
+    scene = {"cover": rt.scenes.cover_scene, "moving": rt.scenes.moving_scene}[name]()
+    desc = scene.desc()
+    ctx.upload_scene(desc)
+    w, h, spp, depth, count = 320, 180, 50, 32, 3
+    n = w * h
+    plist = _params(rt, scene, w, h, spp, depth, [31, 32, 33], diagnostics_stride=stride, focus=6.0 if name != "cover" else None)
+    osc = oracle.OracleScene(desc)
+    ref, ref_diag = None, []
+    for p in plist:
+        ref = osc.sample_batch(p, None if ref is None else {k: ref[k] for k, _ in KEYS})
+        ref_diag.append(ref["diag"])
+    osc.close()
+    assert max(d[:, 0].max() for d in ref_diag) > 10 * spp, "no pixel beyond the bound: nothing was in a hurry"
+    def check(got, what):
+        for k, c in KEYS:
+            assert np.array_equal(got[k].view(np.uint32), ref[k].reshape(n, c).view(np.uint32)), (name, what, k)
+        for b, d in enumerate(got["diag"]):
+            for col in ((0, 3) if stride == 16 else (0,)):          # RayCount and the sample count weight; columns 1 and 2 count visits of this library's own tree
+                assert np.array_equal(d[:, col].view(np.uint32), ref_diag[b][:, col].view(np.uint32)), (name, what, "diagnostics of batch", b, col)
+
+    check(_sequential(rt, ctx, plist, n, stride), "plain launches")
+    for attempt in range(2):                                      # second attempt: chunk order from the measured cost map
+        check(_chained(rt, ctx, plist, n, stride), ("chain", attempt))
+
+
 def test_chain_falls_back_when_batches_differ_or_are_too_many(rt, gpu_context):
     """Batches that differ in more than Seed (here: samples per pixel), more batches than one launch holds (16), and the per-sample RNG policy
     all run as the sequence the chain is defined to equal."""

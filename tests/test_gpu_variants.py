@@ -1,7 +1,7 @@
 """GPU: every compiled variant of the sample kernel, one by one.
 
 The kernel is instantiated per (tree in LDS | in HBM) x scene kind x the (history width, diagnostics, noise source, RNG policy) combinations
-`launchByDiag` (end of csrc/rtow_sample_kernel.hip.h) dispatches to - 334 kernels at the end of round 6, the spilling ones compiled under heavy register pressure.  During development one of them (VOLUMES, spatio-temporal noise,
+`launchByDiag` (end of csrc/rtow_sample_kernel.hip.h) dispatches to - 338 kernels at the end of round 6, the spilling ones compiled under heavy register pressure.  During development one of them (VOLUMES, spatio-temporal noise,
 short diagnostics) was once MISCOMPILED by hipcc (ROCm 7.2): a VGPR spill store was scheduled in front of the `s_or_b64 exec` of a join
 block, so the lanes that had skipped the region kept a stale spill slot and later reloaded it - their ray-count diagnostic came out 0
 while the colours were right.  Any source change reshuffles the register allocation of all of them, so every build
@@ -103,6 +103,50 @@ def test_every_kernel_variant(rt, oracle, kind, in_lds):
                 assert np.array_equal(gpu["diag"][:, 0], ref["diag"][:, 0]), (where, "ray count")        # columns 1, 2 count visits of the (different) tree
                 if stride == 16:
                     assert np.array_equal(gpu["diag"][:, 3].view(np.uint32), ref["diag"][:, 3].view(np.uint32)), (where, "sample count weight")
+    finally:
+        osc.close()
+
+
+@pytest.mark.parametrize("in_lds", [True, False], ids=["lds", "hbm"])
+@pytest.mark.parametrize("kind", ["spheres", "spheres_motion"])
+def test_generic_variants_with_and_without_the_lanes_in_a_hurry(rt, oracle, kind, in_lds):
+    """The static-sphere kind's generic reference-stream variants (paths deeper than 16 segments, or 16-byte records) exist twice since round 6: plain and chained launches run the
+    twins in which a pixel far beyond the mean ray count stops waiting for company (GEO bit 4), batch groups the variants without that code.  test_every_kernel_variant's plain
+    launches reach the twins; here the same batches as a batch group reach the others - both against the oracle, tree in LDS and beyond.  (Moving spheres have no twin: there the
+    two forms run the same kernels, and must agree all the same.)"""
+    scene = _scene(rt, kind)
+    desc = scene.desc()
+    w, h = 40, 24
+    n = w * h
+    keys = (("color", 4), ("normal", 3), ("albedo", 3), ("scw", 1))
+    rng = np.random.default_rng(12)
+    ins = {"color": rng.random((n, 4)).astype(np.float32), "normal": rng.normal(size=(n, 3)).astype(np.float32),
+           "albedo": rng.random((n, 3)).astype(np.float32), "scw": rng.random(n).astype(np.float32)}
+    ins["color"][:, 3] = rng.integers(0, 4, n)
+    osc = oracle.OracleScene(desc)
+    try:
+        with rt.Context(0, lds_scene_budget=0 if in_lds else 1024) as ctx:
+            ctx.upload_scene(desc)
+            assert bool(ctx.scene_info().sceneInLds) == in_lds
+            for depth, stride in ((20, 4), (20, 16), (5, 16)):
+                plist = [rt.scenes.make_params(scene, w, h, spp=12, trace_depth=depth, seed=90 + k, diagnostics_stride=stride) for k in range(2)]
+                refs = [osc.sample_batch(p, ins) for p in plist]
+                src = [rt.DeviceBuffer(ctx).upload(ins[k]) for k, _ in keys]
+                outs = [[rt.DeviceBuffer(ctx, n * c * 4).zero() for _, c in keys] for _ in plist]
+                diags = [rt.DeviceBuffer(ctx, n * stride).zero() for _ in plist]
+                assert rt.sample_batch_group_device(ctx, plist, src, outs, diags) == 0
+                ctx.synchronize()
+                for b, ref in enumerate(refs):
+                    plain = rt.sample_batch_host(ctx, plist[b], ins)
+                    for (k, c), buf in zip(keys, outs[b]):
+                        got = buf.download(np.float32, (n, c)).reshape(ref[k].shape)
+                        assert np.array_equal(got.view(np.uint32), ref[k].view(np.uint32)), (kind, in_lds, depth, stride, b, k, "group")
+                        assert np.array_equal(plain[k].view(np.uint32), ref[k].view(np.uint32)), (kind, in_lds, depth, stride, b, k, "plain")
+                    assert np.array_equal(diags[b].download(np.float32, (n, stride // 4))[:, 0], ref["diag"][:, 0]), (kind, in_lds, depth, stride, b, "ray count")
+                if depth == 20:
+                    assert max(r["diag"][:, 0].max() for r in refs) > 10 * 12, "no pixel beyond the bound of 10 rays per sample: the twins ran like the others"
+                for b in src + [x for o in outs for x in o] + diags:
+                    b.free()
     finally:
         osc.close()
 
