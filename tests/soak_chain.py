@@ -17,7 +17,8 @@ KEYS = (("color", 4), ("normal", 3), ("albedo", 3), ("scw", 1))
 
 def run(ctx, plist, n, chained):
     bufs = [rt.DeviceBuffer(ctx, n * c * 4).zero() for _, c in KEYS]
-    diags = [rt.DeviceBuffer(ctx, n * 4).zero() for _ in plist]
+    stride = max(4, int(plist[0].diagnosticsStride))
+    diags = [rt.DeviceBuffer(ctx, n * stride).zero() for _ in plist]
     if chained:
         rt.lib.check(rt.sample_batch_chain_device(ctx, plist, bufs, bufs, diags), "rtowSampleBatchChainDevice")
     else:
@@ -28,7 +29,7 @@ def run(ctx, plist, n, chained):
             job.OutputDiagnostics = d
             rt.lib.check(job.Schedule().Complete(), "rtowSampleBatchDevice")
     ctx.synchronize()
-    out = [b.download(np.uint32, (n, c)) for b, (_, c) in zip(bufs, KEYS)] + [d.download(np.uint32, (n,)) for d in diags]
+    out = [b.download(np.uint32, (n, c)) for b, (_, c) in zip(bufs, KEYS)] + [d.download(np.uint32, (n, stride // 4)) for d in diags]
     for b in bufs + diags:
         b.free()
     return out
@@ -56,6 +57,9 @@ def main():
              # round 6: chains through the variants whose path history lives in LDS rows, and through the tie watch of the all-triangle kinds
              ("cover depth 32", S.cover_scene, 1920, 1080, 16, 32, 10, {}),
              ("moving depth 24", S.moving_scene, 1280, 720, 16, 24, 10, {}),
+             # ... and through the twins with the lanes in a hurry: 16-byte records with adaptive counts, tree beyond LDS
+             ("cover depth 32, records, adaptive counts", S.cover_scene, 1280, 720, 8, 32, 8, {"spp_max": 50, "extrema": (0.2, 1.4), "diagnostics_stride": 16}),
+             ("stress 10000 depth 24", S.stress_scene, 1280, 720, 12, 24, 6, {}),
              ("triangle layers (tie watch)", S.triangle_layers_scene, 960, 640, 4, 10, 8, {})]
     main_ctx = rt.Context(0)
     bad_total = 0
