@@ -43,7 +43,11 @@ static constexpr unsigned kGroupSlotBlock = RTOW_GROUP_SLOT_BLOCK;
 #define RTOW_PIXEL_GATE 1     // lanes of a wave that must want a pixel boundary before the boundary block runs (1 = at once; the kernel's A.tune[7]); measured: see HISTORY.md round 6
 #endif
 #ifndef RTOW_URGENT_RAYS_PER_SAMPLE
-#define RTOW_URGENT_RAYS_PER_SAMPLE 10.0f   // lanes in a hurry: rays per sample of the batch's (largest) sample count a pixel takes before its lane stops waiting for company (6 ... 14: the same within 1 %)
+// lanes in a hurry (kernel: HURRY): the rate - rays per sample done so far - beyond which a pixel's lane stops waiting for company.  Same box (profiles/r06x_lanes_in_a_hurry.json,
+// run_r06ag.sh / run_r06ah.sh): cover scene at depth 32, chains: 14 -> 7 126 Msamples/s, 18 -> 7 302, 24 -> 6 220 (nobody is in a hurry any more); 10 000 spheres at depth 32:
+// 14 -> 5 370, 18 -> 4 895, 24 -> 4 180.  (Float bits with the low eight zero: they share tune[7] with the pixel gate.)
+#define RTOW_URGENT_RAYS_PER_SAMPLE 18.0f
+#define RTOW_URGENT_RAYS_PER_SAMPLE_BEYOND_LDS 14.0f
 #endif
 #ifndef RTOW_DEFAULT_TUNE
 #define RTOW_DEFAULT_TUNE 24, 32, 1, 32, 28, 1, 3, 1, 16
@@ -418,7 +422,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     const unsigned unitSamples = p->rngPolicy != RTOW_RNG_REFERENCE ? kSampleGroup : (a.sampleCountMax > a.sampleCountMin ? a.sampleCountMax : a.sampleCountMin);
     const int pixelGate = (ctx->regroupSide >> 12) & 15 ? (ctx->regroupSide >> 12) & 15 : (unitSamples <= 64u ? 4 : RTOW_PIXEL_GATE);
     a.tune[7] = pixelGate;
-    // Lanes in a hurry (kernel: HURRY; twins of the static-sphere kind's generic reference-stream variants): a pixel that has taken this many rays in the batch stops waiting for
+    // Lanes in a hurry (kernel: HURRY; twins of the static-sphere kind's generic reference-stream variants): a pixel that runs at more than this many rays per sample stops waiting for
     // company.  Batch groups run a pixel's batches side by side and keep every wave busy to the end: no bound, and the variants without the code.  Static spheres only: measured at
     // depth 32, same box (profiles/r06x_lanes_in_a_hurry.json) - cover scene +17 % (adaptive) / +22 % (chains), 10 000 spheres +14.5 %; moving spheres with a lens -1.6 %, the
     // 250 882-triangle mesh -8.6 % (a stage run for one lane costs the whole wave a memory round trip there).
@@ -427,7 +431,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
         const bool records16 = a.diagnostics && a.diagnosticsStride >= 16;
         const bool twin = !a.chainIndependent && a.layout.sceneKind == SCENE_KIND_SPHERES && !a.layout.exactTies && !ctx->wideCodes && p->rngPolicy == RTOW_RNG_REFERENCE &&
                           a.noiseColor == RTOW_NOISE_WHITE && !(records16 && a.refTree) && historyWords(a.noiseColor, false, false, false, records16, a.traceDepth) == 32;
-        const float urgentRays = twin ? RTOW_URGENT_RAYS_PER_SAMPLE * (float)unitSamples : __builtin_inff();
+        const float urgentRays = !twin ? __builtin_inff() : (a.ldsSceneBytes == a.layout.totalBytes ? RTOW_URGENT_RAYS_PER_SAMPLE : RTOW_URGENT_RAYS_PER_SAMPLE_BEYOND_LDS);
         uint32_t bits;
         memcpy(&bits, &urgentRays, sizeof bits);
         if (!(urgentRays < __builtin_inff())) bits = 0u;                                  // no bound: the variants without the code (they read tune[7] as the pixel gate alone)

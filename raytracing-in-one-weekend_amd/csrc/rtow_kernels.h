@@ -253,8 +253,8 @@ struct SampleKernelArgs {
     int32_t wideCodes;
 
     // scheduler: minimum lane population for a stage to run, indexed by lane state (REGEN TRAV TEST HIT SKY), + box-walk slice.  tune[7]: bits 0 .. 7 = lanes of a wave that must want a
-    // pixel boundary before the boundary block runs; bits 8 .. 31 = the float bits (low eight dropped) of the ray count beyond which a pixel's lane stops waiting for company (kernel: HURRY;
-    // 0 = none: the launch runs the variants without that code)
+    // pixel boundary before the boundary block runs; bits 8 .. 31 = the float bits (low eight dropped) of the rate - rays per sample done so far - beyond which a pixel's lane stops
+    // waiting for company (kernel: HURRY; 0 = none: the launch runs the variants without that code, which read tune[7] as the gate alone)
     int32_t tune[8];
     int32_t travSlice;
 };

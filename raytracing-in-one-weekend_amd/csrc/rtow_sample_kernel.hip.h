@@ -1442,17 +1442,18 @@ __global__ void __launch_bounds__(geo_block_threads(GEO)) sample_batch_kernel(co
         if (chained) { trip++; if ((trip & 7u) == 0u && st == ST_IDLE) st = ST_REGEN; }
         const unsigned long long liveMask = __ballot(st != ST_DEAD && st != ST_IDLE);
         const int live = (int)__popcll(liveMask);
-        auto need = [&](int sixtyFourths) { const int t = (live * sixtyFourths + 63) >> 6; return t < 1 ? 1 : t; };      // (the threshold itself, not its index: an index that is a
-                                                                                                                       // parameter leaves a dead 32-byte copy of A.tune[] in a private segment)
+        auto need = [&](int sixtyFourths) { const int t = (live * sixtyFourths + 63) >> 6; return t < 1 ? 1 : t; };
         // Lanes in a hurry (round 6).  One generator per pixel and batch: a pixel's samples run in a row on one lane, so a launch is never shorter than its slowest pixel - at the
-        // reference host's trace depth 32 a few dozen pixels take 1 100 rays per 50-sample batch where the mean takes 128 - and as plain or chained launches (each batch waits for
-        // the one before it) the frame waits for them: 16.5 ms per batch where the batch groups need 11.7.  A lane whose pixel has taken more than A.urgentRays rays in this batch
-        // does not wait for company - the stage it waits in runs, whoever else waits there rides along - and its wave issues ahead of the three it shares a SIMD with
-        // (STAGE_PRIO).  Scheduling only; off (+INF) in batch groups, which run a pixel's batches side by side.
+        // reference host's trace depth 32 a few dozen pixels (rays trapped in glass: nearly every path runs to the depth limit) take 1 100 rays per 50-sample batch where the mean
+        // takes 128 - and as plain or chained launches (each batch waits for the one before it) the frame waits for them: 16.5 ms per batch where the batch groups need 11.7.  A lane
+        // whose pixel runs at more than c rays per sample - rayCount > c x (samples done + 2) - does not wait for company: the stage it waits in runs, whoever else waits there rides
+        // along, and its wave issues ahead of the three it shares a SIMD with (STAGE_PRIO).  Such a pixel is found within two or three samples; a bound on the batch's total
+        // (c x spp: the first form) found it after a third of its batch (chains +8 ... 10 % between the two forms).  Scheduling only; batch groups run a pixel's batches side by
+        // side and launch the variants without this code.  c shares A.tune[7] with the pixel gate - its float bits above the gate's eight - because one more launch constant held
+        // through the loop costs the variants beyond LDS their freedom from a private segment, and reading it on use a scalar-memory wait per trip.
+        constexpr unsigned kHurryGrace = 2u;
         unsigned long long hurry = 0ull;                                            // the live lanes in a hurry, as of the top of the trip
-        // (the bound shares A.tune[7] with the pixel gate - its float bits above the gate's eight: ray counts are positive floats, whose order is their bit patterns' - because one
-        // more launch constant held through the loop costs the variants beyond LDS their freedom from a private segment, and reading it on use a scalar-memory wait per trip)
-        if (HURRY) hurry = liveMask & __ballot(__float_as_int(rayCount) > (A.tune[7] | 255));
+        if (HURRY) hurry = liveMask & __ballot(rayCount > __int_as_float(A.tune[7] & ~255) * (float)(smp + kHurryGrace));
         auto due = [&](bool waiting, int stage, int sixtyFourths) {
             const unsigned long long m = __ballot(waiting);
             return (int)__popcll(m) >= (force == stage ? 1 : need(sixtyFourths)) || (HURRY && (m & hurry) != 0ull);
