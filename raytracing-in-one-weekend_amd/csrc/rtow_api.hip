@@ -424,8 +424,8 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     a.tune[7] = pixelGate;
     // Lanes in a hurry (kernel: HURRY; twins of the static-sphere kind's generic reference-stream variants): a pixel that runs at more than this many rays per sample stops waiting for
     // company.  Batch groups run a pixel's batches side by side and keep every wave busy to the end: no bound, and the variants without the code.  Static spheres only: measured at
-    // depth 32, same box (profiles/r06x_lanes_in_a_hurry.json) - cover scene +17 % (adaptive) / +22 % (chains), 10 000 spheres +14.5 %; moving spheres with a lens -1.6 %, the
-    // 250 882-triangle mesh -8.6 % (a stage run for one lane costs the whole wave a memory round trip there).
+    // depth 32, same box (profiles/r06x_lanes_in_a_hurry.json) - cover scene +21 % (adaptive) / +33 % (chains), 10 000 spheres +24 %; in its first form (a bound on the batch's
+    // rays) moving spheres with a lens -1.6 %, the 250 882-triangle mesh -8.6 % (a stage run for one lane costs the whole wave a memory round trip there).
     {
         // (exactly the launches launchByDiagGeo serves from a twin: every other variant reads tune[7] as the pixel gate alone)
         const bool records16 = a.diagnostics && a.diagnosticsStride >= 16;
