@@ -429,7 +429,7 @@ int launchSample(RtowContext ctx, const RtowSampleParams* p, const RtowAccumBuff
     {
         // (exactly the launches launchByDiagGeo serves from a twin: every other variant reads tune[7] as the pixel gate alone)
         const bool records16 = a.diagnostics && a.diagnosticsStride >= 16;
-        const bool twin = !a.chainIndependent && a.layout.sceneKind == SCENE_KIND_SPHERES && !a.layout.exactTies && !ctx->wideCodes && p->rngPolicy == RTOW_RNG_REFERENCE &&
+        const bool twin = RTOW_URGENT_LANES && !a.chainIndependent && a.layout.sceneKind == SCENE_KIND_SPHERES && !a.layout.exactTies && !ctx->wideCodes && p->rngPolicy == RTOW_RNG_REFERENCE &&
                           a.noiseColor == RTOW_NOISE_WHITE && !(records16 && a.refTree) && historyWords(a.noiseColor, false, false, false, records16, a.traceDepth) == 32;
         const float urgentRays = !twin ? __builtin_inff() : (a.ldsSceneBytes == a.layout.totalBytes ? RTOW_URGENT_RAYS_PER_SAMPLE : RTOW_URGENT_RAYS_PER_SAMPLE_BEYOND_LDS);
         uint32_t bits;

@@ -84,6 +84,9 @@ inline int historyWords(int noiseColor, bool perSample, bool wide, bool ties, bo
     return 32;
 }
 constexpr unsigned kNoPrimaryList = 0x0000ffffu;   // pixelCandidates[pix].x: first slot empty, second not - "no list, walk the tree"
+#ifndef RTOW_URGENT_LANES
+#define RTOW_URGENT_LANES 1   // 0: A/B build without the lanes in a hurry (rtow_sample_kernel.hip.h HURRY; rtow_api.hip then sets no rate)
+#endif
 #ifndef RTOW_SAMPLE_GROUP
 #define RTOW_SAMPLE_GROUP 16     // (other values: timing builds only - the oracle's restatement of the policy sums groups of 16)
 #endif

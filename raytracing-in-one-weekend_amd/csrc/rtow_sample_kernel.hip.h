@@ -60,9 +60,6 @@
 #ifndef RTOW_TRI_HOT
 #define RTOW_TRI_HOT 1        // 0: A/B build in which the all-triangle kinds test and shade from the 128-byte GpuPrim records (the compact GpuTriHot / GpuTriCold records are still uploaded)
 #endif
-#ifndef RTOW_URGENT_LANES
-#define RTOW_URGENT_LANES 1   // 0: A/B build without the lanes in a hurry (main loop: HURRY)
-#endif
 #ifndef RTOW_PREFETCH
 #define RTOW_PREFETCH 0       // A/B builds, wide-code kernels: bit 0 = the far child's node is requested when it is pushed, bit 1 = a triangle's compact record when it is listed.
                               // Measured on the 250 882-triangle mesh, same box (profiles/r06a_mesh_layout_prefetch_watch.json): 2 178 Msamples/s without, 2 090 with bit 0, 1 990 with
@@ -2531,6 +2528,12 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
     const bool fullDiag = args.diagnostics && args.diagnosticsStride >= 16;
     // (which history width serves the launch is historyWords' decision - rtow_kernels.h - because the host sizes the launch's LDS from it)
     const int hw = historyWords(args.noiseColor, args.unitRecords != nullptr, WIDE, TIES, fullDiag, args.traceDepth);
+    // lanes in a hurry (kGeoHurry): the launch carries a rate in tune[7], above the pixel gate's eight bits (plain and chained launches of static-sphere scenes: rtow_api.hip) - the
+    // twins of that kind's generic variants serve it.  Every other variant reads tune[7] as the pixel gate alone and would wait for millions of lanes at every pixel boundary:
+    // a launch with a rate that no twin serves is refused, loudly, instead of running slowly
+    constexpr bool HAS_HURRY_TWIN = RTOW_URGENT_LANES && !WIDE && !TIES && (KIND & 7) == SCENE_KIND_SPHERES;
+    const bool hurry = ((uint32_t)args.tune[7] >> 8) != 0u;
+    if (hurry && !(HAS_HURRY_TWIN && args.noiseColor == RTOW_NOISE_WHITE && !args.unitRecords && hw == 32 && !(fullDiag && args.refTree))) return hipErrorInvalidValue;
     if (args.noiseColor == RTOW_NOISE_BLUE) return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_BLUE, false, GEO>(args, numBlocks, stream);
     if (args.noiseColor == RTOW_NOISE_SPATIOTEMPORAL_BLUE) return launchVariant<ALL_LDS, KIND, 32, 2, RTOW_NOISE_SPATIOTEMPORAL_BLUE, false, GEO>(args, numBlocks, stream);
     if (args.unitRecords) {      // RTOW_RNG_PER_SAMPLE
@@ -2551,9 +2554,6 @@ hipError_t launchByDiagGeo(const SampleKernelArgs& args, int numBlocks, hipStrea
         if (pinhole && hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO | kGeoPinhole>(args, numBlocks, stream);
     }
     if (hw == 4) return launchVariant<ALL_LDS, KIND, 4, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream);
-    // lanes in a hurry (kGeoHurry): the launch carries a bound on a pixel's rays (plain and chained launches of static-sphere scenes: rtow_api.hip) - the twins of that kind's generic variants
-    constexpr bool HAS_HURRY_TWIN = RTOW_URGENT_LANES && !WIDE && !TIES && (KIND & 7) == SCENE_KIND_SPHERES;
-    const bool hurry = ((uint32_t)args.tune[7] >> 8) != 0u;      // (tune[7] above the pixel gate's eight bits: the bound's float bits, 0 = none)
     if constexpr (WIDE) {
         if constexpr (TIES) { if (hw == 8) return launchVariant<ALL_LDS, KIND, 8, 0, RTOW_NOISE_WHITE, false, GEO>(args, numBlocks, stream); }
     } else {
